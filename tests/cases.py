@@ -1,0 +1,54 @@
+"""Seeded test cases shared by the golden generator, the oracle tests and the GPU parity tests."""
+import numpy as np
+import torch
+
+from dynibar_amd import synthetic as syn
+
+NUM_FRAMES = 24
+REF_FRAME = 11
+NUM_BASIS = 6
+
+
+def t(x):
+  return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def scene_case(name):
+  """name -> (scene dict of torch tensors, ray_o, ray_d, uv, pixel ids)."""
+  cfg = {
+      # small, smooth maps: well-conditioned parity
+      'small': dict(seed=1, H=48, W=64, V=7, n_static=8, smooth=True, R=6),
+      # wide baselines / rotations: many out-of-bounds and behind-camera samples
+      'harsh': dict(seed=2, H=40, W=56, V=5, n_static=11, smooth=True, R=5, t_scale=3.0, r_scale=1.2, near=0.3, far=6.0),
+      # white-noise maps (the bench's data distribution): ill-conditioned bilinear taps, looser tolerance
+      'noise': dict(seed=3, H=32, W=48, V=7, n_static=8, smooth=False, R=4),
+  }[name]
+  R = cfg.pop('R')
+  seed = cfg['seed']
+  sc = syn.make_scene(**cfg)
+  fine = syn.make_scene(**dict(cfg, tag=1))  # fine-stage feature maps come from a second encoder
+  pix = syn.sample_pixels(seed, cfg['H'], cfg['W'], R)
+  o, d, uv = syn.pixel_rays(sc['camera'], pix)
+  scene = {k: t(v) for k, v in sc.items()}
+  scene['featmaps_fine'] = t(fine['featmaps'])
+  scene['static_featmaps_fine'] = t(fine['static_featmaps'])
+  return scene, t(o), t(d), t(uv), pix
+
+
+def model_weights(seed=0):
+  """numpy state dicts for the six DynibarFF nets + DCT bases (model.py:33-101)."""
+  m = {
+      'net_coarse_st': syn.make_weights('static', seed),
+      'net_coarse_dy': syn.make_weights('dynamic', seed),
+      'net_fine_st': syn.make_weights('static', seed + 100),
+      'net_fine_dy': syn.make_weights('dynamic', seed + 100),
+      'motion_mlp': syn.make_weights('motion', seed, num_basis=NUM_BASIS),
+      'motion_mlp_fine': syn.make_weights('motion', seed + 100, num_basis=NUM_BASIS),
+  }
+  return m
+
+
+def time_args(n_views):
+  """(frame_idx, time_embedding[1], time_offset list) like eval_nvidia.py:323-329."""
+  offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else None
+  return REF_FRAME, torch.tensor([REF_FRAME / float(NUM_FRAMES)], dtype=torch.float32), offs

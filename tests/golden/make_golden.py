@@ -1,0 +1,215 @@
+"""Generate golden vectors by running the REAL reference (build container only).
+
+  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference/ibrnet read-only (kornia shimmed, tests/refimport.py), loads the seeded weights
+of dynibar_amd.synthetic into the reference's own nn.Modules, runs the reference's own functions on the
+seeded scenes of tests/cases.py and stores their OUTPUTS in tests/golden/*.npz.  Inputs are not stored: the
+tests regenerate them from the same seeds.  Nothing here is imported by the product.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import cases  # noqa: E402
+import refimport  # noqa: E402
+
+warnings.filterwarnings('ignore')
+torch.set_num_threads(8)
+ref = refimport.import_reference()
+RR, PJ, NET, SR, RI = ref.render_ray, ref.projection, ref.mlp_network, ref.sample_ray, ref.render_image
+
+
+def npy(x):
+  if isinstance(x, torch.Tensor):
+    return x.detach().cpu().numpy().copy()
+  return np.asarray(x)
+
+
+def flat(prefix, d, out):
+  for k, v in d.items():
+    if v is None:
+      continue
+    if isinstance(v, dict):
+      flat(prefix + k + '/', v, out)
+    else:
+      out[prefix + k] = npy(v)
+  return out
+
+
+def ref_args(anti_alias_pooling=1, mask_rgb=0, occ_weights_mode=0):
+  return types.SimpleNamespace(anti_alias_pooling=anti_alias_pooling, mask_rgb=mask_rgb, input_dir=True, input_xyz=False,
+                               occ_weights_mode=occ_weights_mode)
+
+
+def build_ref_model(weights, n_coarse, n_fine, args):
+  def load(mod, sd):
+    missing = mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return mod.eval()
+  m = types.SimpleNamespace()
+  m.net_coarse_st = load(NET.DynibarStatic(args, in_feat_ch=32, n_samples=n_coarse), weights['net_coarse_st'])
+  m.net_coarse_dy = load(NET.DynibarDynamic(args, in_feat_ch=32, n_samples=n_coarse), weights['net_coarse_dy'])
+  m.net_fine_st = load(NET.DynibarStatic(args, in_feat_ch=32, n_samples=n_fine), weights['net_fine_st'])
+  m.net_fine_dy = load(NET.DynibarDynamic(args, in_feat_ch=32, n_samples=n_fine), weights['net_fine_dy'])
+  m.motion_mlp = load(NET.MotionMLP(num_basis=cases.NUM_BASIS), weights['motion_mlp'])
+  m.motion_mlp_fine = load(NET.MotionMLP(num_basis=cases.NUM_BASIS), weights['motion_mlp_fine'])
+  m.trajectory_basis = ref.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  m.trajectory_basis_fine = ref.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  return m
+
+
+def ray_batch_of(scene, o, d, uv):
+  return dict(ray_o=o, ray_d=d, uv_grid=uv, camera=scene['camera'], depth_range=scene['depth_range'],
+              src_rgbs=scene['src_rgbs'], src_cameras=scene['src_cameras'],
+              static_src_rgbs=scene['static_src_rgbs'], static_src_cameras=scene['static_src_cameras'])
+
+
+def stage_goldens(name, S=64):
+  scene, o, d, uv, pix = cases.scene_case(name)
+  out = {}
+  weights = cases.model_weights(0)
+  args = ref_args()
+  model = build_ref_model(weights, S, 2 * S, args)
+  proj = PJ.Projector('cpu')
+  with torch.no_grad():
+    for inv in (True, False):
+      pts, z, s = RR.sample_along_camera_ray(o, d, scene['depth_range'], S, inv_uniform=inv, det=True)
+      out[f'sample/inv{int(inv)}/pts'] = npy(pts); out[f'sample/inv{int(inv)}/z'] = npy(z); out[f'sample/inv{int(inv)}/s'] = npy(s)
+    pts, z, s = RR.sample_along_camera_ray(o, d, scene['depth_range'], S, inv_uniform=True, det=True)
+    Vs = scene['static_src_rgbs'].shape[1]
+    rf, rd, mk = proj.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), scene['camera'], scene['static_src_rgbs'],
+                                           scene['static_src_cameras'], scene['static_featmaps'])
+    out['proj_st/rgb_feat'] = npy(rf); out['proj_st/ray_diff'] = npy(rd); out['proj_st/mask'] = npy(mk)
+    refc = RR.compute_ref_plucker_coordinate(o, d)
+    srcc = RR.compute_src_plucker_coordinate(pts, scene['static_src_cameras'])
+    out['plucker/ref'] = npy(refc); out['plucker/src'] = npy(srcc)
+    ray_dir = torch.nn.functional.normalize(d, dim=-1)
+    for aa, mr in ((1, 0), (0, 1)):
+      net = NET.DynibarStatic(ref_args(aa, mr), in_feat_ch=32, n_samples=S)
+      net.load_state_dict({k: torch.from_numpy(v) for k, v in weights['net_coarse_st'].items()}, strict=False)
+      raw = net.eval()(pts, refc, srcc, rf, ray_dir, rd, mk)
+      out[f'static_net/aa{aa}_mr{mr}/raw'] = npy(raw)
+    raw_st = model.net_coarse_st(pts, refc, srcc, rf, ray_dir, rd, mk)
+    pm_st = mk[..., 0].sum(dim=2) > 1
+    flat('vanilla_st/', RR.raw2outputs_vanilla(raw_st, z, pm_st), out)
+    # motion + dynamic branch
+    fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+    R = pts.shape[0]
+    t_emb = temb[None, None, :].repeat(R, S, 1)
+    coeff = model.motion_mlp(torch.cat([pts, t_emb], -1).float())
+    out['motion/coeff_raw'] = npy(coeff)
+    coeff[:, -int(round(S * 0.1)):, :] *= 0.0
+    B = cases.NUM_BASIS
+    traj = {off: RR.compute_traj_pts(coeff[..., :B], coeff[..., B:2 * B], coeff[..., 2 * B:], model.trajectory_basis[None, None, fidx + off, :])
+            for off in [-3, -2, -1, 0, 1, 2, 3]}
+    pts_seq = torch.stack([pts + (traj[off] - traj[0]) for off in toff], 0)
+    out['motion/pts_seq'] = npy(pts_seq)
+    rf_dy, rd_dy, mk_dy = proj.compute_with_motions(pts, pts_seq, scene['camera'], scene['src_rgbs'], scene['src_cameras'], scene['featmaps'])
+    out['proj_dy/rgb_feat'] = npy(rf_dy); out['proj_dy/ray_diff'] = npy(rd_dy); out['proj_dy/mask'] = npy(mk_dy)
+    tdiff = (torch.from_numpy(np.array(toff)) / float(cases.NUM_FRAMES))[None, None, :, None].expand(R, S, -1, -1)
+    raw_dy = model.net_coarse_dy(pts, rf_dy, ray_dir, rd_dy, tdiff, mk_dy, t_emb)
+    out['dynamic_net/raw'] = npy(raw_dy)
+    pm_dy = mk_dy[..., 0].sum(dim=2) > 1
+    comp = RR.raw2outputs(raw_dy, raw_st, z, pm_dy, pm_st)
+    flat('composite/', comp, out)
+    out['flow/render_flows'] = npy(RR.compute_optical_flow(comp, pts_seq, scene['src_cameras'], uv))
+    # inverse-CDF resampling, both parametrisations, det and with injected u
+    w = comp['weights'].clone()
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(R, S, generator=g)
+    for inv in (True, False):
+      if inv:
+        iz = 1.0 / z
+        bins = torch.flip(0.5 * (iz[:, 1:] + iz[:, :-1]), dims=[1]); ww = torch.flip(w[:, 1:-1], dims=[1])
+      else:
+        bins = 0.5 * (z[:, 1:] + z[:, :-1]); ww = w[:, 1:-1]
+      out[f'pdf/inv{int(inv)}/det'] = npy(RR.sample_pdf(bins.clone(), ww.clone(), S, det=True))
+      torch.manual_seed(77)
+      smp = RR.sample_pdf(bins.clone(), ww.clone(), S, det=False)
+      torch.manual_seed(77)
+      out[f'pdf/inv{int(inv)}/u'] = npy(torch.rand(R, S))
+      out[f'pdf/inv{int(inv)}/rand'] = npy(smp)
+    # full eval paths
+    rb = ray_batch_of(scene, o, d, uv)
+    ret = RR.render_rays_mv((fidx, None), (temb, None), (toff, None), rb, model, proj,
+                            (scene['featmaps'], None, scene['static_featmaps']),
+                            (scene['featmaps_fine'], None, scene['static_featmaps_fine']),
+                            S, args, inv_uniform=True, N_importance=S, det=True, is_train=False)
+    flat('mv/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+    ret = RR.render_rays_mono((fidx, None), (temb, None), (toff, None), rb, model,
+                              (scene['featmaps'], None, scene['static_featmaps']), proj,
+                              S, args, inv_uniform=True, N_importance=0, det=True, is_train=False, num_vv=0)
+    flat('mono/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+  np.savez_compressed(os.path.join(HERE, f'stages_{name}.npz'), **out)
+  print(name, len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
+def sampler_goldens():
+  """RaySamplerSingleImage: all-pixel rays + the RandomState(234) pixel draw (sample_ray.py:8,143-163,237-260)."""
+  scene, o, d, uv, pix = cases.scene_case('small')
+  H, W = 48, 64
+  rs = np.random.RandomState(0)
+  data = dict(camera=scene['camera'], rgb_path='x', depth_range=scene['depth_range'], src_rgbs=scene['src_rgbs'],
+              src_cameras=scene['src_cameras'], static_src_rgbs=scene['static_src_rgbs'],
+              static_src_cameras=scene['static_src_cameras'],
+              rgb=torch.from_numpy(rs.rand(1, H, W, 3).astype(np.float32)),
+              disp=torch.from_numpy(rs.rand(1, H, W).astype(np.float32)),
+              motion_mask=torch.from_numpy((rs.rand(1, H, W) > 0.5).astype(np.float32)),
+              static_mask=torch.from_numpy((rs.rand(1, H, W) > 0.5).astype(np.float32)),
+              flows=torch.from_numpy(rs.rand(1, 6, H, W, 2).astype(np.float32)),
+              masks=torch.from_numpy(rs.rand(1, 6, H, W).astype(np.float32)),
+              anchor_camera=scene['camera'])
+  SR.rng = np.random.RandomState(234)
+  smp = SR.RaySamplerSingleImage(data, 'cpu')
+  out = {'rays_o': npy(smp.rays_o), 'rays_d': npy(smp.rays_d), 'uv_grid': npy(smp.uv_grid)}
+  for i, mode in enumerate(['uniform', 'center', 'uniform']):
+    rb = smp.random_sample(37, mode, 0.8)
+    out[f'rand{i}/selected_inds'] = np.asarray(rb['selected_inds'])
+    out[f'rand{i}/ray_d'] = npy(rb['ray_d']); out[f'rand{i}/rgb'] = npy(rb['rgb']); out[f'rand{i}/flows'] = npy(rb['flows'])
+  smp2 = SR.RaySamplerSingleImage(data, 'cpu', render_stride=2)
+  out['stride2/rays_d'] = npy(smp2.rays_d)
+  np.savez_compressed(os.path.join(HERE, 'sampler.npz'), **out)
+  print('sampler', len(out))
+
+
+def image_goldens():
+  """render_single_image_nvi on a tiny frame, 3 chunks (render_image.py:9-217)."""
+  cfg = dict(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
+  from dynibar_amd import synthetic as syn
+  sc = syn.make_scene(**cfg); fine = syn.make_scene(**dict(cfg, tag=1))
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  data = dict(camera=scene['camera'], rgb_path='x', depth_range=scene['depth_range'], src_rgbs=scene['src_rgbs'],
+              src_cameras=scene['src_cameras'], static_src_rgbs=scene['static_src_rgbs'],
+              static_src_cameras=scene['static_src_cameras'])
+  smp = SR.RaySamplerSingleImage(data, 'cpu')
+  rb = smp.get_all()
+  weights = cases.model_weights(0)
+  args = ref_args()
+  model = build_ref_model(weights, 64, 128, args)
+  fidx, temb, toff = cases.time_args(7)
+  with torch.no_grad():
+    ret = RI.render_single_image_nvi((fidx, None), (temb, None), (toff, None), smp, rb, model, PJ.Projector('cpu'), 80, 64, args,
+                                     inv_uniform=True, N_importance=64, det=True,
+                                     coarse_featmaps=(scene['featmaps'], None, scene['static_featmaps']),
+                                     fine_featmaps=(cases.t(fine['featmaps']), None, cases.t(fine['static_featmaps'])), is_train=False)
+  out = {}
+  for grp in ('outputs_coarse_ref', 'outputs_fine_ref'):
+    for k, v in ret[grp].items():
+      if isinstance(v, torch.Tensor):
+        out[f'{grp}/{k}'] = npy(v)
+  np.savez_compressed(os.path.join(HERE, 'image_nvi.npz'), **out)
+  print('image', {k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+  for n in ('small', 'harsh', 'noise'):
+    stage_goldens(n)
+  sampler_goldens()
+  image_goldens()

@@ -1,0 +1,108 @@
+"""Pin the oracle (oracle/ibr_oracle.py) to golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  Same torch build => bit-exact; a different build may differ by rounding in
+MKL/ATen kernels, hence the tiny tolerance.  Index/boolean outputs must be exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from oracle import ibr_oracle as O
+
+TOL = dict(rtol=2e-6, atol=2e-6)
+
+
+def load(golden_dir, name):
+  return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def close(a, b, **kw):
+  a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+  if a.dtype == np.bool_ or b.dtype == np.bool_ or np.issubdtype(b.dtype, np.integer):
+    np.testing.assert_array_equal(a, b)
+  else:
+    np.testing.assert_allclose(a, b, **(kw or TOL))
+
+
+def check_group(prefix, d, g):
+  n = 0
+  for k, v in d.items():
+    if v is None:
+      continue
+    if isinstance(v, dict):
+      n += check_group(prefix + k + '/', v, g)
+    else:
+      close(v, g[prefix + k]); n += 1
+  return n
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_stages(golden_dir, name):
+  g = load(golden_dir, f'stages_{name}.npz')
+  scene, o, d, uv, pix = cases.scene_case(name)
+  S = 64
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  W['trajectory_basis_fine'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  for inv in (True, False):
+    pts, z, s = O.sample_along_camera_ray(o, d, scene['depth_range'], S, inv, True)
+    close(pts, g[f'sample/inv{int(inv)}/pts']); close(z, g[f'sample/inv{int(inv)}/z']); close(s, g[f'sample/inv{int(inv)}/s'])
+  pts, z, s = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  Vs = scene['static_src_rgbs'].shape[1]
+  rf, rd, mk = O.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), scene['camera'], scene['static_src_rgbs'],
+                                      scene['static_src_cameras'], scene['static_featmaps'])
+  close(rf, g['proj_st/rgb_feat']); close(rd, g['proj_st/ray_diff']); close(mk, g['proj_st/mask'], rtol=0, atol=0)
+  refc, srcc = O.ref_plucker(o, d), O.src_plucker(pts, scene['static_src_cameras'])
+  close(refc, g['plucker/ref']); close(srcc, g['plucker/src'])
+  ray_dir = F.normalize(d, dim=-1)
+  for aa, mr in ((1, 0), (0, 1)):
+    raw = O.static_net(W['net_coarse_st'], pts, refc, srcc, rf, ray_dir, rd, mk, bool(aa), bool(mr))
+    close(raw, g[f'static_net/aa{aa}_mr{mr}/raw'])
+  raw_st = O.static_net(W['net_coarse_st'], pts, refc, srcc, rf, ray_dir, rd, mk, True, False)
+  pm_st = mk[..., 0].sum(dim=2) > 1
+  check_group('vanilla_st/', O.raw2outputs_vanilla(raw_st, z, pm_st), g)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  R = pts.shape[0]
+  t_emb = temb[None, None, :].repeat(R, S, 1)
+  coeff = O.motion_mlp(W['motion_mlp'], torch.cat([pts, t_emb], -1).float())
+  close(coeff, g['motion/coeff_raw'])
+  coeff[:, -int(round(S * 0.1)):, :] *= 0.0
+  traj = O.trajectory_points(coeff, W['trajectory_basis'], fidx)
+  pts_seq = torch.stack([pts + (traj[k] - traj[0]) for k in toff], 0)
+  close(pts_seq, g['motion/pts_seq'])
+  rf_dy, rd_dy, mk_dy = O.compute_with_motions(pts, pts_seq, scene['camera'], scene['src_rgbs'], scene['src_cameras'], scene['featmaps'])
+  close(rf_dy, g['proj_dy/rgb_feat']); close(rd_dy, g['proj_dy/ray_diff']); close(mk_dy, g['proj_dy/mask'], rtol=0, atol=0)
+  tdiff = (torch.from_numpy(np.array(toff)) / float(cases.NUM_FRAMES))[None, None, :, None].expand(R, S, -1, -1)
+  raw_dy = O.dynamic_net(W['net_coarse_dy'], pts, rf_dy, ray_dir, rd_dy, tdiff, mk_dy, t_emb)
+  close(raw_dy, g['dynamic_net/raw'])
+  pm_dy = mk_dy[..., 0].sum(dim=2) > 1
+  comp = O.raw2outputs(raw_dy, raw_st, z, pm_dy, pm_st)
+  check_group('composite/', comp, g)
+  close(O.compute_optical_flow(comp['weights'], pts_seq, scene['src_cameras'], uv), g['flow/render_flows'])
+  w = comp['weights']
+  for inv in (True, False):
+    if inv:
+      iz = 1.0 / z
+      bins = torch.flip(0.5 * (iz[:, 1:] + iz[:, :-1]), dims=[1]); ww = torch.flip(w[:, 1:-1], dims=[1])
+    else:
+      bins = 0.5 * (z[:, 1:] + z[:, :-1]); ww = w[:, 1:-1]
+    close(O.sample_pdf(bins, ww, S, det=True), g[f'pdf/inv{int(inv)}/det'])
+    close(O.sample_pdf(bins, ww, S, det=False, u=torch.from_numpy(g[f'pdf/inv{int(inv)}/u'])), g[f'pdf/inv{int(inv)}/rand'])
+  sc = dict(scene)
+  ret = O.render_rays_mv(W, sc, o, d, uv, fidx, temb, toff, S, S, True, True)
+  n = check_group('mv/', {k: v for k, v in ret.items() if isinstance(v, dict)}, g)
+  assert n == sum(1 for k in g if k.startswith('mv/')), 'oracle mv output key set differs from the reference'
+  ret = O.render_rays_mono_eval(W, sc, o, d, uv, fidx, temb, toff, S, True, True, num_vv=0)
+  n = check_group('mono/', ret, g)
+  assert n == sum(1 for k in g if k.startswith('mono/')), 'oracle mono output key set differs from the reference'
+
+
+def test_image_rays(golden_dir):
+  g = load(golden_dir, 'sampler.npz')
+  scene, *_ = cases.scene_case('small')
+  o, d, uv = O.image_rays(scene['camera'])
+  close(o, g['rays_o']); close(d, g['rays_d']); close(uv, g['uv_grid'])
+  _, d2, _ = O.image_rays(scene['camera'], render_stride=2)
+  close(d2, g['stride2/rays_d'])
