@@ -1,0 +1,48 @@
+"""Build libdynibar_hip.so for gfx950 in-tree (dynibar_amd/csrc/).   python -m dynibar_amd.build [--force]
+
+Two translation units: the geometry/compositing kernels are compiled with -ffp-contract=off (bit-exact sample depths,
+points and indices versus the reference's un-fused fp32 ops), the MFMA network kernels with default contraction.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(CSRC, 'libdynibar_hip.so')
+UNITS = [
+    ('dyn_geometry.hip', ['-ffp-contract=off']),
+    ('dyn_nets.hip', []),
+]
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _deps():
+  return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))] + [
+      os.path.join(os.path.dirname(HERE), 'include', 'dynibar_hip.h')]
+
+
+def build(force=False, verbose=True):
+  hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+  units = [(s, f) for s, f in UNITS if os.path.exists(os.path.join(CSRC, s))]
+  if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
+    return OUT
+  objs = []
+  for src, flags in units:
+    obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+    cmd = [hipcc] + COMMON + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
+    if verbose:
+      print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs.append(obj)
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
+  if verbose:
+    print(' '.join(cmd), flush=True)
+  subprocess.check_call(cmd)
+  return OUT
+
+
+if __name__ == '__main__':
+  print(build(force='--force' in sys.argv))

@@ -1,0 +1,564 @@
+// Geometry / sampling / compositing kernels (HBM-bound byte & index work).  Built with -ffp-contract=off so that
+// the elementwise fp32 arithmetic rounds exactly like the reference's un-fused ATen ops: depth samples, sample
+// points, normalised pixel locations and the inverse-CDF indices are then bit-identical to the CPU oracle wherever the
+// inputs are.
+#include <stdarg.h>
+
+#include "dyn_device.h"
+#include "dyn_host.h"
+
+static thread_local char g_err[512] = "";
+void dyn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dyn_last_error(void) { return g_err; }
+extern "C" int dyn_abi_version(void) { return DYN_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// camera preparation: P = K . inv(c2w)   (projection.py:42-47 does torch.inverse + bmm on [V,4,4])
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void invert4x4(const double* m, double* inv) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = m[i * 4 + j];
+      a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    double best = fabs(a[c][c]);
+    for (int r = c + 1; r < 4; ++r)
+      if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+    if (piv != c)
+      for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    double d = 1.0 / a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] *= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != c) {
+        double f = a[r][c];
+        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+      }
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+}
+
+__global__ void k_prepare_cameras(const float* __restrict__ cams, int V, const float* __restrict__ query_cam,
+                                  float* __restrict__ proj, float* __restrict__ query_center) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) {
+    const float* c = cams + (long)v * 34;
+    double K[16], P[16], W2C[16];
+    for (int i = 0; i < 16; ++i) { K[i] = c[2 + i]; P[i] = c[18 + i]; }
+    invert4x4(P, W2C);
+    float* o = proj + (long)v * 16;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += K[i * 4 + k] * W2C[k * 4 + j];
+        o[i * 4 + j] = (float)s;
+      }
+    o[12] = c[18 + 3];
+    o[13] = c[18 + 7];
+    o[14] = c[18 + 11];
+    o[15] = 0.f;
+  } else if (v == V && query_cam != nullptr) {
+    query_center[0] = query_cam[18 + 3];
+    query_center[1] = query_cam[18 + 7];
+    query_center[2] = query_cam[18 + 11];
+    query_center[3] = 0.f;
+  }
+}
+
+extern "C" int dyn_prepare_cameras(const float* cams, int V, const float* query_cam, float* proj, float* query_center,
+                                   void* stream) {
+  DYN_REQUIRE(cams && proj && V > 0, "dyn_prepare_cameras: null pointer or V<=0");
+  DYN_REQUIRE(query_cam == nullptr || query_center != nullptr, "dyn_prepare_cameras: query_center missing");
+  hipLaunchKernelGGL(k_prepare_cameras, dim3(dyn_cdiv(V + 1, 64)), dim3(64), 0, (hipStream_t)stream, cams, V, query_cam, proj,
+                     query_center);
+  DYN_CHECK_LAUNCH("dyn_prepare_cameras");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NCHW -> NHWC repack of the feature maps (once per target view; 1.2 MB per view at 72x128x32)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int F, int HW) {
+  // block = 64 pixels x all channels through an LDS tile (pad 1) so both sides are coalesced
+  float* tile = reinterpret_cast<float*>(dyn_smem);  // [F][65]
+  const int v = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const float* s = src + (long)v * F * HW;
+  float* d = dst + (long)v * F * HW;
+  for (int i = tid; i < F * 64; i += blockDim.x) {
+    int c = i >> 6, p = i & 63;
+    tile[c * 65 + p] = (p0 + p < HW) ? s[(long)c * HW + p0 + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < F * 64; i += blockDim.x) {
+    int p = i / F, c = i % F;
+    if (p0 + p < HW) d[(long)(p0 + p) * F + c] = tile[c * 65 + p];
+  }
+}
+
+extern "C" int dyn_nchw_to_nhwc(const float* src, float* dst, int V, int F, int Hf, int Wf, void* stream) {
+  DYN_REQUIRE(src && dst && V > 0 && F > 0 && Hf > 0 && Wf > 0, "dyn_nchw_to_nhwc: bad argument");
+  DYN_REQUIRE((size_t)F * 65 * 4 <= 150 * 1024, "dyn_nchw_to_nhwc: F too large");
+  int HW = Hf * Wf;
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(dyn_cdiv(HW, 64), V), dim3(256), (size_t)F * 65 * 4, (hipStream_t)stream, src, dst, F, HW);
+  DYN_CHECK_LAUNCH("dyn_nchw_to_nhwc");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a5 depth sampling  (render_ray.py:67-131)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coarse_depth(int i, int S, float near, float far, int inv_uniform) {
+  if (inv_uniform) {
+    float start = 1.0f / near;
+    float step = (1.0f / far - start) / (float)(S - 1);
+    return 1.0f / (start + (float)i * step);
+  }
+  float step = (far - near) / (float)(S - 1);
+  return near + (float)i * step;
+}
+
+__global__ void k_sample_along_ray(DynSampleParams p) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.R * p.S) return;
+  int r = (int)(idx / p.S), i = (int)(idx % p.S);
+  float near = p.depth_range[0], far = p.depth_range[1];
+  float z = coarse_depth(i, p.S, near, far, p.inv_uniform);
+  if (p.t_rand != nullptr) {
+    float zm = coarse_depth(i > 0 ? i - 1 : 0, p.S, near, far, p.inv_uniform);
+    float zp = coarse_depth(i < p.S - 1 ? i + 1 : i, p.S, near, far, p.inv_uniform);
+    float lower = (i == 0) ? z : 0.5f * (z + zm);
+    float upper = (i == p.S - 1) ? z : 0.5f * (zp + z);
+    z = lower + (upper - lower) * p.t_rand[idx];
+  }
+  p.z_vals[idx] = z;
+  if (p.s_vals != nullptr) p.s_vals[idx] = ((1.0f / z) - (1.0f / near)) / (1.0f / far - 1.0f / near);
+  if (p.pts != nullptr) {
+    for (int c = 0; c < 3; ++c) p.pts[idx * 3 + c] = z * p.ray_d[r * 3 + c] + p.ray_o[r * 3 + c];
+  }
+}
+
+extern "C" int dyn_sample_along_ray(const DynSampleParams* p, void* stream) {
+  DYN_REQUIRE(p && p->ray_o && p->ray_d && p->depth_range && p->z_vals, "dyn_sample_along_ray: null pointer");
+  DYN_REQUIRE(p->R > 0 && p->S > 1, "dyn_sample_along_ray: need R>0, S>1");
+  long n = (long)p->R * p->S;
+  hipLaunchKernelGGL(k_sample_along_ray, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+  DYN_CHECK_LAUNCH("dyn_sample_along_ray");
+  return 0;
+}
+
+__global__ void k_points_from_z(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ z_vals,
+                                const float* __restrict__ depth_range, long n, int S, float* __restrict__ pts, float* __restrict__ s_vals) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int r = (int)(idx / S);
+  float z = z_vals[idx];
+  if (pts != nullptr)
+    for (int c = 0; c < 3; ++c) pts[idx * 3 + c] = z * ray_d[r * 3 + c] + ray_o[r * 3 + c];
+  if (s_vals != nullptr) {
+    float near = depth_range[0], far = depth_range[1];
+    s_vals[idx] = ((1.0f / z) - (1.0f / near)) / (1.0f / far - 1.0f / near);
+  }
+}
+
+extern "C" int dyn_points_from_z(const float* ray_o, const float* ray_d, const float* z_vals, const float* depth_range, int R, int S,
+                                 float* pts, float* s_vals, void* stream) {
+  DYN_REQUIRE(ray_o && ray_d && z_vals && R > 0 && S > 0, "dyn_points_from_z: bad argument");
+  DYN_REQUIRE(s_vals == nullptr || depth_range != nullptr, "dyn_points_from_z: depth_range missing");
+  long n = (long)R * S;
+  hipLaunchKernelGGL(k_points_from_z, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, z_vals, depth_range, n, S, pts,
+                     s_vals);
+  DYN_CHECK_LAUNCH("dyn_points_from_z");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: fused projection + bilinear gather + ray_diff + mask   (projection.py:103-176)
+//
+// One workgroup = PG_ROWS consecutive point-view rows g = (r*S + s)*V + v, so its slice of every output tensor is one
+// contiguous, 128-byte aligned span that is assembled in LDS and stored with full-width coalesced writes.
+// phase 1: one thread per row projects the point and records tap origins / fractions in LDS;
+// phase 2: F/4 lanes per row each blend four 16-byte channel groups of the four taps (a tap is one 128-byte line of the
+//          channels-last feature map), three lanes per row blend the RGB taps;
+// phase 3: the LDS tile streams out as dwordx4 stores.
+// ---------------------------------------------------------------------------------------------------------------
+#define PG_ROWS 128
+#define PG_THREADS 128
+
+struct PGTap {
+  int v;
+  int x0, y0;    // RGB image tap origin (west / north), may be out of bounds
+  float fx, fy;  // fractions towards east / south
+  int xf0, yf0;  // feature-map tap origin
+  float ffx, ffy;
+};
+
+__device__ __forceinline__ float safe_floor_coord(float x, float size) {
+  // taps further than one pixel outside contribute zero either way; the clamp keeps the int conversion defined
+  return fminf(fmaxf(x, -2.0f), size + 1.0f);
+}
+
+__device__ __forceinline__ void normalize3(float x, float y, float z, float& ox, float& oy, float& oz) {
+  // F.normalize(eps=1e-12): v / max(||v||_2, eps)
+  float n = sqrtf(x * x + y * y + z * z);
+  float d = fmaxf(n, 1e-12f);
+  ox = x / d;
+  oy = y / d;
+  oz = z / d;
+}
+
+__global__ void __launch_bounds__(PG_THREADS) k_project_gather(DynProjectGatherParams p) {
+  const int C = 3 + p.F;
+  float* out_tile = reinterpret_cast<float*>(dyn_smem);           // [PG_ROWS][C]
+  float* rd_tile = out_tile + PG_ROWS * C;                        // [PG_ROWS][4]
+  float* mk_tile = rd_tile + PG_ROWS * 4;                         // [PG_ROWS]
+  PGTap* taps = reinterpret_cast<PGTap*>(mk_tile + PG_ROWS);      // [PG_ROWS]
+  const int tid = threadIdx.x;
+  const long N = (long)p.R * p.S * p.V;
+  const long g0 = (long)blockIdx.x * PG_ROWS;
+  const int nrows = (int)((N - g0 < PG_ROWS) ? (N - g0) : PG_ROWS);
+
+  // ---- phase 1 ----
+  if (tid < nrows) {
+    const long g = g0 + tid;
+    const int v = (int)(g % p.V);
+    const long rs = g / p.V;
+    const int r = (int)(rs / p.S);
+    float sx, sy, sz;  // reference-time point (xyz_st)
+    if (p.pts_st != nullptr) {
+      sx = p.pts_st[rs * 3 + 0]; sy = p.pts_st[rs * 3 + 1]; sz = p.pts_st[rs * 3 + 2];
+    } else {
+      const float z = p.z_vals[rs];
+      sx = z * p.ray_d[r * 3 + 0] + p.ray_o[r * 3 + 0];
+      sy = z * p.ray_d[r * 3 + 1] + p.ray_o[r * 3 + 1];
+      sz = z * p.ray_d[r * 3 + 2] + p.ray_o[r * 3 + 2];
+    }
+    float x = sx, y = sy, z3 = sz;  // per-view (motion displaced) point
+    if (p.xyz != nullptr) {
+      const long o = ((long)v * p.R * p.S + rs) * 3;
+      x = p.xyz[o]; y = p.xyz[o + 1]; z3 = p.xyz[o + 2];
+    }
+    const float* P = p.proj + v * 16;
+    const float hx = fmaf(P[3], 1.0f, fmaf(P[2], z3, fmaf(P[1], y, P[0] * x)));
+    const float hy = fmaf(P[7], 1.0f, fmaf(P[6], z3, fmaf(P[5], y, P[4] * x)));
+    const float hz = fmaf(P[11], 1.0f, fmaf(P[10], z3, fmaf(P[9], y, P[8] * x)));
+    const float zc = fmaxf(hz, 1e-8f);
+    float px = hx / zc, py = hy / zc;
+    px = fminf(fmaxf(px, -1e6f), 1e6f);
+    py = fminf(fmaxf(py, -1e6f), 1e6f);
+    const float wm1 = p.img_w - 1.0f, hm1 = p.img_h - 1.0f;
+    const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
+    mk_tile[tid] = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
+    // normalize() then grid_sample's align_corners=True un-normalisation (ATen CPU: (x + 1) * ((size - 1) / 2))
+    const float nx = 2.0f * px / wm1 - 1.0f;
+    const float ny = 2.0f * py / hm1 - 1.0f;
+    PGTap t;
+    t.v = v;
+    {
+      float ix = safe_floor_coord((nx + 1.0f) * ((float)(p.W - 1) / 2.0f), (float)p.W);
+      float iy = safe_floor_coord((ny + 1.0f) * ((float)(p.H - 1) / 2.0f), (float)p.H);
+      float fx0 = floorf(ix), fy0 = floorf(iy);
+      t.x0 = (int)fx0; t.y0 = (int)fy0; t.fx = ix - fx0; t.fy = iy - fy0;
+    }
+    {
+      float ix = safe_floor_coord((nx + 1.0f) * ((float)(p.Wf - 1) / 2.0f), (float)p.Wf);
+      float iy = safe_floor_coord((ny + 1.0f) * ((float)(p.Hf - 1) / 2.0f), (float)p.Hf);
+      float fx0 = floorf(ix), fy0 = floorf(iy);
+      t.xf0 = (int)fx0; t.yf0 = (int)fy0; t.ffx = ix - fx0; t.ffy = iy - fy0;
+    }
+    taps[tid] = t;
+    // compute_angle (projection.py:61-101)
+    float ax, ay, az, bx, by, bz;
+    normalize3(p.query_center[0] - sx, p.query_center[1] - sy, p.query_center[2] - sz, ax, ay, az);
+    normalize3(P[12] - x, P[13] - y, P[14] - z3, bx, by, bz);
+    float dx, dy, dz;
+    normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
+    rd_tile[tid * 4 + 0] = dx;
+    rd_tile[tid * 4 + 1] = dy;
+    rd_tile[tid * 4 + 2] = dz;
+    rd_tile[tid * 4 + 3] = ax * bx + ay * by + az * bz;
+  }
+  __syncthreads();
+
+  // ---- phase 2a: feature taps ----
+  const int F4 = p.F >> 2;
+  for (int i = tid; i < nrows * F4; i += PG_THREADS) {
+    const int row = i / F4, c4 = i - row * F4;
+    const PGTap t = taps[row];
+    const float e = 1.0f - t.ffx, s = 1.0f - t.ffy;
+    const float w_nw = s * e, w_ne = s * t.ffx, w_sw = t.ffy * e, w_se = t.ffy * t.ffx;
+    const bool x0ok = (t.xf0 >= 0) && (t.xf0 < p.Wf), x1ok = (t.xf0 + 1 >= 0) && (t.xf0 + 1 < p.Wf);
+    const bool y0ok = (t.yf0 >= 0) && (t.yf0 < p.Hf), y1ok = (t.yf0 + 1 >= 0) && (t.yf0 + 1 < p.Hf);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* base = reinterpret_cast<const float4*>(p.feat_cl) + ((long)t.v * p.Hf * p.Wf) * F4 + c4;
+    const long o00 = ((long)t.yf0 * p.Wf + t.xf0) * F4;
+    float4 a = (x0ok && y0ok) ? base[o00] : zero4;
+    float4 b = (x1ok && y0ok) ? base[o00 + F4] : zero4;
+    float4 c = (x0ok && y1ok) ? base[o00 + (long)p.Wf * F4] : zero4;
+    float4 d = (x1ok && y1ok) ? base[o00 + (long)p.Wf * F4 + F4] : zero4;
+    float* o = out_tile + row * C + 3 + c4 * 4;
+    o[0] = a.x * w_nw + b.x * w_ne + c.x * w_sw + d.x * w_se;
+    o[1] = a.y * w_nw + b.y * w_ne + c.y * w_sw + d.y * w_se;
+    o[2] = a.z * w_nw + b.z * w_ne + c.z * w_sw + d.z * w_se;
+    o[3] = a.w * w_nw + b.w * w_ne + c.w * w_sw + d.w * w_se;
+  }
+  // ---- phase 2b: RGB taps ----
+  for (int i = tid; i < nrows * 3; i += PG_THREADS) {
+    const int row = i / 3, ch = i - row * 3;
+    const PGTap t = taps[row];
+    const float e = 1.0f - t.fx, s = 1.0f - t.fy;
+    const float w_nw = s * e, w_ne = s * t.fx, w_sw = t.fy * e, w_se = t.fy * t.fx;
+    const bool x0ok = (t.x0 >= 0) && (t.x0 < p.W), x1ok = (t.x0 + 1 >= 0) && (t.x0 + 1 < p.W);
+    const bool y0ok = (t.y0 >= 0) && (t.y0 < p.H), y1ok = (t.y0 + 1 >= 0) && (t.y0 + 1 < p.H);
+    const float* base = p.src_rgb + ((long)t.v * p.H * p.W) * 3 + ch;
+    const long o00 = ((long)t.y0 * p.W + t.x0) * 3;
+    float a = (x0ok && y0ok) ? base[o00] : 0.f;
+    float b = (x1ok && y0ok) ? base[o00 + 3] : 0.f;
+    float c = (x0ok && y1ok) ? base[o00 + (long)p.W * 3] : 0.f;
+    float d = (x1ok && y1ok) ? base[o00 + (long)p.W * 3 + 3] : 0.f;
+    out_tile[row * C + ch] = a * w_nw + b * w_ne + c * w_sw + d * w_se;
+  }
+  __syncthreads();
+
+  // ---- phase 3: coalesced stores ----
+  {
+    const int nflt = nrows * C;
+    float* dst = p.rgb_feat + g0 * C;  // g0*C*4 bytes is a multiple of 512
+    const int n4 = nflt >> 2;
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    const float4* src4 = reinterpret_cast<const float4*>(out_tile);
+    for (int i = tid; i < n4; i += PG_THREADS) dst4[i] = src4[i];
+    for (int i = (n4 << 2) + tid; i < nflt; i += PG_THREADS) dst[i] = out_tile[i];
+    float4* rd4 = reinterpret_cast<float4*>(p.ray_diff + g0 * 4);
+    const float4* rs4 = reinterpret_cast<const float4*>(rd_tile);
+    for (int i = tid; i < nrows; i += PG_THREADS) rd4[i] = rs4[i];
+    for (int i = tid; i < nrows; i += PG_THREADS) p.mask[g0 + i] = mk_tile[i];
+  }
+}
+
+extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {
+  DYN_REQUIRE(p, "dyn_project_gather: null params");
+  DYN_REQUIRE(p->R > 0 && p->S > 0 && p->V > 0, "dyn_project_gather: empty problem");
+  DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 128, "dyn_project_gather: F must be a multiple of 4 (<=128)");
+  DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->ray_diff && p->mask,
+              "dyn_project_gather: null pointer");
+  DYN_REQUIRE(p->pts_st != nullptr || (p->ray_o && p->ray_d && p->z_vals), "dyn_project_gather: need pts_st or (ray_o, ray_d, z_vals)");
+  DYN_REQUIRE(p->H > 1 && p->W > 1 && p->Hf > 1 && p->Wf > 1, "dyn_project_gather: maps must be at least 2x2");
+  const long N = (long)p->R * p->S * p->V;
+  const int C = 3 + p->F;
+  size_t shmem = (size_t)PG_ROWS * (C + 4 + 1) * 4 + (size_t)PG_ROWS * sizeof(PGTap);
+  shmem = (shmem + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(k_project_gather, dim3(dyn_cdiv(N, PG_ROWS)), dim3(PG_THREADS), shmem, (hipStream_t)stream, *p);
+  DYN_CHECK_LAUNCH("dyn_project_gather");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sample masks
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_sample_mask(const float* __restrict__ mask, long RS, int V, float thresh, float* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RS) return;
+  float s = 0.f;
+  for (int v = 0; v < V; ++v) s += mask[i * V + v];
+  out[i] = (s > thresh) ? 1.0f : 0.0f;
+}
+extern "C" int dyn_sample_mask(const float* mask, int RS, int V, float thresh, float* pix_mask, void* stream) {
+  DYN_REQUIRE(mask && pix_mask && RS > 0 && V > 0, "dyn_sample_mask: bad argument");
+  hipLaunchKernelGGL(k_sample_mask, dim3(dyn_cdiv(RS, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long)RS, V, thresh, pix_mask);
+  DYN_CHECK_LAUNCH("dyn_sample_mask");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: alpha compositing, one wavefront per ray   (render_ray.py:134-330)
+// lanes = samples: sigma->alpha elementwise, transmittance = wave-level exclusive product scan, sums = wave reductions.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigma_to_alpha(float sigma, bool last) {
+  // nn.Softplus(beta=1, threshold=20); dists = 1 except the last sample = 1e10 (render_ray.py:154-182)
+  float sp = (sigma > 20.0f) ? sigma : log1pf(expf(sigma));
+  float dist = last ? 1e10f : 1.0f;
+  return 1.0f - expf(-sp * dist);
+}
+
+__global__ void __launch_bounds__(256) k_composite(DynCompositeParams p) {
+  const int lane = dyn_lane();
+  const int r = blockIdx.x * 4 + dyn_wave();
+  const bool two = p.raw_static != nullptr;
+  // every lane of a wave shares r, so the whole wave leaves together (no barrier is used in this kernel)
+  if (r >= p.R) return;
+  float carry = 1.0f;
+  float acc_rgb[3] = {0.f, 0.f, 0.f}, acc_st[3] = {0.f, 0.f, 0.f}, acc_dy[3] = {0.f, 0.f, 0.f};
+  float acc_depth = 0.f, cnt_dy = 0.f, cnt_st = 0.f;
+  for (int s0 = 0; s0 < p.S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool ok = s < p.S;
+    const long i = (long)r * p.S + s;
+    float4 rd = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float z = 0.f, a_dy = 0.f, a_st = 0.f, alpha = 0.f;
+    if (ok) {
+      rd = reinterpret_cast<const float4*>(p.raw_dy)[i];
+      z = p.z_vals[i];
+      a_dy = sigma_to_alpha(rd.w, s == p.S - 1);
+      cnt_dy += p.pix_mask_dy[i];
+      if (two) {
+        rs = reinterpret_cast<const float4*>(p.raw_static)[i];
+        a_st = sigma_to_alpha(rs.w, s == p.S - 1);
+        alpha = 1.0f - (1.0f - a_st) * (1.0f - a_dy);
+        cnt_st += p.pix_mask_st[i];
+      } else {
+        alpha = a_dy;
+      }
+    }
+    const float f = ok ? ((1.0f - alpha) + 1e-10f) : 1.0f;
+    const float incl = wave_inclusive_prod(f, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float T = carry * excl;
+    carry = carry * __shfl(incl, 63);
+    if (ok) {
+      const float w = alpha * T;
+      p.weights[i] = w;
+      if (p.alpha) p.alpha[i] = alpha;
+      acc_depth += w * z;
+      if (two) {
+        const float wd = a_dy * T, ws = a_st * T;
+        if (p.alpha_dy) p.alpha_dy[i] = a_dy;
+        if (p.weights_dy) p.weights_dy[i] = wd;
+        if (p.weights_st) p.weights_st[i] = ws;
+        acc_dy[0] += wd * rd.x; acc_dy[1] += wd * rd.y; acc_dy[2] += wd * rd.z;
+        acc_st[0] += ws * rs.x; acc_st[1] += ws * rs.y; acc_st[2] += ws * rs.z;
+      } else {
+        acc_rgb[0] += w * rd.x; acc_rgb[1] += w * rd.y; acc_rgb[2] += w * rd.z;
+      }
+    }
+  }
+  acc_depth = wave_sum(acc_depth);
+  cnt_dy = wave_sum(cnt_dy);
+  cnt_st = wave_sum(cnt_st);
+  for (int c = 0; c < 3; ++c) {
+    acc_rgb[c] = wave_sum(acc_rgb[c]);
+    acc_dy[c] = wave_sum(acc_dy[c]);
+    acc_st[c] = wave_sum(acc_st[c]);
+  }
+  if (lane == 0) {
+    for (int c = 0; c < 3; ++c) {
+      p.rgb[r * 3 + c] = two ? (acc_dy[c] + acc_st[c]) : acc_rgb[c];
+      if (two && p.rgb_static) p.rgb_static[r * 3 + c] = acc_st[c];
+      if (two && p.rgb_dy) p.rgb_dy[r * 3 + c] = acc_dy[c];
+    }
+    p.depth[r] = acc_depth;
+    p.ray_mask[r] = ((cnt_dy > 8.0f) || (two && cnt_st > 8.0f)) ? 1.0f : 0.0f;
+  }
+}
+
+extern "C" int dyn_composite(const DynCompositeParams* p, void* stream) {
+  DYN_REQUIRE(p && p->raw_dy && p->z_vals && p->pix_mask_dy && p->rgb && p->depth && p->ray_mask && p->weights,
+              "dyn_composite: null pointer");
+  DYN_REQUIRE(p->raw_static == nullptr || p->pix_mask_st != nullptr, "dyn_composite: pix_mask_st missing");
+  DYN_REQUIRE(p->R > 0 && p->S > 0, "dyn_composite: empty problem");
+  hipLaunchKernelGGL(k_composite, dim3(dyn_cdiv(p->R, 4)), dim3(256), 0, (hipStream_t)stream, *p);
+  DYN_CHECK_LAUNCH("dyn_composite");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4: importance sampling + sorted merge, one lane per ray   (render_ray.py:19-64, :790-821)
+// The cdf is a sequential per-ray prefix sum accumulated in double and rounded to fp32 per element, which is what torch.cumsum
+// does on the CPU, so the inverse-CDF indices reproduce the reference's exactly given the same weights.  Per-ray scratch lives in LDS, interleaved by lane.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_fine_samples(DynFineSampleParams p, int T) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  const int t = threadIdx.x;
+  const int r = blockIdx.x * T + t;
+  const int S = p.S, N = p.N, M = S - 2, NB = S - 1;
+  float* cdf = lds;                 // [NB][T]   cdf_0..cdf_M
+  float* bins = lds + (long)NB * T; // [NB][T]
+  float* outz = bins + (long)NB * T;  // [S+N][T]
+  if (r >= p.R) return;  // no barrier in this kernel
+  const float* z = p.z_vals + (long)r * S;
+  const float* w = p.weights + (long)r * S;
+  // normaliser: the fp32 addends summed in double and rounded once, i.e. the correctly rounded sum that torch.sum's
+  // multi-accumulator vector reduction approximates to within an ulp (a plain fp32 running sum is ~1e-6 off when the
+  // weights span many orders of magnitude, which an empty bin of mass 1e-5 amplifies to several percent of its width)
+  double total_d = 0.0;
+  for (int j = 0; j < M; ++j) {
+    float wj = (p.inv_uniform ? w[S - 2 - j] : w[1 + j]) + 1e-5f;
+    total_d += (double)wj;
+  }
+  const float total = (float)total_d;
+  for (int j = 0; j < NB; ++j) {
+    float b;
+    if (p.inv_uniform) {
+      int k = S - 2 - j;
+      b = 0.5f * (1.0f / z[k + 1] + 1.0f / z[k]);
+    } else {
+      b = 0.5f * (z[j + 1] + z[j]);
+    }
+    bins[j * T + t] = b;
+  }
+  // torch.cumsum on the CPU accumulates fp32 inputs in double (at::acc_type<float, false>) and rounds every prefix to fp32
+  double c = 0.0;
+  cdf[t] = 0.f;
+  for (int j = 0; j < M; ++j) {
+    float wj = (p.inv_uniform ? w[S - 2 - j] : w[1 + j]) + 1e-5f;
+    c += (double)(wj / total);
+    cdf[(j + 1) * T + t] = (float)c;
+  }
+  for (int i = 0; i < S; ++i) outz[i * T + t] = z[i];
+  int filled = S;
+  for (int n = 0; n < N; ++n) {
+    float u;
+    if (p.u != nullptr) {
+      u = p.u[(long)r * N + n];
+    } else {
+      // torch.linspace(0, 1, N): start + i*step below the midpoint, end - (N-1-i)*step above it
+      float step = 1.0f / (float)(N - 1);
+      u = (n < N / 2) ? ((float)n * step) : (1.0f - step * (float)(N - 1 - n));
+    }
+    int above = 0;
+    for (int j = 0; j < M; ++j) above += (u >= cdf[j * T + t]) ? 1 : 0;
+    int below = above - 1 < 0 ? 0 : above - 1;
+    float c0 = cdf[below * T + t], c1 = cdf[above * T + t];
+    float b0 = bins[below * T + t], b1 = bins[above * T + t];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;
+    float tt = (u - c0) / denom;
+    float smp = b0 + tt * (b1 - b0);
+    if (p.inv_uniform) smp = 1.0f / smp;
+    if (p.inds) p.inds[(long)r * N + n] = above;
+    if (p.z_samples) p.z_samples[(long)r * N + n] = smp;
+    // insertion into the sorted union (values only, so any correct sort equals torch.sort's values)
+    int k = filled;
+    while (k > 0 && outz[(k - 1) * T + t] > smp) {
+      outz[k * T + t] = outz[(k - 1) * T + t];
+      --k;
+    }
+    outz[k * T + t] = smp;
+    ++filled;
+  }
+  float* zo = p.z_out + (long)r * (S + N);
+  for (int i = 0; i < S + N; ++i) zo[i] = outz[i * T + t];
+}
+
+extern "C" int dyn_fine_samples(const DynFineSampleParams* p, void* stream) {
+  DYN_REQUIRE(p && p->z_vals && p->weights && p->z_out, "dyn_fine_samples: null pointer");
+  DYN_REQUIRE(p->R > 0 && p->S > 2 && p->N > 1, "dyn_fine_samples: need R>0, S>2, N>1");
+  const size_t per_thread = (size_t)(2 * (p->S - 1) + p->S + p->N) * 4;
+  int T = 64;
+  while (T > 1 && per_thread * T > 144 * 1024) T >>= 1;
+  DYN_REQUIRE(per_thread * T <= 144 * 1024, "dyn_fine_samples: S+N too large for LDS");
+  size_t shmem = (per_thread * T + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(k_fine_samples, dim3(dyn_cdiv(p->R, T)), dim3(T), shmem, (hipStream_t)stream, *p, T);
+  DYN_CHECK_LAUNCH("dyn_fine_samples");
+  return 0;
+}

@@ -1,0 +1,134 @@
+"""Tensor-level wrappers of the C-ABI entry points (one function per kernel launch).
+
+PyTorch is used for device memory and streams only; every function below allocates its outputs on the inputs' device
+and launches exactly the HIP kernels named in its docstring on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, params, ptr, stream_of
+
+
+def _f32c(t):
+  if t is None:
+    return None
+  if t.dtype != torch.float32:
+    t = t.float()
+  return t if t.is_contiguous() else t.contiguous()
+
+
+class SourceViews:
+  """Per-target-view prepared source data for one branch: projection matrices, camera centres, channels-last maps.
+
+  Built once per (target view, branch) and reused by every ray chunk, like the reference reuses ``featmaps`` /
+  ``src_cameras`` across the chunk loop (render_image.py:68-117)."""
+
+  def __init__(self, query_camera, src_rgbs, src_cameras, featmaps):
+    assert query_camera.shape[0] == 1 and src_rgbs.shape[0] == 1 and src_cameras.shape[0] == 1, \
+        'only support batch_size=1 for now'  # projection.py:122-126
+    dev = src_rgbs.device
+    self.src_rgbs = _f32c(src_rgbs[0])          # [V,H,W,3] already channels-last in the reference
+    self.cams = _f32c(src_cameras[0])           # [V,34]
+    self.query = _f32c(query_camera[0])         # [34]
+    self.V, self.H, self.W = self.src_rgbs.shape[:3]
+    fm = _f32c(featmaps)
+    assert fm.shape[0] == self.V
+    self.F, self.Hf, self.Wf = fm.shape[1:]
+    self.feat_cl = torch.empty((self.V, self.Hf, self.Wf, self.F), dtype=torch.float32, device=dev)
+    st = stream_of(fm)
+    call('dyn_nchw_to_nhwc', ptr(fm), ptr(self.feat_cl), self.V, self.F, self.Hf, self.Wf, st)
+    self.proj = torch.empty((self.V, 16), dtype=torch.float32, device=dev)
+    self.query_center = torch.empty((4,), dtype=torch.float32, device=dev)
+    call('dyn_prepare_cameras', ptr(self.cams), self.V, ptr(self.query), ptr(self.proj), ptr(self.query_center), st)
+    # normalize()/inbound() use h, w from train_cameras[0][:2] (projection.py:136); read once on the host
+    hw = self.cams[0, :2].tolist()
+    self.img_h, self.img_w = float(hw[0]), float(hw[1])
+
+
+def sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand=None, want_pts=True, want_s=True):
+  """k_sample_along_ray.  depth_range: device tensor [1,2].  -> pts [R,S,3] | None, z_vals [R,S], s_vals [R,S] | None"""
+  ray_o, ray_d = _f32c(ray_o), _f32c(ray_d)
+  R = ray_o.shape[0]
+  dev = ray_o.device
+  z = torch.empty((R, N_samples), dtype=torch.float32, device=dev)
+  s = torch.empty_like(z) if want_s else None
+  pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev) if want_pts else None
+  dr = _f32c(depth_range.reshape(-1))
+  p = params('DynSampleParams', R=R, S=N_samples, inv_uniform=int(bool(inv_uniform)), ray_o=ptr(ray_o), ray_d=ptr(ray_d),
+             depth_range=ptr(dr), t_rand=ptr(_f32c(t_rand)), z_vals=ptr(z), s_vals=ptr(s), pts=ptr(pts))
+  call('dyn_sample_along_ray', ctypes.byref(p), stream_of(ray_o))
+  return pts, z, s
+
+
+def points_from_z(ray_o, ray_d, z_vals, depth_range=None, want_pts=True):
+  ray_o, ray_d, z_vals = _f32c(ray_o), _f32c(ray_d), _f32c(z_vals)
+  R, S = z_vals.shape
+  pts = torch.empty((R, S, 3), dtype=torch.float32, device=z_vals.device) if want_pts else None
+  s = torch.empty_like(z_vals) if depth_range is not None else None
+  dr = _f32c(depth_range.reshape(-1)) if depth_range is not None else None
+  call('dyn_points_from_z', ptr(ray_o), ptr(ray_d), ptr(z_vals), ptr(dr), R, S, ptr(pts), ptr(s), stream_of(z_vals))
+  return pts, s
+
+
+def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None):
+  """k_project_gather -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]."""
+  dev = views.proj.device
+  V, C = views.V, 3 + views.F
+  rgb_feat = torch.empty((R, S, V, C), dtype=torch.float32, device=dev)
+  ray_diff = torch.empty((R, S, V, 4), dtype=torch.float32, device=dev)
+  mask = torch.empty((R, S, V, 1), dtype=torch.float32, device=dev)
+  p = params('DynProjectGatherParams', R=R, S=S, V=V, H=views.H, W=views.W, Hf=views.Hf, Wf=views.Wf, F=views.F,
+             img_h=views.img_h, img_w=views.img_w, ray_o=ptr(_f32c(ray_o)), ray_d=ptr(_f32c(ray_d)), z_vals=ptr(_f32c(z_vals)),
+             pts_st=ptr(_f32c(pts_st)), xyz=ptr(_f32c(xyz)), proj=ptr(views.proj), query_center=ptr(views.query_center),
+             src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask))
+  call('dyn_project_gather', ctypes.byref(p), stream_of(rgb_feat))
+  return rgb_feat, ray_diff, mask
+
+
+def sample_mask(mask, thresh):
+  """pixel_mask = mask[..., 0].sum(dim=2) > thresh  (render_ray.py:736-741) as 0/1 floats [R,S]."""
+  R, S, V = mask.shape[:3]
+  out = torch.empty((R, S), dtype=torch.float32, device=mask.device)
+  call('dyn_sample_mask', ptr(mask), R * S, V, float(thresh), ptr(out), stream_of(mask))
+  return out
+
+
+def composite(raw_dy, z_vals, pix_mask_dy, raw_static=None, pix_mask_st=None, per_sample=True):
+  """k_composite -> dict of tensors with the reference's key set (render_ray.py:202-211 / 316-328)."""
+  raw_dy, z_vals = _f32c(raw_dy), _f32c(z_vals)
+  R, S = z_vals.shape
+  dev = z_vals.device
+  two = raw_static is not None
+  new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+  rgb, depth, rmask, weights = new(R, 3), new(R), new(R), new(R, S)
+  alpha = new(R, S) if per_sample else None
+  rgb_st = new(R, 3) if two else None
+  rgb_dy = new(R, 3) if two else None
+  a_dy = new(R, S) if two and per_sample else None
+  w_dy = new(R, S) if two and per_sample else None
+  w_st = new(R, S) if two and per_sample else None
+  p = params('DynCompositeParams', R=R, S=S, raw_dy=ptr(raw_dy), raw_static=ptr(_f32c(raw_static)), z_vals=ptr(z_vals),
+             pix_mask_dy=ptr(_f32c(pix_mask_dy)), pix_mask_st=ptr(_f32c(pix_mask_st)), rgb=ptr(rgb), rgb_static=ptr(rgb_st),
+             rgb_dy=ptr(rgb_dy), depth=ptr(depth), ray_mask=ptr(rmask), weights=ptr(weights), alpha=ptr(alpha),
+             alpha_dy=ptr(a_dy), weights_dy=ptr(w_dy), weights_st=ptr(w_st))
+  call('dyn_composite', ctypes.byref(p), stream_of(z_vals))
+  return dict(rgb=rgb, rgb_static=rgb_st, rgb_dy=rgb_dy, depth=depth, mask=rmask, weights=weights, alpha=alpha,
+              alpha_dy=a_dy, weights_dy=w_dy, weights_st=w_st, z_vals=z_vals)
+
+
+def fine_samples(z_vals, weights, N_importance, inv_uniform, u=None, want_inds=False):
+  """k_fine_samples -> z_all [R,S+N] sorted, z_samples [R,N], inds [R,N] int32 | None."""
+  z_vals, weights = _f32c(z_vals), _f32c(weights)
+  R, S = z_vals.shape
+  dev = z_vals.device
+  z_out = torch.empty((R, S + N_importance), dtype=torch.float32, device=dev)
+  z_s = torch.empty((R, N_importance), dtype=torch.float32, device=dev)
+  inds = torch.empty((R, N_importance), dtype=torch.int32, device=dev) if want_inds else None
+  p = params('DynFineSampleParams', R=R, S=S, N=N_importance, inv_uniform=int(bool(inv_uniform)), z_vals=ptr(z_vals),
+             weights=ptr(weights), u=ptr(_f32c(u)), z_out=ptr(z_out), z_samples=ptr(z_s), inds=ptr(inds, torch.int32))
+  call('dyn_fine_samples', ctypes.byref(p), stream_of(z_vals))
+  return z_out, z_s, inds

@@ -1,0 +1,127 @@
+/* dynibar_hip.h -- C ABI of libdynibar_hip.so: the MI355X (gfx950) per-ray renderer kernels.
+ *
+ * The reference (google/dynibar) has no FFI layer: its hot path is Python calling PyTorch eager ops.  Each entry
+ * point below replaces one group of those op sites; the citation gives the reference lines (paths under
+ * /root/reference/ibrnet/).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous fp32 (or int32 where noted) unless marked HOST;
+ * `stream` is a hipStream_t passed as void*; calls are stream-ordered, allocate nothing and keep no global state;
+ * return 0 on success or a negative DYN_E_* code, with a message available from dyn_last_error().
+ * All tensors are row-major with the shapes written next to each field.
+ */
+#ifndef DYNIBAR_HIP_H_
+#define DYNIBAR_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYN_ABI_VERSION 1
+#define DYN_E_INVALID (-1)  /* bad argument (NULL pointer, unsupported shape) */
+#define DYN_E_LAUNCH (-2)   /* HIP launch error */
+
+int dyn_abi_version(void);
+const char* dyn_last_error(void);
+
+/* ---- a8 (projection.py:42-47) camera preparation ----------------------------------------------------------
+ * cams [V,34] = [h, w, K(4x4), c2w(4x4)] -> proj [V,16]: rows 0..2 of K.inv(c2w) (12 floats), then the source camera
+ * centre c2w[:3,3] (3 floats), then 0.  query_cam [34] -> query_center[4] (c2w[:3,3], 0).  Replaces torch.inverse+bmm. */
+int dyn_prepare_cameras(const float* cams, int V, const float* query_cam, float* proj, float* query_center, void* stream);
+
+/* ---- featmaps [V,F,Hf,Wf] (NCHW, feature_network.py:302-311) -> channels-last [V,Hf,Wf,F] for 128-byte taps --- */
+int dyn_nchw_to_nhwc(const float* src, float* dst, int V, int F, int Hf, int Wf, void* stream);
+
+/* ---- a5 sample_along_camera_ray (render_ray.py:67-131) -------------------------------------------------------
+ * depth_range: DEVICE [2] = (near, far).  t_rand: [R,S] uniform draws for det=False, NULL for det=True (the host owns the
+ * RNG so tests can inject the reference's draws).  Outputs z_vals [R,S], s_vals [R,S] (may be NULL), pts [R,S,3] (may be NULL). */
+typedef struct {
+  int R, S;
+  int inv_uniform;
+  const float* ray_o;       /* [R,3] */
+  const float* ray_d;       /* [R,3] */
+  const float* depth_range; /* [2] */
+  const float* t_rand;      /* [R,S] or NULL */
+  float* z_vals;            /* [R,S] */
+  float* s_vals;            /* [R,S] or NULL */
+  float* pts;               /* [R,S,3] or NULL */
+} DynSampleParams;
+int dyn_sample_along_ray(const DynSampleParams* p, void* stream);
+
+/* ---- z_vals -> pts, s_vals for the fine pass (render_ray.py:822-831, z_to_s :399-404) ---------------------- */
+int dyn_points_from_z(const float* ray_o, const float* ray_d, const float* z_vals, const float* depth_range, int R, int S,
+                      float* pts, float* s_vals, void* stream);
+
+/* ---- a8-a11 Projector.compute_with_motions (projection.py:103-176), fused ----------------------------------
+ * One kernel: K.inv(c2w) projection, clamp, in-front/in-bounds mask, bilinear zero-padded align_corners taps of the
+ * RGB images and of the feature maps at the same normalised location, ray-direction difference.
+ * Sample points come either from (ray_o, ray_d, z_vals) [pts_st = o + z d] or from an explicit pts_st array; the
+ * per-view points xyz are pts_st itself (static branch, xyz = NULL) or an explicit [V,R,S,3] array (scene motion). */
+typedef struct {
+  int R, S, V;
+  int H, W;                 /* source image size (tensor dims) */
+  int Hf, Wf, F;            /* feature map size / channels (F % 4 == 0) */
+  float img_h, img_w;       /* train_cameras[0][:2], used by normalize()/inbound() (projection.py:136) */
+  const float* ray_o;       /* [R,3]   (used when pts_st == NULL) */
+  const float* ray_d;       /* [R,3] */
+  const float* z_vals;      /* [R,S] */
+  const float* pts_st;      /* [R,S,3] or NULL */
+  const float* xyz;         /* [V,R,S,3] or NULL */
+  const float* proj;        /* [V,16] from dyn_prepare_cameras */
+  const float* query_center;/* [4] */
+  const float* src_rgb;     /* [V,H,W,3] */
+  const float* feat_cl;     /* [V,Hf,Wf,F] channels-last */
+  float* rgb_feat;          /* [R,S,V,3+F] */
+  float* ray_diff;          /* [R,S,V,4] */
+  float* mask;              /* [R,S,V] (the reference's trailing singleton dim is a view) */
+} DynProjectGatherParams;
+int dyn_project_gather(const DynProjectGatherParams* p, void* stream);
+
+/* ---- a20/a21 raw2outputs_vanilla / raw2outputs (render_ray.py:134-330): one wavefront per ray ------------------
+ * raw_static == NULL selects the vanilla (single-branch) form.  pix_mask_*: [R,S] 0/1 floats (the "at least 2 observations"
+ * sample masks).  Per-sample outputs may be NULL when the caller does not need them. */
+typedef struct {
+  int R, S;
+  const float* raw_dy;      /* [R,S,4]  (vanilla: the single raw input) */
+  const float* raw_static;  /* [R,S,4] or NULL */
+  const float* z_vals;      /* [R,S] */
+  const float* pix_mask_dy; /* [R,S] */
+  const float* pix_mask_st; /* [R,S] or NULL */
+  float* rgb;               /* [R,3] */
+  float* rgb_static;        /* [R,3] or NULL */
+  float* rgb_dy;            /* [R,3] or NULL */
+  float* depth;             /* [R] */
+  float* ray_mask;          /* [R] 0/1 */
+  float* weights;           /* [R,S] */
+  float* alpha;             /* [R,S] or NULL */
+  float* alpha_dy;          /* [R,S] or NULL */
+  float* weights_dy;        /* [R,S] or NULL */
+  float* weights_st;        /* [R,S] or NULL */
+} DynCompositeParams;
+int dyn_composite(const DynCompositeParams* p, void* stream);
+
+/* ---- sample masks: pixel_mask[r,s] = (sum_v mask[r,s,v]) > thresh (render_ray.py:736-741) -------------------- */
+int dyn_sample_mask(const float* mask, int RS, int V, float thresh, float* pix_mask, void* stream);
+
+/* ---- a6/a7 fine-sample assembly (render_ray.py:19-64, :790-821): pdf -> cdf -> inverse-CDF -> merge + sort ----
+ * weights: coarse weights [R,S]; the kernel drops the two end samples, adds 1e-5, builds the cdf with a sequential
+ * per-ray prefix sum accumulated in double and rounded to fp32 per element (what torch.cumsum does on the CPU), inverts it at u (NULL = linspace(0,1,N) i.e. det=True) with the
+ * reference's count-of-(u >= cdf_i) rule, and writes the sorted union of coarse and new depths.  inds (optional) returns
+ * the reference's `above_inds` for the bit-exact index check. */
+typedef struct {
+  int R, S, N;              /* S coarse samples, N = N_importance */
+  int inv_uniform;
+  const float* z_vals;      /* [R,S] */
+  const float* weights;     /* [R,S] */
+  const float* u;           /* [R,N] or NULL */
+  float* z_out;             /* [R,S+N] sorted ascending */
+  float* z_samples;         /* [R,N] or NULL: the new depths before the sort */
+  int32_t* inds;            /* [R,N] or NULL */
+} DynFineSampleParams;
+int dyn_fine_samples(const DynFineSampleParams* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNIBAR_HIP_H_ */

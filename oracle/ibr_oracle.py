@@ -143,6 +143,36 @@ def invert_cdf(bins, cdf, u):
   return b_lo + t * (b_hi - b_lo), above
 
 
+def cdf_sample_conditioning(z_vals, weights, N_importance, inv_uniform, det, u=None, band=4e-7, cdf_err=4e-7):
+  """Test helper (not in the reference): per drawn sample, (tie, tol) in the domain sample_pdf works in (1/z if inv_uniform).
+
+  The reference's t = (u - cdf_lo) / (cdf_hi - cdf_lo) divides by the bin's probability mass, so an error `cdf_err` in the cdf
+  (a few ulp of 1.0 from torch.sum / torch.cumsum, whose last bits depend on the CPU vector width) moves the sample by
+  bin_width * cdf_err / mass: in empty bins (mass ~1e-5) that is a few percent of the bin.  `tol` is that bound.  `tie` marks
+  samples whose bin mass is within `band` of the hard 1e-5 threshold (render_ray.py:57-58), where the last bit decides
+  between t = (u-c)/mass and t = (u-c)/1, i.e. between the two edges of an empty bin; tied samples are excluded."""
+  w = weights[:, 1:-1]
+  if inv_uniform:
+    inv_z = 1.0 / z_vals
+    bins = torch.flip(0.5 * (inv_z[:, 1:] + inv_z[:, :-1]), dims=[1])
+    w = torch.flip(w, dims=[1])
+  else:
+    bins = 0.5 * (z_vals[:, 1:] + z_vals[:, :-1])
+  cdf = pdf_to_cdf(w)
+  if det:
+    u = torch.linspace(0.0, 1.0, N_importance).unsqueeze(0).repeat(cdf.shape[0], 1)
+  M = cdf.shape[1] - 1
+  above = torch.zeros_like(u, dtype=torch.long)
+  for i in range(M):
+    above += (u >= cdf[:, i:i + 1]).long()
+  below = torch.clamp(above - 1, min=0)
+  mass = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+  width = (torch.gather(bins, 1, above) - torch.gather(bins, 1, below)).abs()
+  tie = (mass - 1e-5).abs() < band
+  eff = torch.where(mass < 1e-5, torch.ones_like(mass), mass)
+  return tie, width * cdf_err / eff
+
+
 def sample_pdf(bins, weights, N_samples, det=False, u=None, return_inds=False):
   cdf = pdf_to_cdf(weights)
   if det:

@@ -1,0 +1,201 @@
+// Wave-level CPU emulator of the HIP subset used by dynibar_amd/csrc  --  TEST INFRASTRUCTURE ONLY.
+//
+// The product kernels are written for gfx950 only and contain no host/device dual paths.  To debug their
+// indexing (MFMA fragment maps, LDS layouts, cross-lane reductions) without a GPU in the build container,
+// tests/emu builds the *same, unmodified* csrc sources with the host clang++ against this fake
+// <hip/hip_runtime.h>.  One OS thread per GPU thread, blocks run one at a time, __syncthreads() and the
+// wave-level builtins (shuffles, ballot, MFMA) rendezvous on barriers.  Nothing in dynibar_amd/ can load the
+// resulting library: it is built into tests/emu/_build and opened only by tests/emu/*.py.
+#pragma once
+#include <pthread.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ /* all LDS is the single dynamic array `dyn_smem` (see csrc/dyn_device.h) */
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+constexpr hipError_t hipSuccess = 0;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+
+namespace emu {
+constexpr int WAVE = 64;
+constexpr int MAX_THREADS = 1024;
+constexpr size_t LDS_BYTES = 160 * 1024;
+
+struct WaveCtx {
+  pthread_barrier_t bar;
+  int n;
+  alignas(64) uint64_t scratch[2][WAVE][2];  // double-buffered exchange slots (two 64-bit words per lane)
+  int phase = 0;
+};
+struct BlockCtx {
+  pthread_barrier_t bar;
+  std::vector<WaveCtx> waves;
+};
+struct ThreadCtx {
+  dim3 tid, bid, bdim, gdim;
+  int lane, wave;
+  WaveCtx* w;
+  BlockCtx* b;
+  int phase = 0;
+};
+extern thread_local ThreadCtx tc;
+extern "C" char* emu_lds_base();
+}  // namespace emu
+
+#define threadIdx (emu::tc.tid)
+#define blockIdx (emu::tc.bid)
+#define blockDim (emu::tc.bdim)
+#define gridDim (emu::tc.gdim)
+constexpr int warpSize = 64;
+
+alignas(16) extern float4 dyn_smem[];
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu::tc.b->bar); }
+static inline void __builtin_amdgcn_s_barrier() { pthread_barrier_wait(&emu::tc.b->bar); }
+static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
+
+namespace emu {
+// publish two 64-bit words per lane, rendezvous, return the slot array of this exchange
+static inline uint64_t (*exchange(uint64_t a, uint64_t b))[2] {
+  ThreadCtx& t = tc;
+  WaveCtx* w = t.w;
+  int ph = t.phase;
+  t.phase ^= 1;
+  w->scratch[ph][t.lane][0] = a;
+  w->scratch[ph][t.lane][1] = b;
+  pthread_barrier_wait(&w->bar);
+  return w->scratch[ph];
+}
+template <class T> static inline uint64_t bits(T v) { uint64_t u = 0; static_assert(sizeof(T) <= 8); memcpy(&u, &v, sizeof(T)); return u; }
+template <class T> static inline T unbits(uint64_t u) { T v; memcpy(&v, &u, sizeof(T)); return v; }
+}  // namespace emu
+
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  int lane = emu::tc.lane;
+  int base = lane & ~(width - 1);
+  return emu::unbits<T>(s[base + (src & (width - 1))][0]);
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  int lane = emu::tc.lane;
+  int src = lane ^ mask;
+  if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+  return emu::unbits<T>(s[src][0]);
+}
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  int lane = emu::tc.lane;
+  int src = lane + (int)d;
+  if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+  return emu::unbits<T>(s[src][0]);
+}
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  int lane = emu::tc.lane;
+  int src = lane - (int)d;
+  if (src < 0 || (src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+  return emu::unbits<T>(s[src][0]);
+}
+static inline unsigned long long __ballot(int pred) {
+  auto s = emu::exchange(pred ? 1 : 0, 0);
+  unsigned long long m = 0;
+  for (int i = 0; i < emu::tc.w->n; ++i) m |= (unsigned long long)(s[i][0] & 1) << i;
+  return m;
+}
+static inline int __all(int pred) { return __ballot(pred) == __ballot(1); }
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  return emu::unbits<T>(s[0][0]);
+}
+static inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
+
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+// Exact f32 fma chain in k order (cdna_hip_programming.md section 3).
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+  auto s = emu::exchange(emu::bits(a), emu::bits(b));
+  int l = emu::tc.lane, j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(emu::unbits<float>(s[row + 32 * k][0]), emu::unbits<float>(s[j + 32 * k][1]), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+r.
+static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+  auto s = emu::exchange(emu::bits(a), emu::bits(b));
+  int l = emu::tc.lane, j = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = g * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(emu::unbits<float>(s[row + 16 * k][0]), emu::unbits<float>(s[j + 16 * k][1]), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fsqrt_rn(float x) { return sqrtf(x); }
+static inline void sincosf_(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+static inline float atomicAdd(float* p, float v) {
+  float old = *p, nw;
+  do { nw = old + v; } while (!__atomic_compare_exchange(p, &old, &nw, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+  return old;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+namespace emu {
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+template <class K, class... Args>
+static inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  run_grid(grid, block, shmem, [&]() { kernel(args...); });
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(kernel, grid, block, shmem, stream, __VA_ARGS__)

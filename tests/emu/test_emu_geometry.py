@@ -1,0 +1,29 @@
+"""The geometry / compositing / resampling kernels executed under the wave-level emulator, checked against the oracle.
+This is a debugging aid for kernel indexing in a container without a GPU; the authoritative parity run is -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.emu
+
+
+def test_sampling(emu):
+  parity.check_sampling(emu, 'small')
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_project_gather(emu, name):
+  parity.check_project_gather(emu, name)
+
+
+def test_composite(emu):
+  parity.check_composite(emu, R=9, S=64)
+  parity.check_composite(emu, R=6, S=128, seed=1)
+
+
+def test_fine_samples(emu, golden_dir):
+  g = dict(np.load(os.path.join(golden_dir, 'stages_small.npz')))
+  parity.check_fine_samples(emu, g)

@@ -1,0 +1,181 @@
+"""Parity checks HIP-path-vs-oracle, parameterised by device so the same assertions run
+(a) on a real MI355X through libdynibar_hip.so (-m gpu) and (b) under the wave-level emulator on CPU tensors (tests/emu).
+
+Tolerances (stated per check): integer / boolean / index outputs exact; depths, points and normalised distances bit-exact
+(the geometry TU is built with -ffp-contract=off); interpolated colours / features within 2e-5 on smooth maps (coordinate
+rounding times the map gradient) and 5e-4 on white-noise maps; network outputs and rendered colours within 1e-4
+(BASELINE.json north_star)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import cases
+from dynibar_amd import ops
+from oracle import ibr_oracle as O
+
+
+def to_dev(x, device):
+  if isinstance(x, dict):
+    return {k: to_dev(v, device) for k, v in x.items()}
+  return x.to(device) if isinstance(x, torch.Tensor) else x
+
+
+def cpu(x):
+  return x.detach().cpu()
+
+
+def assert_close(a, b, atol, rtol=0.0, what=''):
+  a, b = cpu(a).double(), cpu(b).double()
+  err = (a - b).abs()
+  lim = atol + rtol * b.abs()
+  if not bool((err <= lim).all()):
+    i = int(torch.argmax(err - lim))
+    raise AssertionError(f'{what}: max err {float(err.max()):.3e} (limit {atol:.1e}+{rtol:.1e}*|ref|) at flat index {i}: '
+                         f'{float(a.flatten()[i])} vs {float(b.flatten()[i])}; {int((err > lim).sum())}/{err.numel()} over')
+
+
+def assert_bitexact(a, b, what=''):
+  a, b = cpu(a), cpu(b)
+  if not torch.equal(a, b):
+    d = (a.double() - b.double()).abs()
+    raise AssertionError(f'{what}: not bit-exact, {int((a != b).sum())}/{a.numel()} differ, max abs {float(d.max()):.3e}')
+
+
+def check_sampling(device, name='small', S=64):
+  scene, o, d, uv, _ = cases.scene_case(name)
+  dr = scene['depth_range']
+  g = torch.Generator().manual_seed(3)
+  t_rand = torch.rand(o.shape[0], S, generator=g)
+  for inv in (True, False):
+    for tr in (None, t_rand):
+      pts_r, z_r, s_r = O.sample_along_camera_ray(o, d, dr, S, inv, tr is None, tr)
+      pts, z, s = ops.sample_along_ray(o.to(device), d.to(device), dr.to(device), S, inv, None if tr is None else tr.to(device))
+      assert_bitexact(z, z_r, f'z_vals inv={inv} det={tr is None}')
+      assert_bitexact(pts, pts_r, f'pts inv={inv} det={tr is None}')
+      assert_bitexact(s, s_r, f's_vals inv={inv} det={tr is None}')
+  # fine-pass helper
+  pts_r, z_r, s_r = O.sample_along_camera_ray(o, d, dr, S, True, True)
+  pts, s = ops.points_from_z(o.to(device), d.to(device), z_r.to(device), dr.to(device))
+  assert_bitexact(pts, pts_r, 'points_from_z pts')
+  assert_bitexact(s, s_r, 'points_from_z s_vals')
+
+
+def _mask_check(mask, mask_ref, pix_margin, what):
+  """Masks must be identical except where the oracle's own pixel location sits within ~1e-3 px of the frustum boundary
+  (an fp32 tie: the reference's LU inverse and ours differ in the last bits of K.inv(c2w))."""
+  diff = cpu(mask).reshape(-1) != mask_ref.reshape(-1)
+  bad = diff & ~pix_margin.reshape(-1)
+  assert int(bad.sum()) == 0, f'{what}: {int(bad.sum())} mask mismatches away from the boundary'
+  return int(diff.sum())
+
+
+def boundary_margin(xyz, cams, tol=2e-3):
+  """[R,S,V] bool: oracle pixel location within tol px of an inbound() edge or depth within 1e-5 of the z=0 plane."""
+  pix, _ = O.compute_projections(xyz, cams)
+  h, w = cams[0][:2]
+  K = cams[:, 2:18].reshape(-1, 4, 4)
+  c2w = cams[:, -16:].reshape(-1, 4, 4)
+  xyz_h = torch.cat([xyz.reshape(xyz.shape[0], -1, 3), torch.ones(xyz.shape[0], xyz[0].numel() // 3, 1)], -1)
+  zc = K.bmm(torch.inverse(c2w)).bmm(xyz_h.permute(0, 2, 1))[:, 2].reshape(pix.shape[:-1])
+  near = ((pix[..., 0].abs() < tol) | ((pix[..., 0] - (w - 1)).abs() < tol) | (pix[..., 1].abs() < tol) |
+          ((pix[..., 1] - (h - 1)).abs() < tol) | (zc.abs() < 1e-5))
+  return near.permute(1, 2, 0)
+
+
+def check_ray_diff(rd, rd_ref, xyz_st, xyz, qcam, cams, what):
+  """ray_diff = [unit(a-b), a.b]: the direction is ill-conditioned when the two unit rays nearly coincide, so its tolerance
+  scales with 1/|a-b| (error model: 4 ulp of a unit vector / |a-b|); the dot product is checked to 1e-6."""
+  V = xyz.shape[0]
+  a = F.normalize(qcam[-16:].reshape(4, 4)[:3, 3][None, None, None] - xyz_st[None], dim=-1)
+  b = F.normalize(cams[:, -16:].reshape(-1, 4, 4)[:, :3, 3][:, None, None] - xyz, dim=-1)
+  nrm = (a - b).norm(dim=-1).permute(1, 2, 0).clamp(min=1e-6)
+  err = (cpu(rd) - rd_ref).abs()
+  assert float(err[..., 3].max()) <= 1e-6, f'{what} dot: {float(err[..., 3].max()):.3e}'
+  scaled = float((err[..., :3] * nrm[..., None]).max())
+  assert scaled <= 1e-6, f'{what} direction: scaled err {scaled:.3e}'
+
+
+def check_project_gather(device, name='small', S=64):
+  scene, o, d, uv, _ = cases.scene_case(name)
+  atol = 5e-4 if name == 'noise' else 3e-5
+  pts_r, z_r, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  R = o.shape[0]
+  sd = to_dev(scene, device)
+  # static branch: points generated in-kernel from (o, d, z)
+  Vs = scene['static_src_rgbs'].shape[1]
+  xyz = pts_r[None].repeat(Vs, 1, 1, 1)
+  rf_r, rd_r, mk_r = O.compute_with_motions(pts_r, xyz, scene['camera'], scene['static_src_rgbs'], scene['static_src_cameras'],
+                                            scene['static_featmaps'])
+  views = ops.SourceViews(sd['camera'], sd['static_src_rgbs'], sd['static_src_cameras'], sd['static_featmaps'])
+  rf, rd, mk = ops.project_gather(views, R, S, ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
+  margin = boundary_margin(xyz, scene['static_src_cameras'][0])
+  nflip = _mask_check(mk, mk_r, margin, f'{name} static mask')
+  keep = (~margin)[..., None].float()
+  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} static rgb_feat')
+  check_ray_diff(rd, rd_r, pts_r, xyz, scene['camera'][0], scene['static_src_cameras'][0], f'{name} static ray_diff')
+  # dynamic branch: explicit displaced points (Projector API form)
+  g = torch.Generator().manual_seed(9)
+  V = scene['src_rgbs'].shape[1]
+  xyz = pts_r[None] + 0.05 * torch.randn(V, R, S, 3, generator=g)
+  rf_r, rd_r, mk_r = O.compute_with_motions(pts_r, xyz, scene['camera'], scene['src_rgbs'], scene['src_cameras'], scene['featmaps'])
+  views = ops.SourceViews(sd['camera'], sd['src_rgbs'], sd['src_cameras'], sd['featmaps'])
+  rf, rd, mk = ops.project_gather(views, R, S, pts_st=pts_r.to(device), xyz=xyz.to(device))
+  margin = boundary_margin(xyz, scene['src_cameras'][0])
+  nflip += _mask_check(mk, mk_r, margin, f'{name} dynamic mask')
+  keep = (~margin)[..., None].float()
+  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} dynamic rgb_feat')
+  check_ray_diff(rd, rd_r, pts_r, xyz, scene['camera'][0], scene['src_cameras'][0], f'{name} dynamic ray_diff')
+  pm = ops.sample_mask(mk, 1.0)
+  assert_bitexact(pm, (cpu(mk)[..., 0].sum(dim=2) > 1).float(), 'sample_mask')
+  return nflip
+
+
+def check_composite(device, R=37, S=64, seed=0):
+  g = torch.Generator().manual_seed(seed)
+  raw_dy = torch.randn(R, S, 4, generator=g) * torch.tensor([1, 1, 1, 3.0])
+  raw_st = torch.randn(R, S, 4, generator=g) * torch.tensor([1, 1, 1, 3.0])
+  raw_st[3, 10:20, 3] = -1e9   # masked-out samples (mlp_network.py:510-512)
+  raw_dy[R - 1, :, 3] = 30.0   # softplus linear branch
+  z = torch.sort(torch.rand(R, S, generator=g) * 10 + 0.5, dim=1)[0]
+  pm_dy = (torch.rand(R, S, generator=g) > 0.7)
+  pm_st = (torch.rand(R, S, generator=g) > 0.9)
+  ref = O.raw2outputs(raw_dy, raw_st, z, pm_dy, pm_st)
+  out = ops.composite(raw_dy.to(device), z.to(device), pm_dy.float().to(device), raw_st.to(device), pm_st.float().to(device))
+  for k in ('rgb', 'rgb_static', 'rgb_dy', 'depth', 'alpha_dy', 'weights_dy', 'weights_st', 'alpha', 'weights'):
+    assert_close(out[k], ref[k], 2e-6, 1e-5, f'raw2outputs {k}')
+  assert_bitexact(out['mask'] > 0, ref['mask'], 'raw2outputs mask')
+  ref = O.raw2outputs_vanilla(raw_dy, z, pm_dy)
+  out = ops.composite(raw_dy.to(device), z.to(device), pm_dy.float().to(device))
+  for k in ('rgb', 'depth', 'alpha', 'weights'):
+    assert_close(out[k], ref[k], 2e-6, 1e-5, f'raw2outputs_vanilla {k}')
+  assert_bitexact(out['mask'] > 0, ref['mask'], 'vanilla mask')
+
+
+def check_fine_samples(device, golden, S=64):
+  """Index-exactness protocol: weights come from the golden composite of the real reference; the kernel's
+  sequential cdf must reproduce the reference's above_inds exactly and the sorted depths to 1 ulp-level tolerance."""
+  z = torch.from_numpy(golden['composite/z_vals'])
+  w = torch.from_numpy(golden['composite/weights'])
+  R = z.shape[0]
+  total_mismatch = 0
+  for inv in (True, False):
+    for mode in ('det', 'rand'):
+      u = None if mode == 'det' else torch.from_numpy(golden[f'pdf/inv{int(inv)}/u'])
+      z_all_r, inds_r = O.fine_z_vals(z, w, S, inv, mode == 'det', u, return_inds=True)
+      z_all, z_s, inds = ops.fine_samples(z.to(device), w.to(device), S, inv, None if u is None else u.to(device), want_inds=True)
+      mism = int((cpu(inds).long() != inds_r).sum())
+      total_mismatch += mism
+      assert mism == 0, f'fine samples inv={inv} {mode}: {mism} index mismatches'
+      smp_ref = torch.from_numpy(golden[f'pdf/inv{int(inv)}/{mode}'])     # in sample_pdf's domain (1/z when inv)
+      tie, tol = O.cdf_sample_conditioning(z, w, S, inv, mode == 'det', u)
+      got = 1.0 / cpu(z_s) if inv else cpu(z_s)
+      over = ((got - smp_ref).abs() > tol + 2e-6 * smp_ref.abs() + 1e-7) & ~tie
+      assert int(over.sum()) == 0, (f'z_samples inv={inv} {mode}: {int(over.sum())} samples beyond the conditioning bound, '
+                                    f'worst {float(((got - smp_ref).abs() - tol)[~tie].max()):.3e}')
+      # the merge is pure data movement: bit-exact against a sort of the kernel's own new depths
+      assert_bitexact(z_all, torch.sort(torch.cat([z, cpu(z_s)], dim=1), dim=1)[0], f'sorted union inv={inv} {mode}')
+      clean = ~(tie.any(dim=1))
+      assert_close(cpu(z_all)[clean], z_all_r[clean], 0.0, 0.02, f'z_all vs oracle (coarse sanity) inv={inv} {mode}')
+      zs = cpu(z_all)
+      assert bool((zs[:, 1:] >= zs[:, :-1]).all()), 'fine depths not sorted'
+  return total_mismatch
