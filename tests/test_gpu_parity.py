@@ -1,0 +1,41 @@
+"""-m gpu parity tests: the HIP kernels, called through the C-ABI (libdynibar_hip.so), against the CPU oracle on the same
+seeded inputs and against the committed golden fixtures generated from the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  assert torch.cuda.is_available(), 'the -m gpu tests need an MI355X'
+  from dynibar_amd import _lib
+  _lib.lib()  # fails loudly if the gfx950 library is missing
+  return 'cuda:0'
+
+
+def test_sampling(dev):
+  parity.check_sampling(dev, 'small')
+  parity.check_sampling(dev, 'harsh', S=128)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_project_gather(dev, name):
+  parity.check_project_gather(dev, name)
+
+
+def test_composite(dev):
+  parity.check_composite(dev, R=37, S=64)
+  parity.check_composite(dev, R=1000, S=128, seed=1)
+  parity.check_composite(dev, R=5, S=200, seed=2)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_fine_samples(dev, golden_dir, name):
+  g = dict(np.load(os.path.join(golden_dir, f'stages_{name}.npz')))
+  parity.check_fine_samples(dev, g)
