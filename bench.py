@@ -1,0 +1,172 @@
+"""Hot-path bench: rays/sec of the per-ray renderer on synthetic Balloon1-shaped inputs (BASELINE.json configs[1]).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the static-branch hot path over one batch of R = 4096 rays per GPU (64 coarse samples, 8 source
+views): sample_along_ray -> project_gather -> DynibarStatic (views / points / blend kernels) -> sample_mask -> composite,
+all through the C-ABI of libdynibar_hip.so with inputs resident in HBM.  With N > 1 every rank renders its own tile of rays
+(weak scaling: rays are independent) and each step ends with the RCCL all-gather of the rendered pixels.
+Prints ONE JSON line (rank 0).  The CPU leg times the oracle (the reference algorithm restated on torch-CPU) on a bounded
+sample of the same workload; it is a reported baseline, not the target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, F = 288, 512, 32
+# algorithmic FLOPs (2 x MAC of the reference's Linear layers, mlp_network.py:333-405) per point-view of k_static_views:
+# ray_dir_fc 103x256+256x35, base_fc 210x256+256x128, vis_fc 128x128+128x129, vis_fc2 128x128+128x1
+FLOP_VIEWS_PER_PV = 2 * (103 * 256 + 256 * 35 + 210 * 256 + 256 * 128 + 128 * 128 + 128 * 129 + 128 * 128 + 128)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def static_net_flops_per_point(S, V):
+  """Linear layers + attention matmuls of DynibarStatic, per sample point."""
+  return 0.361e6 + 0.033e6 * (S / 64.0) + 0.4305e6 * V
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--rays', type=int, default=4096, help='rays per step per GPU (N_rand / chunk)')
+  ap.add_argument('--samples', type=int, default=64)
+  ap.add_argument('--views', type=int, default=8)
+  ap.add_argument('--cpu-rays', type=int, default=256, help='rays of the same workload timed on the host oracle (0 = skip)')
+  a = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if a.gpus > 1 and world != a.gpus:
+    raise SystemExit(f'--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(dev)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', device_id=dev)
+
+  from dynibar_amd import _lib, ops, synthetic as syn
+  lib = _lib.lib()
+
+  R, S, V = a.rays, a.samples, a.views
+  sc = syn.make_scene(seed=0, H=H, W=W, V=V, F=F, n_static=V)
+  T = lambda x: torch.from_numpy(x).to(dev)
+  scene = {k: T(v) for k, v in sc.items()}
+  pix = syn.sample_pixels(100 + rank, H, W, R)  # each rank renders its own tile of rays
+  o_np, d_np, _ = syn.pixel_rays(sc['camera'], pix)
+  ray_o, ray_d = T(o_np), T(d_np)
+  weights = syn.make_weights('static', 0, F)
+  net = ops.StaticNet(weights, dev, anti_alias_pooling=True, mask_rgb=False)
+  views = ops.SourceViews(scene['camera'], scene['static_src_rgbs'], scene['static_src_cameras'], scene['static_featmaps'])
+  gathered = torch.empty((world * R, 4), dtype=torch.float32, device=dev) if world > 1 else None
+
+  def step():
+    pts, z, _ = ops.sample_along_ray(ray_o, ray_d, scene['depth_range'], S, True, want_s=False)
+    rgb_feat, ray_diff, mask = ops.project_gather(views, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z)
+    raw = net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
+    pm = ops.sample_mask(mask, 1.0)
+    out = ops.composite(raw, z, pm, per_sample=False)
+    if world > 1:
+      dist.all_gather_into_tensor(gathered, torch.cat([out['rgb'], out['depth'][:, None]], dim=1))
+    return out
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for _ in range(a.warmup):
+    out = step()
+  fence()
+  lib.dyn_profile_enable(1)
+  t0 = time.perf_counter()
+  for _ in range(a.steps):
+    out = step()
+  fence()
+  dt = time.perf_counter() - t0
+  lib.dyn_profile_enable(0)
+  if world > 1:
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+  nk = lib.dyn_profile_count()
+  ms = (ctypes.c_float * nk)()
+  cnt = (ctypes.c_int * nk)()
+  lib.dyn_profile_read(ms, cnt)
+  kernels = {lib.dyn_profile_name(i).decode(): {'launches': cnt[i], 'avg_ms': ms[i] / cnt[i]} for i in range(nk) if cnt[i] > 0}
+
+  if rank != 0:
+    if world > 1:
+      dist.destroy_process_group()
+    return
+
+  value = world * R * a.steps / dt
+  dom = kernels['k_static_views']
+  flops_launch = FLOP_VIEWS_PER_PV * R * S * V
+  achieved = flops_launch / (dom['avg_ms'] * 1e-3) / 1e12
+  net_ms = sum(kernels[k]['avg_ms'] for k in ('k_static_ref_feat', 'k_static_views', 'k_static_points', 'k_static_blend'))
+  net_tflops = static_net_flops_per_point(S, V) * R * S / (net_ms * 1e-3) / 1e12
+  pg = kernels['k_project_gather']
+  pg_bytes = R * S * V * 160 + V * ((H // 4) * (W // 4) * F + H * W * 3) * 4 + R * (24 + 4 * S)
+  res = {
+      'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps,
+      'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'BASELINE configs[1]: Nvidia Balloon1 eval shape, static branch only '
+                             '(sample -> project/gather -> DynibarStatic -> composite)',
+                 'rays_per_step_per_gpu': R, 'samples': S, 'src_views': V, 'src_image': [H, W], 'feature_map': [F, H // 4, W // 4],
+                 'sharding': 'ray tiles per rank + RCCL all-gather of rendered pixels' if world > 1 else 'single GPU'},
+      'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                   'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': dom['avg_ms'],
+                   'algorithmic_flops_per_launch': flops_launch},
+      'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': net_tflops / FP32_MFMA_PEAK_TFLOPS, 'avg_ms': net_ms},
+      'roofline_project_gather': {'bound': 'hbm', 'achieved': pg_bytes / (pg['avg_ms'] * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                                  'frac': pg_bytes / (pg['avg_ms'] * 1e-3) / 8e12, 'avg_launch_ms': pg['avg_ms'],
+                                  'algorithmic_bytes_per_launch': pg_bytes},
+      'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()},
+  }
+
+  if a.cpu_rays > 0 and world == 1:
+    # the oracle (test infrastructure) is used here ONLY as the timed CPU baseline and as the checker of this run's pixels
+    from oracle import ibr_oracle as O
+    n = min(a.cpu_rays, R)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu_scene = {k: torch.from_numpy(v) for k, v in sc.items()}
+    sd = O.tdict(weights)
+    co, cd = torch.from_numpy(o_np[:n]), torch.from_numpy(d_np[:n])
+    with torch.no_grad():
+      O.static_branch_pass(sd, cpu_scene, co[:32], cd[:32], S, True, True)  # warm-up
+      t1 = time.perf_counter()
+      ref = O.static_branch_pass(sd, cpu_scene, co, cd, S, True, True)
+      cpu_dt = time.perf_counter() - t1
+    res['cpu_baseline'] = {'value': n / cpu_dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+                           'sample': f'{n} of the {R} rays of one step, same scene/weights, torch-CPU oracle with {cores} threads, 1 run after warm-up'}
+    err = (out['rgb'][:n].cpu() - ref['rgb']).abs()
+    mse = float((err ** 2).mean())
+    res['check_vs_oracle'] = {'rays': n, 'max_abs_rgb_err': float(err.max()), 'psnr_db': (10 * np.log10(1.0 / mse)) if mse > 0 else float('inf')}
+  print(json.dumps(res))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -17,6 +17,66 @@ void dyn_set_error(const char* fmt, ...) {
 extern "C" const char* dyn_last_error(void) { return g_err; }
 extern "C" int dyn_abi_version(void) { return DYN_ABI_VERSION; }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-kernel timing
+// ---------------------------------------------------------------------------------------------------------------
+#define DYN_PROF_RING 512
+static struct {
+  int on;
+  hipEvent_t ev[DYN_K_COUNT][DYN_PROF_RING][2];
+  int made[DYN_K_COUNT];   // events created so far per slot
+  int used[DYN_K_COUNT];   // records pending since the last read
+  double ms[DYN_K_COUNT];  // carried over when the ring wraps
+  long n[DYN_K_COUNT];
+} g_prof;
+static const char* const g_prof_names[DYN_K_COUNT] = {
+    "k_prepare_cameras", "k_nchw_to_nhwc", "k_sample_along_ray", "k_points_from_z", "k_project_gather", "k_sample_mask", "k_composite",
+    "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest"};
+
+static void prof_flush(int slot) {
+  for (int i = 0; i < g_prof.used[slot]; ++i) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(g_prof.ev[slot][i][1]);
+    if (hipEventElapsedTime(&ms, g_prof.ev[slot][i][0], g_prof.ev[slot][i][1]) == hipSuccess) g_prof.ms[slot] += ms;
+    g_prof.n[slot] += 1;
+  }
+  g_prof.used[slot] = 0;
+}
+void dyn_prof_begin(int slot, hipStream_t stream) {
+  if (!g_prof.on) return;
+  if (g_prof.used[slot] == DYN_PROF_RING) prof_flush(slot);
+  const int i = g_prof.used[slot];
+  if (i >= g_prof.made[slot]) {
+    (void)hipEventCreate(&g_prof.ev[slot][i][0]);
+    (void)hipEventCreate(&g_prof.ev[slot][i][1]);
+    g_prof.made[slot] = i + 1;
+  }
+  (void)hipEventRecord(g_prof.ev[slot][i][0], stream);
+}
+void dyn_prof_end(int slot, hipStream_t stream) {
+  if (!g_prof.on) return;
+  (void)hipEventRecord(g_prof.ev[slot][g_prof.used[slot]][1], stream);
+  g_prof.used[slot] += 1;
+}
+extern "C" int dyn_profile_enable(int on) {
+  g_prof.on = on ? 1 : 0;
+  return 0;
+}
+extern "C" int dyn_profile_count(void) { return DYN_K_COUNT; }
+extern "C" const char* dyn_profile_name(int slot) { return (slot >= 0 && slot < DYN_K_COUNT) ? g_prof_names[slot] : ""; }
+extern "C" int dyn_profile_read(float* total_ms, int* launches) {
+  DYN_REQUIRE(total_ms && launches, "dyn_profile_read: null pointer");
+  for (int s = 0; s < DYN_K_COUNT; ++s) {
+    prof_flush(s);
+    total_ms[s] = (float)g_prof.ms[s];
+    launches[s] = (int)g_prof.n[s];
+    g_prof.ms[s] = 0.0;
+    g_prof.n[s] = 0;
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // camera preparation: P = K . inv(c2w)   (projection.py:42-47 does torch.inverse + bmm on [V,4,4])
 // ---------------------------------------------------------------------------------------------------------------
@@ -77,9 +137,8 @@ extern "C" int dyn_prepare_cameras(const float* cams, int V, const float* query_
                                    void* stream) {
   DYN_REQUIRE(cams && proj && V > 0, "dyn_prepare_cameras: null pointer or V<=0");
   DYN_REQUIRE(query_cam == nullptr || query_center != nullptr, "dyn_prepare_cameras: query_center missing");
-  hipLaunchKernelGGL(k_prepare_cameras, dim3(dyn_cdiv(V + 1, 64)), dim3(64), 0, (hipStream_t)stream, cams, V, query_cam, proj,
+  DYN_LAUNCH(DYN_K_PREPARE_CAMERAS, "dyn_prepare_cameras", k_prepare_cameras, dim3(dyn_cdiv(V + 1, 64)), dim3(64), 0, (hipStream_t)stream, cams, V, query_cam, proj,
                      query_center);
-  DYN_CHECK_LAUNCH("dyn_prepare_cameras");
   return 0;
 }
 
@@ -109,8 +168,7 @@ extern "C" int dyn_nchw_to_nhwc(const float* src, float* dst, int V, int F, int 
   DYN_REQUIRE(src && dst && V > 0 && F > 0 && Hf > 0 && Wf > 0, "dyn_nchw_to_nhwc: bad argument");
   DYN_REQUIRE((size_t)F * 65 * 4 <= 150 * 1024, "dyn_nchw_to_nhwc: F too large");
   int HW = Hf * Wf;
-  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(dyn_cdiv(HW, 64), V), dim3(256), (size_t)F * 65 * 4, (hipStream_t)stream, src, dst, F, HW);
-  DYN_CHECK_LAUNCH("dyn_nchw_to_nhwc");
+  DYN_LAUNCH(DYN_K_NCHW_TO_NHWC, "dyn_nchw_to_nhwc", k_nchw_to_nhwc, dim3(dyn_cdiv(HW, 64), V), dim3(256), (size_t)F * 65 * 4, (hipStream_t)stream, src, dst, F, HW);
   return 0;
 }
 
@@ -151,8 +209,7 @@ extern "C" int dyn_sample_along_ray(const DynSampleParams* p, void* stream) {
   DYN_REQUIRE(p && p->ray_o && p->ray_d && p->depth_range && p->z_vals, "dyn_sample_along_ray: null pointer");
   DYN_REQUIRE(p->R > 0 && p->S > 1, "dyn_sample_along_ray: need R>0, S>1");
   long n = (long)p->R * p->S;
-  hipLaunchKernelGGL(k_sample_along_ray, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
-  DYN_CHECK_LAUNCH("dyn_sample_along_ray");
+  DYN_LAUNCH(DYN_K_SAMPLE, "dyn_sample_along_ray", k_sample_along_ray, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
   return 0;
 }
 
@@ -175,9 +232,8 @@ extern "C" int dyn_points_from_z(const float* ray_o, const float* ray_d, const f
   DYN_REQUIRE(ray_o && ray_d && z_vals && R > 0 && S > 0, "dyn_points_from_z: bad argument");
   DYN_REQUIRE(s_vals == nullptr || depth_range != nullptr, "dyn_points_from_z: depth_range missing");
   long n = (long)R * S;
-  hipLaunchKernelGGL(k_points_from_z, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, z_vals, depth_range, n, S, pts,
+  DYN_LAUNCH(DYN_K_POINTS_FROM_Z, "dyn_points_from_z", k_points_from_z, dim3(dyn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, z_vals, depth_range, n, S, pts,
                      s_vals);
-  DYN_CHECK_LAUNCH("dyn_points_from_z");
   return 0;
 }
 
@@ -357,8 +413,7 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   const int C = 3 + p->F;
   size_t shmem = (size_t)PG_ROWS * (C + 4 + 1) * 4 + (size_t)PG_ROWS * sizeof(PGTap);
   shmem = (shmem + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(k_project_gather, dim3(dyn_cdiv(N, PG_ROWS)), dim3(PG_THREADS), shmem, (hipStream_t)stream, *p);
-  DYN_CHECK_LAUNCH("dyn_project_gather");
+  DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3(dyn_cdiv(N, PG_ROWS)), dim3(PG_THREADS), shmem, (hipStream_t)stream, *p);
   return 0;
 }
 
@@ -374,8 +429,7 @@ __global__ void k_sample_mask(const float* __restrict__ mask, long RS, int V, fl
 }
 extern "C" int dyn_sample_mask(const float* mask, int RS, int V, float thresh, float* pix_mask, void* stream) {
   DYN_REQUIRE(mask && pix_mask && RS > 0 && V > 0, "dyn_sample_mask: bad argument");
-  hipLaunchKernelGGL(k_sample_mask, dim3(dyn_cdiv(RS, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long)RS, V, thresh, pix_mask);
-  DYN_CHECK_LAUNCH("dyn_sample_mask");
+  DYN_LAUNCH(DYN_K_SAMPLE_MASK, "dyn_sample_mask", k_sample_mask, dim3(dyn_cdiv(RS, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long)RS, V, thresh, pix_mask);
   return 0;
 }
 
@@ -466,8 +520,7 @@ extern "C" int dyn_composite(const DynCompositeParams* p, void* stream) {
               "dyn_composite: null pointer");
   DYN_REQUIRE(p->raw_static == nullptr || p->pix_mask_st != nullptr, "dyn_composite: pix_mask_st missing");
   DYN_REQUIRE(p->R > 0 && p->S > 0, "dyn_composite: empty problem");
-  hipLaunchKernelGGL(k_composite, dim3(dyn_cdiv(p->R, 4)), dim3(256), 0, (hipStream_t)stream, *p);
-  DYN_CHECK_LAUNCH("dyn_composite");
+  DYN_LAUNCH(DYN_K_COMPOSITE, "dyn_composite", k_composite, dim3(dyn_cdiv(p->R, 4)), dim3(256), 0, (hipStream_t)stream, *p);
   return 0;
 }
 
@@ -558,7 +611,6 @@ extern "C" int dyn_fine_samples(const DynFineSampleParams* p, void* stream) {
   while (T > 1 && per_thread * T > 144 * 1024) T >>= 1;
   DYN_REQUIRE(per_thread * T <= 144 * 1024, "dyn_fine_samples: S+N too large for LDS");
   size_t shmem = (per_thread * T + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(k_fine_samples, dim3(dyn_cdiv(p->R, T)), dim3(T), shmem, (hipStream_t)stream, *p, T);
-  DYN_CHECK_LAUNCH("dyn_fine_samples");
+  DYN_LAUNCH(DYN_K_FINE_SAMPLES, "dyn_fine_samples", k_fine_samples, dim3(dyn_cdiv(p->R, T)), dim3(T), shmem, (hipStream_t)stream, *p, T);
   return 0;
 }

@@ -1,0 +1,774 @@
+// K3: the per-point multi-view networks (reference ibrnet/mlp_network.py) as register-resident fp32 MFMA chains.
+// See dyn_mlp.h for the engine.  DynibarStatic (mlp_network.py:423-527) is three launches:
+//   A  k_static_views : per point-view chain  ray_dir_fc -> [x ref_feature] -> mean/var -> base_fc -> vis_fc -> vis_fc2,
+//                       then the visibility-weighted mean/var over the views of each point   (one wave = 32 point-views)
+//   B  k_static_points: per point chain  geometry_fc -> 4-head ray attention over the S samples of a ray -> LayerNorm ->
+//                       out_geometry_fc (sigma) and the point part of rgb_fc.0               (one wave = 32 points of one ray)
+//   C  k_static_blend : per point-view  rgb_fc -> masked softmax over views -> blend of the source colours
+// Between A and C the 128-wide per-view feature x is parked in HBM in the lanes' own register order (512 B per point-view).
+#include <functional>
+#include <vector>
+
+#include "dyn_host.h"
+#include "dyn_mlp.h"
+
+// ===================================================================================================================
+// host-side packing
+// ===================================================================================================================
+namespace {
+
+// value of the packed A operand for (output tile t, row i, k-step s, half h)
+using SlotFn = std::function<float(int t, int i, int s, int h)>;
+
+void pack_layer(std::vector<float>& out, int NT, int NSTEPS, const SlotFn& fn) {
+  const int NSG = (NSTEPS + 3) / 4, SGC = 16 / NT, NCH = (NSG + SGC - 1) / SGC;
+  const size_t base = out.size();
+  out.resize(base + (size_t)NCH * DYN_CHUNK, 0.f);
+  for (int c = 0; c < NCH; ++c)
+    for (int g = 0; g < SGC; ++g) {
+      const int sg = c * SGC + g;
+      if (sg >= NSG) continue;
+      for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) {
+            const int s = sg * 4 + q;
+            if (s >= NSTEPS) continue;
+            out[base + (size_t)c * DYN_CHUNK + ((g * NT + t) * 64 + lane) * 4 + q] = fn(t, lane & 31, s, lane >> 5);
+          }
+    }
+}
+
+// input feature of a chained layer: k-step s, half h -> feature of the previous layer's output (D layout)
+inline int chain_feature(int s, int h) { return 32 * (s / 16) + dyn_fi(s % 16, h); }
+
+// Linear [nout, nin] (+bias) fed by a previous layer's D-layout output of `nin` features, bias in the extra k-step.
+// col_of maps a chained feature index to the weight column (identity by default).
+SlotFn chained(const float* W, const float* b, int nout, int nin, int ld, int col0 = 0) {
+  return [=](int t, int i, int s, int h) -> float {
+    const int n = 32 * t + i;
+    if (n >= nout) return 0.f;
+    const int nsteps_in = nin / 2;
+    if (s < nsteps_in) return W[(size_t)n * ld + col0 + chain_feature(s, h)];
+    if (s == nsteps_in && h == 0 && b != nullptr) return b[n];
+    return 0.f;
+  };
+}
+
+// [2][n] table of a single-output Linear over a D-layout activation of n features
+void pack_rowtab(std::vector<float>& out, const float* w, int n) {
+  for (int h = 0; h < 2; ++h)
+    for (int k = 0; k < n / 2; ++k) out.push_back(w[chain_feature(k, h)]);
+}
+
+}  // namespace
+
+// ===================================================================================================================
+// DynibarStatic
+// ===================================================================================================================
+// state-dict order of the tensors handed to dyn_static_net_pack (names as in mlp_network.py:319-421)
+enum {
+  ST_RAYDIR0_W, ST_RAYDIR0_B, ST_RAYDIR2_W, ST_RAYDIR2_B, ST_REFFEAT_W, ST_REFFEAT_B, ST_BASE0_W, ST_BASE0_B, ST_BASE2_W, ST_BASE2_B,
+  ST_VIS0_W, ST_VIS0_B, ST_VIS2_W, ST_VIS2_B, ST_VISB0_W, ST_VISB0_B, ST_VISB2_W, ST_VISB2_B, ST_GEO0_W, ST_GEO0_B, ST_GEO2_W,
+  ST_GEO2_B, ST_WQ, ST_WK, ST_WV, ST_FC, ST_LN_G, ST_LN_B, ST_OG0_W, ST_OG0_B, ST_OG2_W, ST_OG2_B, ST_RGB0_W, ST_RGB0_B,
+  ST_RGB2_W, ST_RGB2_B, ST_RGB4_W, ST_RGB4_B, ST_S, ST_NUM_TENSORS
+};
+
+// k-step counts / tiles of every layer (shared by the packer and the kernels)
+#define SA_L1_STEPS 52   /* ray_dir_fc.0: 45 cos|sin pairs + 7 raw pairs (13 raw inputs + bias) */
+#define SA_L2_STEPS 129  /* ray_dir_fc.2: 256 + bias */
+#define SA_NX 37         /* registers holding the 70-channel per-view feature (18 gathered + 16 + 3 computed) */
+#define SA_L3_STEPS (3 * SA_NX + 1)
+#define SA_L4_STEPS 129
+#define SA_L5_STEPS 65
+constexpr int SA_CHUNKS = dyn_layer_chunks(8, SA_L1_STEPS) + dyn_layer_chunks(2, SA_L2_STEPS) + dyn_layer_chunks(8, SA_L3_STEPS) +
+                          dyn_layer_chunks(4, SA_L4_STEPS) + 3 * dyn_layer_chunks(4, SA_L5_STEPS);
+constexpr int SB_CHUNKS = dyn_layer_chunks(8, 129) + dyn_layer_chunks(4, 129) + 4 * dyn_layer_chunks(4, 64) + 2 * dyn_layer_chunks(4, 65);
+#define SC_L11_STEPS 67
+constexpr int SC_CHUNKS = dyn_layer_chunks(4, SC_L11_STEPS) + dyn_layer_chunks(2, 65);
+// constant tables (floats): A: vis row [2][64] @0, vis_fc2.2 row [2][64] @128, b_vis @256, b_vis2 @257, |s| @258
+#define SA_CT 272
+// B: ln gamma [2][64], ln beta [2][64], out_geometry_fc.2 row [2][64], its bias
+#define SB_CT 400
+// C: rgb_fc.4 row [2][32], bias
+#define SC_CT 80
+constexpr size_t ST_OFF_A = 0;
+constexpr size_t ST_OFF_B = ST_OFF_A + (size_t)SA_CHUNKS * DYN_CHUNK;
+constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * DYN_CHUNK;
+constexpr size_t ST_OFF_CTA = ST_OFF_C + (size_t)SC_CHUNKS * DYN_CHUNK;
+constexpr size_t ST_OFF_CTB = ST_OFF_CTA + SA_CT;
+constexpr size_t ST_OFF_CTC = ST_OFF_CTB + SB_CT;
+constexpr size_t ST_OFF_REF = ST_OFF_CTC + SC_CT;  // ref_feature_fc.0: [35][66] then [35]
+constexpr size_t ST_BLOB_FLOATS = ST_OFF_REF + 35 * 66 + 36;
+
+// channel (0..69, or -1) of the 70-wide per-view feature held by register q of a lane of half h
+__host__ __device__ constexpr int sa_c70(int q, int h) {
+  if (q < 18) return h == 0 ? q : (q < 17 ? 18 + q : -1);
+  if (q < 34) return 35 + dyn_fi(q - 18, h);
+  return h == 0 ? 35 + 32 + (q - 34) : -1;
+}
+
+// reference column of ray_dir_fc.0's input for k-step s, half h  (-1: unused, -2: bias)
+static int sa_l1_col(int s, int h) {
+  if (s < 45) {
+    const int c = s / 5, fi = s % 5;  // coordinate 0..8 (pts xyz, Pluecker 6), frequency index
+    if (c < 3) return 3 + (h * 5 + fi) * 3 + c;
+    return 33 + 6 + (h * 5 + fi) * 6 + (c - 3);
+  }
+  const int k = (s - 45) * 2 + h;  // raw list: pts(3), Pluecker(6), ray_diff(4), ONE
+  if (k < 3) return k;
+  if (k < 9) return 33 + (k - 3);
+  if (k < 13) return 99 + (k - 9);
+  return -2;
+}
+
+extern "C" size_t dyn_static_net_blob_floats(void) { return ST_BLOB_FLOATS; }
+
+extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, size_t blob_floats) {
+  DYN_REQUIRE(T && blob, "dyn_static_net_pack: null pointer");
+  DYN_REQUIRE(F == 32, "dyn_static_net_pack: the kernels are specialised for 32 feature channels (coarse_feat_dim = fine_feat_dim = 32)");
+  DYN_REQUIRE(blob_floats >= ST_BLOB_FLOATS, "dyn_static_net_pack: blob too small");
+  for (int i = 0; i < ST_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_static_net_pack: tensor %d is NULL", i);
+  std::vector<float> o;
+  o.reserve(ST_BLOB_FLOATS);
+  // ---- A ----
+  {
+    const float *W = T[ST_RAYDIR0_W], *b = T[ST_RAYDIR0_B];
+    pack_layer(o, 8, SA_L1_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i, c = sa_l1_col(s, h);
+      return c >= 0 ? W[n * 103 + c] : (c == -2 ? b[n] : 0.f);
+    });
+  }
+  pack_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], T[ST_RAYDIR2_B], 35, 256, 256));
+  {
+    const float *W = T[ST_BASE0_W], *b = T[ST_BASE0_B];
+    pack_layer(o, 8, SA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s == 3 * SA_NX) return h == 0 ? b[n] : 0.f;
+      const int part = s / SA_NX, c = sa_c70(s % SA_NX, h);
+      if (c < 0) return 0.f;
+      return W[n * 210 + (part == 0 ? 140 : (part == 1 ? 0 : 70)) + c];  // x | mean | var   (mlp_network.py:477-481)
+    });
+  }
+  pack_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], T[ST_BASE2_B], 128, 256, 256));
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], T[ST_VIS0_B], 128, 128, 128));
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], T[ST_VIS2_B], 128, 128, 128));  // rows 0..127 = x_res
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], T[ST_VISB0_B], 128, 128, 128));
+  DYN_REQUIRE(o.size() == ST_OFF_B, "static pack: A stream size mismatch");
+  // ---- B ----
+  {
+    const float *W = T[ST_GEO0_W], *b = T[ST_GEO0_B];
+    pack_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];  // mean | var
+      return h == 0 ? W[n * 257 + 256] : b[n];                                          // mean of the weights | bias
+    });
+  }
+  pack_layer(o, 4, 129, chained(T[ST_GEO2_W], T[ST_GEO2_B], 128, 256, 256));
+  pack_layer(o, 4, 64, chained(T[ST_WQ], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[ST_WK], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[ST_WV], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[ST_FC], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 65, chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128));
+  pack_layer(o, 4, 65, chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261));  // columns 0..127 = globalfeat part
+  DYN_REQUIRE(o.size() == ST_OFF_C, "static pack: B stream size mismatch");
+  // ---- C ----
+  {
+    const float* W = T[ST_RGB0_W];
+    pack_layer(o, 4, SC_L11_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < 64) return W[n * 261 + 128 + chain_feature(s, h)];
+      const int k = (s - 64) * 2 + h;  // vis, ray_diff[0..3]
+      return k < 5 ? W[n * 261 + 256 + k] : 0.f;
+    });
+  }
+  pack_layer(o, 2, 65, chained(T[ST_RGB2_W], T[ST_RGB2_B], 64, 128, 128));
+  DYN_REQUIRE(o.size() == ST_OFF_CTA, "static pack: C stream size mismatch");
+  // ---- constant tables ----
+  pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128);
+  pack_rowtab(o, T[ST_VISB2_W], 128);
+  o.push_back(T[ST_VIS2_B][128]);
+  o.push_back(T[ST_VISB2_B][0]);
+  o.push_back(fabsf(T[ST_S][0]));
+  o.resize(ST_OFF_CTB, 0.f);
+  pack_rowtab(o, T[ST_LN_G], 128);
+  pack_rowtab(o, T[ST_LN_B], 128);
+  pack_rowtab(o, T[ST_OG2_W], 128);
+  o.push_back(T[ST_OG2_B][0]);
+  o.resize(ST_OFF_CTC, 0.f);
+  pack_rowtab(o, T[ST_RGB4_W], 64);
+  o.push_back(T[ST_RGB4_B][0]);
+  o.resize(ST_OFF_REF, 0.f);
+  for (int i = 0; i < 35 * 66; ++i) o.push_back(T[ST_REFFEAT_W][i]);
+  for (int i = 0; i < 35; ++i) o.push_back(T[ST_REFFEAT_B][i]);
+  o.resize(ST_BLOB_FLOATS, 0.f);
+  for (size_t i = 0; i < ST_BLOB_FLOATS; ++i) blob[i] = o[i];
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// workspace layout (floats) of one dyn_static_net call
+// -------------------------------------------------------------------------------------------------------------------
+struct StaticWs {
+  long n_pts, n_tiles_a, n_tiles_b;
+  int PT, TPR;  // points per A tile; B tiles per ray (power of two)
+  size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;
+};
+#define SB_GIN_LD 132  // per (point, half): 64 mean, 64 var, [mean weight | 1], pad
+
+static StaticWs static_ws(int R, int S, int V) {
+  StaticWs w;
+  w.n_pts = (long)R * S;
+  w.PT = 32 / V;
+  w.n_tiles_a = (w.n_pts + w.PT - 1) / w.PT;
+  int tpr = (S + 31) / 32;
+  w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : 4);
+  w.n_tiles_b = (long)R * w.TPR;
+  size_t o = 0;
+  w.off_x = o; o += (size_t)w.n_tiles_a * 64 * 64;
+  w.off_vis = o; o += (size_t)w.n_tiles_a * 64;
+  w.off_gin = o; o += (size_t)w.n_pts * 2 * SB_GIN_LD;
+  w.off_nvalid = o; o += (size_t)((w.n_pts + 3) & ~3L);
+  w.off_hg = o; o += (size_t)w.n_pts * 128;
+  w.off_ref = o; o += (size_t)R * 36;
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t dyn_static_net_workspace_bytes(int R, int S, int V) {
+  if (R <= 0 || S <= 0 || V <= 0 || V > 32) return 0;
+  return static_ws(R, S, V).total * sizeof(float);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Fourier features, Pluecker coordinates
+// -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unit3(float x, float y, float z, float& ox, float& oy, float& oz) {
+  const float d = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);  // F.normalize(eps=1e-12)
+  ox = x / d; oy = y / d; oz = z / d;
+}
+
+// ref_feature_fc.0(PE(ref Pluecker)) per ray (mlp_network.py:434,456; render_ray.py:372-377): [R,36]
+__global__ void k_static_ref_feat(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ Wref, int R,
+                                  float* __restrict__ ref_feat) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * 36) return;
+  const int r = idx / 36, ch = idx % 36;
+  if (ch == 35) { ref_feat[idx] = 0.f; return; }
+  float d[3], c[6];
+  unit3(ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2], d[0], d[1], d[2]);
+  const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+  c[0] = d[0]; c[1] = d[1]; c[2] = d[2];
+  c[3] = oy * d[2] - oz * d[1];
+  c[4] = oz * d[0] - ox * d[2];
+  c[5] = ox * d[1] - oy * d[0];
+  const float* w = Wref + ch * 66;
+  float acc = Wref[35 * 66 + ch];
+  for (int k = 0; k < 6; ++k) acc = fmaf(w[k], c[k], acc);
+  for (int fn = 0; fn < 2; ++fn)
+    for (int f = 0; f < 5; ++f)
+      for (int k = 0; k < 6; ++k) {
+        const float a = (float)(1 << f) * c[k];
+        acc = fmaf(w[6 + (fn * 5 + f) * 6 + k], fn == 0 ? cosf(a) : sinf(a), acc);
+      }
+  ref_feat[idx] = acc;
+}
+
+struct StaticArgs {
+  int R, S, V, PT, TPR;
+  int anti_alias, mask_rgb;
+  long n_pts, n_tiles_a, n_tiles_b;
+  const float* blob;
+  const float* pts;       // [R,S,3]
+  const float* rgb_feat;  // [R,S,V,35]
+  const float* ray_diff;  // [R,S,V,4]
+  const float* mask;      // [R,S,V]
+  const float* centers;   // [V,16]: source camera centre at [12..14]
+  float* raw;             // [R,S,4]
+  float* ws;
+  StaticWs o;
+};
+
+// ===================================================================================================================
+// A: per point-view chain
+// ===================================================================================================================
+template <int VSEG>
+__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs p) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* ctab = lds + 2 * DYN_CHUNK;  // [SA_CT]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
+  WeightRing ring;
+  ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
+
+  const int V = p.V;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
+  const int view = j - p_local * V;
+  const long point = tile * p.PT + p_local;
+  const bool valid = (p_local < p.PT) && (point < p.n_pts);
+  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const long pv = valid ? point * V + view : 0;
+
+  // ---- gather the lane's inputs ----
+  float msk = valid ? p.mask[pv] : 0.f;
+  float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float px = 0.f, py = 0.f, pz = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  if (valid) {
+    px = p.pts[point * 3]; py = p.pts[point * 3 + 1]; pz = p.pts[point * 3 + 2];
+    cx = p.centers[view * 16 + 12]; cy = p.centers[view * 16 + 13]; cz = p.centers[view * 16 + 14];
+  }
+  float xin[SA_NX];
+#pragma unroll
+  for (int q = 0; q < 18; ++q) {
+    const int ch = h == 0 ? q : 18 + q;
+    xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] : 0.f;
+  }
+
+  f32x16 a1[8];
+  {
+    // Pluecker coordinates of the source ray through the sample (render_ray.py:380-396)
+    float c9[9];
+    c9[0] = px; c9[1] = py; c9[2] = pz;
+    unit3(px - cx, py - cy, pz - cz, c9[3], c9[4], c9[5]);
+    c9[6] = cy * c9[5] - cz * c9[4];
+    c9[7] = cz * c9[3] - cx * c9[5];
+    c9[8] = cx * c9[4] - cy * c9[3];
+    float in1[SA_L1_STEPS];
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+#pragma unroll
+      for (int f = 0; f < 5; ++f) {
+        float sn, cs;
+        sincosf((float)(1 << f) * c9[c], &sn, &cs);
+        in1[c * 5 + f] = h == 0 ? cs : sn;
+      }
+    const float raw[14] = {c9[0], c9[1], c9[2], c9[3], c9[4], c9[5], c9[6], c9[7], c9[8], rd.x, rd.y, rd.z, rd.w, 1.0f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) in1[45 + k] = h == 0 ? raw[2 * k] : raw[2 * k + 1];
+    acc_zero(a1);
+    mlp_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
+    acc_elu(a1);
+  }
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  {
+    f32x16 a2[2];
+    acc_zero(a2);
+    mlp_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    const float* rf = p.ws + p.o.off_ref + (valid ? (point / p.S) * 36 : 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xin[18 + r] = a2[0][r] * rf[dyn_fi(r, h)];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) xin[34 + r] = h == 0 ? a2[1][r] * rf[32 + r] : 0.f;
+  }
+  if (p.mask_rgb) {
+    const float s3 = (xin[0] + xin[1]) + xin[2];  // the colour channels live in the h = 0 lanes
+    msk *= (__shfl(s3, j) > 1e-3f) ? 1.0f : 0.0f;
+  }
+  // ---- pooling weights (mlp_network.py:462-471) ----
+  float wgt;
+  if (p.anti_alias) {
+    const float e = expf(ctab[258] * (rd.w - 1.0f));
+    wgt = (e - seg_min<VSEG>(e, V, seg_base)) * msk;
+  } else {
+    wgt = msk;
+  }
+  wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
+
+  f32x16 x[4];
+  {
+    acc_zero(a1);  // reuse as base_fc.0 accumulators
+    // k-steps: the 70 channels, their weighted means over the views, their weighted variances (recomputing a mean costs
+    // three cross-lane adds, keeping 37 of them live would spill)
+    mlp_layer<8, SA_L3_STEPS>(ring, a1, [&](int s) {
+      if (s < SA_NX) return xin[s];
+      if (s < 2 * SA_NX) return seg_sum<VSEG>(xin[s - SA_NX] * wgt, V, seg_base);
+      if (s < 3 * SA_NX) {
+        const float m = seg_sum<VSEG>(xin[s - 2 * SA_NX] * wgt, V, seg_base);
+        const float d = xin[s - 2 * SA_NX] - m;
+        return seg_sum<VSEG>(wgt * (d * d), V, seg_base);
+      }
+      return one_h0;
+    });
+    acc_elu(a1);
+    acc_zero(x);
+    mlp_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    acc_elu(x);
+  }
+  float vis;
+  {
+    f32x16 a5[4], a6[4];
+    acc_zero(a5);
+    mlp_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
+    acc_elu(a5);
+    acc_zero(a6);
+    mlp_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
+    vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[t][r] += elu1(a6[t][r]);
+  }
+  float vis2;
+  {
+    f32x16 a7[4];
+    acc_zero(a7);
+    mlp_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
+    acc_elu(a7);
+    vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
+  }
+  // ---- outputs: x and vis2 in lane order, visibility-weighted statistics per point ----
+  const bool tile_ok = tile < p.n_tiles_a;
+  if (tile_ok) {
+    float4* xw = reinterpret_cast<float4*>(p.ws + p.o.off_x) + tile * 16 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xw[(t * 4 + q) * 64] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
+    p.ws[p.o.off_vis + tile * 64 + lane] = vis2;
+  }
+  const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
+  const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
+  const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
+  float* gin = p.ws + p.o.off_gin + (valid ? (point * 2 + h) * SB_GIN_LD : 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m[4], vv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        m[e] = seg_sum<VSEG>(x[t][q * 4 + e] * w2, V, seg_base);
+        const float d = x[t][q * 4 + e] - m[e];
+        vv[e] = seg_sum<VSEG>(w2 * (d * d), V, seg_base);
+      }
+      const int g = t * 4 + q;
+      const bool mine = valid && (VSEG > 0 ? (view == (g & (VSEG - 1))) : (view == 0));
+      if (mine) {
+        reinterpret_cast<float4*>(gin)[g] = make_float4(m[0], m[1], m[2], m[3]);
+        reinterpret_cast<float4*>(gin + 64)[g] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    }
+  if (valid && view == 0) {
+    gin[128] = h == 0 ? wmean : 1.0f;
+    if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
+  }
+}
+
+// ===================================================================================================================
+// B: per point chain with the ray attention
+// ===================================================================================================================
+#define SB_KL_FLOATS 4096         // K of one head, lane-native: [4 tiles][4][64 lanes][4]
+#define SB_VL_LD 132              // V of one head: [32 features][128 points + pad]
+#define SB_VL_FLOATS (32 * SB_VL_LD)
+
+__global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_static_points(StaticArgs p) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* ctab = lds + 2 * DYN_CHUNK;  // [SB_CT]
+  float* Kl = ctab + SB_CT;
+  float* Vl = Kl + SB_KL_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  for (int i = tid; i < SB_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[ST_OFF_CTB + i];
+  WeightRing ring;
+  ring_init(ring, p.blob + ST_OFF_B, SB_CHUNKS, lds);
+
+  const int TPR = p.TPR;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const long ray = tile / TPR;
+  const int kt_self = (int)(tile - ray * TPR);
+  const int smp = kt_self * 32 + j;
+  const bool valid = (ray < p.R) && (smp < p.S);
+  const long point = valid ? ray * p.S + smp : 0;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  const float nvalid = valid ? p.ws[p.o.off_nvalid + point] : 0.f;
+
+  f32x16 g[4];
+  {
+    f32x16 a9[8];
+    {
+      float gin[129];
+      const float4* src = reinterpret_cast<const float4*>(p.ws + p.o.off_gin + (point * 2 + h) * SB_GIN_LD);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const float4 v = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gin[i * 4] = v.x; gin[i * 4 + 1] = v.y; gin[i * 4 + 2] = v.z; gin[i * 4 + 3] = v.w;
+      }
+      gin[128] = valid ? reinterpret_cast<const float*>(src)[128] : (h == 1 ? 1.0f : 0.f);
+      acc_zero(a9);
+      mlp_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
+      acc_elu(a9);
+    }
+    acc_zero(g);
+    mlp_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? a9[s / 16][s % 16] : one_h0; });
+    acc_elu(g);
+  }
+  // ---- multi-head self-attention over the samples of the ray (mlp_network.py:13-31, 56-104) ----
+  f32x16 att[4];
+  {
+    f32x16 qh[4], kh[4], vh[4];
+    acc_zero(qh); acc_zero(kh); acc_zero(vh);
+    mlp_layer<4, 64>(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
+    mlp_layer<4, 64>(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
+    mlp_layer<4, 64>(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
+    const float inv_temp = 1.0f / 5.656854249492381f;  // d_k ** 0.5
+    const bool q_ok = nvalid > 1.0f;                    // mask = (num_valid_obs > 1), applied along the query axis
+    const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      __syncthreads();  // the previous head's K/V images are no longer read
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        reinterpret_cast<float4*>(Kl)[(wave * 4 + q) * 64 + lane] =
+            make_float4(kh[hd][q * 4], kh[hd][q * 4 + 1], kh[hd][q * 4 + 2], kh[hd][q * 4 + 3]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Vl[dyn_fi(r, h) * SB_VL_LD + wave * 32 + j] = vh[hd][r];
+      __syncthreads();
+      f32x16 sc[4];
+      acc_zero(sc);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 a = reinterpret_cast<const float4*>(Kl)[((wave0 + kt) * 4 + q) * 64 + lane];
+            sc[kt] = mfma32(a.x, qh[hd][q * 4 + 0] * inv_temp, sc[kt]);
+            sc[kt] = mfma32(a.y, qh[hd][q * 4 + 1] * inv_temp, sc[kt]);
+            sc[kt] = mfma32(a.z, qh[hd][q * 4 + 2] * inv_temp, sc[kt]);
+            sc[kt] = mfma32(a.w, qh[hd][q * 4 + 3] * inv_temp, sc[kt]);
+          }
+        }
+      // softmax over the keys; register r of half h is key kt*32 + fi(r,h)
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool key_ok = (kt < TPR) && (kt * 32 + dyn_fi(r, h) < p.S);
+          float v = q_ok ? sc[kt][r] : -1e9f;
+          v = key_ok ? v : -3.0e38f;
+          sc[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
+          sc[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      f32x16 oh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oh[r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(Vl + j * SB_VL_LD + (wave0 + kt) * 32 + 8 * q + 4 * h);
+            oh = mfma32(a.x, sc[kt][q * 4 + 0] * inv, oh);
+            oh = mfma32(a.y, sc[kt][q * 4 + 1] * inv, oh);
+            oh = mfma32(a.z, sc[kt][q * 4 + 2] * inv, oh);
+            oh = mfma32(a.w, sc[kt][q * 4 + 3] * inv, oh);
+          }
+        }
+      att[hd] = oh;
+    }
+  }
+  {
+    f32x16 o[4];
+    acc_zero(o);
+    mlp_layer<4, 64>(ring, o, [&](int s) { return att[s / 16][s % 16]; });
+    // residual + LayerNorm(eps = 1e-6) over the 128 features (64 here, 64 in the other half's lane)
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[t][r] += g[t][r];
+        s1 += o[t][r];
+      }
+    s1 += __shfl_xor(s1, 32);
+    const float mu = s1 * (1.0f / 128.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = o[t][r] - mu;
+        s2 += d * d;
+      }
+    s2 += __shfl_xor(s2, 32);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 128.0f) + 1e-6f);
+    const float* gam = ctab + h * 64;
+    const float* bet = ctab + 128 + h * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = (o[t][r] - mu) * rstd * gam[t * 16 + r] + bet[t * 16 + r];
+  }
+  {
+    f32x16 a[4];
+    acc_zero(a);
+    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    acc_elu(a);
+    float sigma = row_dot<4>(a, ctab + 256) + ctab[384];
+    if (nvalid < 1.0f) sigma = -1e9f;
+    if (valid && h == 0) p.raw[point * 4 + 3] = sigma;
+    acc_zero(a);
+    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    if (valid) {
+      float4* dst = reinterpret_cast<float4*>(p.ws + p.o.off_hg + (point * 2 + h) * 64);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[t * 4 + q] = make_float4(a[t][q * 4], a[t][q * 4 + 1], a[t][q * 4 + 2], a[t][q * 4 + 3]);
+    }
+  }
+}
+
+// ===================================================================================================================
+// C: rgb_fc over [globalfeat | x | vis | ray_diff], masked softmax over the views, colour blend
+// ===================================================================================================================
+template <int VSEG>
+__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs p) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* ctab = lds + 2 * DYN_CHUNK;  // [SC_CT]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  if (tid < SC_CT) ctab[tid] = p.blob[ST_OFF_CTC + tid];
+  WeightRing ring;
+  ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
+
+  const int V = p.V;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const bool tile_ok = tile < p.n_tiles_a;
+  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
+  const int view = j - p_local * V;
+  const long point = tile * p.PT + p_local;
+  const bool valid = (p_local < p.PT) && (point < p.n_pts);
+  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const long pv = valid ? point * V + view : 0;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+
+  const float msk = valid ? p.mask[pv] : 0.f;
+  const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float vis2 = tile_ok ? p.ws[p.o.off_vis + tile * 64 + lane] : 0.f;
+  float rgb_in[3] = {0.f, 0.f, 0.f};
+  if (valid) {
+    rgb_in[0] = p.rgb_feat[pv * 35]; rgb_in[1] = p.rgb_feat[pv * 35 + 1]; rgb_in[2] = p.rgb_feat[pv * 35 + 2];
+  }
+  f32x16 a[4];
+  {
+    f32x16 x[4];
+    const float4* xw = reinterpret_cast<const float4*>(p.ws + p.o.off_x) + (tile_ok ? tile : 0) * 16 * 64 + lane;
+    const float4* hg = reinterpret_cast<const float4*>(p.ws + p.o.off_hg + (point * 2 + h) * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = tile_ok ? xw[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
+        const float4 b = valid ? hg[t * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
+      }
+    const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
+    mlp_layer<4, SC_L11_STEPS>(ring, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
+    acc_elu(a);
+  }
+  f32x16 b2[2];
+  acc_zero(b2);
+  mlp_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+  acc_elu(b2);
+  float logit = row_dot<2>(b2, ctab) + ctab[64];
+  if (msk == 0.f) logit = -1e9f;
+  const float mx = seg_max<VSEG>(logit, V, seg_base);
+  const float e = __expf(logit - mx);
+  const float bw = e / seg_sum<VSEG>(e, V, seg_base);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = seg_sum<VSEG>(rgb_in[c] * bw, V, seg_base);
+    if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
+  DYN_REQUIRE(q, "dyn_static_net: null params");
+  DYN_REQUIRE(q->R > 0 && q->S > 0 && q->V > 0, "dyn_static_net: empty problem");
+  DYN_REQUIRE(q->V <= 32, "dyn_static_net: at most 32 source views");
+  DYN_REQUIRE(q->S <= 128, "dyn_static_net: at most 128 samples per ray (the ray attention keeps one ray's keys in LDS)");
+  DYN_REQUIRE(q->blob && q->ray_o && q->ray_d && q->pts && q->rgb_feat && q->ray_diff && q->mask && q->centers && q->raw && q->workspace,
+              "dyn_static_net: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  StaticArgs a;
+  a.R = q->R; a.S = q->S; a.V = q->V;
+  a.o = static_ws(q->R, q->S, q->V);
+  DYN_REQUIRE(q->workspace_bytes >= a.o.total * sizeof(float), "dyn_static_net: workspace too small (%zu < %zu bytes)", q->workspace_bytes,
+              a.o.total * sizeof(float));
+  a.PT = a.o.PT; a.TPR = a.o.TPR;
+  a.anti_alias = q->anti_alias_pooling; a.mask_rgb = q->mask_rgb;
+  a.n_pts = a.o.n_pts; a.n_tiles_a = a.o.n_tiles_a; a.n_tiles_b = a.o.n_tiles_b;
+  a.blob = q->blob; a.pts = q->pts; a.rgb_feat = q->rgb_feat; a.ray_diff = q->ray_diff; a.mask = q->mask; a.centers = q->centers;
+  a.raw = q->raw; a.ws = (float*)q->workspace;
+
+  DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
+             q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
+  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
+  const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_b = (2 * DYN_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  const size_t lds_c = (2 * DYN_CHUNK + SC_CT) * sizeof(float);
+  if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
+  else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk, lds_a, stream, a);
+  DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_static_points, grid_b, blk, lds_b, stream, a);
+  if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk, lds_c, stream, a);
+  else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk, lds_c, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<0>, grid_a, blk, lds_c, stream, a);
+  return 0;
+}
+
+// ===================================================================================================================
+// engine self-test: y = elu(W x + b) for one Linear 64 -> 64, through pack_layer / the weight ring / mlp_layer
+// ===================================================================================================================
+__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_selftest(const float* __restrict__ stream, const float* __restrict__ x, float* __restrict__ y,
+                                                                  int rows) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  WeightRing ring;
+  ring_init(ring, stream, 2 * dyn_layer_chunks(2, 33), lds);
+  const int row = (blockIdx.x * 4 + wave) * 32 + j;
+  f32x16 in[2];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) in[s / 16][s % 16] = row < rows ? x[row * 64 + 32 * (s / 16) + dyn_fi(s % 16, h)] : 0.f;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {  // two chained applications of the same layer
+    f32x16 acc[2];
+    acc_zero(acc);
+    mlp_layer<2, 33>(ring, acc, [&](int s) { return s < 32 ? in[s / 16][s % 16] : one_h0; });
+    acc_elu(acc);
+    in[0] = acc[0];
+    in[1] = acc[1];
+  }
+  if (row < rows)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) y[row * 64 + 32 * (s / 16) + dyn_fi(s % 16, h)] = in[s / 16][s % 16];
+}
+
+extern "C" int dyn_mlp_selftest(const float* W, const float* b, const float* x, float* y, int rows, float* stream_buf, void* stream) {
+  // W [64,64], b [64]: HOST; x [rows,64], y [rows,64], stream_buf [2 * chunks * 4096]: DEVICE (stream_buf is filled here via hipMemcpy)
+  DYN_REQUIRE(W && b && x && y && stream_buf && rows > 0, "dyn_mlp_selftest: bad argument");
+  std::vector<float> o;
+  pack_layer(o, 2, 33, chained(W, b, 64, 64, 64));
+  pack_layer(o, 2, 33, chained(W, b, 64, 64, 64));
+  if (hipMemcpy(stream_buf, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    dyn_set_error("dyn_mlp_selftest: hipMemcpy failed");
+    return DYN_E_LAUNCH;
+  }
+  DYN_LAUNCH(DYN_K_SELFTEST, "k_selftest", k_selftest, dim3(dyn_cdiv(rows, 128)), dim3(DYN_NET_THREADS), 2 * DYN_CHUNK * sizeof(float),
+             (hipStream_t)stream, stream_buf, x, y, rows);
+  return 0;
+}

@@ -21,6 +21,22 @@ def _f32c(t):
   return t if t.is_contiguous() else t.contiguous()
 
 
+class _Keep:
+  """Converts call arguments to contiguous fp32 and keeps the converted tensors alive until the launch has been enqueued
+  (a temporary made by .float()/.contiguous() must outlive the pointer taken from it)."""
+
+  def __init__(self):
+    self.held = []
+
+  def __call__(self, t, dtype=torch.float32):
+    if t is None:
+      return None
+    if dtype == torch.float32:
+      t = _f32c(t)
+    self.held.append(t)
+    return ptr(t, dtype)
+
+
 class SourceViews:
   """Per-target-view prepared source data for one branch: projection matrices, camera centres, channels-last maps.
 
@@ -51,6 +67,7 @@ class SourceViews:
 
 def sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand=None, want_pts=True, want_s=True):
   """k_sample_along_ray.  depth_range: device tensor [1,2].  -> pts [R,S,3] | None, z_vals [R,S], s_vals [R,S] | None"""
+  k = _Keep()
   ray_o, ray_d = _f32c(ray_o), _f32c(ray_d)
   R = ray_o.shape[0]
   dev = ray_o.device
@@ -59,7 +76,7 @@ def sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand=N
   pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev) if want_pts else None
   dr = _f32c(depth_range.reshape(-1))
   p = params('DynSampleParams', R=R, S=N_samples, inv_uniform=int(bool(inv_uniform)), ray_o=ptr(ray_o), ray_d=ptr(ray_d),
-             depth_range=ptr(dr), t_rand=ptr(_f32c(t_rand)), z_vals=ptr(z), s_vals=ptr(s), pts=ptr(pts))
+             depth_range=ptr(dr), t_rand=k(t_rand), z_vals=ptr(z), s_vals=ptr(s), pts=ptr(pts))
   call('dyn_sample_along_ray', ctypes.byref(p), stream_of(ray_o))
   return pts, z, s
 
@@ -76,14 +93,15 @@ def points_from_z(ray_o, ray_d, z_vals, depth_range=None, want_pts=True):
 
 def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None):
   """k_project_gather -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]."""
+  k = _Keep()
   dev = views.proj.device
   V, C = views.V, 3 + views.F
   rgb_feat = torch.empty((R, S, V, C), dtype=torch.float32, device=dev)
   ray_diff = torch.empty((R, S, V, 4), dtype=torch.float32, device=dev)
   mask = torch.empty((R, S, V, 1), dtype=torch.float32, device=dev)
   p = params('DynProjectGatherParams', R=R, S=S, V=V, H=views.H, W=views.W, Hf=views.Hf, Wf=views.Wf, F=views.F,
-             img_h=views.img_h, img_w=views.img_w, ray_o=ptr(_f32c(ray_o)), ray_d=ptr(_f32c(ray_d)), z_vals=ptr(_f32c(z_vals)),
-             pts_st=ptr(_f32c(pts_st)), xyz=ptr(_f32c(xyz)), proj=ptr(views.proj), query_center=ptr(views.query_center),
+             img_h=views.img_h, img_w=views.img_w, ray_o=k(ray_o), ray_d=k(ray_d), z_vals=k(z_vals),
+             pts_st=k(pts_st), xyz=k(xyz), proj=ptr(views.proj), query_center=ptr(views.query_center),
              src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask))
   call('dyn_project_gather', ctypes.byref(p), stream_of(rgb_feat))
   return rgb_feat, ray_diff, mask
@@ -99,6 +117,7 @@ def sample_mask(mask, thresh):
 
 def composite(raw_dy, z_vals, pix_mask_dy, raw_static=None, pix_mask_st=None, per_sample=True):
   """k_composite -> dict of tensors with the reference's key set (render_ray.py:202-211 / 316-328)."""
+  k = _Keep()
   raw_dy, z_vals = _f32c(raw_dy), _f32c(z_vals)
   R, S = z_vals.shape
   dev = z_vals.device
@@ -111,8 +130,8 @@ def composite(raw_dy, z_vals, pix_mask_dy, raw_static=None, pix_mask_st=None, pe
   a_dy = new(R, S) if two and per_sample else None
   w_dy = new(R, S) if two and per_sample else None
   w_st = new(R, S) if two and per_sample else None
-  p = params('DynCompositeParams', R=R, S=S, raw_dy=ptr(raw_dy), raw_static=ptr(_f32c(raw_static)), z_vals=ptr(z_vals),
-             pix_mask_dy=ptr(_f32c(pix_mask_dy)), pix_mask_st=ptr(_f32c(pix_mask_st)), rgb=ptr(rgb), rgb_static=ptr(rgb_st),
+  p = params('DynCompositeParams', R=R, S=S, raw_dy=ptr(raw_dy), raw_static=k(raw_static), z_vals=ptr(z_vals),
+             pix_mask_dy=k(pix_mask_dy), pix_mask_st=k(pix_mask_st), rgb=ptr(rgb), rgb_static=ptr(rgb_st),
              rgb_dy=ptr(rgb_dy), depth=ptr(depth), ray_mask=ptr(rmask), weights=ptr(weights), alpha=ptr(alpha),
              alpha_dy=ptr(a_dy), weights_dy=ptr(w_dy), weights_st=ptr(w_st))
   call('dyn_composite', ctypes.byref(p), stream_of(z_vals))
@@ -122,6 +141,7 @@ def composite(raw_dy, z_vals, pix_mask_dy, raw_static=None, pix_mask_st=None, pe
 
 def fine_samples(z_vals, weights, N_importance, inv_uniform, u=None, want_inds=False):
   """k_fine_samples -> z_all [R,S+N] sorted, z_samples [R,N], inds [R,N] int32 | None."""
+  k = _Keep()
   z_vals, weights = _f32c(z_vals), _f32c(weights)
   R, S = z_vals.shape
   dev = z_vals.device
@@ -129,6 +149,70 @@ def fine_samples(z_vals, weights, N_importance, inv_uniform, u=None, want_inds=F
   z_s = torch.empty((R, N_importance), dtype=torch.float32, device=dev)
   inds = torch.empty((R, N_importance), dtype=torch.int32, device=dev) if want_inds else None
   p = params('DynFineSampleParams', R=R, S=S, N=N_importance, inv_uniform=int(bool(inv_uniform)), z_vals=ptr(z_vals),
-             weights=ptr(weights), u=ptr(_f32c(u)), z_out=ptr(z_out), z_samples=ptr(z_s), inds=ptr(inds, torch.int32))
+             weights=ptr(weights), u=k(u), z_out=ptr(z_out), z_samples=ptr(z_s), inds=ptr(inds, torch.int32))
   call('dyn_fine_samples', ctypes.byref(p), stream_of(z_vals))
   return z_out, z_s, inds
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# networks
+# ----------------------------------------------------------------------------------------------------------------------
+STATIC_TENSORS = (
+    'ray_dir_fc.0.weight', 'ray_dir_fc.0.bias', 'ray_dir_fc.2.weight', 'ray_dir_fc.2.bias', 'ref_feature_fc.0.weight',
+    'ref_feature_fc.0.bias', 'base_fc.0.weight', 'base_fc.0.bias', 'base_fc.2.weight', 'base_fc.2.bias', 'vis_fc.0.weight',
+    'vis_fc.0.bias', 'vis_fc.2.weight', 'vis_fc.2.bias', 'vis_fc2.0.weight', 'vis_fc2.0.bias', 'vis_fc2.2.weight', 'vis_fc2.2.bias',
+    'geometry_fc.0.weight', 'geometry_fc.0.bias', 'geometry_fc.2.weight', 'geometry_fc.2.bias', 'ray_attention.w_qs.weight',
+    'ray_attention.w_ks.weight', 'ray_attention.w_vs.weight', 'ray_attention.fc.weight', 'ray_attention.layer_norm.weight',
+    'ray_attention.layer_norm.bias', 'out_geometry_fc.0.weight', 'out_geometry_fc.0.bias', 'out_geometry_fc.2.weight',
+    'out_geometry_fc.2.bias', 'rgb_fc.0.weight', 'rgb_fc.0.bias', 'rgb_fc.2.weight', 'rgb_fc.2.bias', 'rgb_fc.4.weight', 'rgb_fc.4.bias', 's')
+
+
+def _host_f32(t):
+  """state-dict entry (torch tensor on any device, or numpy array) -> contiguous fp32 numpy array on the host."""
+  import numpy as np
+  if isinstance(t, torch.Tensor):
+    t = t.detach().to('cpu', torch.float32).contiguous().numpy()
+  return np.ascontiguousarray(t, dtype=np.float32)
+
+
+def _pack(fn_pack, fn_size, names, state_dict, F):
+  import numpy as np
+  arrs = [_host_f32(state_dict[n]).reshape(-1) for n in names]
+  ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+  n = int(getattr(_lib.lib(), fn_size)())
+  blob = np.zeros(n, dtype=np.float32)
+  call(fn_pack, ptrs, int(F), ctypes.c_void_p(blob.ctypes.data), n)
+  return torch.from_numpy(blob)
+
+
+class StaticNet:
+  """DynibarStatic (mlp_network.py:319-527) as packed MFMA operand tiles on one device.  ``state_dict``: the module's
+  state dict (torch tensors or numpy arrays; a DataParallel 'module.' prefix is accepted)."""
+
+  def __init__(self, state_dict, device, anti_alias_pooling=True, mask_rgb=False, F=32):
+    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+    self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, sd, F).to(device)
+    self.anti_alias_pooling, self.mask_rgb = int(bool(anti_alias_pooling)), int(bool(mask_rgb))
+    self._ws = None
+
+  def workspace(self, R, S, V, device):
+    need = int(_lib.lib().dyn_static_net_workspace_bytes(R, S, V))
+    if need == 0:
+      raise ValueError(f'dyn_static_net: unsupported shape R={R} S={S} V={V}')
+    if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != torch.device(device):
+      self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    return self._ws, need
+
+  def __call__(self, views: SourceViews, ray_o, ray_d, pts, rgb_feat, ray_diff, mask):
+    """-> raw [R,S,4]  (k_static_ref_feat, k_static_views, k_static_points, k_static_blend)."""
+    k = _Keep()
+    R, S, V = rgb_feat.shape[:3]
+    dev = rgb_feat.device
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
+    ws, need = self.workspace(R, S, V, dev)
+    p = params('DynStaticNetParams', R=R, S=S, V=V, anti_alias_pooling=self.anti_alias_pooling, mask_rgb=self.mask_rgb,
+               blob=ptr(self.blob), ray_o=k(ray_o), ray_d=k(ray_d), pts=k(pts), rgb_feat=k(rgb_feat),
+               ray_diff=k(ray_diff), mask=k(mask), centers=ptr(views.proj), raw=ptr(raw), workspace=ptr(ws),
+               workspace_bytes=need)
+    call('dyn_static_net', ctypes.byref(p), stream_of(raw))
+    return raw

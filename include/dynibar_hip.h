@@ -121,6 +121,51 @@ typedef struct {
 } DynFineSampleParams;
 int dyn_fine_samples(const DynFineSampleParams* p, void* stream);
 
+/* ---- a17 DynibarStatic.forward (mlp_network.py:423-527) incl. a12 Pluecker coordinates (render_ray.py:372-396), a13 Fourier
+ * features (:530-555), a18 ray attention (:13-31,:56-104), a19 weighted mean/variance over views (:115-119) ----------------
+ * Weights: dyn_static_net_pack re-lays the module's state dict out as MFMA operand tiles.  `tensors` are HOST pointers to the
+ * row-major fp32 tensors in this order (state-dict names):
+ *   ray_dir_fc.0.weight .0.bias ray_dir_fc.2.weight .2.bias ref_feature_fc.0.weight .0.bias base_fc.0.weight .0.bias base_fc.2.weight
+ *   .2.bias vis_fc.0.weight .0.bias vis_fc.2.weight .2.bias vis_fc2.0.weight .0.bias vis_fc2.2.weight .2.bias geometry_fc.0.weight
+ *   .0.bias geometry_fc.2.weight .2.bias ray_attention.w_qs.weight ray_attention.w_ks.weight ray_attention.w_vs.weight
+ *   ray_attention.fc.weight ray_attention.layer_norm.weight ray_attention.layer_norm.bias out_geometry_fc.0.weight .0.bias
+ *   out_geometry_fc.2.weight .2.bias rgb_fc.0.weight .0.bias rgb_fc.2.weight .2.bias rgb_fc.4.weight .4.bias s
+ * (39 tensors).  F = feature channels of the maps (must be 32).  blob: HOST buffer of dyn_static_net_blob_floats() floats; the
+ * caller copies it to the device once per model. */
+#define DYN_STATIC_NUM_TENSORS 39
+size_t dyn_static_net_blob_floats(void);
+int dyn_static_net_pack(const float* const* tensors, int F, float* blob, size_t blob_floats);
+size_t dyn_static_net_workspace_bytes(int R, int S, int V);
+typedef struct {
+  int R, S, V;               /* rays, samples per ray (<= 128), source views (<= 32) */
+  int anti_alias_pooling;    /* args.anti_alias_pooling (mlp_network.py:462) */
+  int mask_rgb;              /* args.mask_rgb (:457) */
+  const float* blob;         /* DEVICE copy of the packed weights */
+  const float* ray_o;        /* [R,3] */
+  const float* ray_d;        /* [R,3] */
+  const float* pts;          /* [R,S,3] */
+  const float* rgb_feat;     /* [R,S,V,35] from dyn_project_gather */
+  const float* ray_diff;     /* [R,S,V,4] */
+  const float* mask;         /* [R,S,V] */
+  const float* centers;      /* [V,16]: the proj array of dyn_prepare_cameras (source camera centres at [12..14]) */
+  float* raw;                /* [R,S,4] = (r, g, b, sigma) */
+  void* workspace;           /* DEVICE scratch of dyn_static_net_workspace_bytes(R,S,V) bytes */
+  size_t workspace_bytes;
+} DynStaticNetParams;
+int dyn_static_net(const DynStaticNetParams* p, void* stream);
+
+/* ---- self-test of the MFMA chain engine: y = elu(W elu(W x + b) + b), W [64,64], b [64] HOST; x, y [rows,64] DEVICE;
+ * stream_buf: DEVICE scratch of 2 * 3 * 4096 floats ------------------------------------------------------------------- */
+int dyn_mlp_selftest(const float* W, const float* b, const float* x, float* y, int rows, float* stream_buf, void* stream);
+
+/* ---- per-kernel timing: when enabled, every kernel launched by this library is bracketed by HIP events on its launch stream.
+ * dyn_profile_read synchronises the pending events, returns the summed milliseconds and launch counts per kernel slot
+ * (dyn_profile_count() slots, named by dyn_profile_name) and resets the totals.  Not thread-safe; meant for bench.py. ------ */
+int dyn_profile_enable(int on);
+int dyn_profile_count(void);
+const char* dyn_profile_name(int slot);
+int dyn_profile_read(float* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

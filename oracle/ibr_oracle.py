@@ -419,7 +419,9 @@ def dynamic_net(sd, pts_xyz, rgb_feat, glb_ray_dir, ray_diff, time_diff, mask, t
 
 
 def static_net(sd, pts, ref_rays_coords, src_rays_coords, rgb_feat, glb_ray_dir, ray_diff, mask,
-               anti_alias_pooling=True, mask_rgb=False):
+               anti_alias_pooling=True, mask_rgb=False, exp_jitter=None):
+  """exp_jitter (test hook, not in the reference): multiplies exp(|s|(dot-1)) by (1 + jitter) to probe how strongly the
+  anti-alias pooling weights (e - min_v e), a difference of nearly equal numbers, amplify 1-ulp differences of exp()."""
   V = rgb_feat.shape[2]
   ref_pe = periodic_embed(ref_rays_coords, 5, 5, False)
   src_pe = periodic_embed(src_rays_coords, 5, 5, False)
@@ -435,6 +437,8 @@ def static_net(sd, pts, ref_rays_coords, src_rays_coords, rgb_feat, glb_ray_dir,
   if anti_alias_pooling:
     dot = ray_diff[..., 3:4]
     e = torch.exp(torch.abs(sd['s']) * (dot - 1))
+    if exp_jitter is not None:
+      e = e * (1.0 + exp_jitter)
     weight = (e - torch.min(e, dim=2, keepdim=True)[0]) * mask
     weight = weight / (torch.sum(weight, dim=2, keepdim=True) + 1e-8)
   else:

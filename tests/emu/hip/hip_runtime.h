@@ -47,6 +47,13 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+constexpr int hipMemcpyHostToDevice = 1;
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 
@@ -178,6 +185,16 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
   return c;
 }
 
+
+#define __expf(x) expf(x)
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+// global_load_lds: the LDS destination is the wave-uniform base + lane * size (cdna_hip_programming.md section 5)
+static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,
+                                                    int size, int offset, int) {
+  const char* src = (const char*)(uintptr_t)g + offset;
+  char* dst = (char*)(uintptr_t)l + offset + emu::tc.lane * size;
+  memcpy(dst, src, size);
+}
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -179,3 +179,88 @@ def check_fine_samples(device, golden, S=64):
       zs = cpu(z_all)
       assert bool((zs[:, 1:] >= zs[:, :-1]).all()), 'fine depths not sorted'
   return total_mismatch
+
+
+def static_inputs(name, S, R=None):
+  """Oracle-side stage tensors of the static branch for a seeded scene."""
+  scene, o, d, uv, _ = cases.scene_case(name)
+  if R is not None:
+    o, d = o[:R], d[:R]
+  sd = O.tdict(cases.model_weights(0)['net_coarse_st'])
+  out, st = O.static_branch_pass(sd, scene, o, d, S, True, True, True, False, return_stages=True)
+  return scene, o, d, sd, out, st
+
+
+def check_static_net(device, name='small', S=64, R=None, aa=True, mask_rgb=False, atol=1e-4):
+  """DynibarStatic on the oracle's own stage inputs (isolates the network kernels from the gather)."""
+  scene, o, d, sd, _, st = static_inputs(name, S, R)
+  net_args = (sd, st['pts'], st['ref_rays_coords'], st['src_rays_coords'], st['rgb_feat'], F.normalize(d, dim=-1), st['ray_diff'], st['mask'])
+  raw_ref = O.static_net(*net_args, aa, mask_rgb)
+  # Conditioning of the reference itself: its anti-alias pooling weights are (e - min_v e) with e = exp(|s|(dot-1)) ~ 1, so one ulp
+  # of exp() is amplified by 1/(spread of e over the views) (far samples: ~1e3).  `sens` = how far the oracle's own output moves
+  # under +-1 ulp jitter of e; the tolerance is atol + 4 * sens per element (zero jitter sensitivity -> plain atol).
+  sens = torch.zeros_like(raw_ref)
+  if aa:
+    for k in range(3):
+      jit = (torch.randint(0, 3, st['mask'].shape, generator=torch.Generator().manual_seed(50 + k)).float() - 1.0) * 6e-8
+      sens = torch.maximum(sens, (O.static_net(*net_args, aa, mask_rgb, exp_jitter=jit) - raw_ref).abs())
+  sdev = to_dev(scene, device)
+  views = ops.SourceViews(sdev['camera'], sdev['static_src_rgbs'], sdev['static_src_cameras'], sdev['static_featmaps'])
+  net = ops.StaticNet(cases.model_weights(0)['net_coarse_st'], device, aa, mask_rgb)
+  raw = net(views, o.to(device), d.to(device), st['pts'].to(device), st['rgb_feat'].to(device), st['ray_diff'].to(device),
+            st['mask'].to(device))
+  sig, sig_ref = cpu(raw)[..., 3], raw_ref[..., 3]
+  dead = sig_ref < -1e8
+  assert bool((sig[dead] == sig_ref[dead]).all()), 'sigma of points without a valid view must be -1e9'
+  err = (cpu(raw) - raw_ref).abs()
+  lim = atol + 1e-4 * raw_ref.abs() + 4.0 * sens
+  lim[..., 3][dead] = 0.0
+  err[..., 3][dead] = 0.0
+  over = err > lim
+  assert int(over.sum()) == 0, (f'{name} static net: {int(over.sum())}/{err.numel()} outputs beyond atol {atol:.0e} + 4 x jitter sensitivity; '
+                                f'worst excess {float((err - lim).max()):.3e}, max err rgb {float(err[..., :3].max()):.3e} sigma {float(err[..., 3].max()):.3e}')
+  return float(err[..., :3].max()), float(err[..., 3].max()), float(sens.max())
+
+
+def run_static_pass(device, scene_dev, net, o, d, S, inv_uniform=True):
+  """BASELINE config 2 on the HIP path: sample -> project/gather -> DynibarStatic -> composite."""
+  views = ops.SourceViews(scene_dev['camera'], scene_dev['static_src_rgbs'], scene_dev['static_src_cameras'], scene_dev['static_featmaps'])
+  R = o.shape[0]
+  pts, z, s = ops.sample_along_ray(o, d, scene_dev['depth_range'], S, inv_uniform)
+  rgb_feat, ray_diff, mask = ops.project_gather(views, R, S, ray_o=o, ray_d=d, z_vals=z)
+  raw = net(views, o, d, pts, rgb_feat, ray_diff, mask)
+  pm = ops.sample_mask(mask, 1.0)
+  return ops.composite(raw, z, pm), raw
+
+
+def check_static_pass(device, name='small', S=64, R=None, atol=1e-4):
+  scene, o, d, sd, out_ref, st = static_inputs(name, S, R)
+  net = ops.StaticNet(cases.model_weights(0)['net_coarse_st'], device, True, False)
+  out, raw = run_static_pass(device, to_dev(scene, device), net, o.to(device), d.to(device), S)
+  # a sample whose projection sits on the frustum boundary may flip its mask (fp32 tie, see _mask_check); rays touching one are skipped
+  Vs = scene['static_src_rgbs'].shape[1]
+  margin = boundary_margin(st['pts'][None].repeat(Vs, 1, 1, 1), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
+  keep = ~margin
+  assert int(keep.sum()) > 0
+  tol = 5e-4 if name == 'noise' else atol  # white-noise maps amplify the 1-ulp coordinate differences of the gather
+  assert_close(cpu(out['rgb'])[keep], out_ref['rgb'][keep], tol, 0.0, f'{name} static pass rgb')
+  assert_close(cpu(out['depth'])[keep], out_ref['depth'][keep], 0.0, 2e-4, f'{name} static pass depth')
+  assert_close(cpu(out['weights'])[keep], out_ref['weights'][keep], tol, 0.0, f'{name} static pass weights')
+  assert_bitexact((cpu(out['mask']) > 0)[keep], out_ref['mask'][keep], f'{name} static pass ray mask')
+  return float((cpu(out['rgb'])[keep] - out_ref['rgb'][keep]).abs().max())
+
+
+def check_mlp_selftest(device, rows=1000):
+  import ctypes
+  from dynibar_amd import _lib
+  g = torch.Generator().manual_seed(0)
+  W = (torch.rand(64, 64, generator=g) - 0.5) * 0.4
+  b = torch.rand(64, generator=g) - 0.5
+  x = torch.randn(rows, 64, generator=g)
+  xd = x.to(device)
+  y = torch.full((rows, 64), float('nan'), device=device)
+  buf = torch.zeros(2 * 3 * 4096, device=device)
+  _lib.call('dyn_mlp_selftest', ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(b.data_ptr()), _lib.ptr(xd), _lib.ptr(y), rows, _lib.ptr(buf),
+            _lib.stream_of(xd))
+  ref = F.elu(F.linear(F.elu(F.linear(x, W, b)), W, b))
+  assert_close(y, ref, 2e-6, 0.0, 'mlp engine self-test')

@@ -39,3 +39,18 @@ def test_composite(dev):
 def test_fine_samples(dev, golden_dir, name):
   g = dict(np.load(os.path.join(golden_dir, f'stages_{name}.npz')))
   parity.check_fine_samples(dev, g)
+
+
+def test_mlp_engine(dev):
+  parity.check_mlp_selftest(dev, rows=1000)
+
+
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64), dict(name='harsh', S=40, aa=False, mask_rgb=True),
+                                dict(name='noise', S=128), dict(name='small', S=32, R=3)])
+def test_static_net(dev, kw):
+  parity.check_static_net(dev, **kw)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_static_pass(dev, name):
+  parity.check_static_pass(dev, name)
