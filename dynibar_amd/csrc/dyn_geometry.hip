@@ -3,6 +3,7 @@
 // points, normalised pixel locations and the inverse-CDF indices are then bit-identical to the CPU oracle wherever the
 // inputs are.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "dyn_device.h"
 #include "dyn_host.h"
@@ -240,23 +241,22 @@ extern "C" int dyn_points_from_z(const float* ray_o, const float* ray_d, const f
 // ---------------------------------------------------------------------------------------------------------------
 // K1: fused projection + bilinear gather + ray_diff + mask   (projection.py:103-176)
 //
-// One workgroup = PG_ROWS consecutive point-view rows g = (r*S + s)*V + v, so its slice of every output tensor is one
-// contiguous, 128-byte aligned span that is assembled in LDS and stored with full-width coalesced writes.
-// phase 1: one thread per row projects the point and records tap origins / fractions in LDS;
-// phase 2: F/4 lanes per row each blend four 16-byte channel groups of the four taps (a tap is one 128-byte line of the
-//          channels-last feature map), three lanes per row blend the RGB taps;
-// phase 3: the LDS tile streams out as dwordx4 stores.
+// HBM-bound: 160 B written per point-view, every source map read once.  No LDS and no barriers, so the
+// occupancy is set by registers alone and each wave keeps many taps in flight:
+// one wavefront = 64 consecutive point-view rows g = (r*S + s)*V + v.
+//   phase 1: lane = row.  Project the point, write ray_diff (one dwordx4 per lane, 1 KiB contiguous per wave) and the mask,
+//            blend and write the three RGB taps, keep the feature-tap origin/fractions in registers.
+//   phase 2: lane = (row-in-group, 16-byte channel group).  F/4 lanes cover one 128-byte channels-last tap line; the tap
+//            descriptors come from the owning lane by cross-lane reads.  All four taps of PG_UNROLL row-groups are issued
+//            before the first blend.  Each lane stores its 16 bytes straight into the row (rows are 140 B, so the store is only
+//            4-byte aligned: the wave still covers whole contiguous spans).
+// Workgroup -> rows mapping is XCD-aware: workgroup b runs on XCD b % 8, and XCD x is given the x-th contiguous eighth of the
+// rows, so neighbouring rays (overlapping epipolar footprints) share one L2.
 // ---------------------------------------------------------------------------------------------------------------
-#define PG_ROWS 128
-#define PG_THREADS 128
-
-struct PGTap {
-  int v;
-  int x0, y0;    // RGB image tap origin (west / north), may be out of bounds
-  float fx, fy;  // fractions towards east / south
-  int xf0, yf0;  // feature-map tap origin
-  float ffx, ffy;
-};
+#define PG_THREADS 256
+#define PG_UNROLL 4
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
 __device__ __forceinline__ float safe_floor_coord(float x, float size) {
   // taps further than one pixel outside contribute zero either way; the clamp keeps the int conversion defined
@@ -264,156 +264,183 @@ __device__ __forceinline__ float safe_floor_coord(float x, float size) {
 }
 
 __device__ __forceinline__ void normalize3(float x, float y, float z, float& ox, float& oy, float& oz) {
-  // F.normalize(eps=1e-12): v / max(||v||_2, eps)
-  float n = sqrtf(x * x + y * y + z * z);
-  float d = fmaxf(n, 1e-12f);
-  ox = x / d;
-  oy = y / d;
-  oz = z / d;
+  // F.normalize(eps=1e-12): v / max(||v||_2, eps), as one reciprocal square root (1 ulp) and three multiplies.  ray_diff is
+  // checked to 1e-6, not bitwise: the projection matrices already differ from torch.inverse's in the last bits.
+  const float inv = fminf(rsqrtf(x * x + y * y + z * z), 1e12f);
+  ox = x * inv;
+  oy = y * inv;
+  oz = z * inv;
 }
 
-__global__ void __launch_bounds__(PG_THREADS) k_project_gather(DynProjectGatherParams p) {
-  const int C = 3 + p.F;
-  float* out_tile = reinterpret_cast<float*>(dyn_smem);           // [PG_ROWS][C]
-  float* rd_tile = out_tile + PG_ROWS * C;                        // [PG_ROWS][4]
-  float* mk_tile = rd_tile + PG_ROWS * 4;                         // [PG_ROWS]
-  PGTap* taps = reinterpret_cast<PGTap*>(mk_tile + PG_ROWS);      // [PG_ROWS]
-  const int tid = threadIdx.x;
-  const long N = (long)p.R * p.S * p.V;
-  const long g0 = (long)blockIdx.x * PG_ROWS;
-  const int nrows = (int)((N - g0 < PG_ROWS) ? (N - g0) : PG_ROWS);
+// exact n / d for 32-bit n with the host-made multiplier m = ceil(2^32 / d): the estimate is q or q + 1
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m) {
+  if (d == 1) return n;
+  unsigned q = __umulhi(n, m);
+  return q - ((unsigned long long)q * d > n ? 1u : 0u);
+}
+
+struct PGShape {
+  int R, S, V, H, W, Hf, Wf, F;
+  float img_h, img_w;
+  unsigned mV, mS;  // fast_div multipliers
+  long N, ntask, tasks_per_xcd;
+};
+
+// bilinear tap set of one row on a [Hm, Wm] map: clamped (always loadable) corner coordinates and the four weights, zeroed for
+// corners outside the map (zeros padding).  ix, iy: un-normalised align_corners=True coordinates.
+__device__ __forceinline__ int iclamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+struct Taps {
+  int x0, x1, y0, y1;
+  float w_nw, w_ne, w_sw, w_se;
+};
+__device__ __forceinline__ Taps make_taps(float nx, float ny, int Wm, int Hm) {
+  const float ix = safe_floor_coord((nx + 1.0f) * ((float)(Wm - 1) / 2.0f), (float)Wm);
+  const float iy = safe_floor_coord((ny + 1.0f) * ((float)(Hm - 1) / 2.0f), (float)Hm);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float fx = ix - fx0, fy = iy - fy0;
+  const float e = 1.0f - fx, s = 1.0f - fy;
+  const bool x0ok = (x0 >= 0) && (x0 < Wm), x1ok = (x0 + 1 >= 0) && (x0 + 1 < Wm);
+  const bool y0ok = (y0 >= 0) && (y0 < Hm), y1ok = (y0 + 1 >= 0) && (y0 + 1 < Hm);
+  Taps t;
+  t.x0 = iclamp(x0, Wm - 1); t.x1 = iclamp(x0 + 1, Wm - 1);
+  t.y0 = iclamp(y0, Hm - 1); t.y1 = iclamp(y0 + 1, Hm - 1);
+  t.w_nw = (x0ok && y0ok) ? s * e : 0.f;
+  t.w_ne = (x1ok && y0ok) ? s * fx : 0.f;
+  t.w_sw = (x0ok && y1ok) ? fy * e : 0.f;
+  t.w_se = (x1ok && y1ok) ? fy * fx : 0.f;
+  return t;
+}
+
+__global__ void __launch_bounds__(PG_THREADS, 4)
+k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ z_vals,
+                 const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
+                 const float* __restrict__ query_center, const float* __restrict__ src_rgb, const float4* __restrict__ feat4,
+                 float* __restrict__ rgb_feat, float4* __restrict__ ray_diff, float* __restrict__ mask) {
+  const int lane = dyn_lane();
+  // XCD-aware task id: the (b / 8)-th workgroup of XCD (b % 8) takes tasks from that XCD's contiguous range
+  const long wg = blockIdx.x;
+  const long local = (wg >> 3) * (PG_THREADS / 64) + dyn_wave();
+  const long task = (wg & 7) * q.tasks_per_xcd + local;
+  if (local >= q.tasks_per_xcd || task >= q.ntask) return;  // whole wave leaves; no barriers below
+  const int C = 3 + q.F;
+  const long g0 = task * 64;
+  const bool has = g0 + lane < q.N;
+  const unsigned g = (unsigned)(has ? g0 + lane : q.N - 1);  // idle lanes shadow the last row (loads stay in bounds, stores are skipped)
 
   // ---- phase 1 ----
-  if (tid < nrows) {
-    const long g = g0 + tid;
-    const int v = (int)(g % p.V);
-    const long rs = g / p.V;
-    const int r = (int)(rs / p.S);
-    float sx, sy, sz;  // reference-time point (xyz_st)
-    if (p.pts_st != nullptr) {
-      sx = p.pts_st[rs * 3 + 0]; sy = p.pts_st[rs * 3 + 1]; sz = p.pts_st[rs * 3 + 2];
-    } else {
-      const float z = p.z_vals[rs];
-      sx = z * p.ray_d[r * 3 + 0] + p.ray_o[r * 3 + 0];
-      sy = z * p.ray_d[r * 3 + 1] + p.ray_o[r * 3 + 1];
-      sz = z * p.ray_d[r * 3 + 2] + p.ray_o[r * 3 + 2];
-    }
-    float x = sx, y = sy, z3 = sz;  // per-view (motion displaced) point
-    if (p.xyz != nullptr) {
-      const long o = ((long)v * p.R * p.S + rs) * 3;
-      x = p.xyz[o]; y = p.xyz[o + 1]; z3 = p.xyz[o + 2];
-    }
-    const float* P = p.proj + v * 16;
-    const float hx = fmaf(P[3], 1.0f, fmaf(P[2], z3, fmaf(P[1], y, P[0] * x)));
-    const float hy = fmaf(P[7], 1.0f, fmaf(P[6], z3, fmaf(P[5], y, P[4] * x)));
-    const float hz = fmaf(P[11], 1.0f, fmaf(P[10], z3, fmaf(P[9], y, P[8] * x)));
-    const float zc = fmaxf(hz, 1e-8f);
-    float px = hx / zc, py = hy / zc;
-    px = fminf(fmaxf(px, -1e6f), 1e6f);
-    py = fminf(fmaxf(py, -1e6f), 1e6f);
-    const float wm1 = p.img_w - 1.0f, hm1 = p.img_h - 1.0f;
-    const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
-    mk_tile[tid] = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
-    // normalize() then grid_sample's align_corners=True un-normalisation (ATen CPU: (x + 1) * ((size - 1) / 2))
-    const float nx = 2.0f * px / wm1 - 1.0f;
-    const float ny = 2.0f * py / hm1 - 1.0f;
-    PGTap t;
-    t.v = v;
-    {
-      float ix = safe_floor_coord((nx + 1.0f) * ((float)(p.W - 1) / 2.0f), (float)p.W);
-      float iy = safe_floor_coord((ny + 1.0f) * ((float)(p.H - 1) / 2.0f), (float)p.H);
-      float fx0 = floorf(ix), fy0 = floorf(iy);
-      t.x0 = (int)fx0; t.y0 = (int)fy0; t.fx = ix - fx0; t.fy = iy - fy0;
-    }
-    {
-      float ix = safe_floor_coord((nx + 1.0f) * ((float)(p.Wf - 1) / 2.0f), (float)p.Wf);
-      float iy = safe_floor_coord((ny + 1.0f) * ((float)(p.Hf - 1) / 2.0f), (float)p.Hf);
-      float fx0 = floorf(ix), fy0 = floorf(iy);
-      t.xf0 = (int)fx0; t.yf0 = (int)fy0; t.ffx = ix - fx0; t.ffy = iy - fy0;
-    }
-    taps[tid] = t;
-    // compute_angle (projection.py:61-101)
-    float ax, ay, az, bx, by, bz;
-    normalize3(p.query_center[0] - sx, p.query_center[1] - sy, p.query_center[2] - sz, ax, ay, az);
-    normalize3(P[12] - x, P[13] - y, P[14] - z3, bx, by, bz);
-    float dx, dy, dz;
-    normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
-    rd_tile[tid * 4 + 0] = dx;
-    rd_tile[tid * 4 + 1] = dy;
-    rd_tile[tid * 4 + 2] = dz;
-    rd_tile[tid * 4 + 3] = ax * bx + ay * by + az * bz;
+  const unsigned rs = fast_div(g, (unsigned)q.V, q.mV);
+  const int v = (int)(g - rs * q.V);
+  const unsigned r = fast_div(rs, (unsigned)q.S, q.mS);
+  float sx, sy, sz;  // reference-time point (xyz_st)
+  if (pts_st != nullptr) {
+    sx = pts_st[rs * 3 + 0]; sy = pts_st[rs * 3 + 1]; sz = pts_st[rs * 3 + 2];
+  } else {
+    const float z = z_vals[rs];
+    sx = z * ray_d[r * 3 + 0] + ray_o[r * 3 + 0];
+    sy = z * ray_d[r * 3 + 1] + ray_o[r * 3 + 1];
+    sz = z * ray_d[r * 3 + 2] + ray_o[r * 3 + 2];
   }
-  __syncthreads();
-
-  // ---- phase 2a: feature taps ----
-  const int F4 = p.F >> 2;
-  for (int i = tid; i < nrows * F4; i += PG_THREADS) {
-    const int row = i / F4, c4 = i - row * F4;
-    const PGTap t = taps[row];
-    const float e = 1.0f - t.ffx, s = 1.0f - t.ffy;
-    const float w_nw = s * e, w_ne = s * t.ffx, w_sw = t.ffy * e, w_se = t.ffy * t.ffx;
-    const bool x0ok = (t.xf0 >= 0) && (t.xf0 < p.Wf), x1ok = (t.xf0 + 1 >= 0) && (t.xf0 + 1 < p.Wf);
-    const bool y0ok = (t.yf0 >= 0) && (t.yf0 < p.Hf), y1ok = (t.yf0 + 1 >= 0) && (t.yf0 + 1 < p.Hf);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* base = reinterpret_cast<const float4*>(p.feat_cl) + ((long)t.v * p.Hf * p.Wf) * F4 + c4;
-    const long o00 = ((long)t.yf0 * p.Wf + t.xf0) * F4;
-    float4 a = (x0ok && y0ok) ? base[o00] : zero4;
-    float4 b = (x1ok && y0ok) ? base[o00 + F4] : zero4;
-    float4 c = (x0ok && y1ok) ? base[o00 + (long)p.Wf * F4] : zero4;
-    float4 d = (x1ok && y1ok) ? base[o00 + (long)p.Wf * F4 + F4] : zero4;
-    float* o = out_tile + row * C + 3 + c4 * 4;
-    o[0] = a.x * w_nw + b.x * w_ne + c.x * w_sw + d.x * w_se;
-    o[1] = a.y * w_nw + b.y * w_ne + c.y * w_sw + d.y * w_se;
-    o[2] = a.z * w_nw + b.z * w_ne + c.z * w_sw + d.z * w_se;
-    o[3] = a.w * w_nw + b.w * w_ne + c.w * w_sw + d.w * w_se;
+  float x = sx, y = sy, z3 = sz;  // per-view (motion displaced) point
+  if (xyz != nullptr) {
+    const long o = ((long)v * q.R * q.S + rs) * 3;
+    x = xyz[o]; y = xyz[o + 1]; z3 = xyz[o + 2];
   }
-  // ---- phase 2b: RGB taps ----
-  for (int i = tid; i < nrows * 3; i += PG_THREADS) {
-    const int row = i / 3, ch = i - row * 3;
-    const PGTap t = taps[row];
-    const float e = 1.0f - t.fx, s = 1.0f - t.fy;
-    const float w_nw = s * e, w_ne = s * t.fx, w_sw = t.fy * e, w_se = t.fy * t.fx;
-    const bool x0ok = (t.x0 >= 0) && (t.x0 < p.W), x1ok = (t.x0 + 1 >= 0) && (t.x0 + 1 < p.W);
-    const bool y0ok = (t.y0 >= 0) && (t.y0 < p.H), y1ok = (t.y0 + 1 >= 0) && (t.y0 + 1 < p.H);
-    const float* base = p.src_rgb + ((long)t.v * p.H * p.W) * 3 + ch;
-    const long o00 = ((long)t.y0 * p.W + t.x0) * 3;
-    float a = (x0ok && y0ok) ? base[o00] : 0.f;
-    float b = (x1ok && y0ok) ? base[o00 + 3] : 0.f;
-    float c = (x0ok && y1ok) ? base[o00 + (long)p.W * 3] : 0.f;
-    float d = (x1ok && y1ok) ? base[o00 + (long)p.W * 3 + 3] : 0.f;
-    out_tile[row * C + ch] = a * w_nw + b * w_ne + c * w_sw + d * w_se;
-  }
-  __syncthreads();
-
-  // ---- phase 3: coalesced stores ----
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2], P3 = proj4[v * 4 + 3];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  float px = hx / zc, py = hy / zc;
+  px = fminf(fmaxf(px, -1e6f), 1e6f);
+  py = fminf(fmaxf(py, -1e6f), 1e6f);
+  const float wm1 = q.img_w - 1.0f, hm1 = q.img_h - 1.0f;
+  const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
+  // normalize() then grid_sample's align_corners=True un-normalisation (ATen CPU: (x + 1) * ((size - 1) / 2))
+  const float nx = 2.0f * px / wm1 - 1.0f;
+  const float ny = 2.0f * py / hm1 - 1.0f;
+  const Taps tf = make_taps(nx, ny, q.Wf, q.Hf);
   {
-    const int nflt = nrows * C;
-    float* dst = p.rgb_feat + g0 * C;  // g0*C*4 bytes is a multiple of 512
-    const int n4 = nflt >> 2;
-    float4* dst4 = reinterpret_cast<float4*>(dst);
-    const float4* src4 = reinterpret_cast<const float4*>(out_tile);
-    for (int i = tid; i < n4; i += PG_THREADS) dst4[i] = src4[i];
-    for (int i = (n4 << 2) + tid; i < nflt; i += PG_THREADS) dst[i] = out_tile[i];
-    float4* rd4 = reinterpret_cast<float4*>(p.ray_diff + g0 * 4);
-    const float4* rs4 = reinterpret_cast<const float4*>(rd_tile);
-    for (int i = tid; i < nrows; i += PG_THREADS) rd4[i] = rs4[i];
-    for (int i = tid; i < nrows; i += PG_THREADS) p.mask[g0 + i] = mk_tile[i];
+    // RGB taps of this row: four unconditional 12-byte loads
+    const Taps t = make_taps(nx, ny, q.W, q.H);
+    const float* img = src_rgb + (long)v * q.H * q.W * 3;
+    const f32x3u a = *reinterpret_cast<const f32x3u*>(img + (t.y0 * q.W + t.x0) * 3);
+    const f32x3u b = *reinterpret_cast<const f32x3u*>(img + (t.y0 * q.W + t.x1) * 3);
+    const f32x3u c = *reinterpret_cast<const f32x3u*>(img + (t.y1 * q.W + t.x0) * 3);
+    const f32x3u d = *reinterpret_cast<const f32x3u*>(img + (t.y1 * q.W + t.x1) * 3);
+    // compute_angle (projection.py:61-101), overlapping the tap latency
+    float ax, ay, az, bx, by, bz, dx, dy, dz;
+    normalize3(query_center[0] - sx, query_center[1] - sy, query_center[2] - sz, ax, ay, az);
+    normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
+    normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
+    if (has) {
+      ray_diff[g] = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
+      mask[g] = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
+      f32x3u o3;
+      o3.x = a.x * t.w_nw + b.x * t.w_ne + c.x * t.w_sw + d.x * t.w_se;
+      o3.y = a.y * t.w_nw + b.y * t.w_ne + c.y * t.w_sw + d.y * t.w_se;
+      o3.z = a.z * t.w_nw + b.z * t.w_ne + c.z * t.w_sw + d.z * t.w_se;
+      *reinterpret_cast<f32x3u*>(rgb_feat + (long)g * C) = o3;
+    }
+  }
+  // feature-tap descriptors of this row as float4-element offsets into feat4 (one 128-byte line = F4 elements)
+  const int F4 = q.F >> 2;
+  const int vbase = v * q.Hf * q.Wf;
+  const int o_nw = (vbase + tf.y0 * q.Wf + tf.x0) * F4, o_ne = (vbase + tf.y0 * q.Wf + tf.x1) * F4;
+  const int o_sw = (vbase + tf.y1 * q.Wf + tf.x0) * F4, o_se = (vbase + tf.y1 * q.Wf + tf.x1) * F4;
+
+  // ---- phase 2: F4 lanes per row, RPI rows per pass ----
+  const int RPI = 64 / F4;
+  const int rsub = lane / F4, c4 = lane - rsub * F4;
+  const bool lane_on = rsub < RPI;
+  for (int it0 = 0; it0 * RPI < 64; it0 += PG_UNROLL) {
+    float4 ta[PG_UNROLL], tb[PG_UNROLL], tc[PG_UNROLL], td[PG_UNROLL];
+    float w0[PG_UNROLL], w1[PG_UNROLL], w2[PG_UNROLL], w3[PG_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PG_UNROLL; ++u) {
+      const int src = (it0 + u) * RPI + rsub < 63 ? (it0 + u) * RPI + rsub : 63;  // owning lane of the row (cross-lane reads are executed by every lane)
+      ta[u] = feat4[__shfl(o_nw, src) + c4];
+      tb[u] = feat4[__shfl(o_ne, src) + c4];
+      tc[u] = feat4[__shfl(o_sw, src) + c4];
+      td[u] = feat4[__shfl(o_se, src) + c4];
+      w0[u] = __shfl(tf.w_nw, src); w1[u] = __shfl(tf.w_ne, src); w2[u] = __shfl(tf.w_sw, src); w3[u] = __shfl(tf.w_se, src);
+    }
+#pragma unroll
+    for (int u = 0; u < PG_UNROLL; ++u) {
+      f32x4u o;
+      o.x = ta[u].x * w0[u] + tb[u].x * w1[u] + tc[u].x * w2[u] + td[u].x * w3[u];
+      o.y = ta[u].y * w0[u] + tb[u].y * w1[u] + tc[u].y * w2[u] + td[u].y * w3[u];
+      o.z = ta[u].z * w0[u] + tb[u].z * w1[u] + tc[u].z * w2[u] + td[u].z * w3[u];
+      o.w = ta[u].w * w0[u] + tb[u].w * w1[u] + tc[u].w * w2[u] + td[u].w * w3[u];
+      const int src = (it0 + u) * RPI + rsub;
+      if (lane_on && src < 64 && g0 + src < q.N) *reinterpret_cast<f32x4u*>(rgb_feat + (g0 + src) * C + 3 + c4 * 4) = o;
+    }
   }
 }
 
 extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {
   DYN_REQUIRE(p, "dyn_project_gather: null params");
   DYN_REQUIRE(p->R > 0 && p->S > 0 && p->V > 0, "dyn_project_gather: empty problem");
-  DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 128, "dyn_project_gather: F must be a multiple of 4 (<=128)");
+  DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 256, "dyn_project_gather: F must be a multiple of 4 (<=256)");
   DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->ray_diff && p->mask,
               "dyn_project_gather: null pointer");
   DYN_REQUIRE(p->pts_st != nullptr || (p->ray_o && p->ray_d && p->z_vals), "dyn_project_gather: need pts_st or (ray_o, ray_d, z_vals)");
   DYN_REQUIRE(p->H > 1 && p->W > 1 && p->Hf > 1 && p->Wf > 1, "dyn_project_gather: maps must be at least 2x2");
-  const long N = (long)p->R * p->S * p->V;
-  const int C = 3 + p->F;
-  size_t shmem = (size_t)PG_ROWS * (C + 4 + 1) * 4 + (size_t)PG_ROWS * sizeof(PGTap);
-  shmem = (shmem + 15) & ~(size_t)15;
-  DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3(dyn_cdiv(N, PG_ROWS)), dim3(PG_THREADS), shmem, (hipStream_t)stream, *p);
+  PGShape q;
+  q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
+  q.img_h = p->img_h; q.img_w = p->img_w;
+  q.N = (long)p->R * p->S * p->V;
+  DYN_REQUIRE(q.N < (1L << 31) && (long)p->V * p->H * p->W * 3 < (1L << 31) && (long)p->V * p->Hf * p->Wf * p->F < (1L << 31),
+              "dyn_project_gather: R*S*V and the map sizes must stay below 2^31 elements (split the ray batch)");
+  q.mV = (unsigned)(((1ULL << 32) + p->V - 1) / p->V);
+  q.mS = (unsigned)(((1ULL << 32) + p->S - 1) / p->S);
+  q.ntask = (q.N + 63) / 64;
+  const int wpb = PG_THREADS / 64;
+  q.tasks_per_xcd = ((q.ntask + 7) / 8 + wpb - 1) / wpb * wpb;  // whole workgroups per XCD range
+  const long nblocks = 8 * (q.tasks_per_xcd / wpb);
+  DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3((unsigned)nblocks), dim3(PG_THREADS), 0, (hipStream_t)stream, q,
+             p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
+             reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask);
   return 0;
 }
 
