@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'dynibar_hip.h')
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdynibar_hip.so')
+LIB_PATH = os.environ.get('DYNIBAR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdynibar_hip.so')  # env: developer A/B builds
 
 _CTYPES = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64,

@@ -253,8 +253,18 @@ extern "C" int dyn_points_from_z(const float* ray_o, const float* ray_d, const f
 // Workgroup -> rows mapping is XCD-aware: workgroup b runs on XCD b % 8, and XCD x is given the x-th contiguous eighth of the
 // rows, so neighbouring rays (overlapping epipolar footprints) share one L2.
 // ---------------------------------------------------------------------------------------------------------------
-#define PG_THREADS 256
+#ifndef PG_THREADS
+#define PG_THREADS 64
+#endif
+#ifndef PG_UNROLL
 #define PG_UNROLL 4
+#endif
+#ifndef PG_OCC
+#define PG_OCC 4
+#endif
+#ifndef PG_STAGE
+#define PG_STAGE 1  /* assemble each wave's 64 output rows in LDS and store them as aligned, fully coalesced dwordx4 */
+#endif
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
@@ -281,7 +291,7 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m)
 
 struct PGShape {
   int R, S, V, H, W, Hf, Wf, F;
-  float img_h, img_w;
+  float img_h, img_w, inv_wm1, inv_hm1;
   unsigned mV, mS;  // fast_div multipliers
   long N, ntask, tasks_per_xcd;
 };
@@ -312,7 +322,7 @@ __device__ __forceinline__ Taps make_taps(float nx, float ny, int Wm, int Hm) {
   return t;
 }
 
-__global__ void __launch_bounds__(PG_THREADS, 4)
+__global__ void __launch_bounds__(PG_THREADS, PG_OCC)
 k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ z_vals,
                  const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
                  const float* __restrict__ query_center, const float* __restrict__ src_rgb, const float4* __restrict__ feat4,
@@ -322,8 +332,17 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
   const long wg = blockIdx.x;
   const long local = (wg >> 3) * (PG_THREADS / 64) + dyn_wave();
   const long task = (wg & 7) * q.tasks_per_xcd + local;
-  if (local >= q.tasks_per_xcd || task >= q.ntask) return;  // whole wave leaves; no barriers below
   const int C = 3 + q.F;
+#if PG_STAGE
+  float* tile = reinterpret_cast<float*>(dyn_smem) + dyn_wave() * (64 * C);  // this wave's [64][C] output rows
+  const bool live = local < q.tasks_per_xcd && task < q.ntask;
+  if (!live) {  // keep the workgroup barrier count uniform
+    __syncthreads();
+    return;
+  }
+#else
+  if (local >= q.tasks_per_xcd || task >= q.ntask) return;  // whole wave leaves; no barriers below
+#endif
   const long g0 = task * 64;
   const bool has = g0 + lane < q.N;
   const unsigned g = (unsigned)(has ? g0 + lane : q.N - 1);  // idle lanes shadow the last row (loads stay in bounds, stores are skipped)
@@ -350,15 +369,18 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
   const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  // the pixel location is not bitwise the reference's in any case (K.inv(c2w) is inverted differently), so the perspective
+  // divide and normalize() use the 1-ulp hardware reciprocal instead of IEEE division sequences
   const float zc = fmaxf(hz, 1e-8f);
-  float px = hx / zc, py = hy / zc;
+  const float izc = __builtin_amdgcn_rcpf(zc);
+  float px = hx * izc, py = hy * izc;
   px = fminf(fmaxf(px, -1e6f), 1e6f);
   py = fminf(fmaxf(py, -1e6f), 1e6f);
   const float wm1 = q.img_w - 1.0f, hm1 = q.img_h - 1.0f;
   const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
   // normalize() then grid_sample's align_corners=True un-normalisation (ATen CPU: (x + 1) * ((size - 1) / 2))
-  const float nx = 2.0f * px / wm1 - 1.0f;
-  const float ny = 2.0f * py / hm1 - 1.0f;
+  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
+  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
   const Taps tf = make_taps(nx, ny, q.Wf, q.Hf);
   {
     // RGB taps of this row: four unconditional 12-byte loads
@@ -377,10 +399,14 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
       ray_diff[g] = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
       mask[g] = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
       f32x3u o3;
-      o3.x = a.x * t.w_nw + b.x * t.w_ne + c.x * t.w_sw + d.x * t.w_se;
-      o3.y = a.y * t.w_nw + b.y * t.w_ne + c.y * t.w_sw + d.y * t.w_se;
-      o3.z = a.z * t.w_nw + b.z * t.w_ne + c.z * t.w_sw + d.z * t.w_se;
+      o3.x = fmaf(d.x, t.w_se, fmaf(c.x, t.w_sw, fmaf(b.x, t.w_ne, a.x * t.w_nw)));
+      o3.y = fmaf(d.y, t.w_se, fmaf(c.y, t.w_sw, fmaf(b.y, t.w_ne, a.y * t.w_nw)));
+      o3.z = fmaf(d.z, t.w_se, fmaf(c.z, t.w_sw, fmaf(b.z, t.w_ne, a.z * t.w_nw)));
+#if PG_STAGE
+      tile[lane * C] = o3.x; tile[lane * C + 1] = o3.y; tile[lane * C + 2] = o3.z;
+#else
       *reinterpret_cast<f32x3u*>(rgb_feat + (long)g * C) = o3;
+#endif
     }
   }
   // feature-tap descriptors of this row as float4-element offsets into feat4 (one 128-byte line = F4 elements)
@@ -408,14 +434,33 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #pragma unroll
     for (int u = 0; u < PG_UNROLL; ++u) {
       f32x4u o;
-      o.x = ta[u].x * w0[u] + tb[u].x * w1[u] + tc[u].x * w2[u] + td[u].x * w3[u];
-      o.y = ta[u].y * w0[u] + tb[u].y * w1[u] + tc[u].y * w2[u] + td[u].y * w3[u];
-      o.z = ta[u].z * w0[u] + tb[u].z * w1[u] + tc[u].z * w2[u] + td[u].z * w3[u];
-      o.w = ta[u].w * w0[u] + tb[u].w * w1[u] + tc[u].w * w2[u] + td[u].w * w3[u];
+      o.x = fmaf(td[u].x, w3[u], fmaf(tc[u].x, w2[u], fmaf(tb[u].x, w1[u], ta[u].x * w0[u])));
+      o.y = fmaf(td[u].y, w3[u], fmaf(tc[u].y, w2[u], fmaf(tb[u].y, w1[u], ta[u].y * w0[u])));
+      o.z = fmaf(td[u].z, w3[u], fmaf(tc[u].z, w2[u], fmaf(tb[u].z, w1[u], ta[u].z * w0[u])));
+      o.w = fmaf(td[u].w, w3[u], fmaf(tc[u].w, w2[u], fmaf(tb[u].w, w1[u], ta[u].w * w0[u])));
       const int src = (it0 + u) * RPI + rsub;
+#if PG_STAGE
+      if (lane_on && src < 64) {
+        float* t = tile + src * C + 3 + c4 * 4;
+        t[0] = o.x; t[1] = o.y; t[2] = o.z; t[3] = o.w;
+      }
+#else
       if (lane_on && src < 64 && g0 + src < q.N) *reinterpret_cast<f32x4u*>(rgb_feat + (g0 + src) * C + 3 + c4 * 4) = o;
+#endif
     }
   }
+#if PG_STAGE
+  __syncthreads();  // the wave's LDS writes are complete and visible (one barrier per workgroup; waves only share the barrier)
+  {
+    const long nrow = (q.N - g0 < 64) ? (q.N - g0) : 64;
+    const int nflt = (int)nrow * C;
+    float* dst = rgb_feat + g0 * C;  // g0 * C * 4 bytes = task * 64 * C * 4: 16-byte aligned for any C
+    const float4* src4 = reinterpret_cast<const float4*>(tile);
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    for (int i = lane; i < (nflt >> 2); i += 64) dst4[i] = src4[i];
+    for (int i = (nflt & ~3) + lane; i < nflt; i += 64) dst[i] = tile[i];
+  }
+#endif
 }
 
 extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {
@@ -429,6 +474,7 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   PGShape q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
   q.img_h = p->img_h; q.img_w = p->img_w;
+  q.inv_wm1 = 1.0f / (p->img_w - 1.0f); q.inv_hm1 = 1.0f / (p->img_h - 1.0f);
   q.N = (long)p->R * p->S * p->V;
   DYN_REQUIRE(q.N < (1L << 31) && (long)p->V * p->H * p->W * 3 < (1L << 31) && (long)p->V * p->Hf * p->Wf * p->F < (1L << 31),
               "dyn_project_gather: R*S*V and the map sizes must stay below 2^31 elements (split the ray batch)");
@@ -438,7 +484,8 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   const int wpb = PG_THREADS / 64;
   q.tasks_per_xcd = ((q.ntask + 7) / 8 + wpb - 1) / wpb * wpb;  // whole workgroups per XCD range
   const long nblocks = 8 * (q.tasks_per_xcd / wpb);
-  DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3((unsigned)nblocks), dim3(PG_THREADS), 0, (hipStream_t)stream, q,
+  DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3((unsigned)nblocks), dim3(PG_THREADS),
+             PG_STAGE ? (size_t)(PG_THREADS / 64) * 64 * (3 + p->F) * sizeof(float) : 0, (hipStream_t)stream, q,
              p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
              reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask);
   return 0;

@@ -187,6 +187,7 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
 
 
 #define __expf(x) expf(x)
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 // global_load_lds: the LDS destination is the wave-uniform base + lane * size (cdna_hip_programming.md section 5)

@@ -43,6 +43,12 @@ def main():
   pts, z, s = ops.sample_along_ray(o, d, dr, a.S, True)
   res['sample_along_ray_us'] = timeit(lambda: ops.sample_along_ray(o, d, dr, a.S, True)) * 1e6
   t = timeit(lambda: ops.project_gather(views, a.R, a.S, ray_o=o, ray_d=d, z_vals=z))
+  import ctypes
+  from dynibar_amd import _lib
+  L = _lib.lib(); L.dyn_profile_enable(1)
+  for _ in range(20): ops.project_gather(views, a.R, a.S, ray_o=o, ray_d=d, z_vals=z)
+  nk = L.dyn_profile_count(); ms = (ctypes.c_float * nk)(); cnt = (ctypes.c_int * nk)(); L.dyn_profile_read(ms, cnt); L.dyn_profile_enable(0)
+  t = [ms[i] / cnt[i] for i in range(nk) if cnt[i] > 0][0] * 1e-3
   H, W, Hf, Wf, F = views.H, views.W, views.Hf, views.Wf, views.F
   bytes_alg = a.R * a.S * a.V * 160 + a.V * (Hf * Wf * F + H * W * 3) * 4 + a.R * (24 + 4 * a.S)
   res['project_gather_us'] = t * 1e6
