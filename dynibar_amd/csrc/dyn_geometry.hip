@@ -33,7 +33,8 @@ static struct {
 } g_prof;
 static const char* const g_prof_names[DYN_K_COUNT] = {
     "k_prepare_cameras", "k_nchw_to_nhwc", "k_sample_along_ray", "k_points_from_z", "k_project_gather", "k_sample_mask", "k_composite",
-    "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest"};
+    "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest", "k_dynamic_time_feat",
+    "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points"};
 
 static void prof_flush(int slot) {
   for (int i = 0; i < g_prof.used[slot]; ++i) {
@@ -488,6 +489,47 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
              PG_STAGE ? (size_t)(PG_THREADS / 64) * 64 * (3 + p->F) * sizeof(float) : 0, (hipStream_t)stream, q,
              p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
              reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: DCT-basis trajectory points  (render_ray.py:361-369, :686-709)
+// ---------------------------------------------------------------------------------------------------------------
+struct TrajRows {
+  int n, ref;
+  int rows[32];
+};
+__global__ void k_trajectory_points(const float* __restrict__ coeff, const float* __restrict__ basis, const float* __restrict__ pts, long n_pts,
+                                    int B, TrajRows tr, float* __restrict__ pts_seq) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts) return;
+  const float* c = coeff + i * 3 * B;
+  float t0[3];
+  for (int a = 0; a < 3; ++a) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += c[a * B + b] * basis[(long)tr.ref * B + b];
+    t0[a] = s;
+  }
+  for (int v = 0; v < tr.n; ++v)
+    for (int a = 0; a < 3; ++a) {
+      float p = pts[i * 3 + a];
+      if (tr.rows[v] >= 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += c[a * B + b] * basis[(long)tr.rows[v] * B + b];
+        p = p + (s - t0[a]);
+      }
+      pts_seq[((long)v * n_pts + i) * 3 + a] = p;
+    }
+}
+extern "C" int dyn_trajectory_points(const float* coeff, const float* basis, const float* pts, long n_pts, int B, const int* rows, int n_rows,
+                                     int row_ref, float* pts_seq, void* stream) {
+  DYN_REQUIRE(coeff && basis && pts && rows && pts_seq, "dyn_trajectory_points: null pointer");
+  DYN_REQUIRE(n_pts > 0 && B > 0 && n_rows > 0 && n_rows <= 32 && row_ref >= 0, "dyn_trajectory_points: bad argument");
+  TrajRows tr;
+  tr.n = n_rows; tr.ref = row_ref;
+  for (int i = 0; i < 32; ++i) tr.rows[i] = i < n_rows ? rows[i] : -1;
+  DYN_LAUNCH(DYN_K_TRAJECTORY, "dyn_trajectory_points", k_trajectory_points, dim3(dyn_cdiv(n_pts, 256)), dim3(256), 0, (hipStream_t)stream, coeff,
+             basis, pts, n_pts, B, tr, pts_seq);
   return 0;
 }
 

@@ -6,6 +6,8 @@
 //                       out_geometry_fc (sigma) and the point part of rgb_fc.0               (one wave = 32 points of one ray)
 //   C  k_static_blend : per point-view  rgb_fc -> masked softmax over views -> blend of the source colours
 // Between A and C the 128-wide per-view feature x is parked in HBM in the lanes' own register order (512 B per point-view).
+#include <math.h>
+
 #include <functional>
 #include <vector>
 
@@ -99,6 +101,32 @@ constexpr size_t ST_OFF_CTB = ST_OFF_CTA + SA_CT;
 constexpr size_t ST_OFF_CTC = ST_OFF_CTB + SB_CT;
 constexpr size_t ST_OFF_REF = ST_OFF_CTC + SC_CT;  // ref_feature_fc.0: [35][66] then [35]
 constexpr size_t ST_BLOB_FLOATS = ST_OFF_REF + 35 * 66 + 36;
+
+// ===================================================================================================================
+// DynibarDynamic (mlp_network.py:129-316): layer programs and blob layout
+// ===================================================================================================================
+enum {
+  DT_RAYDIR0_W, DT_RAYDIR0_B, DT_RAYDIR2_W, DT_RAYDIR2_B, DT_BASE0_W, DT_BASE0_B, DT_BASE2_W, DT_BASE2_B, DT_VIS0_W, DT_VIS0_B, DT_VIS2_W,
+  DT_VIS2_B, DT_VISB0_W, DT_VISB0_B, DT_VISB2_W, DT_VISB2_B, DT_GEO0_W, DT_GEO0_B, DT_GEO2_W, DT_GEO2_B, DT_WQ, DT_WK, DT_WV, DT_FC, DT_LN_G,
+  DT_LN_B, DT_REFPTS0_W, DT_REFPTS0_B, DT_REFPTS2_W, DT_REFPTS2_B, DT_OG0_W, DT_OG0_B, DT_OG2_W, DT_OG2_B, DT_RGB0_W, DT_RGB0_B, DT_RGB2_W,
+  DT_RGB2_B, DT_RGB4_W, DT_RGB4_B, DT_NUM_TENSORS
+};
+#define DA_NX 18                      /* registers holding the 35-channel per-view feature */
+#define DA_L3_STEPS (3 * DA_NX + 1)   /* base_fc.0: x | mean | var | bias */
+constexpr int DA_CHUNKS = dyn_layer_chunks(8, DA_L3_STEPS) + dyn_layer_chunks(4, SA_L4_STEPS) + 3 * dyn_layer_chunks(4, SA_L5_STEPS);
+constexpr int DB_CHUNKS = dyn_layer_chunks(8, 129) + dyn_layer_chunks(4, 129) + 4 * dyn_layer_chunks(4, 64) + dyn_layer_chunks(8, 81) +
+                          dyn_layer_chunks(4, 129) + dyn_layer_chunks(4, 65) + dyn_layer_chunks(4, 78) + dyn_layer_chunks(2, 65);
+// B table: ln gamma @0, ln beta @128, out_geometry_fc.2 row @256, its bias @384, rgb_fc.4 biases @385..387, rgb_fc.4 rows [3][2][32] @400
+#define DB_CT 592
+constexpr size_t DY_OFF_A = 0;
+constexpr size_t DY_OFF_B = DY_OFF_A + (size_t)DA_CHUNKS * DYN_CHUNK;
+constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * DYN_CHUNK;
+constexpr size_t DY_OFF_CTB = DY_OFF_CTA + SA_CT;
+constexpr size_t DY_OFF_POSENC = DY_OFF_CTB + DB_CT;                 // [128 positions][2][64]
+constexpr size_t DY_OFF_TIME = DY_OFF_POSENC + 128 * 128;            // ray_dir_fc: W0 [256,21], b0 [256], W2 [35,256], b2 [35]
+constexpr size_t DY_BLOB_FLOATS = DY_OFF_TIME + 256 * 21 + 256 + 35 * 256 + 36;
+// channel (0..34, or -1) of the per-view feature held by register q of a lane of half h
+__host__ __device__ constexpr int da_c35(int q, int h) { return h == 0 ? q : (q < 17 ? 18 + q : -1); }
 
 // channel (0..69, or -1) of the 70-wide per-view feature held by register q of a lane of half h
 __host__ __device__ constexpr int sa_c70(int q, int h) {
@@ -211,11 +239,11 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
 struct StaticWs {
   long n_pts, n_tiles_a, n_tiles_b;
   int PT, TPR;  // points per A tile; B tiles per ray (power of two)
-  size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;
+  size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;  // dynamic net: off_x/off_vis/off_hg unused, off_ref = time feature
 };
 #define SB_GIN_LD 132  // per (point, half): 64 mean, 64 var, [mean weight | 1], pad
 
-static StaticWs static_ws(int R, int S, int V) {
+static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   StaticWs w;
   w.n_pts = (long)R * S;
   w.PT = 32 / V;
@@ -224,12 +252,12 @@ static StaticWs static_ws(int R, int S, int V) {
   w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : 4);
   w.n_tiles_b = (long)R * w.TPR;
   size_t o = 0;
-  w.off_x = o; o += (size_t)w.n_tiles_a * 64 * 64;
-  w.off_vis = o; o += (size_t)w.n_tiles_a * 64;
+  w.off_x = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64 * 64;
+  w.off_vis = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64;
   w.off_gin = o; o += (size_t)w.n_pts * 2 * SB_GIN_LD;
   w.off_nvalid = o; o += (size_t)((w.n_pts + 3) & ~3L);
-  w.off_hg = o; o += (size_t)w.n_pts * 128;
-  w.off_ref = o; o += (size_t)R * 36;
+  w.off_hg = o; o += dynamic ? 0 : (size_t)w.n_pts * 128;
+  w.off_ref = o; o += dynamic ? 64 : (size_t)R * 36;
   w.total = o;
   return w;
 }
@@ -277,7 +305,9 @@ struct StaticArgs {
   int R, S, V, PT, TPR;
   int anti_alias, mask_rgb;
   long n_pts, n_tiles_a, n_tiles_b;
+  float shift;            // dynamic net: subtracted from sigma (mlp_network.py:295)
   const float* blob;
+  const float* ray_d;     // [R,3]   (dynamic net: viewing direction features)
   const float* pts;       // [R,S,3]
   const float* rgb_feat;  // [R,S,V,35]
   const float* ray_diff;  // [R,S,V,4]
@@ -287,6 +317,83 @@ struct StaticArgs {
   float* ws;
   StaticWs o;
 };
+
+// -------------------------------------------------------------------------------------------------------------------
+// shared tail of the per point-view chains (static: mlp_network.py:483-494, dynamic: :266-282):
+// base_fc.2 -> vis_fc -> vis_fc2 -> visibility-weighted mean / variance over the views -> geometry_fc input rows
+// a1: ELU'd base_fc.0 output (256 features).  Constant table: vis row @0, vis_fc2.2 row @128, b_vis @256, b_vis2 @257.
+// -------------------------------------------------------------------------------------------------------------------
+template <int VSEG, bool STORE_X>
+__device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
+                                           long tile, long point, bool valid, int view, int seg_base) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int V = p.V;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  f32x16 x[4];
+  {
+    acc_zero(x);
+    mlp_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    acc_elu(x);
+  }
+  float vis;
+  {
+    f32x16 a5[4], a6[4];
+    acc_zero(a5);
+    mlp_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
+    acc_elu(a5);
+    acc_zero(a6);
+    mlp_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
+    vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[t][r] += elu1(a6[t][r]);
+  }
+  float vis2;
+  {
+    f32x16 a7[4];
+    acc_zero(a7);
+    mlp_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
+    acc_elu(a7);
+    vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
+  }
+  // ---- outputs: x and vis2 in lane order, visibility-weighted statistics per point ----
+  const bool tile_ok = tile < p.n_tiles_a;
+  if (STORE_X && tile_ok) {
+    float4* xw = reinterpret_cast<float4*>(p.ws + p.o.off_x) + tile * 16 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xw[(t * 4 + q) * 64] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
+    p.ws[p.o.off_vis + tile * 64 + lane] = vis2;
+  }
+  const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
+  const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
+  const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
+  float* gin = p.ws + p.o.off_gin + (valid ? (point * 2 + h) * SB_GIN_LD : 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m[4], vv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        m[e] = seg_sum<VSEG>(x[t][q * 4 + e] * w2, V, seg_base);
+        const float d = x[t][q * 4 + e] - m[e];
+        vv[e] = seg_sum<VSEG>(w2 * (d * d), V, seg_base);
+      }
+      const int g = t * 4 + q;
+      const bool mine = valid && (VSEG > 0 ? (view == (g & (VSEG - 1))) : (view == 0));
+      if (mine) {
+        reinterpret_cast<float4*>(gin)[g] = make_float4(m[0], m[1], m[2], m[3]);
+        reinterpret_cast<float4*>(gin + 64)[g] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    }
+  if (valid && view == 0) {
+    gin[128] = h == 0 ? wmean : 1.0f;
+    if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
+  }
+}
 
 // ===================================================================================================================
 // A: per point-view chain
@@ -374,7 +481,6 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
   }
   wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
 
-  f32x16 x[4];
   {
     acc_zero(a1);  // reuse as base_fc.0 accumulators
     // k-steps: the 70 channels, their weighted means over the views, their weighted variances (recomputing a mean costs
@@ -390,68 +496,8 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
       return one_h0;
     });
     acc_elu(a1);
-    acc_zero(x);
-    mlp_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
-    acc_elu(x);
   }
-  float vis;
-  {
-    f32x16 a5[4], a6[4];
-    acc_zero(a5);
-    mlp_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
-    acc_elu(a5);
-    acc_zero(a6);
-    mlp_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
-    vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[t][r] += elu1(a6[t][r]);
-  }
-  float vis2;
-  {
-    f32x16 a7[4];
-    acc_zero(a7);
-    mlp_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
-    acc_elu(a7);
-    vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
-  }
-  // ---- outputs: x and vis2 in lane order, visibility-weighted statistics per point ----
-  const bool tile_ok = tile < p.n_tiles_a;
-  if (tile_ok) {
-    float4* xw = reinterpret_cast<float4*>(p.ws + p.o.off_x) + tile * 16 * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xw[(t * 4 + q) * 64] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
-    p.ws[p.o.off_vis + tile * 64 + lane] = vis2;
-  }
-  const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
-  const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
-  const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
-  float* gin = p.ws + p.o.off_gin + (valid ? (point * 2 + h) * SB_GIN_LD : 0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float m[4], vv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        m[e] = seg_sum<VSEG>(x[t][q * 4 + e] * w2, V, seg_base);
-        const float d = x[t][q * 4 + e] - m[e];
-        vv[e] = seg_sum<VSEG>(w2 * (d * d), V, seg_base);
-      }
-      const int g = t * 4 + q;
-      const bool mine = valid && (VSEG > 0 ? (view == (g & (VSEG - 1))) : (view == 0));
-      if (mine) {
-        reinterpret_cast<float4*>(gin)[g] = make_float4(m[0], m[1], m[2], m[3]);
-        reinterpret_cast<float4*>(gin + 64)[g] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      }
-    }
-  if (valid && view == 0) {
-    gin[128] = h == 0 ? wmean : 1.0f;
-    if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
-  }
+  views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
 }
 
 // ===================================================================================================================
@@ -461,15 +507,19 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
 #define SB_VL_LD 132              // V of one head: [32 features][128 points + pad]
 #define SB_VL_FLOATS (32 * SB_VL_LD)
 
-__global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_static_points(StaticArgs p) {
+// DYN = false: DynibarStatic (no positional encoding; outputs sigma and the point part of rgb_fc.0)
+// DYN = true : DynibarDynamic (+ sinusoid positional encoding, ref_pts_fc, rgb_fc on [feature | PE(view dir)]; outputs raw [R,S,4])
+template <bool DYN>
+__global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * DYN_CHUNK;  // [SB_CT]
-  float* Kl = ctab + SB_CT;
+  float* ctab = lds + 2 * DYN_CHUNK;  // [SB_CT] / [DB_CT]
+  float* Kl = ctab + (DYN ? DB_CT : SB_CT);
   float* Vl = Kl + SB_KL_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  for (int i = tid; i < SB_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[ST_OFF_CTB + i];
+  constexpr int CT = DYN ? DB_CT : SB_CT;
+  for (int i = tid; i < CT; i += DYN_NET_THREADS) ctab[i] = p.blob[(DYN ? DY_OFF_CTB : ST_OFF_CTB) + i];
   WeightRing ring;
-  ring_init(ring, p.blob + ST_OFF_B, SB_CHUNKS, lds);
+  ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), DYN ? DB_CHUNKS : SB_CHUNKS, lds);
 
   const int TPR = p.TPR;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -500,6 +550,17 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_static_points(StaticArgs
     acc_zero(g);
     mlp_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? a9[s / 16][s % 16] : one_h0; });
     acc_elu(g);
+  }
+  if (DYN) {
+    // globalfeat + pos_encoding (mlp_network.py:284): table rows in D-layout order [position][half][64]
+    const float4* pe = reinterpret_cast<const float4*>(p.blob + DY_OFF_POSENC + ((valid ? smp : 0) * 2 + h) * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = pe[t * 4 + q];
+        g[t][q * 4] += v.x; g[t][q * 4 + 1] += v.y; g[t][q * 4 + 2] += v.z; g[t][q * 4 + 3] += v.w;
+      }
   }
   // ---- multi-head self-attention over the samples of the ray (mlp_network.py:13-31, 56-104) ----
   f32x16 att[4];
@@ -610,7 +671,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_static_points(StaticArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[t][r] = (o[t][r] - mu) * rstd * gam[t * 16 + r] + bet[t * 16 + r];
   }
-  {
+  if (!DYN) {
     f32x16 a[4];
     acc_zero(a);
     mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
@@ -627,6 +688,67 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_static_points(StaticArgs
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[t * 4 + q] = make_float4(a[t][q * 4], a[t][q * 4 + 1], a[t][q * 4 + 2], a[t][q * 4 + 3]);
     }
+  } else {
+    // ref_pts_fc([globalfeat, PE(pts)])   (mlp_network.py:289-290)
+    f32x16 g2[4];
+    {
+      float pe[17];  // 15 cos|sin pairs (3 coords x 5 octaves), then (x, y), (z, 1)
+      float c3[3] = {0.f, 0.f, 0.f};
+      if (valid) { c3[0] = p.pts[point * 3]; c3[1] = p.pts[point * 3 + 1]; c3[2] = p.pts[point * 3 + 2]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+          float sn, cs;
+          sincosf((float)(1 << f) * c3[c], &sn, &cs);
+          pe[c * 5 + f] = h == 0 ? cs : sn;
+        }
+      pe[15] = h == 0 ? c3[0] : c3[1];
+      pe[16] = h == 0 ? c3[2] : 1.0f;
+      f32x16 a8[8];
+      acc_zero(a8);
+      mlp_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
+      acc_elu(a8);
+      acc_zero(g2);
+      mlp_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? a8[s / 16][s % 16] : one_h0; });
+      acc_elu(g2);
+    }
+    f32x16 a[4];
+    acc_zero(a);
+    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : one_h0; });
+    acc_elu(a);
+    float sigma = row_dot<4>(a, ctab + 256) + ctab[384] - p.shift;
+    if (nvalid < 1.0f) sigma = -1e9f;
+    // rgb_fc([globalfeat, PE(view dir)])   (mlp_network.py:299-313)
+    float pd[14];  // 12 cos|sin pairs (3 coords x 4 octaves), then (dx, dy), (dz, 1)
+    {
+      float d3[3] = {0.f, 0.f, 1.f};
+      if (valid) unit3(p.ray_d[ray * 3], p.ray_d[ray * 3 + 1], p.ray_d[ray * 3 + 2], d3[0], d3[1], d3[2]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          float sn, cs;
+          sincosf((float)(1 << f) * d3[c], &sn, &cs);
+          pd[c * 4 + f] = h == 0 ? cs : sn;
+        }
+      pd[12] = h == 0 ? d3[0] : d3[1];
+      pd[13] = h == 0 ? d3[2] : 1.0f;
+    }
+    acc_zero(a);
+    mlp_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
+    acc_elu(a);
+    f32x16 b2[2];
+    acc_zero(b2);
+    mlp_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+    acc_elu(b2);
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rgb[c] = sigmoid1(row_dot<2>(b2, ctab + 400 + c * 64) + ctab[385 + c]);
+      if (nvalid == 0.f) rgb[c] = 0.f;  // masked_fill(sum(mask) == 0, 0)
+    }
+    if (valid && h == 0) reinterpret_cast<float4*>(p.raw)[point] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   }
 }
 
@@ -723,10 +845,365 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
   else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk, lds_a, stream, a);
-  DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_static_points, grid_b, blk, lds_b, stream, a);
+  DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_net_points<false>, grid_b, blk, lds_b, stream, a);
   if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk, lds_c, stream, a);
   else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk, lds_c, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<0>, grid_a, blk, lds_c, stream, a);
+  return 0;
+}
+
+// ===================================================================================================================
+// DynibarDynamic: packing
+// ===================================================================================================================
+extern "C" size_t dyn_dynamic_net_blob_floats(void) { return DY_BLOB_FLOATS; }
+
+extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, size_t blob_floats) {
+  DYN_REQUIRE(T && blob, "dyn_dynamic_net_pack: null pointer");
+  DYN_REQUIRE(F == 32, "dyn_dynamic_net_pack: the kernels are specialised for 32 feature channels");
+  DYN_REQUIRE(blob_floats >= DY_BLOB_FLOATS, "dyn_dynamic_net_pack: blob too small");
+  for (int i = 0; i < DT_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_dynamic_net_pack: tensor %d is NULL", i);
+  std::vector<float> o;
+  o.reserve(DY_BLOB_FLOATS);
+  {
+    const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];
+    pack_layer(o, 8, DA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s == 3 * DA_NX) return h == 0 ? b[n] : 0.f;
+      const int part = s / DA_NX, c = da_c35(s % DA_NX, h);
+      if (c < 0) return 0.f;
+      return W[n * 105 + (part == 0 ? 70 : (part == 1 ? 0 : 35)) + c];  // x | mean | var   (mlp_network.py:262-266)
+    });
+  }
+  pack_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], T[DT_BASE2_B], 128, 256, 256));
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], T[DT_VIS0_B], 128, 128, 128));
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], T[DT_VIS2_B], 128, 128, 128));
+  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], T[DT_VISB0_B], 128, 128, 128));
+  DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
+  {
+    const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
+    pack_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];
+      return h == 0 ? W[n * 257 + 256] : b[n];
+    });
+  }
+  pack_layer(o, 4, 129, chained(T[DT_GEO2_W], T[DT_GEO2_B], 128, 256, 256));
+  pack_layer(o, 4, 64, chained(T[DT_WQ], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[DT_WK], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[DT_WV], nullptr, 128, 128, 128));
+  pack_layer(o, 4, 64, chained(T[DT_FC], nullptr, 128, 128, 128));
+  {
+    const float *W = T[DT_REFPTS0_W], *b = T[DT_REFPTS0_B];  // [256, 128 + 33]
+    pack_layer(o, 8, 81, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < 64) return W[n * 161 + chain_feature(s, h)];
+      if (s < 79) { const int c = (s - 64) / 5, f = (s - 64) % 5; return W[n * 161 + 128 + 3 + (h * 5 + f) * 3 + c]; }
+      if (s == 79) return W[n * 161 + 128 + h];
+      return h == 0 ? W[n * 161 + 128 + 2] : b[n];
+    });
+  }
+  pack_layer(o, 4, 129, chained(T[DT_REFPTS2_W], T[DT_REFPTS2_B], 128, 256, 256));
+  pack_layer(o, 4, 65, chained(T[DT_OG0_W], T[DT_OG0_B], 128, 128, 128));
+  {
+    const float *W = T[DT_RGB0_W], *b = T[DT_RGB0_B];  // [128, 128 + 27]
+    pack_layer(o, 4, 78, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < 64) return W[n * 155 + chain_feature(s, h)];
+      if (s < 76) { const int c = (s - 64) / 4, f = (s - 64) % 4; return W[n * 155 + 128 + 3 + (h * 4 + f) * 3 + c]; }
+      if (s == 76) return W[n * 155 + 128 + h];
+      return h == 0 ? W[n * 155 + 128 + 2] : b[n];
+    });
+  }
+  pack_layer(o, 2, 65, chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128));
+  DYN_REQUIRE(o.size() == DY_OFF_CTA, "dynamic pack: B stream size mismatch");
+  pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128);
+  pack_rowtab(o, T[DT_VISB2_W], 128);
+  o.push_back(T[DT_VIS2_B][128]);
+  o.push_back(T[DT_VISB2_B][0]);
+  o.resize(DY_OFF_CTB, 0.f);
+  pack_rowtab(o, T[DT_LN_G], 128);
+  pack_rowtab(o, T[DT_LN_B], 128);
+  pack_rowtab(o, T[DT_OG2_W], 128);
+  o.push_back(T[DT_OG2_B][0]);
+  for (int c = 0; c < 3; ++c) o.push_back(T[DT_RGB4_B][c]);
+  o.resize(DY_OFF_CTB + 400, 0.f);
+  for (int c = 0; c < 3; ++c) pack_rowtab(o, T[DT_RGB4_W] + c * 64, 64);
+  o.resize(DY_OFF_POSENC, 0.f);
+  // sinusoid table (mlp_network.py:218-234), evaluated in double like numpy, stored in D-layout order [pos][half][64]
+  for (int pos = 0; pos < 128; ++pos)
+    for (int h = 0; h < 2; ++h)
+      for (int k = 0; k < 64; ++k) {
+        const int f = chain_feature(k, h);
+        const double ang = (double)pos / pow(10000.0, 2.0 * (f / 2) / 128.0);
+        o.push_back((float)((f % 2 == 0) ? sin(ang) : cos(ang)));
+      }
+  for (int i = 0; i < 256 * 21; ++i) o.push_back(T[DT_RAYDIR0_W][i]);
+  for (int i = 0; i < 256; ++i) o.push_back(T[DT_RAYDIR0_B][i]);
+  for (int i = 0; i < 35 * 256; ++i) o.push_back(T[DT_RAYDIR2_W][i]);
+  for (int i = 0; i < 35; ++i) o.push_back(T[DT_RAYDIR2_B][i]);
+  o.resize(DY_BLOB_FLOATS, 0.f);
+  for (size_t i = 0; i < DY_BLOB_FLOATS; ++i) blob[i] = o[i];
+  return 0;
+}
+
+extern "C" size_t dyn_dynamic_net_workspace_bytes(int R, int S, int V) {
+  if (R <= 0 || S <= 0 || V <= 0 || V > 32) return 0;
+  return static_ws(R, S, V, true).total * sizeof(float);
+}
+
+// direction_feat = ray_dir_fc(PE(time))  (mlp_network.py:240-247): the same 35-vector for every ray, sample and view
+__global__ void __launch_bounds__(256) k_dynamic_time_feat(const float* __restrict__ Wt, const float* __restrict__ time, float* __restrict__ out) {
+  float* hid = reinterpret_cast<float*>(dyn_smem);  // [256]
+  const int tid = threadIdx.x;
+  const float t = time[0];
+  float pe[21];
+  pe[0] = t;
+  for (int f = 0; f < 10; ++f) {
+    const float a = (float)(1 << f) * t;
+    pe[1 + f] = cosf(a);
+    pe[11 + f] = sinf(a);
+  }
+  {
+    const float* w = Wt + tid * 21;
+    float acc = Wt[256 * 21 + tid];
+    for (int k = 0; k < 21; ++k) acc = fmaf(w[k], pe[k], acc);
+    hid[tid] = acc > 0.f ? acc : expm1f(acc);
+  }
+  __syncthreads();
+  if (tid < 35) {
+    const float* w = Wt + 256 * 21 + 256 + tid * 256;
+    float acc = Wt[256 * 21 + 256 + 35 * 256 + tid];
+    for (int k = 0; k < 256; ++k) acc = fmaf(w[k], hid[k], acc);
+    out[tid] = acc > 0.f ? acc : expm1f(acc);
+  } else if (tid < 36) {
+    out[tid] = 0.f;
+  }
+}
+
+// per point-view chain of the dynamic net: (rgb_feat + direction_feat) -> mean/var (mask weights) -> base_fc -> shared tail
+template <int VSEG>
+__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_dynamic_views(StaticArgs p) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* ctab = lds + 2 * DYN_CHUNK;  // [SA_CT]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
+  WeightRing ring;
+  ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
+
+  const int V = p.V;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
+  const int view = j - p_local * V;
+  const long point = tile * p.PT + p_local;
+  const bool valid = (p_local < p.PT) && (point < p.n_pts);
+  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const long pv = valid ? point * V + view : 0;
+  const float msk = valid ? p.mask[pv] : 0.f;
+  const float* tf = p.ws + p.o.off_ref;
+  float xin[DA_NX];
+#pragma unroll
+  for (int q = 0; q < DA_NX; ++q) {
+    const int ch = h == 0 ? q : 18 + q;
+    xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] + tf[ch] : 0.f;
+  }
+  const float wgt = msk / (seg_sum<VSEG>(msk, V, seg_base) + 1e-8f);
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  f32x16 a1[8];
+  acc_zero(a1);
+  mlp_layer<8, DA_L3_STEPS>(ring, a1, [&](int s) {
+    if (s < DA_NX) return xin[s];
+    if (s < 2 * DA_NX) return seg_sum<VSEG>(xin[s - DA_NX] * wgt, V, seg_base);
+    if (s < 3 * DA_NX) {
+      const float m = seg_sum<VSEG>(xin[s - 2 * DA_NX] * wgt, V, seg_base);
+      const float d = xin[s - 2 * DA_NX] - m;
+      return seg_sum<VSEG>(wgt * (d * d), V, seg_base);
+    }
+    return one_h0;
+  });
+  acc_elu(a1);
+  views_tail<VSEG, false>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
+}
+
+extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
+  DYN_REQUIRE(q, "dyn_dynamic_net: null params");
+  DYN_REQUIRE(q->R > 0 && q->S > 0 && q->V > 0, "dyn_dynamic_net: empty problem");
+  DYN_REQUIRE(q->V <= 32, "dyn_dynamic_net: at most 32 source views");
+  DYN_REQUIRE(q->S <= 128, "dyn_dynamic_net: at most 128 samples per ray (the ray attention keeps one ray's keys in LDS)");
+  DYN_REQUIRE(q->blob && q->ray_d && q->pts && q->rgb_feat && q->mask && q->time && q->raw && q->workspace, "dyn_dynamic_net: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  StaticArgs a;
+  a.R = q->R; a.S = q->S; a.V = q->V;
+  a.o = static_ws(q->R, q->S, q->V, true);
+  DYN_REQUIRE(q->workspace_bytes >= a.o.total * sizeof(float), "dyn_dynamic_net: workspace too small (%zu < %zu bytes)", q->workspace_bytes,
+              a.o.total * sizeof(float));
+  a.PT = a.o.PT; a.TPR = a.o.TPR;
+  a.anti_alias = 0; a.mask_rgb = 0;
+  a.n_pts = a.o.n_pts; a.n_tiles_a = a.o.n_tiles_a; a.n_tiles_b = a.o.n_tiles_b;
+  a.shift = q->shift;
+  a.blob = q->blob; a.ray_d = q->ray_d; a.pts = q->pts; a.rgb_feat = q->rgb_feat; a.ray_diff = nullptr; a.mask = q->mask; a.centers = nullptr;
+  a.raw = q->raw; a.ws = (float*)q->workspace;
+  DYN_LAUNCH(DYN_K_DYNAMIC_TIME, "k_dynamic_time_feat", k_dynamic_time_feat, dim3(1), dim3(256), 256 * sizeof(float), stream,
+             q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
+  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
+  const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_b = (2 * DYN_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  if (q->V == 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk, lds_a, stream, a);
+  else if (q->V == 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk, lds_a, stream, a);
+  DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", k_net_points<true>, grid_b, blk, lds_b, stream, a);
+  return 0;
+}
+
+// ===================================================================================================================
+// MotionMLP (mlp_network.py:558-618): 8 x 256 ReLU MLP over PE(x, y, z, t) with a skip into layer 5, 3B DCT coefficients out
+// one wave = 32 sample points; the 132 Fourier features are recomputed for the skip instead of being kept in registers
+// ===================================================================================================================
+enum { MT_L0_W, MT_L0_B, MT_L1_W, MT_L1_B, MT_L2_W, MT_L2_B, MT_L3_W, MT_L3_B, MT_L4_W, MT_L4_B, MT_L5_W, MT_L5_B, MT_L6_W, MT_L6_B, MT_L7_W,
+       MT_L7_B, MT_COEFF_W, MT_COEFF_B, MT_NUM_TENSORS };
+#define MO_PE_STEPS 66  /* 64 cos|sin pairs (4 coords x 16 frequencies), (x, y), (z, t) */
+constexpr int MO_CHUNKS = dyn_layer_chunks(8, MO_PE_STEPS + 1) + 4 * dyn_layer_chunks(8, 129) + dyn_layer_chunks(8, MO_PE_STEPS + 129) +
+                          2 * dyn_layer_chunks(8, 129) + dyn_layer_chunks(1, 129);
+constexpr size_t MO_OFF_FREQ = (size_t)MO_CHUNKS * DYN_CHUNK;  // the 16 frequencies of torch.linspace(1, 17, 16)
+constexpr size_t MO_BLOB_FLOATS = MO_OFF_FREQ + 16;
+
+extern "C" size_t dyn_motion_mlp_blob_floats(void) { return MO_BLOB_FLOATS; }
+
+// reference column of the 132-wide embedding for PE k-step s (< MO_PE_STEPS), half h
+static int mo_pe_col(int s, int h) {
+  if (s < 64) { const int c = s / 16, f = s % 16; return 4 + (h * 16 + f) * 4 + c; }
+  return (s - 64) * 2 + h;
+}
+
+extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* blob, size_t blob_floats) {
+  DYN_REQUIRE(T && blob, "dyn_motion_mlp_pack: null pointer");
+  DYN_REQUIRE(num_basis >= 1 && 3 * num_basis <= 32, "dyn_motion_mlp_pack: 3 * num_basis must be at most 32");
+  DYN_REQUIRE(blob_floats >= MO_BLOB_FLOATS, "dyn_motion_mlp_pack: blob too small");
+  for (int i = 0; i < MT_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_motion_mlp_pack: tensor %d is NULL", i);
+  std::vector<float> o;
+  o.reserve(MO_BLOB_FLOATS);
+  {
+    const float *W = T[MT_L0_W], *b = T[MT_L0_B];
+    pack_layer(o, 8, MO_PE_STEPS + 1, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < MO_PE_STEPS) return W[n * 132 + mo_pe_col(s, h)];
+      return h == 0 ? b[n] : 0.f;
+    });
+  }
+  for (int l = 1; l <= 4; ++l) pack_layer(o, 8, 129, chained(T[MT_L0_W + 2 * l], T[MT_L0_B + 2 * l], 256, 256, 256));
+  {
+    const float *W = T[MT_L5_W], *b = T[MT_L5_B];  // input = cat([embedding(132), h(256)])
+    pack_layer(o, 8, MO_PE_STEPS + 129, [=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i;
+      if (s < MO_PE_STEPS) return W[n * 388 + mo_pe_col(s, h)];
+      const int s2 = s - MO_PE_STEPS;
+      if (s2 < 128) return W[n * 388 + 132 + chain_feature(s2, h)];
+      return h == 0 ? b[n] : 0.f;
+    });
+  }
+  pack_layer(o, 8, 129, chained(T[MT_L6_W], T[MT_L6_B], 256, 256, 256));
+  pack_layer(o, 8, 129, chained(T[MT_L7_W], T[MT_L7_B], 256, 256, 256));
+  pack_layer(o, 1, 129, chained(T[MT_COEFF_W], T[MT_COEFF_B], 3 * num_basis, 256, 256));
+  DYN_REQUIRE(o.size() == MO_OFF_FREQ, "motion pack: stream size mismatch");
+  {
+    // torch.linspace(1, 17, 16) in fp32: start + i * step below the midpoint, end - (n - 1 - i) * step above it
+    const float step = (17.0f - 1.0f) / 15.0f;
+    for (int i = 0; i < 16; ++i) o.push_back(i < 8 ? 1.0f + (float)i * step : 17.0f - (float)(15 - i) * step);
+  }
+  for (size_t i = 0; i < MO_BLOB_FLOATS; ++i) blob[i] = o[i];
+  return 0;
+}
+
+__device__ __forceinline__ void motion_embed(const float (&c4)[4], const float* __restrict__ freq, int h, float (&pe)[MO_PE_STEPS]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      float sn, cs;
+      sincosf(freq[f] * c4[c], &sn, &cs);
+      pe[c * 16 + f] = h == 0 ? cs : sn;
+    }
+  pe[64] = h == 0 ? c4[0] : c4[1];
+  pe[65] = h == 0 ? c4[2] : c4[3];
+}
+
+__device__ __forceinline__ void acc_relu8(f32x16 (&acc)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+}
+
+__global__ void __launch_bounds__(DYN_NET_THREADS, 1)
+k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, const float* __restrict__ time, long n_pts, int S, int n_zero_last,
+             int n_out, float inv_div, float* __restrict__ coeff) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  WeightRing ring;
+  ring_init(ring, blob, MO_CHUNKS, lds);
+  const long point = ((long)blockIdx.x * 4 + wave) * 32 + j;
+  const bool valid = point < n_pts;
+  float c4[4] = {0.f, 0.f, 0.f, time[0]};
+  if (valid) { c4[0] = pts[point * 3]; c4[1] = pts[point * 3 + 1]; c4[2] = pts[point * 3 + 2]; }
+  const float* freq = blob + MO_OFF_FREQ;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  f32x16 a[8], b[8];
+  {
+    float pe[MO_PE_STEPS];
+    motion_embed(c4, freq, h, pe);
+    acc_zero(a);
+    mlp_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
+    acc_relu8(a);
+  }
+  acc_zero(b);
+  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  acc_relu8(b);
+  acc_zero(a);
+  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  acc_relu8(a);
+  acc_zero(b);
+  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  acc_relu8(b);
+  acc_zero(a);
+  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  acc_relu8(a);
+  {
+    float pe[MO_PE_STEPS];
+    motion_embed(c4, freq, h, pe);
+    acc_zero(b);
+    mlp_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
+      if (s < MO_PE_STEPS) return pe[s];
+      return s - MO_PE_STEPS < 128 ? a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16] : one_h0;
+    });
+    acc_relu8(b);
+  }
+  acc_zero(a);
+  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  acc_relu8(a);
+  acc_zero(b);
+  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  acc_relu8(b);
+  f32x16 c1[1];
+  acc_zero(c1);
+  mlp_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  if (valid) {
+    // raw_coeff[:, -n_zero_last:, :] *= 0 (render_ray.py:684): the last samples of every ray carry no motion
+    const int smp = (int)(point % S);
+    const float keep = (smp >= S - n_zero_last) ? 0.f : inv_div;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = dyn_fi(r, h);
+      if (f < n_out) coeff[point * n_out + f] = c1[0][r] * keep;
+    }
+  }
+}
+
+extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* time, int R, int S, int num_basis, int n_zero_last,
+                              float sf_mag_div, float* coeff, void* stream) {
+  DYN_REQUIRE(blob && pts && time && coeff, "dyn_motion_mlp: null pointer");
+  DYN_REQUIRE(R > 0 && S > 0 && num_basis >= 1 && 3 * num_basis <= 32 && n_zero_last >= 0 && sf_mag_div != 0.f, "dyn_motion_mlp: bad argument");
+  const long n_pts = (long)R * S;
+  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), 2 * DYN_CHUNK * sizeof(float),
+             (hipStream_t)stream, blob, pts, time, n_pts, S, n_zero_last, 3 * num_basis, 1.0f / sf_mag_div, coeff);
   return 0;
 }
 

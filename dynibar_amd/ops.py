@@ -190,8 +190,7 @@ class StaticNet:
   state dict (torch tensors or numpy arrays; a DataParallel 'module.' prefix is accepted)."""
 
   def __init__(self, state_dict, device, anti_alias_pooling=True, mask_rgb=False, F=32):
-    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
-    self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, sd, F).to(device)
+    self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, _strip_module(state_dict), F).to(device)
     self.anti_alias_pooling, self.mask_rgb = int(bool(anti_alias_pooling)), int(bool(mask_rgb))
     self._ws = None
 
@@ -216,3 +215,80 @@ class StaticNet:
                workspace_bytes=need)
     call('dyn_static_net', ctypes.byref(p), stream_of(raw))
     return raw
+
+
+DYNAMIC_TENSORS = (
+    'ray_dir_fc.0.weight', 'ray_dir_fc.0.bias', 'ray_dir_fc.2.weight', 'ray_dir_fc.2.bias', 'base_fc.0.weight', 'base_fc.0.bias',
+    'base_fc.2.weight', 'base_fc.2.bias', 'vis_fc.0.weight', 'vis_fc.0.bias', 'vis_fc.2.weight', 'vis_fc.2.bias', 'vis_fc2.0.weight',
+    'vis_fc2.0.bias', 'vis_fc2.2.weight', 'vis_fc2.2.bias', 'geometry_fc.0.weight', 'geometry_fc.0.bias', 'geometry_fc.2.weight',
+    'geometry_fc.2.bias', 'ray_attention.w_qs.weight', 'ray_attention.w_ks.weight', 'ray_attention.w_vs.weight', 'ray_attention.fc.weight',
+    'ray_attention.layer_norm.weight', 'ray_attention.layer_norm.bias', 'ref_pts_fc.0.weight', 'ref_pts_fc.0.bias', 'ref_pts_fc.2.weight',
+    'ref_pts_fc.2.bias', 'out_geometry_fc.0.weight', 'out_geometry_fc.0.bias', 'out_geometry_fc.2.weight', 'out_geometry_fc.2.bias',
+    'rgb_fc.0.weight', 'rgb_fc.0.bias', 'rgb_fc.2.weight', 'rgb_fc.2.bias', 'rgb_fc.4.weight', 'rgb_fc.4.bias')
+MOTION_TENSORS = tuple(f'pts_linears.{i}.{n}' for i in range(8) for n in ('weight', 'bias')) + ('coeff_linear.weight', 'coeff_linear.bias')
+
+
+def _strip_module(state_dict):
+  return {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+
+
+class _Workspace:
+  def __init__(self):
+    self.buf = None
+
+  def get(self, need, device):
+    if need == 0:
+      raise ValueError('unsupported network shape (R, S, V)')
+    if self.buf is None or self.buf.numel() * 4 < need or self.buf.device != torch.device(device):
+      self.buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    return self.buf
+
+
+class DynamicNet:
+  """DynibarDynamic (mlp_network.py:129-316) on one device.  ``shift`` as passed to the module's constructor."""
+
+  def __init__(self, state_dict, device, shift=0.0, F=32):
+    self.blob = _pack('dyn_dynamic_net_pack', 'dyn_dynamic_net_blob_floats', DYNAMIC_TENSORS, _strip_module(state_dict), F).to(device)
+    self.shift = float(shift)
+    self._ws = _Workspace()
+
+  def __call__(self, ray_d, pts, rgb_feat, mask, time):
+    """time: device tensor [1] (the reference time embedding) -> raw [R,S,4]  (k_dynamic_time_feat, k_dynamic_views, k_dynamic_points)."""
+    k = _Keep()
+    R, S, V = rgb_feat.shape[:3]
+    dev = rgb_feat.device
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
+    need = int(_lib.lib().dyn_dynamic_net_workspace_bytes(R, S, V))
+    ws = self._ws.get(need, dev)
+    p = params('DynDynamicNetParams', R=R, S=S, V=V, shift=self.shift, blob=ptr(self.blob), ray_d=k(ray_d), pts=k(pts), rgb_feat=k(rgb_feat),
+               mask=k(mask), time=k(time.reshape(-1)), raw=ptr(raw), workspace=ptr(ws), workspace_bytes=need)
+    call('dyn_dynamic_net', ctypes.byref(p), stream_of(raw))
+    return raw
+
+
+class MotionMLP:
+  """MotionMLP (mlp_network.py:558-618) on one device."""
+
+  def __init__(self, state_dict, device, num_basis=6, sf_mag_div=1.0):
+    self.blob = _pack('dyn_motion_mlp_pack', 'dyn_motion_mlp_blob_floats', MOTION_TENSORS, _strip_module(state_dict), num_basis).to(device)
+    self.num_basis, self.sf_mag_div = int(num_basis), float(sf_mag_div)
+
+  def __call__(self, pts, time, n_zero_last):
+    """pts [R,S,3], time device [1] -> raw coefficients [R,S,3B] with the last n_zero_last samples of every ray zeroed (k_motion_mlp)."""
+    k = _Keep()
+    R, S = pts.shape[:2]
+    coeff = torch.empty((R, S, 3 * self.num_basis), dtype=torch.float32, device=pts.device)
+    call('dyn_motion_mlp', ptr(self.blob), k(pts), k(time.reshape(-1)), R, S, self.num_basis, int(n_zero_last), self.sf_mag_div, ptr(coeff),
+         stream_of(coeff))
+    return coeff
+
+
+def trajectory_points(coeff, basis, pts, rows, row_ref):
+  """k_trajectory_points: pts_seq [len(rows), R, S, 3]; rows = basis row per source view (frame + offset), < 0 = undisplaced."""
+  k = _Keep()
+  R, S = pts.shape[:2]
+  B = basis.shape[1]
+  out = torch.empty((len(rows), R, S, 3), dtype=torch.float32, device=pts.device)
+  arr = (ctypes.c_int * len(rows))(*[int(r) for r in rows])
+  call('dyn_trajectory_points', k(coeff), k(basis), k(pts), R * S, B, arr, len(rows), int(row_ref), ptr(out), stream_of(out))
+  return out

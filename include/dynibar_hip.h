@@ -154,6 +154,49 @@ typedef struct {
 } DynStaticNetParams;
 int dyn_static_net(const DynStaticNetParams* p, void* stream);
 
+/* ---- a16 DynibarDynamic.forward (mlp_network.py:236-316) ---------------------------------------------------------------
+ * tensors for dyn_dynamic_net_pack (HOST pointers, state-dict names, 40 tensors):
+ *   ray_dir_fc.0.weight .0.bias ray_dir_fc.2.weight .2.bias base_fc.0.weight .0.bias base_fc.2.weight .2.bias vis_fc.0.weight .0.bias
+ *   vis_fc.2.weight .2.bias vis_fc2.0.weight .0.bias vis_fc2.2.weight .2.bias geometry_fc.0.weight .0.bias geometry_fc.2.weight .2.bias
+ *   ray_attention.w_qs.weight ray_attention.w_ks.weight ray_attention.w_vs.weight ray_attention.fc.weight
+ *   ray_attention.layer_norm.weight ray_attention.layer_norm.bias ref_pts_fc.0.weight .0.bias ref_pts_fc.2.weight .2.bias
+ *   out_geometry_fc.0.weight .0.bias out_geometry_fc.2.weight .2.bias rgb_fc.0.weight .0.bias rgb_fc.2.weight .2.bias rgb_fc.4.weight .4.bias
+ * The net ignores ray_diff and time_diff (anti_alias_pooling is hard-wired off, mlp_network.py:135), so they are not inputs. */
+#define DYN_DYNAMIC_NUM_TENSORS 40
+size_t dyn_dynamic_net_blob_floats(void);
+int dyn_dynamic_net_pack(const float* const* tensors, int F, float* blob, size_t blob_floats);
+size_t dyn_dynamic_net_workspace_bytes(int R, int S, int V);
+typedef struct {
+  int R, S, V;               /* rays, samples per ray (<= 128; must equal the module's n_samples), source views (<= 32) */
+  float shift;               /* subtracted from sigma (DynibarMono builds its dynamic net with shift = 5, model.py:307) */
+  const float* blob;         /* DEVICE copy of the packed weights */
+  const float* ray_d;        /* [R,3] (normalised in the kernel, render_ray.py:655) */
+  const float* pts;          /* [R,S,3] reference-time sample points */
+  const float* rgb_feat;     /* [R,S,V,35] */
+  const float* mask;         /* [R,S,V] */
+  const float* time;         /* DEVICE [1]: reference time embedding */
+  float* raw;                /* [R,S,4] */
+  void* workspace;           /* DEVICE scratch of dyn_dynamic_net_workspace_bytes(R,S,V) bytes */
+  size_t workspace_bytes;
+} DynDynamicNetParams;
+int dyn_dynamic_net(const DynDynamicNetParams* p, void* stream);
+
+/* ---- a14 MotionMLP.forward (mlp_network.py:605-618) + the zeroing of the last samples' coefficients (render_ray.py:684) -------
+ * tensors for dyn_motion_mlp_pack (HOST, 18 tensors): pts_linears.0.weight .0.bias ... pts_linears.7.weight .7.bias
+ * coeff_linear.weight coeff_linear.bias.   coeff: [R,S,3*num_basis].  n_zero_last = int(round(S * 0.1)). */
+#define DYN_MOTION_NUM_TENSORS 18
+size_t dyn_motion_mlp_blob_floats(void);
+int dyn_motion_mlp_pack(const float* const* tensors, int num_basis, float* blob, size_t blob_floats);
+int dyn_motion_mlp(const float* blob, const float* pts, const float* time, int R, int S, int num_basis, int n_zero_last, float sf_mag_div,
+                   float* coeff, void* stream);
+
+/* ---- a15 compute_traj_pts + the per-view displaced points (render_ray.py:361-369, :686-709) -------------------------------
+ * pts_seq[v] = pts + (traj(row_v) - traj(row_ref)), traj(row) = (sum_b cx_b basis[row,b], sum_b cy_b .., sum_b cz_b ..);
+ * rows: HOST array of n_rows basis-row indices (frame + offset); a row index < 0 means "no motion" (virtual views, :988-989).
+ * basis: DEVICE [num_frames, B].  pts_seq: DEVICE [n_rows, n_pts, 3]. */
+int dyn_trajectory_points(const float* coeff, const float* basis, const float* pts, long n_pts, int B, const int* rows, int n_rows, int row_ref,
+                          float* pts_seq, void* stream);
+
 /* ---- self-test of the MFMA chain engine: y = elu(W elu(W x + b) + b), W [64,64], b [64] HOST; x, y [rows,64] DEVICE;
  * stream_buf: DEVICE scratch of 2 * 3 * 4096 floats ------------------------------------------------------------------- */
 int dyn_mlp_selftest(const float* W, const float* b, const float* x, float* y, int rows, float* stream_buf, void* stream);

@@ -264,3 +264,52 @@ def check_mlp_selftest(device, rows=1000):
             _lib.stream_of(xd))
   ref = F.elu(F.linear(F.elu(F.linear(x, W, b)), W, b))
   assert_close(y, ref, 2e-6, 0.0, 'mlp engine self-test')
+
+
+def dynamic_inputs(name, S, R=None):
+  """Oracle-side stage tensors of the dynamic branch (motion MLP -> trajectory points -> projection) for a seeded scene."""
+  scene, o, d, uv, _ = cases.scene_case(name)
+  if R is not None:
+    o, d = o[:R], d[:R]
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  basis = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  pts, z, s = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  Rn = pts.shape[0]
+  t_emb = temb[None, None, :].repeat(Rn, S, 1)
+  coeff = O.motion_mlp(W['motion_mlp'], torch.cat([pts, t_emb], -1).float())
+  n_last = int(round(S * 0.1))
+  coeff[:, -n_last:, :] *= 0.0
+  traj = O.trajectory_points(coeff, basis, fidx)
+  pts_seq = torch.stack([pts + (traj[k] - traj[0]) for k in toff], 0)
+  rf, rd, mk = O.compute_with_motions(pts, pts_seq, scene['camera'], scene['src_rgbs'], scene['src_cameras'], scene['featmaps'])
+  return dict(scene=scene, o=o, d=d, W=W, basis=basis, pts=pts, z=z, fidx=fidx, temb=temb, toff=toff, t_emb=t_emb, coeff=coeff,
+              pts_seq=pts_seq, rgb_feat=rf, ray_diff=rd, mask=mk, n_last=n_last)
+
+
+def check_motion(device, name='small', S=64, R=None):
+  di = dynamic_inputs(name, S, R)
+  mm = ops.MotionMLP(cases.model_weights(0)['motion_mlp'], device, cases.NUM_BASIS)
+  coeff = mm(di['pts'].to(device), di['temb'].to(device), di['n_last'])
+  # 8 ReLU layers of width 256 on Fourier features up to 17 * |x|: fp32 round-off grows with the argument of sin/cos
+  assert_close(coeff, di['coeff'], 2e-5, 1e-4, f'{name} motion coefficients')
+  rows = [di['fidx'] + k for k in di['toff']]
+  seq = ops.trajectory_points(di['coeff'].to(device), di['basis'].to(device), di['pts'].to(device), rows, di['fidx'])
+  assert_close(seq, di['pts_seq'], 1e-6, 1e-6, f'{name} trajectory points')
+  return float((cpu(coeff) - di['coeff']).abs().max())
+
+
+def check_dynamic_net(device, name='small', S=64, R=None, shift=0.0, atol=1e-4):
+  di = dynamic_inputs(name, S, R)
+  Vd = di['rgb_feat'].shape[2]
+  tdiff = torch.zeros(di['pts'].shape[0], S, Vd, 1)
+  raw_ref = O.dynamic_net(di['W']['net_coarse_dy'], di['pts'], di['rgb_feat'], F.normalize(di['d'], dim=-1), di['ray_diff'], tdiff, di['mask'],
+                          di['t_emb'], shift=shift)
+  net = ops.DynamicNet(cases.model_weights(0)['net_coarse_dy'], device, shift=shift)
+  raw = net(di['d'].to(device), di['pts'].to(device), di['rgb_feat'].to(device), di['mask'].to(device), di['temb'].to(device))
+  sig, sig_ref = cpu(raw)[..., 3], raw_ref[..., 3]
+  dead = sig_ref < -1e8
+  assert bool((sig[dead] == sig_ref[dead]).all()), 'sigma of points without a valid view must be -1e9'
+  assert_close(sig[~dead], sig_ref[~dead], atol, 1e-4, f'{name} dynamic sigma')
+  assert_close(cpu(raw)[..., :3], raw_ref[..., :3], atol, 0.0, f'{name} dynamic rgb')
+  return float((cpu(raw) - raw_ref)[..., :3].abs().max()), float((sig[~dead] - sig_ref[~dead]).abs().max())

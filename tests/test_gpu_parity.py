@@ -54,3 +54,13 @@ def test_static_net(dev, kw):
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
+
+
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64, shift=5.0), dict(name='noise', S=128), dict(name='small', S=32, R=3)])
+def test_dynamic_net(dev, kw):
+  parity.check_dynamic_net(dev, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=128)])
+def test_motion_mlp(dev, kw):
+  parity.check_motion(dev, **kw)
