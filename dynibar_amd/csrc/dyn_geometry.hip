@@ -34,7 +34,7 @@ static struct {
 static const char* const g_prof_names[DYN_K_COUNT] = {
     "k_prepare_cameras", "k_nchw_to_nhwc", "k_sample_along_ray", "k_points_from_z", "k_project_gather", "k_sample_mask", "k_composite",
     "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest", "k_dynamic_time_feat",
-    "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points"};
+    "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points", "k_render_flows", "k_expected_scene_flow", "k_image_rays"};
 
 static void prof_flush(int slot) {
   for (int i = 0; i < g_prof.used[slot]; ++i) {
@@ -530,6 +530,107 @@ extern "C" int dyn_trajectory_points(const float* coeff, const float* basis, con
   for (int i = 0; i < 32; ++i) tr.rows[i] = i < n_rows ? rows[i] : -1;
   DYN_LAUNCH(DYN_K_TRAJECTORY, "dyn_trajectory_points", k_trajectory_points, dim3(dyn_cdiv(n_pts, 256)), dim3(256), 0, (hipStream_t)stream, coeff,
              basis, pts, n_pts, B, tr, pts_seq);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a22 expected optical flow (render_ray.py:333-358) and expected scene flow (:584-595, :1086-1096): one wavefront per ray
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_render_flows(const float* __restrict__ weights, const float* __restrict__ pts_seq, const float* __restrict__ proj,
+                                                      const float* __restrict__ uv, int R, int S, int V, float* __restrict__ flows) {
+  const int lane = dyn_lane();
+  const long w = (long)blockIdx.x * 4 + dyn_wave();  // (view, ray)
+  if (w >= (long)V * R) return;
+  const int v = (int)(w / R), r = (int)(w % R);
+  float ex = 0.f, ey = 0.f, ez = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float wt = weights[(long)r * S + s];
+    const float* q = pts_seq + (((long)v * R + r) * S + s) * 3;
+    ex += wt * q[0]; ey += wt * q[1]; ez += wt * q[2];
+  }
+  ex = wave_sum(ex); ey = wave_sum(ey); ez = wave_sum(ez);
+  if (lane == 0) {
+    const float* P = proj + v * 16;  // rows of K . inv(c2w)
+    const float hx = P[0] * ex + P[1] * ey + P[2] * ez + P[3];
+    const float hy = P[4] * ex + P[5] * ey + P[6] * ez + P[7];
+    const float hz = P[8] * ex + P[9] * ey + P[10] * ez + P[11];
+    flows[((long)v * R + r) * 2 + 0] = hx / hz - uv[r * 2 + 0];
+    flows[((long)v * R + r) * 2 + 1] = hy / hz - uv[r * 2 + 1];
+  }
+}
+extern "C" int dyn_render_flows(const float* weights, const float* pts_seq, const float* proj, const float* uv, int R, int S, int V, float* flows,
+                                void* stream) {
+  DYN_REQUIRE(weights && pts_seq && proj && uv && flows && R > 0 && S > 0 && V > 0, "dyn_render_flows: bad argument");
+  DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_render_flows", k_render_flows, dim3(dyn_cdiv((long)V * R, 4)), dim3(256), 0, (hipStream_t)stream, weights,
+             pts_seq, proj, uv, R, S, V, flows);
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_expected_scene_flow(const float* __restrict__ weights, const float* __restrict__ coeff,
+                                                             const float* __restrict__ basis, int R, int S, int B, int row_p, int row_m,
+                                                             int row_ref, float* __restrict__ out) {
+  const int lane = dyn_lane();
+  const int r = blockIdx.x * 4 + dyn_wave();
+  if (r >= R) return;
+  float ap[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f};
+  for (int s = lane; s < S; s += 64) {
+    const float wt = weights[(long)r * S + s];
+    const float* c = coeff + ((long)r * S + s) * 3 * B;
+    for (int a = 0; a < 3; ++a) {
+      float t0 = 0.f, tp = 0.f, tm = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float cb = c[a * B + b];
+        t0 += cb * basis[(long)row_ref * B + b];
+        tp += cb * basis[(long)row_p * B + b];
+        tm += cb * basis[(long)row_m * B + b];
+      }
+      ap[a] += wt * (tp - t0);
+      am[a] += wt * (tm - t0);
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    ap[a] = wave_sum(ap[a]);
+    am[a] = wave_sum(am[a]);
+    if (lane == 0) out[r * 3 + a] = fmaxf(ap[a], am[a]);
+  }
+}
+extern "C" int dyn_expected_scene_flow(const float* weights, const float* coeff, const float* basis, int R, int S, int B, int row_p, int row_m,
+                                       int row_ref, float* exp_sf, void* stream) {
+  DYN_REQUIRE(weights && coeff && basis && exp_sf && R > 0 && S > 0 && B > 0, "dyn_expected_scene_flow: bad argument");
+  DYN_REQUIRE(row_p >= 0 && row_m >= 0 && row_ref >= 0, "dyn_expected_scene_flow: basis rows must be non-negative");
+  DYN_LAUNCH(DYN_K_SCENE_FLOW, "dyn_expected_scene_flow", k_expected_scene_flow, dim3(dyn_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, weights,
+             coeff, basis, R, S, B, row_p, row_m, row_ref, exp_sf);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a2 all-pixel rays of a target view (sample_ray.py:143-163): d = c2w[:3,:3] . inv(K[:3,:3]) . [u, v, 1], o = c2w[:3,3]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_image_rays(const float* __restrict__ camera, int Ws, int n, int stride, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // M = R . inv(K3) in double (the reference inverts K with LAPACK in fp32; agreement is to ~1e-7 relative, not bitwise)
+  double K[9], Rm[9], Ki[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) { K[a * 3 + b] = camera[2 + a * 4 + b]; Rm[a * 3 + b] = camera[18 + a * 4 + b]; }
+  const double det = K[0] * (K[4] * K[8] - K[5] * K[7]) - K[1] * (K[3] * K[8] - K[5] * K[6]) + K[2] * (K[3] * K[7] - K[4] * K[6]);
+  Ki[0] = (K[4] * K[8] - K[5] * K[7]) / det; Ki[1] = (K[2] * K[7] - K[1] * K[8]) / det; Ki[2] = (K[1] * K[5] - K[2] * K[4]) / det;
+  Ki[3] = (K[5] * K[6] - K[3] * K[8]) / det; Ki[4] = (K[0] * K[8] - K[2] * K[6]) / det; Ki[5] = (K[2] * K[3] - K[0] * K[5]) / det;
+  Ki[6] = (K[3] * K[7] - K[4] * K[6]) / det; Ki[7] = (K[1] * K[6] - K[0] * K[7]) / det; Ki[8] = (K[0] * K[4] - K[1] * K[3]) / det;
+  const float u = (float)((i % Ws) * stride), v = (float)((i / Ws) * stride);
+  for (int a = 0; a < 3; ++a) {
+    const float m0 = (float)(Rm[a * 3] * Ki[0] + Rm[a * 3 + 1] * Ki[3] + Rm[a * 3 + 2] * Ki[6]);
+    const float m1 = (float)(Rm[a * 3] * Ki[1] + Rm[a * 3 + 1] * Ki[4] + Rm[a * 3 + 2] * Ki[7]);
+    const float m2 = (float)(Rm[a * 3] * Ki[2] + Rm[a * 3 + 1] * Ki[5] + Rm[a * 3 + 2] * Ki[8]);
+    rays_d[i * 3 + a] = fmaf(m0, u, fmaf(m1, v, m2));
+    rays_o[i * 3 + a] = camera[18 + a * 4 + 3];
+  }
+}
+extern "C" int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream) {
+  DYN_REQUIRE(camera && rays_o && rays_d && H > 0 && W > 0 && render_stride > 0, "dyn_image_rays: bad argument");
+  const int Hs = (H + render_stride - 1) / render_stride, Ws = (W + render_stride - 1) / render_stride;
+  DYN_LAUNCH(DYN_K_IMAGE_RAYS, "dyn_image_rays", k_image_rays, dim3(dyn_cdiv((long)Hs * Ws, 256)), dim3(256), 0, (hipStream_t)stream, camera, Ws,
+             Hs * Ws, render_stride, rays_o, rays_d);
   return 0;
 }
 

@@ -1,0 +1,254 @@
+"""Drop-in for the reference's ``ibrnet/render_ray.py``: ``render_rays_mv`` / ``render_rays_mono`` (and the helpers the
+reference scripts import) with the reference signatures and output dictionaries (reference render_ray.py:600-867, :870-1277),
+executed by the HIP kernels of libdynibar_hip.so.
+
+``model`` is the reference's ``DynibarFF`` / ``DynibarMono`` object (or any object with the same attributes): its sub-networks
+may be ``nn.Module``s (optionally ``DataParallel``-wrapped) or plain state dicts.  Their weights are packed into MFMA operand
+tiles once and re-packed only when a parameter's version counter changes.
+
+Scope: forward rendering.  The kernels have no backward pass yet, so the tensors returned here carry no
+autograd graph; ``render_rays_mono(is_train=True)``, whose only extra work is the cross-time supervision branch, raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+USE_DISTANCE = False   # reference render_ray.py:14-16 (module constants; the kernels implement exactly this setting)
+USE_SOFTPLUS = True
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# model adapter
+# ----------------------------------------------------------------------------------------------------------------------
+def _unwrap(net):
+  return net.module if hasattr(net, 'module') and not isinstance(net, dict) else net
+
+
+def _state_dict(net):
+  net = _unwrap(net)
+  return net.state_dict() if hasattr(net, 'state_dict') else net
+
+
+def _version(net):
+  net = _unwrap(net)
+  if hasattr(net, 'parameters'):
+    return tuple((p.data_ptr(), p._version) for p in net.parameters())
+  return tuple((k, getattr(v, '_version', 0), v.data_ptr() if isinstance(v, torch.Tensor) else id(v)) for k, v in sorted(net.items()))
+
+
+class _Packed:
+  """Packed networks of one ``model`` on one device, keyed by attribute name."""
+
+  def __init__(self):
+    self.entries = {}
+
+  def get(self, model, name, device, build):
+    net = getattr(model, name)
+    ver = (_version(net), str(device))
+    ent = self.entries.get(name)
+    if ent is None or ent[0] != ver:
+      ent = (ver, build(_state_dict(net)))
+      self.entries[name] = ent
+    return ent[1]
+
+
+def _packed(model):
+  p = getattr(model, '_dynibar_amd_packed', None)
+  if p is None:
+    p = _Packed()
+    try:
+      model._dynibar_amd_packed = p
+    except AttributeError:
+      pass
+  return p
+
+
+def _flag(net, args, name, default):
+  net = _unwrap(net)
+  if hasattr(net, name):
+    return bool(getattr(net, name))
+  return bool(getattr(args, name, default))
+
+
+def _static_net(model, name, args, device):
+  net = getattr(model, name)
+  aa, mr = _flag(net, args, 'anti_alias_pooling', True), _flag(net, args, 'mask_rgb', False)
+  return _packed(model).get(model, name, device, lambda sd: ops.StaticNet(sd, device, aa, mr))
+
+
+def _dynamic_net(model, name, device):
+  shift = float(getattr(_unwrap(getattr(model, name)), 'shift', 0.0))
+  return _packed(model).get(model, name, device, lambda sd: ops.DynamicNet(sd, device, shift=shift))
+
+
+def _motion_mlp(model, name, device, num_basis):
+  div = float(getattr(_unwrap(getattr(model, name)), 'sf_mag_div', 1.0))
+  return _packed(model).get(model, name, device, lambda sd: ops.MotionMLP(sd, device, num_basis, div))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reference helpers with the reference signatures
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False):
+  """(render_ray.py:67-131) -> pts [R,S,3], z_vals [R,S], s_vals [R,S]."""
+  t_rand = None if det else torch.rand(ray_o.shape[0], N_samples, device=ray_o.device)
+  return ops.sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand)
+
+
+def z_to_s(z_vals, near_depth_value, far_depth_value):
+  """(render_ray.py:399-404); callers that also need the points use ops.points_from_z, which fuses both."""
+  return ((1.0 / z_vals) - (1.0 / near_depth_value)) / (1.0 / far_depth_value - 1.0 / near_depth_value)
+
+
+def fine_z_vals(z_vals, weights, N_importance, inv_uniform, det):
+  """Coarse weights -> sorted coarse+fine depths: sample_pdf + cat + sort of render_ray.py:790-821 in one kernel."""
+  u = None if det else torch.rand(z_vals.shape[0], N_importance, device=z_vals.device)
+  return ops.fine_samples(z_vals, weights, N_importance, inv_uniform, u)[0]
+
+
+def _as_out(d, keys):
+  return OrderedDict((k, d[k]) for k in keys)
+
+
+def raw2outputs_vanilla(raw, z_vals, mask, white_bkgd=False):
+  """(render_ray.py:134-211) mask: [R,S] bool / 0-1."""
+  out = ops.composite(raw, z_vals, mask.float())
+  out['mask'] = out['mask'] > 0
+  return _as_out(out, ('rgb', 'depth', 'weights', 'mask', 'alpha', 'z_vals'))
+
+
+def raw2outputs(raw_dy, raw_static, z_vals, mask_dy, mask_static, raw_noise_std=0.0, white_bkgd=False):
+  """(render_ray.py:214-330); raw_noise_std is accepted and unused, as in the reference."""
+  out = ops.composite(raw_dy, z_vals, mask_dy.float(), raw_static, mask_static.float())
+  out['mask'] = out['mask'] > 0
+  return _as_out(out, ('rgb', 'rgb_static', 'rgb_dy', 'depth', 'alpha_dy', 'weights_dy', 'weights_st', 'alpha', 'weights', 'mask', 'z_vals'))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one dynamic + static evaluation at given sample points (the body shared by render_ray.py:672-784, :461-597, :948-1098)
+# ----------------------------------------------------------------------------------------------------------------------
+def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps_st, pts, z_vals, ref_frame_idx, ref_time_embedding,
+                 ref_time_offset, num_vv=0):
+  dev = pts.device
+  ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
+  R, S = z_vals.shape
+  basis = getattr(model, names['basis']).detach()
+  num_basis = basis.shape[1]
+  n_last = int(round(S * 0.1))
+  time = ref_time_embedding.reshape(-1)[:1].to(dev).float()
+  # raw_coeff[:, -n_last:, :] *= 0 : with n_last == 0 the reference's slice [-0:] is the whole array (render_ray.py:684)
+  coeff = _motion_mlp(model, names['motion'], dev, num_basis)(pts, time, n_last if n_last > 0 else S)
+  nf = basis.shape[0]
+  rows = [(int(ref_frame_idx) + int(o)) % nf for o in ref_time_offset] + [-1] * num_vv  # negative rows wrap like basis[idx] does
+  pts_seq = ops.trajectory_points(coeff, basis, pts, rows, int(ref_frame_idx) % nf)
+  views_dy = projector.source_views(ray_batch['camera'], ray_batch['src_rgbs'], ray_batch['src_cameras'], featmaps_dy)
+  views_st = projector.source_views(ray_batch['camera'], ray_batch['static_src_rgbs'], ray_batch['static_src_cameras'], featmaps_st)
+  assert views_dy.V == len(rows), 'one time offset (or virtual view) per dynamic source view'
+  rgb_feat_dy, _, mask_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq)
+  rgb_feat_st, ray_diff_st, mask_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals)
+  pm_dy = ops.sample_mask(mask_dy, 1.0)  # at least 2 observations (render_ray.py:736-741)
+  pm_st = ops.sample_mask(mask_st, 1.0)
+  raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
+  raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
+  return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis)
+
+
+def _finish(stage, z_vals, keys2, keys1):
+  out = ops.composite(stage['raw_dy'], z_vals, stage['pm_dy'], stage['raw_st'], stage['pm_st'])
+  out['mask'] = out['mask'] > 0
+  return _as_out(out, keys2)
+
+
+_KEYS2 = ('rgb', 'rgb_static', 'rgb_dy', 'depth', 'alpha_dy', 'weights_dy', 'weights_st', 'alpha', 'weights', 'mask', 'z_vals')
+_KEYS1 = ('rgb', 'depth', 'weights', 'mask', 'alpha', 'z_vals')
+
+
+def _vanilla(raw, z_vals, pm):
+  out = ops.composite(raw, z_vals, pm)
+  out['mask'] = out['mask'] > 0
+  return _as_out(out, _KEYS1)
+
+
+def _motion_outputs(out, stage, ray_batch, ref_frame_idx, sf_off, flow_views=None):
+  """render_flows (render_ray.py:333-358) and exp_sf (:584-595 / :1086-1096) of a composited stage."""
+  R, S = out['weights'].shape
+  views = stage['views_dy']
+  fv = stage['pts_seq'].shape[0] if flow_views is None else min(flow_views, stage['pts_seq'].shape[0])
+  flows = torch.empty((fv, R, 2), dtype=torch.float32, device=out['weights'].device)
+  uv = ray_batch['uv_grid'].float().contiguous()
+  ops.call('dyn_render_flows', ops.ptr(out['weights']), ops.ptr(stage['pts_seq']), ops.ptr(views.proj), ops.ptr(uv), R, S, fv, ops.ptr(flows),
+           ops.stream_of(flows))
+  out['render_flows'] = flows
+  exp_sf = torch.empty((R, 3), dtype=torch.float32, device=flows.device)
+  basis = stage['basis'].float().contiguous()
+  ops.call('dyn_expected_scene_flow', ops.ptr(out['weights']), ops.ptr(stage['coeff']), ops.ptr(basis), R, S, basis.shape[1],
+           (int(ref_frame_idx) + sf_off) % basis.shape[0], (int(ref_frame_idx) - sf_off) % basis.shape[0], int(ref_frame_idx) % basis.shape[0],
+           ops.ptr(exp_sf), ops.stream_of(exp_sf))
+  return exp_sf
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# render_rays_mv  (Nvidia dynamic-scenes path: coarse + fine)
+# ----------------------------------------------------------------------------------------------------------------------
+def render_rays_mv(frame_idx, time_embedding, time_offset, ray_batch, model, projector, coarse_featmaps, fine_featmaps, N_samples, args,
+                   inv_uniform=False, N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True):
+  """Reference render_ray.py:600-867.  Returns the same dictionary: outputs_coarse_ref, outputs_fine_ref, outputs_fine_ref_dy,
+  outputs_fine_anchor (None), outputs_fine_anchor_dy (None)."""
+  ref_frame_idx, ref_time_embedding, ref_time_offset = frame_idx[0], time_embedding[0], time_offset[0]
+  ret = {'outputs_coarse': None, 'outputs_fine': None}
+  ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
+  pts, z_vals, _ = sample_along_camera_ray(ray_o, ray_d, ray_batch['depth_range'], N_samples, inv_uniform, det)
+  names = dict(dy='net_coarse_dy', st='net_coarse_st', motion='motion_mlp', basis='trajectory_basis')
+  stage = _dual_branch(model, names, args, projector, ray_batch, coarse_featmaps[0], coarse_featmaps[2], pts, z_vals, ref_frame_idx,
+                       ref_time_embedding, ref_time_offset)
+  out_c = _finish(stage, z_vals, _KEYS2, _KEYS1)
+  ret['outputs_coarse_ref'] = out_c
+  assert N_importance > 0
+  z_all = fine_z_vals(z_vals, out_c['weights'], N_importance, inv_uniform, det)
+  pts_f, s_all = ops.points_from_z(ray_o, ray_d, z_all, ray_batch['depth_range'])
+  names = dict(dy='net_fine_dy', st='net_fine_st', motion='motion_mlp_fine', basis='trajectory_basis_fine')
+  stage = _dual_branch(model, names, args, projector, ray_batch, fine_featmaps[0], fine_featmaps[2], pts_f, z_all, ref_frame_idx,
+                       ref_time_embedding, ref_time_offset)
+  out_f = _finish(stage, z_all, _KEYS2, _KEYS1)
+  out_f_dy = _vanilla(stage['raw_dy'], z_all, stage['pm_dy'])
+  exp_sf = _motion_outputs(out_f, stage, ray_batch, ref_frame_idx, 2)
+  out_f['s_vals'] = s_all
+  out_f['exp_sf'] = exp_sf
+  ret['outputs_fine_ref'] = out_f
+  ret['outputs_fine_ref_dy'] = out_f_dy
+  ret['outputs_fine_anchor'] = None
+  ret['outputs_fine_anchor_dy'] = None
+  return ret
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# render_rays_mono  (monocular path: coarse only)
+# ----------------------------------------------------------------------------------------------------------------------
+def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, featmaps, projector, N_samples, args, inv_uniform=False,
+                     N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True, num_vv=2):
+  """Reference render_ray.py:870-1277 with is_train=False: outputs_coarse_ref, outputs_coarse_ref_dy, outputs_coarse_st."""
+  if is_train:
+    raise NotImplementedError('render_rays_mono(is_train=True) needs the cross-time supervision branch and autograd; '
+                              'the HIP kernels are forward-only in this release (SURVEY.md section 8f)')
+  ref_frame_idx, ref_time_embedding, ref_time_offset = frame_idx[0], time_embedding[0], time_offset[0]
+  ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
+  pts, z_vals, s_vals = sample_along_camera_ray(ray_o, ray_d, ray_batch['depth_range'], N_samples, inv_uniform, det)
+  names = dict(dy='net_coarse_dy', st='net_coarse_st', motion='motion_mlp', basis='trajectory_basis')
+  stage = _dual_branch(model, names, args, projector, ray_batch, featmaps[0], featmaps[2], pts, z_vals, ref_frame_idx, ref_time_embedding,
+                       ref_time_offset, num_vv=num_vv)
+  out = _finish(stage, z_vals, _KEYS2, _KEYS1)
+  out_st = _vanilla(stage['raw_st'], z_vals, stage['pm_st'])
+  out_dy = _vanilla(stage['raw_dy'], z_vals, stage['pm_dy'])
+  exp_sf = _motion_outputs(out, stage, ray_batch, ref_frame_idx, 1, flow_views=6)
+  out['s_vals'] = s_vals
+  out['exp_sf'] = exp_sf
+  ret = {'outputs_coarse': None, 'outputs_fine': None}
+  ret['outputs_coarse_ref'] = out
+  ret['outputs_coarse_ref_dy'] = out_dy
+  ret['outputs_coarse_st'] = out_st
+  return ret

@@ -197,6 +197,16 @@ int dyn_motion_mlp(const float* blob, const float* pts, const float* time, int R
 int dyn_trajectory_points(const float* coeff, const float* basis, const float* pts, long n_pts, int B, const int* rows, int n_rows, int row_ref,
                           float* pts_seq, void* stream);
 
+/* ---- a22 compute_optical_flow (render_ray.py:333-358): flows[v,r] = project_v(sum_s w[r,s] pts_seq[v,r,s]) - uv[r] ------------
+ * proj: [V,16] from dyn_prepare_cameras (rows of K.inv(c2w)); flows: [V,R,2]. */
+int dyn_render_flows(const float* weights, const float* pts_seq, const float* proj, const float* uv, int R, int S, int V, float* flows,
+                     void* stream);
+/* ---- expected scene flow (render_ray.py:584-595 / :1086-1096): max(sum_s w (traj(row_p) - traj(row_ref)), sum_s w (traj(row_m) - traj(row_ref))) */
+int dyn_expected_scene_flow(const float* weights, const float* coeff, const float* basis, int R, int S, int B, int row_p, int row_m, int row_ref,
+                            float* exp_sf, void* stream);
+/* ---- a2 RaySamplerSingleImage.get_rays_single_image (sample_ray.py:143-163): camera DEVICE [34]; rays_o, rays_d [(H/stride)*(W/stride),3] */
+int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream);
+
 /* ---- self-test of the MFMA chain engine: y = elu(W elu(W x + b) + b), W [64,64], b [64] HOST; x, y [rows,64] DEVICE;
  * stream_buf: DEVICE scratch of 2 * 3 * 4096 floats ------------------------------------------------------------------- */
 int dyn_mlp_selftest(const float* W, const float* b, const float* x, float* y, int rows, float* stream_buf, void* stream);

@@ -313,3 +313,171 @@ def check_dynamic_net(device, name='small', S=64, R=None, shift=0.0, atol=1e-4):
   assert_close(sig[~dead], sig_ref[~dead], atol, 1e-4, f'{name} dynamic sigma')
   assert_close(cpu(raw)[..., :3], raw_ref[..., :3], atol, 0.0, f'{name} dynamic rgb')
   return float((cpu(raw) - raw_ref)[..., :3].abs().max()), float((sig[~dead] - sig_ref[~dead]).abs().max())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the drop-in layer (dynibar_amd.sample_ray / projection / render_ray / render_image) against the golden outputs of the REAL reference
+# ----------------------------------------------------------------------------------------------------------------------
+def make_model(device, seed=0):
+  """An object with the attribute names of the reference's DynibarFF (model.py:33-101) holding plain state dicts."""
+  import types
+  W = cases.model_weights(seed)
+  m = types.SimpleNamespace(**W)
+  m.trajectory_basis = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES).to(device)
+  m.trajectory_basis_fine = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES).to(device)
+  return m
+
+
+def make_ray_batch(scene, o, d, uv, device):
+  b = {k: scene[k].to(device) for k in ('camera', 'src_rgbs', 'src_cameras', 'static_src_rgbs', 'static_src_cameras', 'depth_range')}
+  b.update(ray_o=o.to(device), ray_d=d.to(device), uv_grid=uv.to(device))
+  return b
+
+
+def _group_tol(key, name):
+  # per-sample probabilities and rendered colours: 1e-4 (north_star); depths scale with the scene; flows are pixel differences
+  loose = 5.0 if name == 'noise' else 1.0
+  if key in ('depth', 'z_vals', 's_vals'):
+    return dict(atol=2e-4 * loose, rtol=2e-4)
+  if key in ('render_flows',):
+    return dict(atol=2e-2 * loose, rtol=1e-3)
+  if key in ('exp_sf',):
+    return dict(atol=2e-5 * loose, rtol=1e-3)
+  return dict(atol=1e-4 * loose, rtol=1e-4)
+
+
+def check_group_vs_golden(prefix, out, golden, name, skip_rays=None):
+  n = 0
+  for k, v in out.items():
+    if v is None:
+      continue
+    ref = torch.from_numpy(golden[prefix + k])
+    got = cpu(v)
+    if skip_rays is not None and skip_rays.any():
+      ax = 1 if got.dim() == 3 and got.shape[1] == skip_rays.numel() else 0
+      keep = ~skip_rays
+      got, ref = (got[:, keep], ref[:, keep]) if ax == 1 else (got[keep], ref[keep])
+    if ref.dtype == torch.bool:
+      assert_bitexact(got, ref, prefix + k)
+    else:
+      tol = _group_tol(k, name)
+      assert_close(got.float(), ref.float(), tol['atol'], tol['rtol'], prefix + k)
+    n += 1
+  return n
+
+
+def check_render_rays_mv(device, golden, name='small', S=64):
+  """render_rays_mv (coarse 64 + fine 64, dynamic + static, det=True, inv_uniform=True) against the real reference's outputs."""
+  import types
+  from dynibar_amd import projection, render_ray
+  scene, o, d, uv, _ = cases.scene_case(name)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  proj = projection.Projector(device)
+  batch = make_ray_batch(scene, o, d, uv, device)
+  cfeat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
+  ffeat = (scene['featmaps_fine'].to(device), None, scene['static_featmaps_fine'].to(device))
+  ret = render_ray.render_rays_mv((fidx, None), (temb.to(device), None), (toff, None), batch, model, proj, cfeat, ffeat, S, args,
+                                  inv_uniform=True, N_importance=S, det=True, is_train=False)
+  # rays whose coarse or fine samples touch a frustum edge within fp32 rounding may flip a mask bit (see _mask_check): skipped
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_fine_ref', 'outputs_fine_ref_dy'):
+    n += check_group_vs_golden(f'mv/{grp}/', ret[grp], golden, name)
+  assert n == sum(1 for k in golden if k.startswith('mv/')), 'render_rays_mv output key set differs from the reference'
+  assert ret['outputs_fine_anchor'] is None and ret['outputs_fine_anchor_dy'] is None
+  return n
+
+
+def check_render_rays_mono(device, golden, name='small', S=64):
+  import types
+  from dynibar_amd import projection, render_ray
+  scene, o, d, uv, _ = cases.scene_case(name)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  proj = projection.Projector(device)
+  batch = make_ray_batch(scene, o, d, uv, device)
+  feat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
+  ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, proj, S, args, inv_uniform=True,
+                                    det=True, is_train=False, num_vv=0)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_coarse_ref_dy', 'outputs_coarse_st'):
+    n += check_group_vs_golden(f'mono/{grp}/', ret[grp], golden, name)
+  assert n == sum(1 for k in golden if k.startswith('mono/')), 'render_rays_mono output key set differs from the reference'
+  return n
+
+
+def sampler_data():
+  """The seeded `data` dict of tests/golden/make_golden.py:sampler_goldens."""
+  scene, o, d, uv, pix = cases.scene_case('small')
+  H, W = 48, 64
+  rs = np.random.RandomState(0)
+  f32 = lambda a: torch.from_numpy(a.astype(np.float32))
+  return dict(camera=scene['camera'], rgb_path='x', depth_range=scene['depth_range'], src_rgbs=scene['src_rgbs'], src_cameras=scene['src_cameras'],
+              static_src_rgbs=scene['static_src_rgbs'], static_src_cameras=scene['static_src_cameras'], rgb=f32(rs.rand(1, H, W, 3)),
+              disp=f32(rs.rand(1, H, W)), motion_mask=f32(rs.rand(1, H, W) > 0.5), static_mask=f32(rs.rand(1, H, W) > 0.5),
+              flows=f32(rs.rand(1, 6, H, W, 2)), masks=f32(rs.rand(1, 6, H, W)), anchor_camera=scene['camera'])
+
+
+def check_ray_sampler(device, golden):
+  from dynibar_amd import sample_ray as SR
+  data = sampler_data()
+  SR.rng = np.random.RandomState(234)
+  smp = SR.RaySamplerSingleImage(data, device)
+  assert_close(smp.rays_o, torch.from_numpy(golden['rays_o']), 0.0, 0.0, 'rays_o')
+  assert_close(smp.rays_d, torch.from_numpy(golden['rays_d']), 1e-6, 2e-6, 'rays_d')
+  assert_bitexact(smp.uv_grid, torch.from_numpy(golden['uv_grid']), 'uv_grid')
+  for i, mode in enumerate(['uniform', 'center', 'uniform']):
+    rb = smp.random_sample(37, mode, 0.8)
+    assert np.array_equal(np.asarray(rb['selected_inds']), golden[f'rand{i}/selected_inds']), f'selected_inds draw {i} differs from the reference'
+    assert_close(rb['ray_d'], torch.from_numpy(golden[f'rand{i}/ray_d']), 1e-6, 2e-6, f'rand{i} ray_d')
+    assert_bitexact(rb['rgb'], torch.from_numpy(golden[f'rand{i}/rgb']), f'rand{i} rgb')
+    assert_bitexact(rb['flows'], torch.from_numpy(golden[f'rand{i}/flows']), f'rand{i} flows')
+  smp2 = SR.RaySamplerSingleImage(data, device, render_stride=2)
+  assert_close(smp2.rays_d, torch.from_numpy(golden['stride2/rays_d']), 1e-6, 2e-6, 'stride-2 rays_d')
+  allb = smp.get_all()
+  assert allb['ray_o'].shape == (48 * 64, 3) and allb['flows'].shape == (6, 48 * 64, 2) and allb['disp'].shape == (48 * 64,)
+
+
+def image_case(device):
+  from dynibar_amd import synthetic as syn
+  cfg = dict(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
+  sc = syn.make_scene(**cfg)
+  fine = syn.make_scene(**dict(cfg, tag=1))
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  data = dict(camera=scene['camera'], rgb_path='x', depth_range=scene['depth_range'], src_rgbs=scene['src_rgbs'], src_cameras=scene['src_cameras'],
+              static_src_rgbs=scene['static_src_rgbs'], static_src_cameras=scene['static_src_cameras'])
+  cfeat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
+  ffeat = (cases.t(fine['featmaps']).to(device), None, cases.t(fine['static_featmaps']).to(device))
+  return data, cfeat, ffeat
+
+
+def check_render_image_nvi(device, golden, chunk_size=80):
+  """render_single_image_nvi on a 12x16 frame in 3 chunks against the real reference's frame."""
+  import types
+  from dynibar_amd import projection, render_image, sample_ray
+  data, cfeat, ffeat = image_case(device)
+  smp = sample_ray.RaySamplerSingleImage(data, device)
+  rb = smp.get_all()
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  fidx, temb, toff = cases.time_args(7)
+  ret = render_image.render_single_image_nvi((fidx, None), (temb.to(device), None), (toff, None), smp, rb, model, projection.Projector(device),
+                                             chunk_size, 64, args, inv_uniform=True, N_importance=64, det=True, coarse_featmaps=cfeat,
+                                             fine_featmaps=ffeat, is_train=False)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_fine_ref'):
+    for k, v in ret[grp].items():
+      ref = torch.from_numpy(golden[f'{grp}/{k}'])
+      assert tuple(v.shape) == tuple(ref.shape), f'{grp}/{k}: shape {tuple(v.shape)} vs reference {tuple(ref.shape)}'
+      assert v.device.type == 'cpu', 'render_single_image_* returns host tensors like the reference'
+      if ref.dtype == torch.bool:
+        assert_bitexact(v, ref, f'{grp}/{k}')
+      else:
+        tol = _group_tol(k, 'small')
+        assert_close(v.float(), ref.float(), tol['atol'], tol['rtol'], f'{grp}/{k}')
+      n += 1
+  assert n == len(golden), 'render_single_image_nvi output key set differs from the reference'
+  assert ret['outputs_fine'] is None
+  return ret

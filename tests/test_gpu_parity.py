@@ -64,3 +64,25 @@ def test_dynamic_net(dev, kw):
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=128)])
 def test_motion_mlp(dev, kw):
   parity.check_motion(dev, **kw)
+
+
+def _golden(golden_dir, fn):
+  return dict(np.load(os.path.join(golden_dir, fn)))
+
+
+def test_ray_sampler(dev, golden_dir):
+  parity.check_ray_sampler(dev, _golden(golden_dir, 'sampler.npz'))
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_render_rays_mv(dev, golden_dir, name):
+  parity.check_render_rays_mv(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_render_rays_mono(dev, golden_dir, name):
+  parity.check_render_rays_mono(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
+
+
+def test_render_single_image_nvi(dev, golden_dir):
+  parity.check_render_image_nvi(dev, _golden(golden_dir, 'image_nvi.npz'))
