@@ -8,9 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-@pytest.fixture(scope='session')
+@pytest.fixture(scope='module')
 def emu():
-  """Build the csrc sources against the wave-level emulator and point the ctypes binding at it for this session."""
+  """Build the csrc sources against the wave-level emulator and point the ctypes binding at it for the duration of one test module."""
   import emu_build
   from dynibar_amd import _lib
   path = emu_build.build()

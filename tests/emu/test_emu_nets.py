@@ -1,0 +1,27 @@
+"""The MFMA network kernels (weight ring, register-resident layer chains, ray attention) executed under the wave-level emulator on
+one ray, checked against the oracle.  Debugging aid for fragment maps / packing in a container without a GPU; -m gpu is authoritative."""
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.emu
+
+
+def test_mlp_engine(emu):
+  parity.check_mlp_selftest(emu, rows=70)
+
+
+def test_static_net(emu):
+  parity.check_static_net(emu, 'small', S=32, R=1)
+
+
+def test_static_net_generic_views(emu):
+  parity.check_static_net(emu, 'harsh', S=32, R=1, aa=False, mask_rgb=True)  # 11 views: the non-power-of-two segment path
+
+
+def test_dynamic_net(emu):
+  parity.check_dynamic_net(emu, 'small', S=32, R=1, shift=5.0)
+
+
+def test_motion_mlp(emu):
+  parity.check_motion(emu, 'small', S=32, R=1)
