@@ -116,41 +116,25 @@ __device__ __forceinline__ void acc_elu(f32x16 (&acc)[NT]) {
     for (int r = 0; r < 16; ++r) acc[t][r] = elu1(acc[t][r]);
 }
 
-// ---- reductions over the V consecutive lanes (views) of one point -------------------------------------------------
-// VSEG > 0: V == VSEG is a power of two and segments are aligned -> xor butterfly (every lane gets the bit-identical sum).
-// VSEG == 0: any V <= 32: fixed-order gather of the segment's lanes (seg_base .. seg_base+V-1), again identical in all lanes.
+// ---- reductions over the VSEG consecutive lanes (views, padded to a power of two) of one point: xor butterflies, so every lane
+// of the segment ends with the bit-identical result.  (V, seg_base are unused; kept so call sites read like the maths.)
 template <int VSEG>
-__device__ __forceinline__ float seg_sum(float v, int V, int seg_base) {
-  if (VSEG > 0) {
+__device__ __forceinline__ float seg_sum(float v, int, int) {
 #pragma unroll
-    for (int m = 1; m < VSEG; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-  }
-  float s = 0.f;
-  for (int k = 0; k < V; ++k) s += __shfl(v, seg_base + k);
-  return s;
+  for (int m = 1; m < VSEG; m <<= 1) v += __shfl_xor(v, m);
+  return v;
 }
 template <int VSEG>
-__device__ __forceinline__ float seg_min(float v, int V, int seg_base) {
-  if (VSEG > 0) {
+__device__ __forceinline__ float seg_min(float v, int, int) {
 #pragma unroll
-    for (int m = 1; m < VSEG; m <<= 1) v = fminf(v, __shfl_xor(v, m));
-    return v;
-  }
-  float s = __shfl(v, seg_base);
-  for (int k = 1; k < V; ++k) s = fminf(s, __shfl(v, seg_base + k));
-  return s;
+  for (int m = 1; m < VSEG; m <<= 1) v = fminf(v, __shfl_xor(v, m));
+  return v;
 }
 template <int VSEG>
-__device__ __forceinline__ float seg_max(float v, int V, int seg_base) {
-  if (VSEG > 0) {
+__device__ __forceinline__ float seg_max(float v, int, int) {
 #pragma unroll
-    for (int m = 1; m < VSEG; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-  }
-  float s = __shfl(v, seg_base);
-  for (int k = 1; k < V; ++k) s = fmaxf(s, __shfl(v, seg_base + k));
-  return s;
+  for (int m = 1; m < VSEG; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
 }
 
 // dot product of the lane's 16*NTI activation registers with a [2][16*NTI] table in LDS (row h), summed over both halves

@@ -246,7 +246,7 @@ struct StaticWs {
 static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   StaticWs w;
   w.n_pts = (long)R * S;
-  w.PT = 32 / V;
+  w.PT = 32 / (V <= 4 ? 4 : (V <= 8 ? 8 : (V <= 16 ? 16 : 32)));  // points per wave: views are padded to a power-of-two lane segment
   w.n_tiles_a = (w.n_pts + w.PT - 1) / w.PT;
   int tpr = (S + 31) / 32;
   w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : 4);
@@ -383,7 +383,8 @@ __device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], co
         vv[e] = seg_sum<VSEG>(w2 * (d * d), V, seg_base);
       }
       const int g = t * 4 + q;
-      const bool mine = valid && (VSEG > 0 ? (view == (g & (VSEG - 1))) : (view == 0));
+      const int sel = g & (VSEG - 1);  // spread the 32 row groups over the segment's real lanes
+      const bool mine = valid && (view == (sel < V ? sel : 0));
       if (mine) {
         reinterpret_cast<float4*>(gin)[g] = make_float4(m[0], m[1], m[2], m[3]);
         reinterpret_cast<float4*>(gin + 64)[g] = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -409,11 +410,12 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
-  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
-  const int view = j - p_local * V;
+  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
+  const int p_local = j / VSEG;
+  const int view = j & (VSEG - 1);
   const long point = tile * p.PT + p_local;
-  const bool valid = (p_local < p.PT) && (point < p.n_pts);
-  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const bool valid = (view < V) && (point < p.n_pts);
+  const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
 
   // ---- gather the lane's inputs ----
@@ -474,7 +476,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
   // ---- pooling weights (mlp_network.py:462-471) ----
   float wgt;
   if (p.anti_alias) {
-    const float e = expf(ctab[258] * (rd.w - 1.0f));
+    const float e = (view < V) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;  // padding lanes never set the minimum over the views
     wgt = (e - seg_min<VSEG>(e, V, seg_base)) * msk;
   } else {
     wgt = msk;
@@ -767,11 +769,12 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
   const bool tile_ok = tile < p.n_tiles_a;
-  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
-  const int view = j - p_local * V;
+  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
+  const int p_local = j / VSEG;
+  const int view = j & (VSEG - 1);
   const long point = tile * p.PT + p_local;
-  const bool valid = (p_local < p.PT) && (point < p.n_pts);
-  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const bool valid = (view < V) && (point < p.n_pts);
+  const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
 
@@ -806,6 +809,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs 
   acc_elu(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;
+  if (view >= V) logit = -3.0e38f;  // padding lanes take no share even when every real view is masked (uniform 1/V then)
   const float mx = seg_max<VSEG>(logit, V, seg_base);
   const float e = __expf(logit - mx);
   const float bw = e / seg_sum<VSEG>(e, V, seg_base);
@@ -842,13 +846,15 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
   const size_t lds_b = (2 * DYN_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (2 * DYN_CHUNK + SC_CT) * sizeof(float);
-  if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
-  else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
-  else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk, lds_a, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk, lds_a, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk, lds_a, stream, a);
   DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_net_points<false>, grid_b, blk, lds_b, stream, a);
-  if (q->V == 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk, lds_c, stream, a);
-  else if (q->V == 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk, lds_c, stream, a);
-  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<0>, grid_a, blk, lds_c, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_a, blk, lds_c, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk, lds_c, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk, lds_c, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_a, blk, lds_c, stream, a);
   return 0;
 }
 
@@ -992,11 +998,12 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_dynamic_views(StaticArgs
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
-  const int p_local = (VSEG > 0) ? (j / VSEG) : (j / V);
-  const int view = j - p_local * V;
+  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
+  const int p_local = j / VSEG;
+  const int view = j & (VSEG - 1);
   const long point = tile * p.PT + p_local;
-  const bool valid = (p_local < p.PT) && (point < p.n_pts);
-  const int seg_base = (lane & 32) + (p_local < p.PT ? p_local * V : 0);
+  const bool valid = (view < V) && (point < p.n_pts);
+  const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
   const float msk = valid ? p.mask[pv] : 0.f;
   const float* tf = p.ws + p.o.off_ref;
@@ -1047,9 +1054,10 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
   const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
   const size_t lds_b = (2 * DYN_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  if (q->V == 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk, lds_a, stream, a);
-  else if (q->V == 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk, lds_a, stream, a);
-  else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk, lds_a, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk, lds_a, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk, lds_a, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk, lds_a, stream, a);
   DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", k_net_points<true>, grid_b, blk, lds_b, stream, a);
   return 0;
 }
