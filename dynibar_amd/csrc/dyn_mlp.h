@@ -155,3 +155,155 @@ __device__ __forceinline__ float row_dot(const f32x16 (&act)[NTI], const float* 
     }
   return s + __shfl_xor(s, 32);
 }
+
+// ====================================================================================================================
+// "B6" engine: the same register-resident chains on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate)
+// at fp32 accuracy.  Every fp32 operand is split exactly into three bf16 parts, x = hi + mid + lo (round-to-nearest twice,
+// |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; the three parts carry all 24 mantissa bits), and a product keeps the six partial
+// products down to 2^-18: hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi; the three dropped terms are below 2^-26 |x w|, i.e.
+// below fp32's own product rounding.  bf16 x bf16 is exact in fp32 and the MFMA accumulates in fp32, so a dot product has fp32
+// round-off (measured: slightly better than an fp32 fma chain).  6 MFMAs x 32 cycles cover K = 16 against 8 x 64 cycles of
+// v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
+// Layouts: A (weights) lane (n = l & 31, h = l >> 5) holds W[n][k = 8h + i], B (activations) lane (j, h) holds act[k = 8h + i][j],
+// i = 0..7; the D layout is unchanged, so MFMA group m of input tile T consumes the lane's registers r = 8m + i, i.e. feature
+// 32T + fi(8m + i, h): the chain still never leaves the register file.  Weights are split on the host; a (k-group, output tile)
+// pair is three 1 KiB lane-linear images [hi | mid | lo], a chunk is 8 pairs = 24 KiB.
+// ====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+#ifndef B6_SCHED
+#define B6_SCHED 0  /* sched_group_barrier pinning: blows up hipcc compile time on these fully unrolled kernels; keep off */
+#endif
+#define B6_CHUNK 6144       // floats per chunk (24 KiB = 8 pairs of 3 KiB)
+#define B6_PAIR_FLOATS 768  // 3 parts x 64 lanes x 4 dwords
+
+struct WeightRing6 {
+  const float* gsrc;
+  float* buf;
+  int next, total;
+};
+
+__device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
+  const float* g = R.gsrc + (long)chunk * B6_CHUNK;
+  float* l = R.buf + (chunk & 1) * B6_CHUNK + (threadIdx.x >> 6) * 256;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(l + i * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds) {
+  R.gsrc = stream + threadIdx.x * 4;
+  R.buf = lds;
+  R.next = 0;
+  R.total = total;
+  ring6_issue(R, 0);
+}
+__device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  const int c = R.next++;
+  if (c + 1 < R.total) ring6_issue(R, c + 1);
+  return R.buf + (c & 1) * B6_CHUNK;
+}
+
+// exact three-way bf16 split of two fp32 values, each part packed as (first in the low half, second in the high half)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  f32x2v v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+  f32x2v hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  f32x2v r1 = v - hf;
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2v));
+  f32x2v mf = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+  f32x2v r2 = r1 - mf;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2v));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS) { return (((NSLOTS + 7) / 8) + (8 / NT) - 1) / (8 / NT); }
+
+// One Linear layer on the B6 engine: NT output tiles, NSLOTS input register slots (one fp32 activation per lane per slot; slot s of
+// half h is the layer's input feature fixed at pack time).  feed(s) as in mlp_layer.
+struct B6A {
+  u32x4v hi, mid, lo;
+};
+__device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
+  const u32x4v* w = reinterpret_cast<const u32x4v*>(pair) + lane;
+  B6A a;
+  a.hi = w[0]; a.mid = w[64]; a.lo = w[128];
+  return a;
+}
+
+template <int NT, int NSLOTS, class Feed>
+__device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], Feed&& feed) {
+  constexpr int NG = (NSLOTS + 7) / 8;
+  constexpr int GPC = 8 / NT;
+  constexpr int NCH = (NG + GPC - 1) / GPC;
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "tiles per layer must divide 8");
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float* buf = ring6_acquire(R);
+    constexpr int NPAIR_MAX = 8;
+    // software pipeline over the (k-group, output tile) pairs of the chunk: the A parts of pair p + 1 are in flight while the six
+    // MFMAs of pair p issue (two 12-register operand sets alive)
+    B6A cur = b6_load_a(buf, lane);
+    u32x4v bh, bm, bl;
+#pragma unroll
+    for (int pr = 0; pr < NPAIR_MAX; ++pr) {
+      const int gi = pr / NT, t = pr % NT;
+      const int g = c * GPC + gi;
+      if (g < NG) {
+        if (t == 0) {
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            const float v0 = (g * 8 + 2 * p2 < NSLOTS) ? feed(g * 8 + 2 * p2) : 0.f;
+            const float v1 = (g * 8 + 2 * p2 + 1 < NSLOTS) ? feed(g * 8 + 2 * p2 + 1) : 0.f;
+            unsigned h_, m_, l_;
+            split3_pair(v0, v1, h_, m_, l_);
+            bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
+          }
+        }
+        B6A nxt = cur;
+        const bool more = (pr + 1 < NPAIR_MAX) && (c * GPC + (pr + 1) / NT < NG);
+        if (more) nxt = b6_load_a(buf + (pr + 1) * B6_PAIR_FLOATS, lane);
+        // smallest partial products first
+        acc[t] = mfma_bf16(cur.lo, bh, acc[t]);
+        acc[t] = mfma_bf16(cur.hi, bl, acc[t]);
+        acc[t] = mfma_bf16(cur.mid, bm, acc[t]);
+        acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
+        acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
+        acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
+        cur = nxt;
+#if B6_SCHED
+        // pin the order "next pair's three A loads, then this pair's six MFMAs" so the LDS latency hides under the matrix pipe
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
+      }
+    }
+  }
+}
+
+// ---- engine selection for the network kernels (A/B builds: -DDYN_ENGINE_B6=0 selects the fp32 MFMA engine) --------------
+#ifndef DYN_ENGINE_B6
+#define DYN_ENGINE_B6 1
+#endif
+#if DYN_ENGINE_B6
+typedef WeightRing6 NetRing;
+#define NET_CHUNK B6_CHUNK
+#define net_ring_init ring6_init
+#define net_layer mlp_layer_b6
+__host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return b6_layer_chunks(NT, NSLOTS); }
+#else
+typedef WeightRing NetRing;
+#define NET_CHUNK DYN_CHUNK
+#define net_ring_init ring_init
+#define net_layer mlp_layer
+__host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return dyn_layer_chunks(NT, NSLOTS); }
+#endif

@@ -7,6 +7,7 @@
 //   C  k_static_blend : per point-view  rgb_fc -> masked softmax over views -> blend of the source colours
 // Between A and C the 128-wide per-view feature x is parked in HBM in the lanes' own register order (512 B per point-view).
 #include <math.h>
+#include <string.h>
 
 #include <functional>
 #include <vector>
@@ -38,6 +39,56 @@ void pack_layer(std::vector<float>& out, int NT, int NSTEPS, const SlotFn& fn) {
             out[base + (size_t)c * DYN_CHUNK + ((g * NT + t) * 64 + lane) * 4 + q] = fn(t, lane & 31, s, lane >> 5);
           }
     }
+}
+
+// round-to-nearest-even bf16 bits of an fp32 value (no NaN inputs here)
+unsigned short bf16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+float bf16_to_f32(unsigned short b) {
+  unsigned u = (unsigned)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
+void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
+  const int NG = (NSLOTS + 7) / 8, GPC = 8 / NT, NCH = (NG + GPC - 1) / GPC;
+  const size_t base = out.size();
+  out.resize(base + (size_t)NCH * B6_CHUNK, 0.f);
+  unsigned short* img = reinterpret_cast<unsigned short*>(out.data() + base);
+  for (int c = 0; c < NCH; ++c)
+    for (int gi = 0; gi < GPC; ++gi) {
+      const int g = c * GPC + gi;
+      if (g >= NG) continue;
+      for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int s = g * 8 + e;
+            if (s >= NSLOTS) continue;
+            const float w = fn(t, lane & 31, s, lane >> 5);
+            const unsigned short hi = bf16_rne(w);
+            const float r1 = w - bf16_to_f32(hi);
+            const unsigned short mid = bf16_rne(r1);
+            const unsigned short lo = bf16_rne(r1 - bf16_to_f32(mid));
+            const size_t pair = (size_t)c * B6_CHUNK * 2 + (size_t)(gi * NT + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
+            img[pair + 0 * 512 + lane * 8 + e] = hi;
+            img[pair + 1 * 512 + lane * 8 + e] = mid;
+            img[pair + 2 * 512 + lane * 8 + e] = lo;
+          }
+    }
+}
+
+void pack_net_layer(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
+#if DYN_ENGINE_B6
+  pack_layer_b6(out, NT, NSLOTS, fn);
+#else
+  pack_layer(out, NT, NSLOTS, fn);
+#endif
 }
 
 // input feature of a chained layer: k-step s, half h -> feature of the previous layer's output (D layout)
@@ -82,11 +133,11 @@ enum {
 #define SA_L3_STEPS (3 * SA_NX + 1)
 #define SA_L4_STEPS 129
 #define SA_L5_STEPS 65
-constexpr int SA_CHUNKS = dyn_layer_chunks(8, SA_L1_STEPS) + dyn_layer_chunks(2, SA_L2_STEPS) + dyn_layer_chunks(8, SA_L3_STEPS) +
-                          dyn_layer_chunks(4, SA_L4_STEPS) + 3 * dyn_layer_chunks(4, SA_L5_STEPS);
-constexpr int SB_CHUNKS = dyn_layer_chunks(8, 129) + dyn_layer_chunks(4, 129) + 4 * dyn_layer_chunks(4, 64) + 2 * dyn_layer_chunks(4, 65);
+constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3_STEPS) +
+                          net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
+constexpr int SB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + 2 * net_layer_chunks(4, 65);
 #define SC_L11_STEPS 67
-constexpr int SC_CHUNKS = dyn_layer_chunks(4, SC_L11_STEPS) + dyn_layer_chunks(2, 65);
+constexpr int SC_CHUNKS = net_layer_chunks(4, SC_L11_STEPS) + net_layer_chunks(2, 65);
 // constant tables (floats): A: vis row [2][64] @0, vis_fc2.2 row [2][64] @128, b_vis @256, b_vis2 @257, |s| @258
 #define SA_CT 272
 // B: ln gamma [2][64], ln beta [2][64], out_geometry_fc.2 row [2][64], its bias
@@ -94,9 +145,9 @@ constexpr int SC_CHUNKS = dyn_layer_chunks(4, SC_L11_STEPS) + dyn_layer_chunks(2
 // C: rgb_fc.4 row [2][32], bias
 #define SC_CT 80
 constexpr size_t ST_OFF_A = 0;
-constexpr size_t ST_OFF_B = ST_OFF_A + (size_t)SA_CHUNKS * DYN_CHUNK;
-constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * DYN_CHUNK;
-constexpr size_t ST_OFF_CTA = ST_OFF_C + (size_t)SC_CHUNKS * DYN_CHUNK;
+constexpr size_t ST_OFF_B = ST_OFF_A + (size_t)SA_CHUNKS * NET_CHUNK;
+constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * NET_CHUNK;
+constexpr size_t ST_OFF_CTA = ST_OFF_C + (size_t)SC_CHUNKS * NET_CHUNK;
 constexpr size_t ST_OFF_CTB = ST_OFF_CTA + SA_CT;
 constexpr size_t ST_OFF_CTC = ST_OFF_CTB + SB_CT;
 constexpr size_t ST_OFF_REF = ST_OFF_CTC + SC_CT;  // ref_feature_fc.0: [35][66] then [35]
@@ -113,14 +164,14 @@ enum {
 };
 #define DA_NX 18                      /* registers holding the 35-channel per-view feature */
 #define DA_L3_STEPS (3 * DA_NX + 1)   /* base_fc.0: x | mean | var | bias */
-constexpr int DA_CHUNKS = dyn_layer_chunks(8, DA_L3_STEPS) + dyn_layer_chunks(4, SA_L4_STEPS) + 3 * dyn_layer_chunks(4, SA_L5_STEPS);
-constexpr int DB_CHUNKS = dyn_layer_chunks(8, 129) + dyn_layer_chunks(4, 129) + 4 * dyn_layer_chunks(4, 64) + dyn_layer_chunks(8, 81) +
-                          dyn_layer_chunks(4, 129) + dyn_layer_chunks(4, 65) + dyn_layer_chunks(4, 78) + dyn_layer_chunks(2, 65);
+constexpr int DA_CHUNKS = net_layer_chunks(8, DA_L3_STEPS) + net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
+constexpr int DB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + net_layer_chunks(8, 81) +
+                          net_layer_chunks(4, 129) + net_layer_chunks(4, 65) + net_layer_chunks(4, 78) + net_layer_chunks(2, 65);
 // B table: ln gamma @0, ln beta @128, out_geometry_fc.2 row @256, its bias @384, rgb_fc.4 biases @385..387, rgb_fc.4 rows [3][2][32] @400
 #define DB_CT 592
 constexpr size_t DY_OFF_A = 0;
-constexpr size_t DY_OFF_B = DY_OFF_A + (size_t)DA_CHUNKS * DYN_CHUNK;
-constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * DYN_CHUNK;
+constexpr size_t DY_OFF_B = DY_OFF_A + (size_t)DA_CHUNKS * NET_CHUNK;
+constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * NET_CHUNK;
 constexpr size_t DY_OFF_CTB = DY_OFF_CTA + SA_CT;
 constexpr size_t DY_OFF_POSENC = DY_OFF_CTB + DB_CT;                 // [128 positions][2][64]
 constexpr size_t DY_OFF_TIME = DY_OFF_POSENC + 128 * 128;            // ray_dir_fc: W0 [256,21], b0 [256], W2 [35,256], b2 [35]
@@ -161,15 +212,15 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   // ---- A ----
   {
     const float *W = T[ST_RAYDIR0_W], *b = T[ST_RAYDIR0_B];
-    pack_layer(o, 8, SA_L1_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, SA_L1_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i, c = sa_l1_col(s, h);
       return c >= 0 ? W[n * 103 + c] : (c == -2 ? b[n] : 0.f);
     });
   }
-  pack_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], T[ST_RAYDIR2_B], 35, 256, 256));
+  pack_net_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], T[ST_RAYDIR2_B], 35, 256, 256));
   {
     const float *W = T[ST_BASE0_W], *b = T[ST_BASE0_B];
-    pack_layer(o, 8, SA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, SA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s == 3 * SA_NX) return h == 0 ? b[n] : 0.f;
       const int part = s / SA_NX, c = sa_c70(s % SA_NX, h);
@@ -177,39 +228,39 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
       return W[n * 210 + (part == 0 ? 140 : (part == 1 ? 0 : 70)) + c];  // x | mean | var   (mlp_network.py:477-481)
     });
   }
-  pack_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], T[ST_BASE2_B], 128, 256, 256));
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], T[ST_VIS0_B], 128, 128, 128));
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], T[ST_VIS2_B], 128, 128, 128));  // rows 0..127 = x_res
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], T[ST_VISB0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], T[ST_BASE2_B], 128, 256, 256));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], T[ST_VIS0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], T[ST_VIS2_B], 128, 128, 128));  // rows 0..127 = x_res
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], T[ST_VISB0_B], 128, 128, 128));
   DYN_REQUIRE(o.size() == ST_OFF_B, "static pack: A stream size mismatch");
   // ---- B ----
   {
     const float *W = T[ST_GEO0_W], *b = T[ST_GEO0_B];
-    pack_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];  // mean | var
       return h == 0 ? W[n * 257 + 256] : b[n];                                          // mean of the weights | bias
     });
   }
-  pack_layer(o, 4, 129, chained(T[ST_GEO2_W], T[ST_GEO2_B], 128, 256, 256));
-  pack_layer(o, 4, 64, chained(T[ST_WQ], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[ST_WK], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[ST_WV], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[ST_FC], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 65, chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128));
-  pack_layer(o, 4, 65, chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261));  // columns 0..127 = globalfeat part
+  pack_net_layer(o, 4, 129, chained(T[ST_GEO2_W], T[ST_GEO2_B], 128, 256, 256));
+  pack_net_layer(o, 4, 64, chained(T[ST_WQ], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[ST_WK], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[ST_WV], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[ST_FC], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 65, chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128));
+  pack_net_layer(o, 4, 65, chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261));  // columns 0..127 = globalfeat part
   DYN_REQUIRE(o.size() == ST_OFF_C, "static pack: B stream size mismatch");
   // ---- C ----
   {
     const float* W = T[ST_RGB0_W];
-    pack_layer(o, 4, SC_L11_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 4, SC_L11_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 261 + 128 + chain_feature(s, h)];
       const int k = (s - 64) * 2 + h;  // vis, ray_diff[0..3]
       return k < 5 ? W[n * 261 + 256 + k] : 0.f;
     });
   }
-  pack_layer(o, 2, 65, chained(T[ST_RGB2_W], T[ST_RGB2_B], 64, 128, 128));
+  pack_net_layer(o, 2, 65, chained(T[ST_RGB2_W], T[ST_RGB2_B], 64, 128, 128));
   DYN_REQUIRE(o.size() == ST_OFF_CTA, "static pack: C stream size mismatch");
   // ---- constant tables ----
   pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128);
@@ -324,7 +375,7 @@ struct StaticArgs {
 // a1: ELU'd base_fc.0 output (256 features).  Constant table: vis row @0, vis_fc2.2 row @128, b_vis @256, b_vis2 @257.
 // -------------------------------------------------------------------------------------------------------------------
 template <int VSEG, bool STORE_X>
-__device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
+__device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
                                            long tile, long point, bool valid, int view, int seg_base) {
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int V = p.V;
@@ -332,17 +383,17 @@ __device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], co
   f32x16 x[4];
   {
     acc_zero(x);
-    mlp_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
     acc_elu(x);
   }
   float vis;
   {
     f32x16 a5[4], a6[4];
     acc_zero(a5);
-    mlp_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
+    net_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
     acc_elu(a5);
     acc_zero(a6);
-    mlp_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
+    net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
     vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -353,7 +404,7 @@ __device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], co
   {
     f32x16 a7[4];
     acc_zero(a7);
-    mlp_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
+    net_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
     acc_elu(a7);
     vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
   }
@@ -402,11 +453,11 @@ __device__ __forceinline__ void views_tail(WeightRing& ring, f32x16 (&a1)[8], co
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * DYN_CHUNK;  // [SA_CT]
+  float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
-  WeightRing ring;
-  ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
+  NetRing ring;
+  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -455,14 +506,14 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
 #pragma unroll
     for (int k = 0; k < 7; ++k) in1[45 + k] = h == 0 ? raw[2 * k] : raw[2 * k + 1];
     acc_zero(a1);
-    mlp_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
+    net_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
     acc_elu(a1);
   }
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
   {
     f32x16 a2[2];
     acc_zero(a2);
-    mlp_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
     const float* rf = p.ws + p.o.off_ref + (valid ? (point / p.S) * 36 : 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xin[18 + r] = a2[0][r] * rf[dyn_fi(r, h)];
@@ -487,7 +538,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
     acc_zero(a1);  // reuse as base_fc.0 accumulators
     // k-steps: the 70 channels, their weighted means over the views, their weighted variances (recomputing a mean costs
     // three cross-lane adds, keeping 37 of them live would spill)
-    mlp_layer<8, SA_L3_STEPS>(ring, a1, [&](int s) {
+    net_layer<8, SA_L3_STEPS>(ring, a1, [&](int s) {
       if (s < SA_NX) return xin[s];
       if (s < 2 * SA_NX) return seg_sum<VSEG>(xin[s - SA_NX] * wgt, V, seg_base);
       if (s < 3 * SA_NX) {
@@ -514,14 +565,14 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
 template <bool DYN>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * DYN_CHUNK;  // [SB_CT] / [DB_CT]
+  float* ctab = lds + 2 * NET_CHUNK;  // [SB_CT] / [DB_CT]
   float* Kl = ctab + (DYN ? DB_CT : SB_CT);
   float* Vl = Kl + SB_KL_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   constexpr int CT = DYN ? DB_CT : SB_CT;
   for (int i = tid; i < CT; i += DYN_NET_THREADS) ctab[i] = p.blob[(DYN ? DY_OFF_CTB : ST_OFF_CTB) + i];
-  WeightRing ring;
-  ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), DYN ? DB_CHUNKS : SB_CHUNKS, lds);
+  NetRing ring;
+  net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), DYN ? DB_CHUNKS : SB_CHUNKS, lds);
 
   const int TPR = p.TPR;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -546,11 +597,11 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       }
       gin[128] = valid ? reinterpret_cast<const float*>(src)[128] : (h == 1 ? 1.0f : 0.f);
       acc_zero(a9);
-      mlp_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
+      net_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
       acc_elu(a9);
     }
     acc_zero(g);
-    mlp_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? a9[s / 16][s % 16] : one_h0; });
+    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? a9[s / 16][s % 16] : one_h0; });
     acc_elu(g);
   }
   if (DYN) {
@@ -569,9 +620,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   {
     f32x16 qh[4], kh[4], vh[4];
     acc_zero(qh); acc_zero(kh); acc_zero(vh);
-    mlp_layer<4, 64>(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
-    mlp_layer<4, 64>(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
-    mlp_layer<4, 64>(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
+    net_layer<4, 64>(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
+    net_layer<4, 64>(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
+    net_layer<4, 64>(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
     const float inv_temp = 1.0f / 5.656854249492381f;  // d_k ** 0.5
     const bool q_ok = nvalid > 1.0f;                    // mask = (num_valid_obs > 1), applied along the query axis
     const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
@@ -644,7 +695,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   {
     f32x16 o[4];
     acc_zero(o);
-    mlp_layer<4, 64>(ring, o, [&](int s) { return att[s / 16][s % 16]; });
+    net_layer<4, 64>(ring, o, [&](int s) { return att[s / 16][s % 16]; });
     // residual + LayerNorm(eps = 1e-6) over the 128 features (64 here, 64 in the other half's lane)
     float s1 = 0.f;
 #pragma unroll
@@ -676,13 +727,13 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   if (!DYN) {
     f32x16 a[4];
     acc_zero(a);
-    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
     acc_elu(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384];
     if (nvalid < 1.0f) sigma = -1e9f;
     if (valid && h == 0) p.raw[point * 4 + 3] = sigma;
     acc_zero(a);
-    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
     if (valid) {
       float4* dst = reinterpret_cast<float4*>(p.ws + p.o.off_hg + (point * 2 + h) * 64);
 #pragma unroll
@@ -709,15 +760,15 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       pe[16] = h == 0 ? c3[2] : 1.0f;
       f32x16 a8[8];
       acc_zero(a8);
-      mlp_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
+      net_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
       acc_elu(a8);
       acc_zero(g2);
-      mlp_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? a8[s / 16][s % 16] : one_h0; });
+      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? a8[s / 16][s % 16] : one_h0; });
       acc_elu(g2);
     }
     f32x16 a[4];
     acc_zero(a);
-    mlp_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : one_h0; });
+    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : one_h0; });
     acc_elu(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384] - p.shift;
     if (nvalid < 1.0f) sigma = -1e9f;
@@ -738,11 +789,11 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       pd[13] = h == 0 ? d3[2] : 1.0f;
     }
     acc_zero(a);
-    mlp_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
+    net_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
     acc_elu(a);
     f32x16 b2[2];
     acc_zero(b2);
-    mlp_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
     acc_elu(b2);
     float rgb[3];
 #pragma unroll
@@ -760,11 +811,11 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * DYN_CHUNK;  // [SC_CT]
+  float* ctab = lds + 2 * NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   if (tid < SC_CT) ctab[tid] = p.blob[ST_OFF_CTC + tid];
-  WeightRing ring;
-  ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
+  NetRing ring;
+  net_ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -800,12 +851,12 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs 
         a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
       }
     const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
-    mlp_layer<4, SC_L11_STEPS>(ring, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
+    net_layer<4, SC_L11_STEPS>(ring, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
     acc_elu(a);
   }
   f32x16 b2[2];
   acc_zero(b2);
-  mlp_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+  net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
   acc_elu(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;
@@ -843,9 +894,9 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
-  const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
-  const size_t lds_b = (2 * DYN_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  const size_t lds_c = (2 * DYN_CHUNK + SC_CT) * sizeof(float);
+  const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  const size_t lds_c = (2 * NET_CHUNK + SC_CT) * sizeof(float);
   if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
@@ -872,7 +923,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   o.reserve(DY_BLOB_FLOATS);
   {
     const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];
-    pack_layer(o, 8, DA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, DA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s == 3 * DA_NX) return h == 0 ? b[n] : 0.f;
       const int part = s / DA_NX, c = da_c35(s % DA_NX, h);
@@ -880,27 +931,27 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
       return W[n * 105 + (part == 0 ? 70 : (part == 1 ? 0 : 35)) + c];  // x | mean | var   (mlp_network.py:262-266)
     });
   }
-  pack_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], T[DT_BASE2_B], 128, 256, 256));
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], T[DT_VIS0_B], 128, 128, 128));
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], T[DT_VIS2_B], 128, 128, 128));
-  pack_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], T[DT_VISB0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], T[DT_BASE2_B], 128, 256, 256));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], T[DT_VIS0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], T[DT_VIS2_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], T[DT_VISB0_B], 128, 128, 128));
   DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
   {
     const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
-    pack_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];
       return h == 0 ? W[n * 257 + 256] : b[n];
     });
   }
-  pack_layer(o, 4, 129, chained(T[DT_GEO2_W], T[DT_GEO2_B], 128, 256, 256));
-  pack_layer(o, 4, 64, chained(T[DT_WQ], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[DT_WK], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[DT_WV], nullptr, 128, 128, 128));
-  pack_layer(o, 4, 64, chained(T[DT_FC], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 129, chained(T[DT_GEO2_W], T[DT_GEO2_B], 128, 256, 256));
+  pack_net_layer(o, 4, 64, chained(T[DT_WQ], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[DT_WK], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[DT_WV], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, 64, chained(T[DT_FC], nullptr, 128, 128, 128));
   {
     const float *W = T[DT_REFPTS0_W], *b = T[DT_REFPTS0_B];  // [256, 128 + 33]
-    pack_layer(o, 8, 81, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 81, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 161 + chain_feature(s, h)];
       if (s < 79) { const int c = (s - 64) / 5, f = (s - 64) % 5; return W[n * 161 + 128 + 3 + (h * 5 + f) * 3 + c]; }
@@ -908,11 +959,11 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
       return h == 0 ? W[n * 161 + 128 + 2] : b[n];
     });
   }
-  pack_layer(o, 4, 129, chained(T[DT_REFPTS2_W], T[DT_REFPTS2_B], 128, 256, 256));
-  pack_layer(o, 4, 65, chained(T[DT_OG0_W], T[DT_OG0_B], 128, 128, 128));
+  pack_net_layer(o, 4, 129, chained(T[DT_REFPTS2_W], T[DT_REFPTS2_B], 128, 256, 256));
+  pack_net_layer(o, 4, 65, chained(T[DT_OG0_W], T[DT_OG0_B], 128, 128, 128));
   {
     const float *W = T[DT_RGB0_W], *b = T[DT_RGB0_B];  // [128, 128 + 27]
-    pack_layer(o, 4, 78, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 4, 78, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 155 + chain_feature(s, h)];
       if (s < 76) { const int c = (s - 64) / 4, f = (s - 64) % 4; return W[n * 155 + 128 + 3 + (h * 4 + f) * 3 + c]; }
@@ -920,7 +971,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
       return h == 0 ? W[n * 155 + 128 + 2] : b[n];
     });
   }
-  pack_layer(o, 2, 65, chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128));
+  pack_net_layer(o, 2, 65, chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128));
   DYN_REQUIRE(o.size() == DY_OFF_CTA, "dynamic pack: B stream size mismatch");
   pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128);
   pack_rowtab(o, T[DT_VISB2_W], 128);
@@ -990,11 +1041,11 @@ __global__ void __launch_bounds__(256) k_dynamic_time_feat(const float* __restri
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_dynamic_views(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * DYN_CHUNK;  // [SA_CT]
+  float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
-  WeightRing ring;
-  ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
+  NetRing ring;
+  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -1017,7 +1068,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_dynamic_views(StaticArgs
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
   f32x16 a1[8];
   acc_zero(a1);
-  mlp_layer<8, DA_L3_STEPS>(ring, a1, [&](int s) {
+  net_layer<8, DA_L3_STEPS>(ring, a1, [&](int s) {
     if (s < DA_NX) return xin[s];
     if (s < 2 * DA_NX) return seg_sum<VSEG>(xin[s - DA_NX] * wgt, V, seg_base);
     if (s < 3 * DA_NX) {
@@ -1052,8 +1103,8 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   DYN_LAUNCH(DYN_K_DYNAMIC_TIME, "k_dynamic_time_feat", k_dynamic_time_feat, dim3(1), dim3(256), 256 * sizeof(float), stream,
              q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
-  const size_t lds_a = (2 * DYN_CHUNK + SA_CT) * sizeof(float);
-  const size_t lds_b = (2 * DYN_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_b = (2 * NET_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk, lds_a, stream, a);
@@ -1069,9 +1120,9 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
 enum { MT_L0_W, MT_L0_B, MT_L1_W, MT_L1_B, MT_L2_W, MT_L2_B, MT_L3_W, MT_L3_B, MT_L4_W, MT_L4_B, MT_L5_W, MT_L5_B, MT_L6_W, MT_L6_B, MT_L7_W,
        MT_L7_B, MT_COEFF_W, MT_COEFF_B, MT_NUM_TENSORS };
 #define MO_PE_STEPS 66  /* 64 cos|sin pairs (4 coords x 16 frequencies), (x, y), (z, t) */
-constexpr int MO_CHUNKS = dyn_layer_chunks(8, MO_PE_STEPS + 1) + 4 * dyn_layer_chunks(8, 129) + dyn_layer_chunks(8, MO_PE_STEPS + 129) +
-                          2 * dyn_layer_chunks(8, 129) + dyn_layer_chunks(1, 129);
-constexpr size_t MO_OFF_FREQ = (size_t)MO_CHUNKS * DYN_CHUNK;  // the 16 frequencies of torch.linspace(1, 17, 16)
+constexpr int MO_CHUNKS = net_layer_chunks(8, MO_PE_STEPS + 1) + 4 * net_layer_chunks(8, 129) + net_layer_chunks(8, MO_PE_STEPS + 129) +
+                          2 * net_layer_chunks(8, 129) + net_layer_chunks(1, 129);
+constexpr size_t MO_OFF_FREQ = (size_t)MO_CHUNKS * NET_CHUNK;  // the 16 frequencies of torch.linspace(1, 17, 16)
 constexpr size_t MO_BLOB_FLOATS = MO_OFF_FREQ + 16;
 
 extern "C" size_t dyn_motion_mlp_blob_floats(void) { return MO_BLOB_FLOATS; }
@@ -1091,16 +1142,16 @@ extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* 
   o.reserve(MO_BLOB_FLOATS);
   {
     const float *W = T[MT_L0_W], *b = T[MT_L0_B];
-    pack_layer(o, 8, MO_PE_STEPS + 1, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, MO_PE_STEPS + 1, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < MO_PE_STEPS) return W[n * 132 + mo_pe_col(s, h)];
       return h == 0 ? b[n] : 0.f;
     });
   }
-  for (int l = 1; l <= 4; ++l) pack_layer(o, 8, 129, chained(T[MT_L0_W + 2 * l], T[MT_L0_B + 2 * l], 256, 256, 256));
+  for (int l = 1; l <= 4; ++l) pack_net_layer(o, 8, 129, chained(T[MT_L0_W + 2 * l], T[MT_L0_B + 2 * l], 256, 256, 256));
   {
     const float *W = T[MT_L5_W], *b = T[MT_L5_B];  // input = cat([embedding(132), h(256)])
-    pack_layer(o, 8, MO_PE_STEPS + 129, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, MO_PE_STEPS + 129, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < MO_PE_STEPS) return W[n * 388 + mo_pe_col(s, h)];
       const int s2 = s - MO_PE_STEPS;
@@ -1108,9 +1159,9 @@ extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* 
       return h == 0 ? b[n] : 0.f;
     });
   }
-  pack_layer(o, 8, 129, chained(T[MT_L6_W], T[MT_L6_B], 256, 256, 256));
-  pack_layer(o, 8, 129, chained(T[MT_L7_W], T[MT_L7_B], 256, 256, 256));
-  pack_layer(o, 1, 129, chained(T[MT_COEFF_W], T[MT_COEFF_B], 3 * num_basis, 256, 256));
+  pack_net_layer(o, 8, 129, chained(T[MT_L6_W], T[MT_L6_B], 256, 256, 256));
+  pack_net_layer(o, 8, 129, chained(T[MT_L7_W], T[MT_L7_B], 256, 256, 256));
+  pack_net_layer(o, 1, 129, chained(T[MT_COEFF_W], T[MT_COEFF_B], 3 * num_basis, 256, 256));
   DYN_REQUIRE(o.size() == MO_OFF_FREQ, "motion pack: stream size mismatch");
   {
     // torch.linspace(1, 17, 16) in fp32: start + i * step below the midpoint, end - (n - 1 - i) * step above it
@@ -1146,8 +1197,8 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
              int n_out, float inv_div, float* __restrict__ coeff) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  WeightRing ring;
-  ring_init(ring, blob, MO_CHUNKS, lds);
+  NetRing ring;
+  net_ring_init(ring, blob, MO_CHUNKS, lds);
   const long point = ((long)blockIdx.x * 4 + wave) * 32 + j;
   const bool valid = point < n_pts;
   float c4[4] = {0.f, 0.f, 0.f, time[0]};
@@ -1159,40 +1210,40 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
     float pe[MO_PE_STEPS];
     motion_embed(c4, freq, h, pe);
     acc_zero(a);
-    mlp_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
+    net_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
     acc_relu8(a);
   }
   acc_zero(b);
-  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
   acc_relu8(b);
   acc_zero(a);
-  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   acc_relu8(a);
   acc_zero(b);
-  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
   acc_relu8(b);
   acc_zero(a);
-  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   acc_relu8(a);
   {
     float pe[MO_PE_STEPS];
     motion_embed(c4, freq, h, pe);
     acc_zero(b);
-    mlp_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
+    net_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
       if (s < MO_PE_STEPS) return pe[s];
       return s - MO_PE_STEPS < 128 ? a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16] : one_h0;
     });
     acc_relu8(b);
   }
   acc_zero(a);
-  mlp_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   acc_relu8(a);
   acc_zero(b);
-  mlp_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
   acc_relu8(b);
   f32x16 c1[1];
   acc_zero(c1);
-  mlp_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  net_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   if (valid) {
     // raw_coeff[:, -n_zero_last:, :] *= 0 (render_ray.py:684): the last samples of every ray carry no motion
     const int smp = (int)(point % S);
@@ -1210,7 +1261,7 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
   DYN_REQUIRE(blob && pts && time && coeff, "dyn_motion_mlp: null pointer");
   DYN_REQUIRE(R > 0 && S > 0 && num_basis >= 1 && 3 * num_basis <= 32 && n_zero_last >= 0 && sf_mag_div != 0.f, "dyn_motion_mlp: bad argument");
   const long n_pts = (long)R * S;
-  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), 2 * DYN_CHUNK * sizeof(float),
+  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), 2 * NET_CHUNK * sizeof(float),
              (hipStream_t)stream, blob, pts, time, n_pts, S, n_zero_last, 3 * num_basis, 1.0f / sf_mag_div, coeff);
   return 0;
 }
@@ -1222,8 +1273,8 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_selftest(const float* __
                                                                   int rows) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-  WeightRing ring;
-  ring_init(ring, stream, 2 * dyn_layer_chunks(2, 33), lds);
+  NetRing ring;
+  net_ring_init(ring, stream, 2 * net_layer_chunks(2, 33), lds);
   const int row = (blockIdx.x * 4 + wave) * 32 + j;
   f32x16 in[2];
 #pragma unroll
@@ -1233,7 +1284,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_selftest(const float* __
   for (int rep = 0; rep < 2; ++rep) {  // two chained applications of the same layer
     f32x16 acc[2];
     acc_zero(acc);
-    mlp_layer<2, 33>(ring, acc, [&](int s) { return s < 32 ? in[s / 16][s % 16] : one_h0; });
+    net_layer<2, 33>(ring, acc, [&](int s) { return s < 32 ? in[s / 16][s % 16] : one_h0; });
     acc_elu(acc);
     in[0] = acc[0];
     in[1] = acc[1];
@@ -1247,13 +1298,13 @@ extern "C" int dyn_mlp_selftest(const float* W, const float* b, const float* x, 
   // W [64,64], b [64]: HOST; x [rows,64], y [rows,64], stream_buf [2 * chunks * 4096]: DEVICE (stream_buf is filled here via hipMemcpy)
   DYN_REQUIRE(W && b && x && y && stream_buf && rows > 0, "dyn_mlp_selftest: bad argument");
   std::vector<float> o;
-  pack_layer(o, 2, 33, chained(W, b, 64, 64, 64));
-  pack_layer(o, 2, 33, chained(W, b, 64, 64, 64));
+  pack_net_layer(o, 2, 33, chained(W, b, 64, 64, 64));
+  pack_net_layer(o, 2, 33, chained(W, b, 64, 64, 64));
   if (hipMemcpy(stream_buf, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     dyn_set_error("dyn_mlp_selftest: hipMemcpy failed");
     return DYN_E_LAUNCH;
   }
-  DYN_LAUNCH(DYN_K_SELFTEST, "k_selftest", k_selftest, dim3(dyn_cdiv(rows, 128)), dim3(DYN_NET_THREADS), 2 * DYN_CHUNK * sizeof(float),
+  DYN_LAUNCH(DYN_K_SELFTEST, "k_selftest", k_selftest, dim3(dyn_cdiv(rows, 128)), dim3(DYN_NET_THREADS), 2 * NET_CHUNK * sizeof(float),
              (hipStream_t)stream, stream_buf, x, y, rows);
   return 0;
 }

@@ -65,7 +65,7 @@ constexpr size_t LDS_BYTES = 160 * 1024;
 struct WaveCtx {
   pthread_barrier_t bar;
   int n;
-  alignas(64) uint64_t scratch[2][WAVE][2];  // double-buffered exchange slots (two 64-bit words per lane)
+  alignas(64) uint64_t scratch[2][WAVE][4];  // double-buffered exchange slots (four 64-bit words per lane)
   int phase = 0;
 };
 struct BlockCtx {
@@ -102,13 +102,15 @@ static inline void __builtin_amdgcn_s_sleep(int) {}
 
 namespace emu {
 // publish two 64-bit words per lane, rendezvous, return the slot array of this exchange
-static inline uint64_t (*exchange(uint64_t a, uint64_t b))[2] {
+static inline uint64_t (*exchange(uint64_t a, uint64_t b, uint64_t c = 0, uint64_t d = 0))[4] {
   ThreadCtx& t = tc;
   WaveCtx* w = t.w;
   int ph = t.phase;
   t.phase ^= 1;
   w->scratch[ph][t.lane][0] = a;
   w->scratch[ph][t.lane][1] = b;
+  w->scratch[ph][t.lane][2] = c;
+  w->scratch[ph][t.lane][3] = d;
   pthread_barrier_wait(&w->bar);
   return w->scratch[ph];
 }
@@ -196,6 +198,30 @@ static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address
   const char* src = (const char*)(uintptr_t)g + offset;
   char* dst = (char*)(uintptr_t)l + offset + emu::tc.lane * size;
   memcpy(dst, src, size);
+}
+
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+// v_mfma_f32_32x32x16_bf16: A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31], e = 0..7; D as the 32x32 f32 form.
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
+  uint64_t aw[2], bw[2];
+  memcpy(aw, &a, 16);
+  memcpy(bw, &b, 16);
+  auto s = emu::exchange(aw[0], aw[1], bw[0], bw[1]);
+  auto elem = [&](int lane, int which, int e) -> float {  // which: 0 = a, 1 = b
+    uint64_t w = s[lane][which * 2 + (e >> 2)];
+    unsigned bits = (unsigned)((w >> (16 * (e & 3))) & 0xffffu) << 16;
+    float f; memcpy(&f, &bits, 4); return f;
+  };
+  int l = emu::tc.lane, j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(elem(row + 32 * (k >> 3), 0, k & 7), elem(j + 32 * (k >> 3), 1, k & 7), acc);
+    c[r] = acc;
+  }
+  return c;
 }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
