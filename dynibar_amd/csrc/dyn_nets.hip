@@ -326,6 +326,22 @@ __device__ __forceinline__ void unit3(float x, float y, float z, float& ox, floa
   ox = x / d; oy = y / d; oz = z / d;
 }
 
+// cos | sin of 2^f x for f = 0..NF-1 (the reference's octave PeriodicEmbed, mlp_network.py:530-555): one accurate sincosf and
+// NF-1 double-angle steps.  2^f x is exact in fp32, so the only difference from evaluating each octave directly is the recurrence's
+// round-off (about 2^f ulp, <= 1e-6 at the fifth octave), far inside the 1e-4 budget, for a fifth of the transcendental work.
+template <int NF>
+__device__ __forceinline__ void octave_embed(float x, int h, float* out) {
+  float sn, cs;
+  sincosf(x, &sn, &cs);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    out[f] = h == 0 ? cs : sn;
+    const float s2 = 2.0f * sn * cs;
+    cs = cs * cs - sn * sn;
+    sn = s2;
+  }
+}
+
 // ref_feature_fc.0(PE(ref Pluecker)) per ray (mlp_network.py:434,456; render_ray.py:372-377): [R,36]
 __global__ void k_static_ref_feat(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ Wref, int R,
                                   float* __restrict__ ref_feat) {
@@ -495,13 +511,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs 
     c9[8] = cx * c9[4] - cy * c9[3];
     float in1[SA_L1_STEPS];
 #pragma unroll
-    for (int c = 0; c < 9; ++c)
-#pragma unroll
-      for (int f = 0; f < 5; ++f) {
-        float sn, cs;
-        sincosf((float)(1 << f) * c9[c], &sn, &cs);
-        in1[c * 5 + f] = h == 0 ? cs : sn;
-      }
+    for (int c = 0; c < 9; ++c) octave_embed<5>(c9[c], h, in1 + c * 5);
     const float raw[14] = {c9[0], c9[1], c9[2], c9[3], c9[4], c9[5], c9[6], c9[7], c9[8], rd.x, rd.y, rd.z, rd.w, 1.0f};
 #pragma unroll
     for (int k = 0; k < 7; ++k) in1[45 + k] = h == 0 ? raw[2 * k] : raw[2 * k + 1];
@@ -749,13 +759,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       float c3[3] = {0.f, 0.f, 0.f};
       if (valid) { c3[0] = p.pts[point * 3]; c3[1] = p.pts[point * 3 + 1]; c3[2] = p.pts[point * 3 + 2]; }
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-          float sn, cs;
-          sincosf((float)(1 << f) * c3[c], &sn, &cs);
-          pe[c * 5 + f] = h == 0 ? cs : sn;
-        }
+      for (int c = 0; c < 3; ++c) octave_embed<5>(c3[c], h, pe + c * 5);
       pe[15] = h == 0 ? c3[0] : c3[1];
       pe[16] = h == 0 ? c3[2] : 1.0f;
       f32x16 a8[8];
@@ -778,13 +782,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       float d3[3] = {0.f, 0.f, 1.f};
       if (valid) unit3(p.ray_d[ray * 3], p.ray_d[ray * 3 + 1], p.ray_d[ray * 3 + 2], d3[0], d3[1], d3[2]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          float sn, cs;
-          sincosf((float)(1 << f) * d3[c], &sn, &cs);
-          pd[c * 4 + f] = h == 0 ? cs : sn;
-        }
+      for (int c = 0; c < 3; ++c) octave_embed<4>(d3[c], h, pd + c * 4);
       pd[12] = h == 0 ? d3[0] : d3[1];
       pd[13] = h == 0 ? d3[2] : 1.0f;
     }

@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#define DYN_PIN(x) ((void)0)
 #define __global__
 #define __device__
 #define __host__
@@ -95,6 +96,7 @@ static inline void __syncthreads() { pthread_barrier_wait(&emu::tc.b->bar); }
 static inline void __builtin_amdgcn_s_barrier() { pthread_barrier_wait(&emu::tc.b->bar); }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void __builtin_amdgcn_wave_barrier() { pthread_barrier_wait(&emu::tc.w->bar); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
