@@ -37,6 +37,17 @@ void dyn_prof_end(int slot, hipStream_t stream);
 
 #define DYN_LAUNCH(slot, name, kernel, grid, block, shmem, stream, ...)              \
   do {                                                                              \
+    if ((size_t)(shmem) > 65536) { /* dynamic LDS beyond 64 KiB must be opted into, once per kernel */ \
+      static bool attr_done_ = false;                                               \
+      if (!attr_done_) {                                                            \
+        hipError_t ea_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem)); \
+        if (ea_ != hipSuccess) {                                                    \
+          dyn_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, (size_t)(shmem), hipGetErrorString(ea_)); \
+          return DYN_E_LAUNCH;                                                      \
+        }                                                                           \
+        attr_done_ = true;                                                          \
+      }                                                                             \
+    }                                                                               \
     dyn_prof_begin(slot, stream);                                                   \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);            \
     dyn_prof_end(slot, stream);                                                     \

@@ -17,7 +17,8 @@
 #include "dyn_device.h"
 
 #define DYN_CHUNK 4096        // floats per weight chunk (16 KiB)
-#define DYN_NET_THREADS 256   // 4 waves per workgroup share one weight ring
+#define DYN_NET_THREADS 256   // workgroup of the point-level kernels: 4 waves share one weight ring
+#define DYN_VIEW_THREADS 512  // workgroup of the view-level kernels: 8 waves (2 per SIMD) share one weight ring
 
 // feature index (within a 32-feature tile) held in register r by a lane of half h
 __host__ __device__ constexpr int dyn_fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -31,12 +32,14 @@ struct WeightRing {
 
 __device__ __forceinline__ void ring_issue(const WeightRing& R, int chunk) {
   const float* g = R.gsrc + (long)chunk * DYN_CHUNK;
-  // wave-uniform LDS base; the hardware adds lane*16 bytes
+  // wave-uniform LDS base; the hardware adds lane*16 bytes.  One round = blockDim.x * 16 bytes.
   float* l = R.buf + (chunk & 1) * DYN_CHUNK + (threadIdx.x >> 6) * 256;
+  const int round = blockDim.x * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(l + i * 1024), 16, 0, 0);
+    if (i * round < DYN_CHUNK)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round),
+                                       (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
 }
 
 __device__ __forceinline__ void ring_init(WeightRing& R, const float* stream, int total, float* lds) {
@@ -167,7 +170,8 @@ __device__ __forceinline__ float row_dot(const f32x16 (&act)[NTI], const float* 
 // Layouts: A (weights) lane (n = l & 31, h = l >> 5) holds W[n][k = 8h + i], B (activations) lane (j, h) holds act[k = 8h + i][j],
 // i = 0..7; the D layout is unchanged, so MFMA group m of input tile T consumes the lane's registers r = 8m + i, i.e. feature
 // 32T + fi(8m + i, h): the chain still never leaves the register file.  Weights are split on the host; a (k-group, output tile)
-// pair is three 1 KiB lane-linear images [hi | mid | lo], a chunk is 8 pairs = 24 KiB.
+// pair is three 1 KiB lane-linear images [hi | mid | lo], a chunk is 16 pairs = 48 KiB (3072 matrix-pipe cycles per wave, longer than
+// the ~1.1 us an LDS-DMA chunk needs from issue to landing).
 // ====================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -177,7 +181,8 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #ifndef B6_SCHED
 #define B6_SCHED 0  /* sched_group_barrier pinning: blows up hipcc compile time on these fully unrolled kernels; keep off */
 #endif
-#define B6_CHUNK 6144       // floats per chunk (24 KiB = 8 pairs of 3 KiB)
+#define B6_CHUNK 12288      // floats per chunk (48 KiB = 16 pairs of 3 KiB)
+#define B6_CHUNK_PAIRS 16
 #define B6_PAIR_FLOATS 768  // 3 parts x 64 lanes x 4 dwords
 
 struct WeightRing6 {
@@ -189,10 +194,12 @@ struct WeightRing6 {
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
   const float* g = R.gsrc + (long)chunk * B6_CHUNK;
   float* l = R.buf + (chunk & 1) * B6_CHUNK + (threadIdx.x >> 6) * 256;
+  const int round = blockDim.x * 4;  // floats moved by the whole workgroup per instruction
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(l + i * 1024), 16, 0, 0);
+  for (int i = 0; i < 12; ++i)
+    if (i * round < B6_CHUNK)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round),
+                                       (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
 }
 __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds) {
   R.gsrc = stream + threadIdx.x * 4;
@@ -225,7 +232,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS) { return (((NSLOTS + 7) / 8) + (8 / NT) - 1) / (8 / NT); }
+__host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS) {
+  return (((NSLOTS + 7) / 8) + (B6_CHUNK_PAIRS / NT) - 1) / (B6_CHUNK_PAIRS / NT);
+}
 
 // One Linear layer on the B6 engine: NT output tiles, NSLOTS input register slots (one fp32 activation per lane per slot; slot s of
 // half h is the layer's input feature fixed at pack time).  feed(s) as in mlp_layer.
@@ -242,14 +251,14 @@ __device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
 template <int NT, int NSLOTS, class Feed>
 __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], Feed&& feed) {
   constexpr int NG = (NSLOTS + 7) / 8;
-  constexpr int GPC = 8 / NT;
+  constexpr int GPC = B6_CHUNK_PAIRS / NT;
   constexpr int NCH = (NG + GPC - 1) / GPC;
-  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "tiles per layer must divide 8");
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8 || NT == 16, "tiles per layer must divide 16");
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const float* buf = ring6_acquire(R);
-    constexpr int NPAIR_MAX = 8;
+    constexpr int NPAIR_MAX = B6_CHUNK_PAIRS;
     // software pipeline over the (k-group, output tile) pairs of the chunk: the A parts of pair p + 1 are in flight while the six
     // MFMAs of pair p issue (two 12-register operand sets alive)
     B6A cur = b6_load_a(buf, lane);

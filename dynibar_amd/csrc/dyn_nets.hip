@@ -57,7 +57,7 @@ float bf16_to_f32(unsigned short b) {
 
 // B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
 void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
-  const int NG = (NSLOTS + 7) / 8, GPC = 8 / NT, NCH = (NG + GPC - 1) / GPC;
+  const int NG = (NSLOTS + 7) / 8, GPC = B6_CHUNK_PAIRS / NT, NCH = (NG + GPC - 1) / GPC;
   const size_t base = out.size();
   out.resize(base + (size_t)NCH * B6_CHUNK, 0.f);
   unsigned short* img = reinterpret_cast<unsigned short*>(out.data() + base);
@@ -467,16 +467,16 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
 // A: per point-view chain
 // ===================================================================================================================
 template <int VSEG>
-__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_views(StaticArgs p) {
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
+  for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
   NetRing ring;
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
 
   const int V = p.V;
-  const long tile = (long)blockIdx.x * 4 + wave;
+  const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
   const int p_local = j / VSEG;
   const int view = j & (VSEG - 1);
@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 // C: rgb_fc over [globalfeat | x | vis | ray_diff], masked softmax over the views, colour blend
 // ===================================================================================================================
 template <int VSEG>
-__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs p) {
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_static_blend(StaticArgs 
   net_ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
 
   const int V = p.V;
-  const long tile = (long)blockIdx.x * 4 + wave;
+  const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   const bool tile_ok = tile < p.n_tiles_a;
   // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
   const int p_local = j / VSEG;
@@ -891,19 +891,19 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
 
   DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
-  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
+  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (2 * NET_CHUNK + SC_CT) * sizeof(float);
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk, lds_a, stream, a);
-  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk, lds_a, stream, a);
-  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk, lds_a, stream, a);
-  else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk, lds_a, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk_v, lds_a, stream, a);
   DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_net_points<false>, grid_b, blk, lds_b, stream, a);
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_a, blk, lds_c, stream, a);
-  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk, lds_c, stream, a);
-  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk, lds_c, stream, a);
-  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_a, blk, lds_c, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_a, blk_v, lds_c, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk_v, lds_c, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk_v, lds_c, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_a, blk_v, lds_c, stream, a);
   return 0;
 }
 
@@ -1037,16 +1037,16 @@ __global__ void __launch_bounds__(256) k_dynamic_time_feat(const float* __restri
 
 // per point-view chain of the dynamic net: (rgb_feat + direction_feat) -> mean/var (mask weights) -> base_fc -> shared tail
 template <int VSEG>
-__global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_dynamic_views(StaticArgs p) {
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  for (int i = tid; i < SA_CT; i += DYN_NET_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
+  for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
 
   const int V = p.V;
-  const long tile = (long)blockIdx.x * 4 + wave;
+  const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
   const int p_local = j / VSEG;
   const int view = j & (VSEG - 1);
@@ -1100,13 +1100,13 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   a.raw = q->raw; a.ws = (float*)q->workspace;
   DYN_LAUNCH(DYN_K_DYNAMIC_TIME, "k_dynamic_time_feat", k_dynamic_time_feat, dim3(1), dim3(256), 256 * sizeof(float), stream,
              q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
-  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, 4)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS);
+  const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk, lds_a, stream, a);
-  else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk, lds_a, stream, a);
-  else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk, lds_a, stream, a);
-  else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk, lds_a, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk_v, lds_a, stream, a);
+  else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk_v, lds_a, stream, a);
   DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", k_net_points<true>, grid_b, blk, lds_b, stream, a);
   return 0;
 }
