@@ -119,25 +119,41 @@ __device__ __forceinline__ void acc_elu(f32x16 (&acc)[NT]) {
     for (int r = 0; r < 16; ++r) acc[t][r] = elu1(acc[t][r]);
 }
 
-// ---- reductions over the VSEG consecutive lanes (views, padded to a power of two) of one point: xor butterflies, so every lane
-// of the segment ends with the bit-identical result.  (V, seg_base are unused; kept so call sites read like the maths.)
+// ---- reductions over the VSEG consecutive lanes (views, padded to a power of two) of one point ------------------------------
+// Butterflies on the DPP lane-select of the VALU (the add / min / max itself carries the cross-lane read: one instruction per step,
+// no LDS traffic and no lgkmcnt wait): quad_perm for xor 1 and xor 2, row_half_mirror / row_mirror to join the two halves of 8 / 16
+// lanes (after the quad steps every lane of a half holds the half's value, so joining with the mirrored lane is an all-reduce);
+// only the 32-lane case needs one ds_bpermute for its last step.  Every lane of the segment ends with the bit-identical result.
+// (V, seg_base are unused; kept so call sites read like the maths.)
+#define DYN_DPP_XOR1 0xB1         /* quad_perm [1,0,3,2] */
+#define DYN_DPP_XOR2 0x4E         /* quad_perm [2,3,0,1] */
+#define DYN_DPP_HALF_MIRROR 0x141 /* lane i <-> 7 - i within 8 */
+#define DYN_DPP_ROW_MIRROR 0x140  /* lane i <-> 15 - i within 16 */
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int VSEG, class Op>
+__device__ __forceinline__ float seg_reduce(float v, Op op) {
+  static_assert(VSEG == 4 || VSEG == 8 || VSEG == 16 || VSEG == 32, "segments are 4, 8, 16 or 32 lanes");
+  v = op(v, dpp_get<DYN_DPP_XOR1>(v));
+  v = op(v, dpp_get<DYN_DPP_XOR2>(v));
+  if (VSEG >= 8) v = op(v, dpp_get<DYN_DPP_HALF_MIRROR>(v));
+  if (VSEG >= 16) v = op(v, dpp_get<DYN_DPP_ROW_MIRROR>(v));
+  if (VSEG >= 32) v = op(v, __shfl_xor(v, 16));
+  return v;
+}
 template <int VSEG>
 __device__ __forceinline__ float seg_sum(float v, int, int) {
-#pragma unroll
-  for (int m = 1; m < VSEG; m <<= 1) v += __shfl_xor(v, m);
-  return v;
+  return seg_reduce<VSEG>(v, [](float a, float b) { return a + b; });
 }
 template <int VSEG>
 __device__ __forceinline__ float seg_min(float v, int, int) {
-#pragma unroll
-  for (int m = 1; m < VSEG; m <<= 1) v = fminf(v, __shfl_xor(v, m));
-  return v;
+  return seg_reduce<VSEG>(v, [](float a, float b) { return fminf(a, b); });
 }
 template <int VSEG>
 __device__ __forceinline__ float seg_max(float v, int, int) {
-#pragma unroll
-  for (int m = 1; m < VSEG; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
-  return v;
+  return seg_reduce<VSEG>(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // dot product of the lane's 16*NTI activation registers with a [2][16*NTI] table in LDS (row h), summed over both halves

@@ -225,6 +225,17 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, e
   }
   return c;
 }
+
+// v_mov_b32_dpp for the lane selects used by csrc: quad_perm (ctrl < 0x100), row_half_mirror (0x141), row_mirror (0x140)
+static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) {
+  auto s = emu::exchange(emu::bits(v), 0);
+  int lane = emu::tc.lane, src;
+  if (ctrl < 0x100) src = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl == 0x141) src = (lane & ~7) | (7 - (lane & 7));
+  else if (ctrl == 0x140) src = (lane & ~15) | (15 - (lane & 15));
+  else { fprintf(stderr, "emu: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
+  return emu::unbits<int>(s[src][0]);
+}
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
