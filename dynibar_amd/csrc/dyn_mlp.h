@@ -315,6 +315,73 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
   }
 }
 
+// The same layer shared out over the waves of a workgroup: all waves stream the chunks of an NT-tile layer, wave w evaluates only
+// output tile `my_tile` (for NCOL column tiles of 32 rows each; feed(c, s) is the lane's activation of column tile c, slot s).
+// Used where the rows are few and shared by the whole workgroup (per-point statistics pooled over the workgroup's points).
+template <int NT, int NSLOTS, int NCOL, class Feed>
+__device__ __forceinline__ void mlp_layer_b6_tile(WeightRing6& R, int my_tile, f32x16 (&acc)[NCOL], Feed&& feed) {
+  constexpr int NG = (NSLOTS + 7) / 8;
+  constexpr int GPC = B6_CHUNK_PAIRS / NT;
+  constexpr int NCH = (NG + GPC - 1) / GPC;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float* buf = ring6_acquire(R);
+#pragma unroll
+    for (int gi = 0; gi < GPC; ++gi) {
+      const int g = c * GPC + gi;
+      if (g < NG) {
+        const u32x4v* w = reinterpret_cast<const u32x4v*>(buf + (gi * NT + my_tile) * B6_PAIR_FLOATS) + lane;
+        const u32x4v ah = w[0], am = w[64], al = w[128];
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+          u32x4v bh, bm, bl;
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            const float v0 = (g * 8 + 2 * p2 < NSLOTS) ? feed(col, g * 8 + 2 * p2) : 0.f;
+            const float v1 = (g * 8 + 2 * p2 + 1 < NSLOTS) ? feed(col, g * 8 + 2 * p2 + 1) : 0.f;
+            unsigned h_, m_, l_;
+            split3_pair(v0, v1, h_, m_, l_);
+            bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
+          }
+          acc[col] = mfma_bf16(al, bh, acc[col]);
+          acc[col] = mfma_bf16(ah, bl, acc[col]);
+          acc[col] = mfma_bf16(am, bm, acc[col]);
+          acc[col] = mfma_bf16(am, bh, acc[col]);
+          acc[col] = mfma_bf16(ah, bm, acc[col]);
+          acc[col] = mfma_bf16(ah, bh, acc[col]);
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int NSTEPS, int NCOL, class Feed>
+__device__ __forceinline__ void mlp_layer_tile(WeightRing& R, int my_tile, f32x16 (&acc)[NCOL], Feed&& feed) {
+  constexpr int NSG = (NSTEPS + 3) / 4;
+  constexpr int SGC = 16 / NT;
+  constexpr int NCH = (NSG + SGC - 1) / SGC;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float* buf = ring_acquire(R);
+#pragma unroll
+    for (int g = 0; g < SGC; ++g) {
+      const int sg = c * SGC + g;
+      if (sg < NSG) {
+        const float4 a = *reinterpret_cast<const float4*>(buf + ((g * NT + my_tile) * 64 + lane) * 4);
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+          if (sg * 4 + 0 < NSTEPS) acc[col] = mfma32(a.x, feed(col, sg * 4 + 0), acc[col]);
+          if (sg * 4 + 1 < NSTEPS) acc[col] = mfma32(a.y, feed(col, sg * 4 + 1), acc[col]);
+          if (sg * 4 + 2 < NSTEPS) acc[col] = mfma32(a.z, feed(col, sg * 4 + 2), acc[col]);
+          if (sg * 4 + 3 < NSTEPS) acc[col] = mfma32(a.w, feed(col, sg * 4 + 3), acc[col]);
+        }
+      }
+    }
+  }
+}
+
 // ---- engine selection for the network kernels (A/B builds: -DDYN_ENGINE_B6=0 selects the fp32 MFMA engine) --------------
 #ifndef DYN_ENGINE_B6
 #define DYN_ENGINE_B6 1
@@ -324,11 +391,13 @@ typedef WeightRing6 NetRing;
 #define NET_CHUNK B6_CHUNK
 #define net_ring_init ring6_init
 #define net_layer mlp_layer_b6
+#define net_layer_tile mlp_layer_b6_tile
 __host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return b6_layer_chunks(NT, NSLOTS); }
 #else
 typedef WeightRing NetRing;
 #define NET_CHUNK DYN_CHUNK
 #define net_ring_init ring_init
 #define net_layer mlp_layer
+#define net_layer_tile mlp_layer_tile
 __host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return dyn_layer_chunks(NT, NSLOTS); }
 #endif

@@ -131,9 +131,11 @@ enum {
 #define SA_L2_STEPS 129  /* ray_dir_fc.2: 256 + bias */
 #define SA_NX 37         /* registers holding the 70-channel per-view feature (18 gathered + 16 + 3 computed) */
 #define SA_L3_STEPS (3 * SA_NX + 1)
+#define SA_L3P_STEPS (2 * SA_NX)  /* per-point part of base_fc.0: [mean | var] slots, evaluated once per point for the whole workgroup */
+#define SA_L3V_STEPS (SA_NX + 1)  /* per-view part: the 70 channels + bias */
 #define SA_L4_STEPS 129
 #define SA_L5_STEPS 65
-constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3_STEPS) +
+constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3P_STEPS) + net_layer_chunks(8, SA_L3V_STEPS) +
                           net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
 constexpr int SB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + 2 * net_layer_chunks(4, 65);
 #define SC_L11_STEPS 67
@@ -164,7 +166,9 @@ enum {
 };
 #define DA_NX 18                      /* registers holding the 35-channel per-view feature */
 #define DA_L3_STEPS (3 * DA_NX + 1)   /* base_fc.0: x | mean | var | bias */
-constexpr int DA_CHUNKS = net_layer_chunks(8, DA_L3_STEPS) + net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
+#define DA_L3P_STEPS (2 * DA_NX)
+#define DA_L3V_STEPS (DA_NX + 1)
+constexpr int DA_CHUNKS = net_layer_chunks(8, DA_L3P_STEPS) + net_layer_chunks(8, DA_L3V_STEPS) + net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
 constexpr int DB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + net_layer_chunks(8, 81) +
                           net_layer_chunks(4, 129) + net_layer_chunks(4, 65) + net_layer_chunks(4, 78) + net_layer_chunks(2, 65);
 // B table: ln gamma @0, ln beta @128, out_geometry_fc.2 row @256, its bias @384, rgb_fc.4 biases @385..387, rgb_fc.4 rows [3][2][32] @400
@@ -219,13 +223,18 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   }
   pack_net_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], T[ST_RAYDIR2_B], 35, 256, 256));
   {
+    // base_fc.0 (mlp_network.py:477-481, input [mean | var | x]): the [mean | var] columns act on per-point statistics and are
+    // evaluated once per point for the whole workgroup, the x columns (+ bias) per view
     const float *W = T[ST_BASE0_W], *b = T[ST_BASE0_B];
-    pack_net_layer(o, 8, SA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, SA_L3P_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int c = sa_c70(s % SA_NX, h);
+      return c < 0 ? 0.f : W[(32 * t + i) * 210 + (s / SA_NX) * 70 + c];
+    });
+    pack_net_layer(o, 8, SA_L3V_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
-      if (s == 3 * SA_NX) return h == 0 ? b[n] : 0.f;
-      const int part = s / SA_NX, c = sa_c70(s % SA_NX, h);
-      if (c < 0) return 0.f;
-      return W[n * 210 + (part == 0 ? 140 : (part == 1 ? 0 : 70)) + c];  // x | mean | var   (mlp_network.py:477-481)
+      if (s == SA_NX) return h == 0 ? b[n] : 0.f;
+      const int c = sa_c70(s, h);
+      return c < 0 ? 0.f : W[n * 210 + 140 + c];
     });
   }
   pack_net_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], T[ST_BASE2_B], 128, 256, 256));
@@ -386,6 +395,63 @@ struct StaticArgs {
 };
 
 // -------------------------------------------------------------------------------------------------------------------
+// base_fc.0 of the view chains.  Its input is [mean | var | x]: the weighted mean / variance over the views are per-POINT values,
+// so their 4 NX columns of the weight matrix are applied once per point instead of once per view: the 8 waves pool their points'
+// statistics in LDS (32 points at 8 views), wave w evaluates output tile w for all pooled points, the result comes back through LDS
+// as the initial value of every view's accumulators, and only the NX + 1 per-view slots remain per wave.
+// (V <= 4, 64 pooled points, does not fit the LDS budget and keeps the statistics slots per view.)
+// LDS: pool [2 NX slots][2 halves][32 points], res [256 features][32 points].
+// -------------------------------------------------------------------------------------------------------------------
+#define POOL_FLOATS(NX) (2 * (NX) * 2 * 32)
+#define RES_FLOATS (256 * 32)
+template <int VSEG, int NX>
+__device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], float wgt, int V, int view, int p_local, float* pool,
+                                         f32x16 (&a1)[8]) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  if (VSEG >= 8) {
+    static_assert(DYN_VIEW_THREADS / 64 == 8, "one output tile of base_fc.0 per wave");
+    constexpr int PT = 32 / VSEG;
+    float* res = pool + POOL_FLOATS(NX);
+    const int col = wave * PT + p_local;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const float m = seg_sum<VSEG>(xin[q] * wgt, V, 0);
+      const float d = xin[q] - m;
+      const float vr = seg_sum<VSEG>(wgt * (d * d), V, 0);
+      if (view == 0) {
+        pool[(q * 2 + h) * 32 + col] = m;
+        pool[((NX + q) * 2 + h) * 32 + col] = vr;
+      }
+    }
+    if (8 * PT < 32 && threadIdx.x < 2 * 2 * NX)  // unused point columns: keep them finite (they are computed and discarded)
+      for (int c = 8 * PT; c < 32; ++c) pool[threadIdx.x * 32 + c] = 0.f;
+    __syncthreads();
+    f32x16 accp[1];
+    acc_zero(accp);
+    net_layer_tile<8, 2 * NX, 1>(ring, wave, accp, [&](int, int s) { return pool[(s * 2 + h) * 32 + j]; });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[t][r] = res[(t * 32 + dyn_fi(r, h)) * 32 + col];
+  } else {
+    acc_zero(a1);
+    net_layer<8, 2 * NX>(ring, a1, [&](int s) {
+      const int q = s < NX ? s : s - NX;
+      const float m = seg_sum<VSEG>(xin[q] * wgt, V, 0);
+      if (s < NX) return m;
+      const float d = xin[q] - m;
+      return seg_sum<VSEG>(wgt * (d * d), V, 0);
+    });
+  }
+  net_layer<8, NX + 1>(ring, a1, [&](int s) { return s < NX ? xin[s] : one_h0; });
+  acc_elu(a1);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // shared tail of the per point-view chains (static: mlp_network.py:483-494, dynamic: :266-282):
 // base_fc.2 -> vis_fc -> vis_fc2 -> visibility-weighted mean / variance over the views -> geometry_fc input rows
 // a1: ELU'd base_fc.0 output (256 features).  Constant table: vis row @0, vis_fc2.2 row @128, b_vis @256, b_vis2 @257.
@@ -544,22 +610,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   }
   wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
 
-  {
-    acc_zero(a1);  // reuse as base_fc.0 accumulators
-    // k-steps: the 70 channels, their weighted means over the views, their weighted variances (recomputing a mean costs
-    // three cross-lane adds, keeping 37 of them live would spill)
-    net_layer<8, SA_L3_STEPS>(ring, a1, [&](int s) {
-      if (s < SA_NX) return xin[s];
-      if (s < 2 * SA_NX) return seg_sum<VSEG>(xin[s - SA_NX] * wgt, V, seg_base);
-      if (s < 3 * SA_NX) {
-        const float m = seg_sum<VSEG>(xin[s - 2 * SA_NX] * wgt, V, seg_base);
-        const float d = xin[s - 2 * SA_NX] - m;
-        return seg_sum<VSEG>(wgt * (d * d), V, seg_base);
-      }
-      return one_h0;
-    });
-    acc_elu(a1);
-  }
+  base_fc0<VSEG, SA_NX>(ring, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
   views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
 }
 
@@ -892,7 +943,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
-  const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (2 * NET_CHUNK + SC_CT) * sizeof(float);
   if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
@@ -920,13 +971,16 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   std::vector<float> o;
   o.reserve(DY_BLOB_FLOATS);
   {
-    const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];
-    pack_net_layer(o, 8, DA_L3_STEPS, [=](int t, int i, int s, int h) -> float {
+    const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];  // input [mean | var | x]  (mlp_network.py:262-266)
+    pack_net_layer(o, 8, DA_L3P_STEPS, [=](int t, int i, int s, int h) -> float {
+      const int c = da_c35(s % DA_NX, h);
+      return c < 0 ? 0.f : W[(32 * t + i) * 105 + (s / DA_NX) * 35 + c];
+    });
+    pack_net_layer(o, 8, DA_L3V_STEPS, [=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
-      if (s == 3 * DA_NX) return h == 0 ? b[n] : 0.f;
-      const int part = s / DA_NX, c = da_c35(s % DA_NX, h);
-      if (c < 0) return 0.f;
-      return W[n * 105 + (part == 0 ? 70 : (part == 1 ? 0 : 35)) + c];  // x | mean | var   (mlp_network.py:262-266)
+      if (s == DA_NX) return h == 0 ? b[n] : 0.f;
+      const int c = da_c35(s, h);
+      return c < 0 ? 0.f : W[n * 105 + 70 + c];
     });
   }
   pack_net_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], T[DT_BASE2_B], 128, 256, 256));
@@ -1063,20 +1117,8 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
     xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] + tf[ch] : 0.f;
   }
   const float wgt = msk / (seg_sum<VSEG>(msk, V, seg_base) + 1e-8f);
-  const float one_h0 = h == 0 ? 1.0f : 0.0f;
   f32x16 a1[8];
-  acc_zero(a1);
-  net_layer<8, DA_L3_STEPS>(ring, a1, [&](int s) {
-    if (s < DA_NX) return xin[s];
-    if (s < 2 * DA_NX) return seg_sum<VSEG>(xin[s - DA_NX] * wgt, V, seg_base);
-    if (s < 3 * DA_NX) {
-      const float m = seg_sum<VSEG>(xin[s - 2 * DA_NX] * wgt, V, seg_base);
-      const float d = xin[s - 2 * DA_NX] - m;
-      return seg_sum<VSEG>(wgt * (d * d), V, seg_base);
-    }
-    return one_h0;
-  });
-  acc_elu(a1);
+  base_fc0<VSEG, DA_NX>(ring, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
   views_tail<VSEG, false>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
 }
 
@@ -1101,7 +1143,7 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   DYN_LAUNCH(DYN_K_DYNAMIC_TIME, "k_dynamic_time_feat", k_dynamic_time_feat, dim3(1), dim3(256), 256 * sizeof(float), stream,
              q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
-  const size_t lds_a = (2 * NET_CHUNK + SA_CT) * sizeof(float);
+  const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);
