@@ -202,6 +202,8 @@ static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address
   memcpy(dst, src, size);
 }
 
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 // v_mfma_f32_32x32x16_bf16: A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31], e = 0..7; D as the 32x32 f32 form.
