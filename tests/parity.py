@@ -481,3 +481,44 @@ def check_render_image_nvi(device, golden, chunk_size=80):
   assert n == len(golden), 'render_single_image_nvi output key set differs from the reference'
   assert ret['outputs_fine'] is None
   return ret
+
+
+def check_full_size_properties(device, R=4096, S=64, V=8, N_importance=64):
+  """BASELINE configs[1] at its full size (4096 rays x 64 samples x 8 views, 288x512 sources), where the oracle would take minutes:
+  size-independent properties + an oracle spot check on a few rays."""
+  from dynibar_amd import synthetic as syn
+  sc = syn.make_scene(seed=0, H=288, W=512, V=V, n_static=V)
+  scene = {k: torch.from_numpy(v).to(device) for k, v in sc.items()}
+  pix = syn.sample_pixels(7, 288, 512, R)
+  o_np, d_np, _ = syn.pixel_rays(sc['camera'], pix)
+  o, d = torch.from_numpy(o_np).to(device), torch.from_numpy(d_np).to(device)
+  wts = syn.make_weights('static', 0)
+  net = ops.StaticNet(wts, device, True, False)
+  out, raw = run_static_pass(device, scene, net, o, d, S)
+  # (1) chunk invariance: rays are independent, so rendering the batch in two halves is bit-identical (what multi-GPU tiling relies on)
+  h = R // 2
+  out_a, _ = run_static_pass(device, scene, net, o[:h], d[:h], S)
+  out_b, _ = run_static_pass(device, scene, net, o[h:], d[h:], S)
+  for k in ('rgb', 'depth', 'weights', 'mask'):
+    assert_bitexact(torch.cat([out_a[k], out_b[k]], 0), out[k], f'chunk invariance of {k}')
+  # (2) compositing invariants (render_ray.py:185-199): alpha, weights in [0,1], sum of weights <= 1, depth inside the sampled range
+  w = cpu(out['weights'])
+  assert float(w.min()) >= 0.0 and float(w.max()) <= 1.0 + 1e-6 and float(w.sum(dim=1).max()) <= 1.0 + 1e-5
+  z = cpu(out['z_vals'])
+  dep = cpu(out['depth'])
+  assert bool((dep <= z[:, -1] * (1 + 1e-5)).all()) and bool((dep >= 0).all())
+  assert bool(torch.isfinite(cpu(raw)[..., :3]).all()) and float(cpu(out['rgb']).min()) >= -1e-6 and float(cpu(out['rgb']).max()) <= 1.0 + 1e-5
+  # (3) importance resampling at full size: sorted, inside [near, far], the coarse depths are a subset (bitwise)
+  z_all, z_s, _ = ops.fine_samples(out['z_vals'], out['weights'], N_importance, True)
+  za = cpu(z_all)
+  near, far = float(sc['depth_range'][0, 0]), float(sc['depth_range'][0, 1])
+  assert bool((za[:, 1:] >= za[:, :-1]).all()) and float(za.min()) >= near * (1 - 1e-6) and float(za.max()) <= far * (1 + 1e-6)
+  merged = torch.sort(torch.cat([z, cpu(z_s)], 1), 1)[0]
+  assert_bitexact(za, merged, 'fine depths = sorted union of coarse and new depths')
+  # (4) oracle spot check on 48 of the 4096 rays
+  idx = torch.arange(0, R, R // 48)[:48]
+  cs = {k: torch.from_numpy(v) for k, v in sc.items()}
+  ref = O.static_branch_pass(O.tdict(wts), cs, torch.from_numpy(o_np)[idx], torch.from_numpy(d_np)[idx], S, True, True)
+  assert_close(cpu(out['rgb'])[idx], ref['rgb'], 1e-4, 0.0, 'full-size rgb vs oracle (48 rays)')
+  assert_close(cpu(out['depth'])[idx], ref['depth'], 0.0, 3e-4, 'full-size depth vs oracle (48 rays)')
+  return float((cpu(out['rgb'])[idx] - ref['rgb']).abs().max())
