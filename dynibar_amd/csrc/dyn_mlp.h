@@ -108,6 +108,19 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
+// accumulators start at the layer's bias: table [2][16 * NT] in D-layout order (pack_rowtab), normally in LDS
+template <int NT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const float* tab) {
+  const float4* t4 = reinterpret_cast<const float4*>(tab + ((threadIdx.x & 63) >> 5) * 16 * NT);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = t4[t * 4 + q];
+      acc[t][q * 4] = b.x; acc[t][q * 4 + 1] = b.y; acc[t][q * 4 + 2] = b.z; acc[t][q * 4 + 3] = b.w;
+    }
+}
+
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (__expf(v) - 1.0f); }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + __expf(-v)); }
 

@@ -128,24 +128,24 @@ enum {
 
 // k-step counts / tiles of every layer (shared by the packer and the kernels)
 #define SA_L1_STEPS 52   /* ray_dir_fc.0: 45 cos|sin pairs + 7 raw pairs (13 raw inputs + bias) */
-#define SA_L2_STEPS 129  /* ray_dir_fc.2: 256 + bias */
+#define SA_L2_STEPS 128  /* ray_dir_fc.2: 256 (bias = accumulator init) */
 #define SA_NX 37         /* registers holding the 70-channel per-view feature (18 gathered + 16 + 3 computed) */
 #define SA_L3_STEPS (3 * SA_NX + 1)
 #define SA_L3P_STEPS (2 * SA_NX)  /* per-point part of base_fc.0: [mean | var] slots, evaluated once per point for the whole workgroup */
 #define SA_L3V_STEPS (SA_NX + 1)  /* per-view part: the 70 channels + bias */
-#define SA_L4_STEPS 129
-#define SA_L5_STEPS 65
+#define SA_L4_STEPS 128  /* base_fc.2 (bias = accumulator init) */
+#define SA_L5_STEPS 64   /* vis_fc.0 / vis_fc.2 / vis_fc2.0 */
 constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3P_STEPS) + net_layer_chunks(8, SA_L3V_STEPS) +
                           net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
 constexpr int SB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + 2 * net_layer_chunks(4, 65);
 #define SC_L11_STEPS 67
-constexpr int SC_CHUNKS = net_layer_chunks(4, SC_L11_STEPS) + net_layer_chunks(2, 65);
+constexpr int SC_CHUNKS = net_layer_chunks(4, SC_L11_STEPS) + net_layer_chunks(2, 64);
 // constant tables (floats): A: vis row [2][64] @0, vis_fc2.2 row [2][64] @128, b_vis @256, b_vis2 @257, |s| @258
-#define SA_CT 272
+#define SA_CT 848   /* + bias tables: base_fc.2 @272, vis_fc.0 @400, vis_fc.2 @528, vis_fc2.0 @656, ray_dir_fc.2 @784 (64) */
 // B: ln gamma [2][64], ln beta [2][64], out_geometry_fc.2 row [2][64], its bias
 #define SB_CT 400
 // C: rgb_fc.4 row [2][32], bias
-#define SC_CT 80
+#define SC_CT 144   /* + bias table of rgb_fc.2 @80 (64) */
 constexpr size_t ST_OFF_A = 0;
 constexpr size_t ST_OFF_B = ST_OFF_A + (size_t)SA_CHUNKS * NET_CHUNK;
 constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * NET_CHUNK;
@@ -221,7 +221,7 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
       return c >= 0 ? W[n * 103 + c] : (c == -2 ? b[n] : 0.f);
     });
   }
-  pack_net_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], T[ST_RAYDIR2_B], 35, 256, 256));
+  pack_net_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], nullptr, 35, 256, 256));
   {
     // base_fc.0 (mlp_network.py:477-481, input [mean | var | x]): the [mean | var] columns act on per-point statistics and are
     // evaluated once per point for the whole workgroup, the x columns (+ bias) per view
@@ -237,10 +237,10 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
       return c < 0 ? 0.f : W[n * 210 + 140 + c];
     });
   }
-  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], T[ST_BASE2_B], 128, 256, 256));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], T[ST_VIS0_B], 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], T[ST_VIS2_B], 128, 128, 128));  // rows 0..127 = x_res
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], T[ST_VISB0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], nullptr, 128, 256, 256));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], nullptr, 128, 128, 128));  // rows 0..127 = x_res
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], nullptr, 128, 128, 128));
   DYN_REQUIRE(o.size() == ST_OFF_B, "static pack: A stream size mismatch");
   // ---- B ----
   {
@@ -269,7 +269,7 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
       return k < 5 ? W[n * 261 + 256 + k] : 0.f;
     });
   }
-  pack_net_layer(o, 2, 65, chained(T[ST_RGB2_W], T[ST_RGB2_B], 64, 128, 128));
+  pack_net_layer(o, 2, 64, chained(T[ST_RGB2_W], nullptr, 64, 128, 128));
   DYN_REQUIRE(o.size() == ST_OFF_CTA, "static pack: C stream size mismatch");
   // ---- constant tables ----
   pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128);
@@ -277,6 +277,16 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   o.push_back(T[ST_VIS2_B][128]);
   o.push_back(T[ST_VISB2_B][0]);
   o.push_back(fabsf(T[ST_S][0]));
+  o.resize(ST_OFF_CTA + 272, 0.f);
+  pack_rowtab(o, T[ST_BASE2_B], 128);
+  pack_rowtab(o, T[ST_VIS0_B], 128);
+  pack_rowtab(o, T[ST_VIS2_B], 128);
+  pack_rowtab(o, T[ST_VISB0_B], 128);
+  {
+    float b64[64] = {0.f};
+    for (int i = 0; i < 35; ++i) b64[i] = T[ST_RAYDIR2_B][i];
+    pack_rowtab(o, b64, 64);
+  }
   o.resize(ST_OFF_CTB, 0.f);
   pack_rowtab(o, T[ST_LN_G], 128);
   pack_rowtab(o, T[ST_LN_B], 128);
@@ -285,6 +295,8 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   o.resize(ST_OFF_CTC, 0.f);
   pack_rowtab(o, T[ST_RGB4_W], 64);
   o.push_back(T[ST_RGB4_B][0]);
+  o.resize(ST_OFF_CTC + 80, 0.f);
+  pack_rowtab(o, T[ST_RGB2_B], 64);
   o.resize(ST_OFF_REF, 0.f);
   for (int i = 0; i < 35 * 66; ++i) o.push_back(T[ST_REFFEAT_W][i]);
   for (int i = 0; i < 35; ++i) o.push_back(T[ST_REFFEAT_B][i]);
@@ -461,21 +473,20 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
                                            long tile, long point, bool valid, int view, int seg_base) {
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int V = p.V;
-  const float one_h0 = h == 0 ? 1.0f : 0.0f;
   f32x16 x[4];
   {
-    acc_zero(x);
-    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    acc_init_bias<4>(x, ctab + 272);
+    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return a1[s / 16][s % 16]; });
     acc_elu(x);
   }
   float vis;
   {
     f32x16 a5[4], a6[4];
-    acc_zero(a5);
-    net_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return s < 64 ? x[s / 16][s % 16] * wgt : one_h0; });
+    acc_init_bias<4>(a5, ctab + 400);
+    net_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return x[s / 16][s % 16] * wgt; });
     acc_elu(a5);
-    acc_zero(a6);
-    net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return s < 64 ? a5[s / 16][s % 16] : one_h0; });
+    acc_init_bias<4>(a6, ctab + 528);
+    net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return a5[s / 16][s % 16]; });
     vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -485,8 +496,8 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
   float vis2;
   {
     f32x16 a7[4];
-    acc_zero(a7);
-    net_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return s < 64 ? x[s / 16][s % 16] * vis : one_h0; });
+    acc_init_bias<4>(a7, ctab + 656);
+    net_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return x[s / 16][s % 16] * vis; });
     acc_elu(a7);
     vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
   }
@@ -585,11 +596,10 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     net_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
     acc_elu(a1);
   }
-  const float one_h0 = h == 0 ? 1.0f : 0.0f;
   {
     f32x16 a2[2];
-    acc_zero(a2);
-    net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return s < 128 ? a1[s / 16][s % 16] : one_h0; });
+    acc_init_bias<2>(a2, ctab + 784);
+    net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return a1[s / 16][s % 16]; });
     const float* rf = p.ws + p.o.off_ref + (valid ? (point / p.S) * 36 : 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xin[18 + r] = a2[0][r] * rf[dyn_fi(r, h)];
@@ -862,7 +872,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  if (tid < SC_CT) ctab[tid] = p.blob[ST_OFF_CTC + tid];
+  for (int i = tid; i < SC_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
   NetRing ring;
   net_ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
 
@@ -876,7 +886,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
   const bool valid = (view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
-  const float one_h0 = h == 0 ? 1.0f : 0.0f;
 
   const float msk = valid ? p.mask[pv] : 0.f;
   const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -904,8 +913,8 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
     acc_elu(a);
   }
   f32x16 b2[2];
-  acc_zero(b2);
-  net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+  acc_init_bias<2>(b2, ctab + 80);
+  net_layer<2, 64>(ring, b2, [&](int s) { return a[s / 16][s % 16]; });
   acc_elu(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;
@@ -983,10 +992,10 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
       return c < 0 ? 0.f : W[n * 105 + 70 + c];
     });
   }
-  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], T[DT_BASE2_B], 128, 256, 256));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], T[DT_VIS0_B], 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], T[DT_VIS2_B], 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], T[DT_VISB0_B], 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], nullptr, 128, 256, 256));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], nullptr, 128, 128, 128));
   DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
   {
     const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
@@ -1029,6 +1038,11 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   pack_rowtab(o, T[DT_VISB2_W], 128);
   o.push_back(T[DT_VIS2_B][128]);
   o.push_back(T[DT_VISB2_B][0]);
+  o.resize(DY_OFF_CTA + 272, 0.f);
+  pack_rowtab(o, T[DT_BASE2_B], 128);
+  pack_rowtab(o, T[DT_VIS0_B], 128);
+  pack_rowtab(o, T[DT_VIS2_B], 128);
+  pack_rowtab(o, T[DT_VISB0_B], 128);
   o.resize(DY_OFF_CTB, 0.f);
   pack_rowtab(o, T[DT_LN_G], 128);
   pack_rowtab(o, T[DT_LN_B], 128);
