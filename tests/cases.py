@@ -22,6 +22,9 @@ def scene_case(name):
       'harsh': dict(seed=2, H=40, W=56, V=5, n_static=11, smooth=True, R=5, t_scale=3.0, r_scale=1.2, near=0.3, far=6.0),
       # white-noise maps (the bench's data distribution): ill-conditioned bilinear taps, looser tolerance
       'noise': dict(seed=3, H=32, W=48, V=7, n_static=8, smooth=False, R=4),
+      # view counts that exercise the other lane-segment widths of the network kernels (4 and 32 lanes per point)
+      'few': dict(seed=5, H=32, W=48, V=3, n_static=4, smooth=True, R=5),
+      'many': dict(seed=6, H=32, W=48, V=13, n_static=20, smooth=True, R=3),
   }[name]
   R = cfg.pop('R')
   seed = cfg['seed']
@@ -50,5 +53,5 @@ def model_weights(seed=0):
 
 def time_args(n_views):
   """(frame_idx, time_embedding[1], time_offset list) like eval_nvidia.py:323-329."""
-  offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else None
+  offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else [((i * 5) % 7) - 3 for i in range(n_views)]
   return REF_FRAME, torch.tensor([REF_FRAME / float(NUM_FRAMES)], dtype=torch.float32), offs

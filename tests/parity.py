@@ -522,3 +522,33 @@ def check_full_size_properties(device, R=4096, S=64, V=8, N_importance=64):
   assert_close(cpu(out['rgb'])[idx], ref['rgb'], 1e-4, 0.0, 'full-size rgb vs oracle (48 rays)')
   assert_close(cpu(out['depth'])[idx], ref['depth'], 0.0, 3e-4, 'full-size depth vs oracle (48 rays)')
   return float((cpu(out['rgb'])[idx] - ref['rgb']).abs().max())
+
+
+def check_render_rays_mono_vv(device, name='small', S=64, num_vv=2):
+  import types
+  from dynibar_amd import projection, render_ray
+  scene, o, d, uv, _ = cases.scene_case(name)
+  Vd = scene['src_rgbs'].shape[1]
+  fidx, temb, toff = cases.time_args(Vd)
+  toff = toff[:Vd - num_vv]  # the last num_vv source views are the virtual ones: no time offset, no displacement
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  ref = O.render_rays_mono_eval(W, dict(scene), o, d, uv, fidx, temb, toff, S, True, True, num_vv=num_vv)
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  batch = make_ray_batch(scene, o, d, uv, device)
+  feat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
+  ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, projection.Projector(device), S, args,
+                                    inv_uniform=True, det=True, is_train=False, num_vv=num_vv)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_coarse_ref_dy', 'outputs_coarse_st'):
+    assert list(ret[grp].keys()) == list(ref[grp].keys()), f'{grp}: key order differs from the reference'
+    for k, v in ret[grp].items():
+      r = ref[grp][k]
+      if r.dtype == torch.bool:
+        assert_bitexact(v, r, f'{grp}/{k}')
+      else:
+        tol = _group_tol(k, name)
+        assert_close(cpu(v).float(), r.float(), tol['atol'], tol['rtol'], f'mono vv {grp}/{k}')
+      n += 1
+  return n

@@ -91,3 +91,16 @@ def test_render_single_image_nvi(dev, golden_dir):
 def test_full_size_properties(dev):
   """BASELINE configs[1] at full size: chunk invariance (bit-exact), compositing / resampling invariants, oracle spot check."""
   parity.check_full_size_properties(dev)
+
+
+@pytest.mark.parametrize('name', ['few', 'many'])
+def test_networks_other_segment_widths(dev, name):
+  """3 / 4 views (4-lane segments, unpooled base_fc.0) and 13 / 20 views (16- and 32-lane segments)."""
+  parity.check_static_net(dev, name, S=64)
+  parity.check_dynamic_net(dev, name, S=64)
+  parity.check_static_pass(dev, name)
+
+
+def test_render_rays_mono_virtual_views(dev):
+  """num_vv = 2 undisplaced virtual source views appended to the dynamic branch (render_ray.py:988-989), against the oracle."""
+  parity.check_render_rays_mono_vv(dev)
