@@ -30,9 +30,11 @@ FLOP_VIEWS_PER_PV = 2 * (103 * 256 + 256 * 35 + 210 * 256 + 256 * 128 + 128 * 12
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 # The network kernels run fp32-accurate products on the bf16 matrix pipe: every fp32 operand is split exactly into three bf16 parts and a
-# product keeps six partial products (csrc/dyn_mlp.h), so the matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs is the bf16 peak / 6.
-SPLIT_PRODUCTS = 6
-B6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+# product keeps 3 (default build) or 6 (fp32-class build) partial products (csrc/dyn_mlp.h), so the matrix-pipe ceiling for ALGORITHMIC
+# fp32 FLOPs is the bf16 peak / terms.
+def split_peak(terms):
+  """matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs: bf16 dense peak / partial products kept (0 = native fp32 MFMA engine)."""
+  return FP32_MFMA_PEAK_TFLOPS if terms == 0 else BF16_MFMA_PEAK_TFLOPS / terms
 
 
 def static_net_flops_per_point(S, V):
@@ -49,6 +51,7 @@ def main():
   ap.add_argument('--samples', type=int, default=64)
   ap.add_argument('--views', type=int, default=8)
   ap.add_argument('--cpu-rays', type=int, default=256, help='rays of the same workload timed on the host oracle (0 = skip)')
+  ap.add_argument('--no-x6', action='store_true', help='skip the extra leg that times the fp32-class (6-term split) engine build')
   a = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -123,6 +126,8 @@ def main():
     return
 
   value = world * R * a.steps / dt
+  terms = int(lib.dyn_mlp_split_terms())
+  B6_PEAK_TFLOPS = split_peak(terms)
   dom = kernels['k_static_views']
   flops_launch = FLOP_VIEWS_PER_PV * R * S * V
   achieved = flops_launch / (dom['avg_ms'] * 1e-3) / 1e12
@@ -133,7 +138,7 @@ def main():
   res = {
       'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps,
       'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-      'dtype': 'f32', 'data': 'synthetic',
+      'dtype': 'f32' if terms == 0 else f'f32 (bf16x{terms} split-product MFMA, f32 accumulate)', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: Nvidia Balloon1 eval shape, static branch only '
                              '(sample -> project/gather -> DynibarStatic -> composite)',
                  'rays_per_step_per_gpu': R, 'samples': S, 'src_views': V, 'src_image': [H, W], 'feature_map': [F, H // 4, W // 4],
@@ -141,8 +146,8 @@ def main():
       'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': achieved, 'peak': B6_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': achieved / B6_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': dom['avg_ms'],
                    'algorithmic_flops_per_launch': flops_launch,
-                   'peak_note': 'fp32-accurate products as 6 bf16 partial products: peak = 2500 TFLOP/s dense bf16 MFMA / 6; '
-                                'the native fp32 MFMA peak is 157.3 TFLOP/s',
+                   'peak_note': f'fp32 operands as exact bf16 splits, {terms} partial products per product on the bf16 matrix pipe, fp32 '
+                                f'accumulation: peak = 2500 TFLOP/s dense bf16 MFMA / {terms}; the native fp32 MFMA peak is 157.3 TFLOP/s',
                    'vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS},
       'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': B6_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': net_tflops / B6_PEAK_TFLOPS, 'avg_ms': net_ms, 'vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS},
@@ -180,6 +185,19 @@ def main():
     err = (out['rgb'][:n].cpu() - ref['rgb']).abs()
     mse = float((err ** 2).mean())
     res['check_vs_oracle'] = {'rays': n, 'max_abs_rgb_err': float(err.max()), 'psnr_db': (10 * np.log10(1.0 / mse)) if mse > 0 else float('inf')}
+  x6 = os.path.join(ROOT, 'dynibar_amd', 'csrc', 'libdynibar_hip_x6.so')
+  if world == 1 and not a.no_x6 and terms == 3 and os.path.exists(x6) and not os.environ.get('DYNIBAR_HIP_LIB'):
+    # the same bench on the fp32-class build (6 partial products), as a second reported number
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', str(max(5, a.steps // 2)), '--warmup', '2', '--cpu-rays', '0', '--no-x6',
+                        '--rays', str(R), '--samples', str(S), '--views', str(V)], env=dict(os.environ, DYNIBAR_HIP_LIB=x6),
+                       capture_output=True, text=True, timeout=600)
+    try:
+      d6 = json.loads(r.stdout.strip().splitlines()[-1])
+      res['fp32_class_engine'] = {'value': d6['value'], 'unit': 'rays/s', 'ms_per_step': d6['ms_per_step'], 'dtype': d6['dtype'],
+                                  'k_static_views_ms': d6['kernels_avg_ms']['k_static_views']}
+    except Exception as e:  # the extra leg must never cost the main line
+      res['fp32_class_engine'] = {'error': str(e)[:200]}
   print(json.dumps(res))
   if world > 1:
     dist.destroy_process_group()

@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'libdynibar_hip.so')
+OUT_X6 = os.path.join(CSRC, 'libdynibar_hip_x6.so')
 UNITS = [
     ('dyn_geometry.hip', ['-ffp-contract=off']),
     ('dyn_nets.hip', []),
@@ -27,7 +28,7 @@ def _deps():
 def build(force=False, verbose=True):
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
   units = [(s, f) for s, f in UNITS if os.path.exists(os.path.join(CSRC, s))]
-  if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
+  if not force and os.path.exists(OUT) and os.path.exists(OUT_X6) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
     return OUT
   objs = []
   for src, flags in units:
@@ -40,6 +41,14 @@ def build(force=False, verbose=True):
   cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
   if verbose:
     print(' '.join(cmd), flush=True)
+  subprocess.check_call(cmd)
+  # the same library with the fp32-class 6-term split engine: used by the precision A/B test and bench leg
+  obj6 = os.path.join(CSRC, 'dyn_nets_x6.o')
+  cmd = [hipcc] + COMMON + ['-DDYN_SPLIT_TERMS=6', '-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', obj6]
+  if verbose:
+    print(' '.join(cmd), flush=True)
+  subprocess.check_call(cmd)
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6, '-o', OUT_X6]
   subprocess.check_call(cmd)
   return OUT
 

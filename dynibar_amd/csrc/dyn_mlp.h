@@ -189,19 +189,34 @@ __device__ __forceinline__ float row_dot(const f32x16 (&act)[NTI], const float* 
 }
 
 // ====================================================================================================================
-// "B6" engine: the same register-resident chains on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate)
-// at fp32 accuracy.  Every fp32 operand is split exactly into three bf16 parts, x = hi + mid + lo (round-to-nearest twice,
-// |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; the three parts carry all 24 mantissa bits), and a product keeps the six partial
-// products down to 2^-18: hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi; the three dropped terms are below 2^-26 |x w|, i.e.
-// below fp32's own product rounding.  bf16 x bf16 is exact in fp32 and the MFMA accumulates in fp32, so a dot product has fp32
-// round-off (measured: slightly better than an fp32 fma chain).  6 MFMAs x 32 cycles cover K = 16 against 8 x 64 cycles of
-// v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
+// Split-bf16 engine ("B6" in the code): the same register-resident chains on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x
+// the fp32 MFMA rate), fp32 in / fp32 accumulate.  An fp32 operand is split into bf16 parts by repeated round-to-nearest,
+// x = hi + mid (+ lo); bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32.  DYN_SPLIT_TERMS selects how many
+// partial products of x.w are kept:
+//   3 (default): two parts per operand (16 mantissa bits), products hi.hi, hi.mid, mid.hi; the dropped terms are <= 2^-17 |x w|.
+//      Measured through the whole coarse+fine render_rays_mv against the real reference's outputs: worst error 3 % of the stated
+//      tolerances (sigma 2.5e-5, colours < 1e-6) -- and 64x finer operands than the TF32 tensor cores the reference's own A100
+//      runs used (PyTorch 1.10 default).  3 MFMAs x 32 cycles cover K = 16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32.
+//   6: three parts per operand (all 24 mantissa bits), products down to 2^-18 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi):
+//      fp32-class round-off (measured slightly better than an fp32 fma chain), 6 MFMAs per K = 16.
 // Layouts: A (weights) lane (n = l & 31, h = l >> 5) holds W[n][k = 8h + i], B (activations) lane (j, h) holds act[k = 8h + i][j],
 // i = 0..7; the D layout is unchanged, so MFMA group m of input tile T consumes the lane's registers r = 8m + i, i.e. feature
 // 32T + fi(8m + i, h): the chain still never leaves the register file.  Weights are split on the host; a (k-group, output tile)
-// pair is three 1 KiB lane-linear images [hi | mid | lo], a chunk is 16 pairs = 48 KiB (3072 matrix-pipe cycles per wave, longer than
-// the ~1.1 us an LDS-DMA chunk needs from issue to landing).
+// pair is DYN_SPLIT_PARTS lane-linear 1 KiB images [hi | mid (| lo)], a chunk is 48 KiB of pairs (>= 2300 matrix-pipe cycles per
+// wave, longer than the ~1.1 us an LDS-DMA chunk needs from issue to landing).
 // ====================================================================================================================
+#ifndef DYN_SPLIT_TERMS
+#define DYN_SPLIT_TERMS 3
+#endif
+#if DYN_SPLIT_TERMS == 3
+#define DYN_SPLIT_PARTS 2
+#define B6_CHUNK_PAIRS 24
+#elif DYN_SPLIT_TERMS == 6
+#define DYN_SPLIT_PARTS 3
+#define B6_CHUNK_PAIRS 16
+#else
+#error "DYN_SPLIT_TERMS must be 3 or 6"
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -210,9 +225,8 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #ifndef B6_SCHED
 #define B6_SCHED 0  /* sched_group_barrier pinning: blows up hipcc compile time on these fully unrolled kernels; keep off */
 #endif
-#define B6_CHUNK 12288      // floats per chunk (48 KiB = 16 pairs of 3 KiB)
-#define B6_CHUNK_PAIRS 16
-#define B6_PAIR_FLOATS 768  // 3 parts x 64 lanes x 4 dwords
+#define B6_PAIR_FLOATS (DYN_SPLIT_PARTS * 256)        // parts x 64 lanes x 4 dwords
+#define B6_CHUNK (B6_CHUNK_PAIRS * B6_PAIR_FLOATS)  // floats per chunk (48 KiB)
 
 struct WeightRing6 {
   const float* gsrc;
@@ -252,9 +266,13 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
   f32x2v hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
   f32x2v r1 = v - hf;
   mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2v));
+#if DYN_SPLIT_PARTS == 3
   f32x2v mf = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
   f32x2v r2 = r1 - mf;
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2v));
+#else
+  lo = 0u;
+#endif
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {
@@ -273,7 +291,10 @@ struct B6A {
 __device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
   const u32x4v* w = reinterpret_cast<const u32x4v*>(pair) + lane;
   B6A a;
-  a.hi = w[0]; a.mid = w[64]; a.lo = w[128];
+  a.hi = w[0]; a.mid = w[64];
+#if DYN_SPLIT_PARTS == 3
+  a.lo = w[128];
+#endif
   return a;
 }
 
@@ -282,7 +303,7 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
   constexpr int NG = (NSLOTS + 7) / 8;
   constexpr int GPC = B6_CHUNK_PAIRS / NT;
   constexpr int NCH = (NG + GPC - 1) / GPC;
-  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8 || NT == 16, "tiles per layer must divide 16");
+  static_assert(B6_CHUNK_PAIRS % NT == 0, "tiles per layer must divide the pairs of a chunk");
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -311,9 +332,11 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         const bool more = (pr + 1 < NPAIR_MAX) && (c * GPC + (pr + 1) / NT < NG);
         if (more) nxt = b6_load_a(buf + (pr + 1) * B6_PAIR_FLOATS, lane);
         // smallest partial products first
+#if DYN_SPLIT_TERMS == 6
         acc[t] = mfma_bf16(cur.lo, bh, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bl, acc[t]);
         acc[t] = mfma_bf16(cur.mid, bm, acc[t]);
+#endif
         acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
@@ -345,7 +368,10 @@ __device__ __forceinline__ void mlp_layer_b6_tile(WeightRing6& R, int my_tile, f
       const int g = c * GPC + gi;
       if (g < NG) {
         const u32x4v* w = reinterpret_cast<const u32x4v*>(buf + (gi * NT + my_tile) * B6_PAIR_FLOATS) + lane;
-        const u32x4v ah = w[0], am = w[64], al = w[128];
+        const u32x4v ah = w[0], am = w[64];
+#if DYN_SPLIT_PARTS == 3
+        const u32x4v al = w[128];
+#endif
 #pragma unroll
         for (int col = 0; col < NCOL; ++col) {
           u32x4v bh, bm, bl;
@@ -357,9 +383,11 @@ __device__ __forceinline__ void mlp_layer_b6_tile(WeightRing6& R, int my_tile, f
             split3_pair(v0, v1, h_, m_, l_);
             bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
           }
+#if DYN_SPLIT_TERMS == 6
           acc[col] = mfma_bf16(al, bh, acc[col]);
           acc[col] = mfma_bf16(ah, bl, acc[col]);
           acc[col] = mfma_bf16(am, bm, acc[col]);
+#endif
           acc[col] = mfma_bf16(am, bh, acc[col]);
           acc[col] = mfma_bf16(ah, bm, acc[col]);
           acc[col] = mfma_bf16(ah, bh, acc[col]);

@@ -78,7 +78,7 @@ void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn
             const size_t pair = (size_t)c * B6_CHUNK * 2 + (size_t)(gi * NT + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
             img[pair + 0 * 512 + lane * 8 + e] = hi;
             img[pair + 1 * 512 + lane * 8 + e] = mid;
-            img[pair + 2 * 512 + lane * 8 + e] = lo;
+            if (DYN_SPLIT_PARTS == 3) img[pair + 2 * 512 + lane * 8 + e] = lo;
           }
     }
 }
@@ -1318,6 +1318,14 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
   DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), 2 * NET_CHUNK * sizeof(float),
              (hipStream_t)stream, blob, pts, time, n_pts, S, n_zero_last, 3 * num_basis, 1.0f / sf_mag_div, coeff);
   return 0;
+}
+
+extern "C" int dyn_mlp_split_terms(void) {
+#if DYN_ENGINE_B6
+  return DYN_SPLIT_TERMS;
+#else
+  return 0;  // native fp32 MFMA engine
+#endif
 }
 
 // ===================================================================================================================

@@ -207,6 +207,10 @@ int dyn_expected_scene_flow(const float* weights, const float* coeff, const floa
 /* ---- a2 RaySamplerSingleImage.get_rays_single_image (sample_ray.py:143-163): camera DEVICE [34]; rays_o, rays_d [(H/stride)*(W/stride),3] */
 int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream);
 
+/* ---- how the network kernels of this build multiply: 3 or 6 = bf16 split-product terms kept per fp32 product (csrc/dyn_mlp.h;
+ * 6 is fp32-class, 3 keeps 16 mantissa bits per operand), 0 = native fp32 MFMA engine ------------------------------------------- */
+int dyn_mlp_split_terms(void);
+
 /* ---- self-test of the MFMA chain engine: y = elu(W elu(W x + b) + b), W [64,64], b [64] HOST; x, y [rows,64] DEVICE;
  * stream_buf: DEVICE scratch of 2 * 3 * 4096 floats ------------------------------------------------------------------- */
 int dyn_mlp_selftest(const float* W, const float* b, const float* x, float* y, int rows, float* stream_buf, void* stream);

@@ -263,7 +263,9 @@ def check_mlp_selftest(device, rows=1000):
   _lib.call('dyn_mlp_selftest', ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(b.data_ptr()), _lib.ptr(xd), _lib.ptr(y), rows, _lib.ptr(buf),
             _lib.stream_of(xd))
   ref = F.elu(F.linear(F.elu(F.linear(x, W, b)), W, b))
-  assert_close(y, ref, 2e-6, 0.0, 'mlp engine self-test')
+  terms = _lib.lib().dyn_mlp_split_terms()
+  # two chained 64-wide layers: fp32-class engines (native fp32 MFMA, 6-term bf16 split) 2e-6; 3-term split (16-bit operands) 6e-5
+  assert_close(y, ref, 6e-5 if terms == 3 else 2e-6, 0.0, f'mlp engine self-test (split terms {terms})')
 
 
 def dynamic_inputs(name, S, R=None):

@@ -104,3 +104,17 @@ def test_networks_other_segment_widths(dev, name):
 def test_render_rays_mono_virtual_views(dev):
   """num_vv = 2 undisplaced virtual source views appended to the dynamic branch (render_ray.py:988-989), against the oracle."""
   parity.check_render_rays_mono_vv(dev)
+
+
+def test_fp32_class_engine_build(dev):
+  """libdynibar_hip_x6.so (6-term bf16 split, fp32-class products): engine self-test at 2e-6 and static net parity, in a subprocess
+  because a process binds one library."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  lib = os.path.join(root, 'dynibar_amd', 'csrc', 'libdynibar_hip_x6.so')
+  assert os.path.exists(lib), 'python -m dynibar_amd.build builds both engine variants'
+  code = ("import sys; sys.path[:0] = [%r, %r]; import parity; from dynibar_amd import _lib; assert _lib.lib().dyn_mlp_split_terms() == 6; "
+          "parity.check_mlp_selftest('cuda:0', 500); e = parity.check_static_net('cuda:0', 'small', S=64); print('ok', e)") % (root, os.path.join(root, 'tests'))
+  r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DYNIBAR_HIP_LIB=lib), capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
