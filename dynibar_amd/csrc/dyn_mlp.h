@@ -121,7 +121,9 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const float* ta
     }
 }
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : (__expf(v) - 1.0f); }
+// ELU as a median: for v > 0, v <= e^v - 1 and 0 < v; for v <= 0, v <= e^v - 1 <= 0 -- so elu(v) = med3(v, e^v - 1, 0) in one instruction
+// instead of a compare + select (which also hides worse under the matrix pipe, tools/ubench/mfma_valu_kind.hip)
+__device__ __forceinline__ float elu1(float v) { return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f); }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 template <int NT>
@@ -228,6 +230,29 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #define B6_PAIR_FLOATS (DYN_SPLIT_PARTS * 256)        // parts x 64 lanes x 4 dwords
 #define B6_CHUNK (B6_CHUNK_PAIRS * B6_PAIR_FLOATS)  // floats per chunk (48 KiB)
 
+// developer instrumentation (tools/phasebench.py): cycle stamps of wave 0 of two workgroups at the layer boundaries of the view chain
+#ifdef DYN_PHASE_TIMING
+__device__ unsigned long long g_phase[2][64];  // [0..31] layer boundaries, [32..63] cycles waited in the ring acquire of chunk c
+#define DYN_PHASE(i)                                                                                  \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))                         \
+      g_phase[blockIdx.x != 0][i] = __builtin_readcyclecounter();                                     \
+  } while (0)
+extern "C" int dyn_debug_phases(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 1;
+}
+#define DYN_PHASE_T0 const unsigned long long phase_t0 = __builtin_readcyclecounter();
+#define DYN_PHASE_WAIT(c)                                                                             \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && (c) < 32)             \
+      g_phase[blockIdx.x != 0][32 + (c)] = __builtin_readcyclecounter() - phase_t0;                   \
+  } while (0)
+#else
+#define DYN_PHASE(i)
+#define DYN_PHASE_T0
+#define DYN_PHASE_WAIT(c)
+#endif
+
 struct WeightRing6 {
   const float* gsrc;
   float* buf;
@@ -252,9 +277,11 @@ __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, 
   ring6_issue(R, 0);
 }
 __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
+  DYN_PHASE_T0
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   const int c = R.next++;
+  DYN_PHASE_WAIT(c);
   if (c + 1 < R.total) ring6_issue(R, c + 1);
   return R.buf + (c & 1) * B6_CHUNK;
 }
@@ -298,39 +325,78 @@ __device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
   return a;
 }
 
+// split pairs [P0, P1) of k-group g of the lane's B operand (slots 8 g + 2 p, 8 g + 2 p + 1) into their bf16 parts
+template <int NSLOTS, int P0, int P1, class Feed>
+__device__ __forceinline__ void b6_split_pairs(Feed& feed, int g, u32x4v& bh, u32x4v& bm, u32x4v& bl) {
+#pragma unroll
+  for (int p2 = P0; p2 < P1; ++p2) {
+    const float v0 = (g * 8 + 2 * p2 < NSLOTS) ? feed(g * 8 + 2 * p2) : 0.f;
+    const float v1 = (g * 8 + 2 * p2 + 1 < NSLOTS) ? feed(g * 8 + 2 * p2 + 1) : 0.f;
+    unsigned h_, m_, l_;
+    split3_pair(v0, v1, h_, m_, l_);
+    bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
+  }
+}
+
+// Scheduling: the layer is a software pipeline over (k-group, output tile) pairs.  While the MFMAs of pair p issue, the A parts of
+// pairs p + 1 .. p + B6_AHEAD are in flight from LDS and a slice of the B operand of the next k-group is produced (feed -> ELU etc.
+// -> bf16 split).  A scheduling barrier after every pair keeps that interleave: without it the compiler hoists a whole chunk's VALU work (feeds,
+// splits) above the chunk's MFMAs, and since the chunk barrier has just aligned the waves, both waves of a SIMD then sit in the
+// VALU phase together and in the MFMA phase together -- matrix pipe and VALU never overlap (measured: layer time = sum of both).
+// feed(s) is called exactly once per slot, in slot order.
+#ifndef B6_AHEAD
+#define B6_AHEAD 1  // pairs of A operands in flight from LDS ahead of the pair whose MFMAs issue
+#endif
+#ifndef B6_VALU_PER_PAIR
+#define B6_VALU_PER_PAIR 1  // 1: the next k-group's B operand is produced in NT slices, one beside each tile; 0: all beside tile 0
+#endif
 template <int NT, int NSLOTS, class Feed>
 __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], Feed&& feed) {
   constexpr int NG = (NSLOTS + 7) / 8;
   constexpr int GPC = B6_CHUNK_PAIRS / NT;
   constexpr int NCH = (NG + GPC - 1) / GPC;
   static_assert(B6_CHUNK_PAIRS % NT == 0, "tiles per layer must divide the pairs of a chunk");
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "output tiles per layer");
   const int lane = threadIdx.x & 63;
+  u32x4v bh, bm, bl, nh, nm, nl;
+  b6_split_pairs<NSLOTS, 0, 4>(feed, 0, bh, bm, bl);
+  nh = bh; nm = bm; nl = bl;
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const float* buf = ring6_acquire(R);
-    constexpr int NPAIR_MAX = B6_CHUNK_PAIRS;
-    // software pipeline over the (k-group, output tile) pairs of the chunk: the A parts of pair p + 1 are in flight while the six
-    // MFMAs of pair p issue (two 12-register operand sets alive)
-    B6A cur = b6_load_a(buf, lane);
-    u32x4v bh, bm, bl;
+    constexpr int NPC_MAX = B6_CHUNK_PAIRS;
+    const int npc = (NG - c * GPC < GPC ? NG - c * GPC : GPC) * NT;  // pairs of this chunk (compile-time after unrolling)
+    B6A q[B6_AHEAD + 1];
 #pragma unroll
-    for (int pr = 0; pr < NPAIR_MAX; ++pr) {
-      const int gi = pr / NT, t = pr % NT;
-      const int g = c * GPC + gi;
-      if (g < NG) {
-        if (t == 0) {
+    for (int i = 0; i < B6_AHEAD; ++i)
+      if (i < npc) q[i] = b6_load_a(buf + i * B6_PAIR_FLOATS, lane);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int p2 = 0; p2 < 4; ++p2) {
-            const float v0 = (g * 8 + 2 * p2 < NSLOTS) ? feed(g * 8 + 2 * p2) : 0.f;
-            const float v1 = (g * 8 + 2 * p2 + 1 < NSLOTS) ? feed(g * 8 + 2 * p2 + 1) : 0.f;
-            unsigned h_, m_, l_;
-            split3_pair(v0, v1, h_, m_, l_);
-            bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
-          }
+    for (int pr = 0; pr < NPC_MAX; ++pr) {
+      if (pr < npc) {
+        const int gi = pr / NT, t = pr % NT;
+        const int g = c * GPC + gi;
+        if (pr + B6_AHEAD < npc) q[(pr + B6_AHEAD) % (B6_AHEAD + 1)] = b6_load_a(buf + (pr + B6_AHEAD) * B6_PAIR_FLOATS, lane);
+        if (g + 1 < NG) {
+#if B6_VALU_PER_PAIR
+          // this tile's share of the next k-group's operand: pairs [4 t / NT, 4 (t + 1) / NT)
+          if (NT == 1) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
+          if (NT == 2 && t == 0) b6_split_pairs<NSLOTS, 0, 2>(feed, g + 1, nh, nm, nl);
+          if (NT == 2 && t == 1) b6_split_pairs<NSLOTS, 2, 4>(feed, g + 1, nh, nm, nl);
+          if (NT == 4 && t == 0) b6_split_pairs<NSLOTS, 0, 1>(feed, g + 1, nh, nm, nl);
+          if (NT == 4 && t == 1) b6_split_pairs<NSLOTS, 1, 2>(feed, g + 1, nh, nm, nl);
+          if (NT == 4 && t == 2) b6_split_pairs<NSLOTS, 2, 3>(feed, g + 1, nh, nm, nl);
+          if (NT == 4 && t == 3) b6_split_pairs<NSLOTS, 3, 4>(feed, g + 1, nh, nm, nl);
+          if (NT == 8 && t == 0) b6_split_pairs<NSLOTS, 0, 1>(feed, g + 1, nh, nm, nl);
+          if (NT == 8 && t == 2) b6_split_pairs<NSLOTS, 1, 2>(feed, g + 1, nh, nm, nl);
+          if (NT == 8 && t == 4) b6_split_pairs<NSLOTS, 2, 3>(feed, g + 1, nh, nm, nl);
+          if (NT == 8 && t == 6) b6_split_pairs<NSLOTS, 3, 4>(feed, g + 1, nh, nm, nl);
+#else
+          if (t == 0) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
+#endif
         }
-        B6A nxt = cur;
-        const bool more = (pr + 1 < NPAIR_MAX) && (c * GPC + (pr + 1) / NT < NG);
-        if (more) nxt = b6_load_a(buf + (pr + 1) * B6_PAIR_FLOATS, lane);
+        const B6A& cur = q[pr % (B6_AHEAD + 1)];
         // smallest partial products first
 #if DYN_SPLIT_TERMS == 6
         acc[t] = mfma_bf16(cur.lo, bh, acc[t]);
@@ -340,12 +406,8 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
-        cur = nxt;
-#if B6_SCHED
-        // pin the order "next pair's three A loads, then this pair's six MFMAs" so the LDS latency hides under the matrix pipe
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-#endif
+        if (t == NT - 1) { bh = nh; bm = nm; bl = nl; }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

@@ -438,10 +438,12 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     }
     if (8 * PT < 32 && threadIdx.x < 2 * 2 * NX)  // unused point columns: keep them finite (they are computed and discarded)
       for (int c = 8 * PT; c < 32; ++c) pool[threadIdx.x * 32 + c] = 0.f;
+    DYN_PHASE(6);
     __syncthreads();
     f32x16 accp[1];
     acc_zero(accp);
     net_layer_tile<8, 2 * NX, 1>(ring, wave, accp, [&](int, int s) { return pool[(s * 2 + h) * 32 + j]; });
+    DYN_PHASE(7);
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
     __syncthreads();
@@ -449,6 +451,7 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[t][r] = res[(t * 32 + dyn_fi(r, h)) * 32 + col];
+    DYN_PHASE(8);
   } else {
     acc_zero(a1);
     net_layer<8, 2 * NX>(ring, a1, [&](int s) {
@@ -460,13 +463,14 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     });
   }
   net_layer<8, NX + 1>(ring, a1, [&](int s) { return s < NX ? xin[s] : one_h0; });
-  acc_elu(a1);
+  DYN_PHASE(9);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
 // shared tail of the per point-view chains (static: mlp_network.py:483-494, dynamic: :266-282):
 // base_fc.2 -> vis_fc -> vis_fc2 -> visibility-weighted mean / variance over the views -> geometry_fc input rows
-// a1: ELU'd base_fc.0 output (256 features).  Constant table: vis row @0, vis_fc2.2 row @128, b_vis @256, b_vis2 @257.
+// a1: base_fc.0 output before its ELU (256 features); every ELU is applied in the feed of the layer that consumes it, so that it
+// interleaves with that layer's MFMAs.  Constant table: vis row @0, vis_fc2.2 row @128, b_vis @256, b_vis2 @257.
 // -------------------------------------------------------------------------------------------------------------------
 template <int VSEG, bool STORE_X>
 __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
@@ -476,17 +480,27 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
   f32x16 x[4];
   {
     acc_init_bias<4>(x, ctab + 272);
-    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return a1[s / 16][s % 16]; });
-    acc_elu(x);
+    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return elu1(a1[s / 16][s % 16]); });
+    DYN_PHASE(11);
   }
   float vis;
   {
     f32x16 a5[4], a6[4];
     acc_init_bias<4>(a5, ctab + 400);
-    net_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) { return x[s / 16][s % 16] * wgt; });
-    acc_elu(a5);
+    DYN_PHASE(12);
+    net_layer<4, SA_L5_STEPS>(ring, a5, [&](int s) {
+      const float r = elu1(x[s / 16][s % 16]);  // x = ELU(base_fc.2)
+      x[s / 16][s % 16] = r;
+      return r * wgt;
+    });
+    DYN_PHASE(13);
     acc_init_bias<4>(a6, ctab + 528);
-    net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) { return a5[s / 16][s % 16]; });
+    net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) {
+      const float r = elu1(a5[s / 16][s % 16]);
+      a5[s / 16][s % 16] = r;
+      return r;
+    });
+    DYN_PHASE(14);
     vis = sigmoid1(elu1(row_dot<4>(a5, ctab) + ctab[256])) * msk;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -497,10 +511,13 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
   {
     f32x16 a7[4];
     acc_init_bias<4>(a7, ctab + 656);
+    DYN_PHASE(15);
     net_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return x[s / 16][s % 16] * vis; });
+    DYN_PHASE(16);
     acc_elu(a7);
     vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
   }
+  DYN_PHASE(17);
   // ---- outputs: x and vis2 in lane order, visibility-weighted statistics per point ----
   const bool tile_ok = tile < p.n_tiles_a;
   if (STORE_X && tile_ok) {
@@ -511,6 +528,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
       for (int q = 0; q < 4; ++q) xw[(t * 4 + q) * 64] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
     p.ws[p.o.off_vis + tile * 64 + lane] = vis2;
   }
+  DYN_PHASE(18);
   const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
   const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
   const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
@@ -550,6 +568,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
   NetRing ring;
+  DYN_PHASE(0);
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
 
   const int V = p.V;
@@ -571,12 +590,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     cx = p.centers[view * 16 + 12]; cy = p.centers[view * 16 + 13]; cz = p.centers[view * 16 + 14];
   }
   float xin[SA_NX];
-#pragma unroll
-  for (int q = 0; q < 18; ++q) {
-    const int ch = h == 0 ? q : 18 + q;
-    xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] : 0.f;
-  }
-
   f32x16 a1[8];
   {
     // Pluecker coordinates of the source ray through the sample (render_ray.py:380-396)
@@ -593,19 +606,32 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 #pragma unroll
     for (int k = 0; k < 7; ++k) in1[45 + k] = h == 0 ? raw[2 * k] : raw[2 * k + 1];
     acc_zero(a1);
+    DYN_PHASE(1);
     net_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
-    acc_elu(a1);
+    DYN_PHASE(2);
   }
   {
     f32x16 a2[2];
     acc_init_bias<2>(a2, ctab + 784);
-    net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) { return a1[s / 16][s % 16]; });
+    // The gathered colours / features are first needed after ray_dir_fc: their loads are issued from inside the layer's feed (half
+    // way through it), which keeps 18 registers free during the 256-wide first layer and hides the HBM latency under this layer.
+    net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) {
+      if (s == 64) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+          const int ch = h == 0 ? q : 18 + q;
+          xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] : 0.f;
+        }
+      }
+      return elu1(a1[s / 16][s % 16]);  // ELU of ray_dir_fc.0 where it is consumed
+    });
     const float* rf = p.ws + p.o.off_ref + (valid ? (point / p.S) * 36 : 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xin[18 + r] = a2[0][r] * rf[dyn_fi(r, h)];
 #pragma unroll
     for (int r = 0; r < 3; ++r) xin[34 + r] = h == 0 ? a2[1][r] * rf[32 + r] : 0.f;
   }
+  DYN_PHASE(4);
   if (p.mask_rgb) {
     const float s3 = (xin[0] + xin[1]) + xin[2];  // the colour channels live in the h = 0 lanes
     msk *= (__shfl(s3, j) > 1e-3f) ? 1.0f : 0.0f;
@@ -620,8 +646,11 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   }
   wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
 
+  DYN_PHASE(5);
   base_fc0<VSEG, SA_NX>(ring, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
+  DYN_PHASE(10);
   views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
+  DYN_PHASE(20);
 }
 
 // ===================================================================================================================
@@ -669,10 +698,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       gin[128] = valid ? reinterpret_cast<const float*>(src)[128] : (h == 1 ? 1.0f : 0.f);
       acc_zero(a9);
       net_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
-      acc_elu(a9);
     }
     acc_zero(g);
-    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? a9[s / 16][s % 16] : one_h0; });
+    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? elu1(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
     acc_elu(g);
   }
   if (DYN) {
@@ -826,14 +854,17 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       f32x16 a8[8];
       acc_zero(a8);
       net_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
-      acc_elu(a8);
       acc_zero(g2);
-      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? a8[s / 16][s % 16] : one_h0; });
-      acc_elu(g2);
+      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? elu1(a8[s / 16][s % 16]) : one_h0; });
     }
     f32x16 a[4];
     acc_zero(a);
-    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : one_h0; });
+    net_layer<4, 65>(ring, a, [&](int s) {
+      if (s >= 64) return one_h0;
+      const float r = elu1(g2[s / 16][s % 16]);  // g2 = ELU(out_geometry_fc.2) is kept: rgb_fc reads it again
+      g2[s / 16][s % 16] = r;
+      return r;
+    });
     acc_elu(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384] - p.shift;
     if (nvalid < 1.0f) sigma = -1e9f;
@@ -849,10 +880,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     }
     acc_zero(a);
     net_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
-    acc_elu(a);
     f32x16 b2[2];
     acc_zero(b2);
-    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? a[s / 16][s % 16] : one_h0; });
+    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? elu1(a[s / 16][s % 16]) : one_h0; });
     acc_elu(b2);
     float rgb[3];
 #pragma unroll
@@ -910,11 +940,10 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
       }
     const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
     net_layer<4, SC_L11_STEPS>(ring, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
-    acc_elu(a);
   }
   f32x16 b2[2];
   acc_init_bias<2>(b2, ctab + 80);
-  net_layer<2, 64>(ring, b2, [&](int s) { return a[s / 16][s % 16]; });
+  net_layer<2, 64>(ring, b2, [&](int s) { return elu1(a[s / 16][s % 16]); });
   acc_elu(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;

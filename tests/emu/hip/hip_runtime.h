@@ -191,6 +191,8 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
 
 
 #define __expf(x) expf(x)
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}

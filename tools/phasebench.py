@@ -1,0 +1,57 @@
+"""Cycle stamps at the layer boundaries of the static view chain (developer tool).
+
+  python tools/phasebench.py --build     (here: cross-compiles csrc/libdynibar_hip_phase.so with -DDYN_PHASE_TIMING)
+  python tools/phasebench.py             (on the GPU box)
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'dynibar_amd', 'csrc')
+TAG = os.environ.get('PHASE_TAG', '')
+LIB = os.path.join(CSRC, 'libdynibar_hip_phase%s.so' % TAG)
+NAMES = {0: 'start', 1: 'inputs+embed', 2: 'L1 ray_dir_fc.0 (52 steps x 8 tiles)', 3: 'elu(256)', 4: 'L2 ray_dir_fc.2 + ref mult', 5: 'weights',
+         6: 'pool stats -> LDS', 7: 'base_fc.0 pooled tile', 8: 'res exchange', 9: 'base_fc.0 per-view', 10: 'elu(256)', 11: 'L4 base_fc.2',
+         12: 'elu(128)+bias', 13: 'L5 vis_fc.0', 14: 'elu + L6 vis_fc.2(x)', 15: 'vis, x+=', 16: 'L7 vis_fc2.0', 17: 'elu, vis2', 18: 'store x',
+         20: 'weighted stats + stores'}
+
+if '--build' in sys.argv:
+  hipcc = '/opt/rocm/bin/hipcc'
+  common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+  subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG)])
+  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry.o'), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), '-o', LIB])
+  sys.exit(0)
+
+os.environ['DYNIBAR_HIP_LIB'] = LIB
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dynibar_amd import ops, synthetic as syn  # noqa: E402
+
+R, S, V, dev = 4096, 64, 8, 'cuda:0'
+sc = syn.make_scene(seed=0, H=288, W=512, V=V, F=32, n_static=V)
+T = lambda x: torch.from_numpy(x).to(dev)
+scene = {k: T(v) for k, v in sc.items()}
+o_np, d_np, _ = syn.pixel_rays(sc['camera'], syn.sample_pixels(100, 288, 512, R))
+ray_o, ray_d = T(o_np), T(d_np)
+net = ops.StaticNet(syn.make_weights('static', 0, 32), dev, anti_alias_pooling=True, mask_rgb=False)
+views = ops.SourceViews(scene['camera'], scene['static_src_rgbs'], scene['static_src_cameras'], scene['static_featmaps'])
+pts, z, _ = ops.sample_along_ray(ray_o, ray_d, scene['depth_range'], S, True, want_s=False)
+rgb_feat, ray_diff, mask = ops.project_gather(views, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z)
+for _ in range(3):
+  net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
+torch.cuda.synchronize()
+raw = ctypes.CDLL(LIB)
+buf = (ctypes.c_ulonglong * 128)()
+assert raw.dyn_debug_phases(buf) == 0
+for b in range(2):
+  st = [buf[b * 64 + i] for i in range(32)]
+  waits = [buf[b * 64 + 32 + i] for i in range(32)]
+  print('workgroup', 'first' if b == 0 else 'middle', 'total cycles', st[20] - st[0])
+  prev = st[0]
+  for i in range(1, 21):
+    if i in NAMES and st[i]:
+      print('  %-44s %8d' % (NAMES[i], st[i] - prev))
+      prev = st[i]
+  print('  cycles waited at the ring acquire of each weight chunk (s_waitcnt vmcnt(0) + barrier):', waits, 'sum', sum(waits))

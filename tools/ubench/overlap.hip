@@ -22,6 +22,17 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
       }
     }
+    if (MODE == 7 || MODE == 8) {  // fine interleave inside every wave: 1 MFMA, then 16 (MODE 7) / 8 (MODE 8) fmas, 16 times per iteration
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < (MODE == 7 ? 4 : 2); ++q) { v0 = fmaf(v0, v1, v2); v1 = fmaf(v1, v2, v3); v2 = fmaf(v2, v3, v0); v3 = fmaf(v3, v0, v1); }
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < (MODE == 7 ? 4 : 2); ++q) { v0 = fmaf(v0, v1, v2); v1 = fmaf(v1, v2, v3); v2 = fmaf(v2, v3, v0); v3 = fmaf(v3, v0, v1); }
+      }
+    }
     if (do_valu) {
 #pragma unroll
       for (int i = 0; i < 64; ++i) {
@@ -56,5 +67,7 @@ int main() {
   printf("waves 4-7 VALU, waves 0-3 idle    : %.3f ms\n", run<4>(out, iters));
   printf("waves 0-3 MFMA, waves 4-7 idle    : %.3f ms\n", run<5>(out, iters));
   printf("even waves MFMA, odd waves VALU   : %.3f ms\n", run<6>(out, iters));
+  printf("per wave 16 x (MFMA + 16 fma)      : %.3f ms   (same work as 'MFMA block + VALU block')\n", run<7>(out, iters));
+  printf("per wave 16 x (MFMA + 8 fma)       : %.3f ms   (half the VALU work)\n", run<8>(out, iters));
   return 0;
 }
