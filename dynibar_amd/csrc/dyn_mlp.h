@@ -160,7 +160,11 @@ __device__ __forceinline__ float seg_reduce(float v, Op op) {
 }
 template <int VSEG>
 __device__ __forceinline__ float seg_sum(float v, int, int) {
-  return seg_reduce<VSEG>(v, [](float a, float b) { return a + b; });
+  // contraction off: "x * w + dpp(x * w)" fused into an fma cannot take the DPP operand, a plain add folds the lane move into v_add_f32_dpp
+  return seg_reduce<VSEG>(v, [](float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+  });
 }
 template <int VSEG>
 __device__ __forceinline__ float seg_min(float v, int, int) {

@@ -426,14 +426,20 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     constexpr int PT = 32 / VSEG;
     float* res = pool + POOL_FLOATS(NX);
     const int col = wave * PT + p_local;
+    // all statistics first, one predicated block of stores after: a branch per feature would split the DPP reductions into
+    // basic blocks and keep their lane moves from folding into the adds
+    float pm[NX], pvr[NX];
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
-      const float m = seg_sum<VSEG>(xin[q] * wgt, V, 0);
-      const float d = xin[q] - m;
-      const float vr = seg_sum<VSEG>(wgt * (d * d), V, 0);
-      if (view == 0) {
-        pool[(q * 2 + h) * 32 + col] = m;
-        pool[((NX + q) * 2 + h) * 32 + col] = vr;
+      pm[q] = seg_sum<VSEG>(xin[q] * wgt, V, 0);
+      const float d = xin[q] - pm[q];
+      pvr[q] = seg_sum<VSEG>(wgt * (d * d), V, 0);
+    }
+    if (view == 0) {
+#pragma unroll
+      for (int q = 0; q < NX; ++q) {
+        pool[(q * 2 + h) * 32 + col] = pm[q];
+        pool[((NX + q) * 2 + h) * 32 + col] = pvr[q];
       }
     }
     if (8 * PT < 32 && threadIdx.x < 2 * 2 * NX)  // unused point columns: keep them finite (they are computed and discarded)
