@@ -177,8 +177,8 @@ constexpr size_t DY_OFF_A = 0;
 constexpr size_t DY_OFF_B = DY_OFF_A + (size_t)DA_CHUNKS * NET_CHUNK;
 constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * NET_CHUNK;
 constexpr size_t DY_OFF_CTB = DY_OFF_CTA + SA_CT;
-constexpr size_t DY_OFF_POSENC = DY_OFF_CTB + DB_CT;                 // [128 positions][2][64]
-constexpr size_t DY_OFF_TIME = DY_OFF_POSENC + 128 * 128;            // ray_dir_fc: W0 [256,21], b0 [256], W2 [35,256], b2 [35]
+constexpr size_t DY_OFF_POSENC = DY_OFF_CTB + DB_CT;                 // [256 positions][2][64]
+constexpr size_t DY_OFF_TIME = DY_OFF_POSENC + 256 * 128;            // ray_dir_fc: W0 [256,21], b0 [256], W2 [35,256], b2 [35]
 constexpr size_t DY_BLOB_FLOATS = DY_OFF_TIME + 256 * 21 + 256 + 35 * 256 + 36;
 // channel (0..34, or -1) of the per-view feature held by register q of a lane of half h
 __host__ __device__ constexpr int da_c35(int q, int h) { return h == 0 ? q : (q < 17 ? 18 + q : -1); }
@@ -310,9 +310,11 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
 // -------------------------------------------------------------------------------------------------------------------
 struct StaticWs {
   long n_pts, n_tiles_a, n_tiles_b;
-  int PT, TPR;  // points per A tile; B tiles per ray (power of two)
+  int PT, TPR;  // points per A tile; B tiles per ray (1, 2, 4 or -- rays of more than 128 samples -- a multiple of 4)
   size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;  // dynamic net: off_x/off_vis/off_hg unused, off_ref = time feature
+  size_t off_qkvg;  // long rays only: per B tile [g | q | k | v][4][4][64 lanes][4] (the two-pass point chain hands these over)
 };
+#define DYN_MAX_SAMPLES 256  // samples per ray the point chain is built for (sinusoid table, LDS key blocks of 128)
 #define SB_GIN_LD 132  // per (point, half): 64 mean, 64 var, [mean weight | 1], pad
 
 static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
@@ -321,7 +323,7 @@ static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   w.PT = 32 / (V <= 4 ? 4 : (V <= 8 ? 8 : (V <= 16 ? 16 : 32)));  // points per wave: views are padded to a power-of-two lane segment
   w.n_tiles_a = (w.n_pts + w.PT - 1) / w.PT;
   int tpr = (S + 31) / 32;
-  w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : 4);
+  w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : ((tpr + 3) / 4) * 4);
   w.n_tiles_b = (long)R * w.TPR;
   size_t o = 0;
   w.off_x = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64 * 64;
@@ -330,6 +332,8 @@ static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   w.off_nvalid = o; o += (size_t)((w.n_pts + 3) & ~3L);
   w.off_hg = o; o += dynamic ? 0 : (size_t)w.n_pts * 128;
   w.off_ref = o; o += dynamic ? 64 : (size_t)R * 36;
+  o = (o + 3) & ~(size_t)3;
+  w.off_qkvg = o; o += w.TPR > 4 ? (size_t)w.n_tiles_b * 4 * 4096 : 0;
   w.total = o;
   return w;
 }
@@ -668,7 +672,11 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 
 // DYN = false: DynibarStatic (no positional encoding; outputs sigma and the point part of rgb_fc.0)
 // DYN = true : DynibarDynamic (+ sinusoid positional encoding, ref_pts_fc, rgb_fc on [feature | PE(view dir)]; outputs raw [R,S,4])
-template <bool DYN>
+// PHASE 0: the whole chain in one launch (rays of <= 128 samples: a ray's tiles sit in one workgroup and K / V never leave the chip).
+// Longer rays run it in two launches: PHASE 1 ends after the Q/K/V projections and stores g, q, k, v per tile; PHASE 2 picks them up,
+// streams the ray's keys through LDS in blocks of 128 with a running softmax, and finishes the chain.
+constexpr int SB_CHUNKS_QKV = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 3 * net_layer_chunks(4, 64);
+template <bool DYN, int PHASE>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SB_CT] / [DB_CT]
@@ -678,7 +686,10 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   constexpr int CT = DYN ? DB_CT : SB_CT;
   for (int i = tid; i < CT; i += DYN_NET_THREADS) ctab[i] = p.blob[(DYN ? DY_OFF_CTB : ST_OFF_CTB) + i];
   NetRing ring;
-  net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), DYN ? DB_CHUNKS : SB_CHUNKS, lds);
+  if (PHASE == 2)
+    net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * NET_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds);
+  else
+    net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds);
 
   const int TPR = p.TPR;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -690,8 +701,21 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
   const float nvalid = valid ? p.ws[p.o.off_nvalid + point] : 0.f;
 
+  float4* hand = reinterpret_cast<float4*>(p.ws + p.o.off_qkvg) + (PHASE == 0 ? 0 : tile * 4096) + lane;  // [which][t][q][64 lanes]
   f32x16 g[4];
-  {
+  if (PHASE == 2) {
+    if (ray < p.R) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = hand[(t * 4 + q) * 64];
+          g[t][q * 4] = v.x; g[t][q * 4 + 1] = v.y; g[t][q * 4 + 2] = v.z; g[t][q * 4 + 3] = v.w;
+        }
+    } else {
+      acc_zero(g);
+    }
+  } else {
     f32x16 a9[8];
     {
       float gin[129];
@@ -709,7 +733,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? elu1(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
     acc_elu(g);
   }
-  if (DYN) {
+  if (DYN && PHASE != 2) {
     // globalfeat + pos_encoding (mlp_network.py:284): table rows in D-layout order [position][half][64]
     const float4* pe = reinterpret_cast<const float4*>(p.blob + DY_OFF_POSENC + ((valid ? smp : 0) * 2 + h) * 64);
 #pragma unroll
@@ -722,14 +746,113 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   }
   // ---- multi-head self-attention over the samples of the ray (mlp_network.py:13-31, 56-104) ----
   f32x16 att[4];
-  {
+  const float inv_temp = 1.0f / 5.656854249492381f;  // d_k ** 0.5
+  const bool q_ok = nvalid > 1.0f;                    // mask = (num_valid_obs > 1), applied along the query axis
+  if (PHASE == 2) {
+    // ---- long rays: keys / values of the whole ray come back from the workspace, 128 at a time, under a running softmax ----
+    f32x16 qh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = hand[(16 + t * 4 + q) * 64];
+        qh[t][q * 4] = v.x * inv_temp; qh[t][q * 4 + 1] = v.y * inv_temp; qh[t][q * 4 + 2] = v.z * inv_temp; qh[t][q * 4 + 3] = v.w * inv_temp;
+      }
+    const float4* ray_hand = reinterpret_cast<const float4*>(p.ws + p.o.off_qkvg) + ray * TPR * 4096;  // tile kt of the ray at + kt * 4096
+    const int n_blocks = TPR / 4;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      float run_max = -3.0e38f, run_sum = 0.f;
+      f32x16 oh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oh[r] = 0.f;
+      for (int kb = 0; kb < n_blocks; ++kb) {
+        __syncthreads();  // the previous block's K/V images are no longer read
+        {
+          const float4* kv = ray_hand + (long)(kb * 4 + wave) * 4096 + lane;  // this wave copies key tile kb * 4 + wave
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            reinterpret_cast<float4*>(Kl)[(wave * 4 + q) * 64 + lane] = kv[(32 + hd * 4 + q) * 64];
+            const float4 v = kv[(48 + hd * 4 + q) * 64];
+            Vl[dyn_fi(q * 4 + 0, h) * SB_VL_LD + wave * 32 + j] = v.x;
+            Vl[dyn_fi(q * 4 + 1, h) * SB_VL_LD + wave * 32 + j] = v.y;
+            Vl[dyn_fi(q * 4 + 2, h) * SB_VL_LD + wave * 32 + j] = v.z;
+            Vl[dyn_fi(q * 4 + 3, h) * SB_VL_LD + wave * 32 + j] = v.w;
+          }
+        }
+        __syncthreads();
+        f32x16 sc[4];
+        acc_zero(sc);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 a = reinterpret_cast<const float4*>(Kl)[(kt * 4 + q) * 64 + lane];
+            sc[kt] = mfma32(a.x, qh[hd][q * 4 + 0], sc[kt]);
+            sc[kt] = mfma32(a.y, qh[hd][q * 4 + 1], sc[kt]);
+            sc[kt] = mfma32(a.z, qh[hd][q * 4 + 2], sc[kt]);
+            sc[kt] = mfma32(a.w, qh[hd][q * 4 + 3], sc[kt]);
+          }
+        float mx = run_max;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool key_ok = (kb * 4 + kt) * 32 + dyn_fi(r, h) < p.S;
+            float v = q_ok ? sc[kt][r] : -1e9f;
+            v = key_ok ? v : -3.0e38f;
+            sc[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float rescale = __expf(run_max - mx);  // 0 for the first block
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
+            sc[kt][r] = e;
+            sum += e;
+          }
+        sum += __shfl_xor(sum, 32);
+        run_sum = run_sum * rescale + sum;
+        run_max = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oh[r] *= rescale;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(Vl + j * SB_VL_LD + kt * 32 + 8 * q + 4 * h);
+            oh = mfma32(a.x, sc[kt][q * 4 + 0], oh);
+            oh = mfma32(a.y, sc[kt][q * 4 + 1], oh);
+            oh = mfma32(a.z, sc[kt][q * 4 + 2], oh);
+            oh = mfma32(a.w, sc[kt][q * 4 + 3], oh);
+          }
+      }
+      const float inv = 1.0f / run_sum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) att[hd][r] = oh[r] * inv;
+    }
+  } else {
     f32x16 qh[4], kh[4], vh[4];
     acc_zero(qh); acc_zero(kh); acc_zero(vh);
     net_layer<4, 64>(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
     net_layer<4, 64>(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
     net_layer<4, 64>(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
-    const float inv_temp = 1.0f / 5.656854249492381f;  // d_k ** 0.5
-    const bool q_ok = nvalid > 1.0f;                    // mask = (num_valid_obs > 1), applied along the query axis
+    if (PHASE == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hand[(t * 4 + q) * 64] = make_float4(g[t][q * 4], g[t][q * 4 + 1], g[t][q * 4 + 2], g[t][q * 4 + 3]);
+          hand[(16 + t * 4 + q) * 64] = make_float4(qh[t][q * 4], qh[t][q * 4 + 1], qh[t][q * 4 + 2], qh[t][q * 4 + 3]);
+          hand[(32 + t * 4 + q) * 64] = make_float4(kh[t][q * 4], kh[t][q * 4 + 1], kh[t][q * 4 + 2], kh[t][q * 4 + 3]);
+          hand[(48 + t * 4 + q) * 64] = make_float4(vh[t][q * 4], vh[t][q * 4 + 1], vh[t][q * 4 + 2], vh[t][q * 4 + 3]);
+        }
+      return;
+    }
     const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
@@ -969,7 +1092,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   DYN_REQUIRE(q, "dyn_static_net: null params");
   DYN_REQUIRE(q->R > 0 && q->S > 0 && q->V > 0, "dyn_static_net: empty problem");
   DYN_REQUIRE(q->V <= 32, "dyn_static_net: at most 32 source views");
-  DYN_REQUIRE(q->S <= 128, "dyn_static_net: at most 128 samples per ray (the ray attention keeps one ray's keys in LDS)");
+  DYN_REQUIRE(q->S <= DYN_MAX_SAMPLES, "dyn_static_net: at most %d samples per ray", DYN_MAX_SAMPLES);
   DYN_REQUIRE(q->blob && q->ray_o && q->ray_d && q->pts && q->rgb_feat && q->ray_diff && q->mask && q->centers && q->raw && q->workspace,
               "dyn_static_net: null pointer");
   hipStream_t stream = (hipStream_t)stream_;
@@ -994,7 +1117,12 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk_v, lds_a, stream, a);
-  DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", k_net_points<false>, grid_b, blk, lds_b, stream, a);
+  if (a.TPR <= 4) {
+    DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 0>), grid_b, blk, lds_b, stream, a);
+  } else {
+    DYN_LAUNCH(DYN_K_STATIC_POINTS_QKV, "k_static_points_qkv", (k_net_points<false, 1>), grid_b, blk, lds_b, stream, a);
+    DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 2>), grid_b, blk, lds_b, stream, a);
+  }
   if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_a, blk_v, lds_c, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk_v, lds_c, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk_v, lds_c, stream, a);
@@ -1088,7 +1216,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   for (int c = 0; c < 3; ++c) pack_rowtab(o, T[DT_RGB4_W] + c * 64, 64);
   o.resize(DY_OFF_POSENC, 0.f);
   // sinusoid table (mlp_network.py:218-234), evaluated in double like numpy, stored in D-layout order [pos][half][64]
-  for (int pos = 0; pos < 128; ++pos)
+  for (int pos = 0; pos < DYN_MAX_SAMPLES; ++pos)
     for (int h = 0; h < 2; ++h)
       for (int k = 0; k < 64; ++k) {
         const int f = chain_feature(k, h);
@@ -1175,7 +1303,7 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   DYN_REQUIRE(q, "dyn_dynamic_net: null params");
   DYN_REQUIRE(q->R > 0 && q->S > 0 && q->V > 0, "dyn_dynamic_net: empty problem");
   DYN_REQUIRE(q->V <= 32, "dyn_dynamic_net: at most 32 source views");
-  DYN_REQUIRE(q->S <= 128, "dyn_dynamic_net: at most 128 samples per ray (the ray attention keeps one ray's keys in LDS)");
+  DYN_REQUIRE(q->S <= DYN_MAX_SAMPLES, "dyn_dynamic_net: at most %d samples per ray", DYN_MAX_SAMPLES);
   DYN_REQUIRE(q->blob && q->ray_d && q->pts && q->rgb_feat && q->mask && q->time && q->raw && q->workspace, "dyn_dynamic_net: null pointer");
   hipStream_t stream = (hipStream_t)stream_;
   StaticArgs a;
@@ -1198,7 +1326,12 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk_v, lds_a, stream, a);
-  DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", k_net_points<true>, grid_b, blk, lds_b, stream, a);
+  if (a.TPR <= 4) {
+    DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", (k_net_points<true, 0>), grid_b, blk, lds_b, stream, a);
+  } else {
+    DYN_LAUNCH(DYN_K_DYNAMIC_POINTS_QKV, "k_dynamic_points_qkv", (k_net_points<true, 1>), grid_b, blk, lds_b, stream, a);
+    DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", (k_net_points<true, 2>), grid_b, blk, lds_b, stream, a);
+  }
   return 0;
 }
 

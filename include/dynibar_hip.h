@@ -137,7 +137,7 @@ size_t dyn_static_net_blob_floats(void);
 int dyn_static_net_pack(const float* const* tensors, int F, float* blob, size_t blob_floats);
 size_t dyn_static_net_workspace_bytes(int R, int S, int V);
 typedef struct {
-  int R, S, V;               /* rays, samples per ray (<= 128), source views (<= 32) */
+  int R, S, V;               /* rays, samples per ray (<= 256), source views (<= 32) */
   int anti_alias_pooling;    /* args.anti_alias_pooling (mlp_network.py:462) */
   int mask_rgb;              /* args.mask_rgb (:457) */
   const float* blob;         /* DEVICE copy of the packed weights */
@@ -167,7 +167,7 @@ size_t dyn_dynamic_net_blob_floats(void);
 int dyn_dynamic_net_pack(const float* const* tensors, int F, float* blob, size_t blob_floats);
 size_t dyn_dynamic_net_workspace_bytes(int R, int S, int V);
 typedef struct {
-  int R, S, V;               /* rays, samples per ray (<= 128; must equal the module's n_samples), source views (<= 32) */
+  int R, S, V;               /* rays, samples per ray (<= 256; must equal the module's n_samples), source views (<= 32) */
   float shift;               /* subtracted from sigma (DynibarMono builds its dynamic net with shift = 5, model.py:307) */
   const float* blob;         /* DEVICE copy of the packed weights */
   const float* ray_d;        /* [R,3] (normalised in the kernel, render_ray.py:655) */

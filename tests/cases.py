@@ -25,6 +25,8 @@ def scene_case(name):
       # view counts that exercise the other lane-segment widths of the network kernels (4 and 32 lanes per point)
       'few': dict(seed=5, H=32, W=48, V=3, n_static=4, smooth=True, R=5),
       'many': dict(seed=6, H=32, W=48, V=13, n_static=20, smooth=True, R=3),
+      # BASELINE configs[4] (stress): 16 views in both branches, rendered with 128 + 128 samples
+      'stress': dict(seed=7, H=32, W=48, V=16, n_static=16, smooth=True, R=4),  # not 3 rays: torch.cross without dim (reference quirk)
   }[name]
   R = cfg.pop('R')
   seed = cfg['seed']

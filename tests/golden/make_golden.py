@@ -208,8 +208,31 @@ def image_goldens():
   print('image', {k: v.shape for k, v in out.items()})
 
 
+def stress_goldens():
+  """BASELINE configs[4]: render_rays_mv with 16 views in both branches and 128 coarse + 128 fine samples (fine pass: 256 per ray)."""
+  name, S = 'stress', 128
+  scene, o, d, uv, pix = cases.scene_case(name)
+  args = ref_args()
+  model = build_ref_model(cases.model_weights(0), S, 2 * S, args)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  out = {}
+  with torch.no_grad():
+    ret = RR.render_rays_mv((fidx, None), (temb, None), (toff, None), ray_batch_of(scene, o, d, uv), model, PJ.Projector('cpu'),
+                            (scene['featmaps'], None, scene['static_featmaps']),
+                            (scene['featmaps_fine'], None, scene['static_featmaps_fine']),
+                            S, args, inv_uniform=True, N_importance=S, det=True, is_train=False)
+  flat('mv/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+  np.savez_compressed(os.path.join(HERE, 'stress_mv.npz'), **out)
+  print(name, len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
+  import sys
+  if 'stress' in sys.argv[1:]:
+    stress_goldens()
+    sys.exit(0)
   for n in ('small', 'harsh', 'noise'):
     stage_goldens(n)
+  stress_goldens()
   sampler_goldens()
   image_goldens()

@@ -46,7 +46,7 @@ def test_mlp_engine(dev):
 
 
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64), dict(name='harsh', S=40, aa=False, mask_rgb=True),
-                                dict(name='noise', S=128), dict(name='small', S=32, R=3)])
+                                dict(name='noise', S=128), dict(name='small', S=32, R=3), dict(name='small', S=256, R=6), dict(name='harsh', S=160, R=5)])
 def test_static_net(dev, kw):
   parity.check_static_net(dev, **kw)
 
@@ -56,7 +56,7 @@ def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
 
 
-@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64, shift=5.0), dict(name='noise', S=128), dict(name='small', S=32, R=3)])
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64, shift=5.0), dict(name='noise', S=128), dict(name='small', S=32, R=3), dict(name='small', S=256, R=6), dict(name='harsh', S=160, R=5, shift=2.0)])
 def test_dynamic_net(dev, kw):
   parity.check_dynamic_net(dev, **kw)
 
@@ -77,6 +77,11 @@ def test_ray_sampler(dev, golden_dir):
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_render_rays_mv(dev, golden_dir, name):
   parity.check_render_rays_mv(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
+
+
+def test_render_rays_mv_stress(dev, golden_dir):
+  """BASELINE configs[4]: 16 views in both branches, 128 + 128 samples (the long-ray, two-launch point chain) vs the real reference."""
+  parity.check_render_rays_mv(dev, _golden(golden_dir, 'stress_mv.npz'), 'stress', S=128)
 
 
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])

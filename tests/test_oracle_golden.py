@@ -99,6 +99,19 @@ def test_stages(golden_dir, name):
   assert n == sum(1 for k in g if k.startswith('mono/')), 'oracle mono output key set differs from the reference'
 
 
+def test_stress_mv(golden_dir):
+  """BASELINE configs[4]: the oracle's render_rays_mv at 16 + 16 views, 128 + 128 samples against the real reference's outputs."""
+  g = load(golden_dir, 'stress_mv.npz')
+  scene, o, d, uv, pix = cases.scene_case('stress')
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  W['trajectory_basis_fine'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
+  ret = O.render_rays_mv(W, dict(scene), o, d, uv, fidx, temb, toff, 128, 128, True, True)
+  n = check_group('mv/', {k: v for k, v in ret.items() if isinstance(v, dict)}, g)
+  assert n == sum(1 for k in g if k.startswith('mv/')), 'oracle mv output key set differs from the reference'
+
+
 def test_image_rays(golden_dir):
   g = load(golden_dir, 'sampler.npz')
   scene, *_ = cases.scene_case('small')
