@@ -234,33 +234,41 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #define B6_PAIR_FLOATS (DYN_SPLIT_PARTS * 256)        // parts x 64 lanes x 4 dwords
 #define B6_CHUNK (B6_CHUNK_PAIRS * B6_PAIR_FLOATS)  // floats per chunk (48 KiB)
 
-// developer instrumentation (tools/phasebench.py): cycle stamps of wave 0 of two workgroups at the layer boundaries of the view chain
+// developer instrumentation (tools/phasebench.py): cycle stamps of wave 0 of two workgroups of each network kernel
+// (PHASE_KID 0: view chain, 1: point chain, 2: blend) at layer boundaries, and the cycles waited at every ring acquire
 #ifdef DYN_PHASE_TIMING
-__device__ unsigned long long g_phase[2][64];  // [0..31] layer boundaries, [32..63] cycles waited in the ring acquire of chunk c
+__device__ unsigned long long g_phase[3][2][160];  // [0..31] layer boundaries, [32..95] cycles waited in the ring acquire of chunk c, [96..159] its time
+#define DYN_PHASE_ON (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
 #define DYN_PHASE(i)                                                                                  \
   do {                                                                                                \
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))                         \
-      g_phase[blockIdx.x != 0][i] = __builtin_readcyclecounter();                                     \
+    if (DYN_PHASE_ON) g_phase[PHASE_KID][blockIdx.x != 0][i] = __builtin_readcyclecounter();          \
   } while (0)
 extern "C" int dyn_debug_phases(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 1;
 }
 #define DYN_PHASE_T0 const unsigned long long phase_t0 = __builtin_readcyclecounter();
-#define DYN_PHASE_WAIT(c)                                                                             \
+#define DYN_PHASE_WAIT(R, c)                                                                          \
   do {                                                                                                \
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && (c) < 32)             \
-      g_phase[blockIdx.x != 0][32 + (c)] = __builtin_readcyclecounter() - phase_t0;                   \
+    if (DYN_PHASE_ON && (c) < 64) {                                                                   \
+      g_phase[(R).kid][blockIdx.x != 0][32 + (c)] = __builtin_readcyclecounter() - phase_t0;          \
+      g_phase[(R).kid][blockIdx.x != 0][96 + (c)] = phase_t0;                                         \
+    }                                                                                                 \
   } while (0)
+#define DYN_PHASE_RING_KID(R, k) (R).kid = (k)
 #else
 #define DYN_PHASE(i)
 #define DYN_PHASE_T0
-#define DYN_PHASE_WAIT(c)
+#define DYN_PHASE_WAIT(R, c)
+#define DYN_PHASE_RING_KID(R, k)
 #endif
 
 struct WeightRing6 {
   const float* gsrc;
   float* buf;
   int next, total;
+#ifdef DYN_PHASE_TIMING
+  int kid;
+#endif
 };
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
@@ -278,6 +286,7 @@ __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, 
   R.buf = lds;
   R.next = 0;
   R.total = total;
+  DYN_PHASE_RING_KID(R, 0);
   ring6_issue(R, 0);
 }
 __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
@@ -285,7 +294,7 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   const int c = R.next++;
-  DYN_PHASE_WAIT(c);
+  DYN_PHASE_WAIT(R, c);
   if (c + 1 < R.total) ring6_issue(R, c + 1);
   return R.buf + (c & 1) * B6_CHUNK;
 }

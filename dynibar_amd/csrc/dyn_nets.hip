@@ -315,7 +315,11 @@ struct StaticWs {
   size_t off_qkvg;  // long rays only: per B tile [g | q | k | v][4][4][64 lanes][4] (the two-pass point chain hands these over)
 };
 #define DYN_MAX_SAMPLES 256  // samples per ray the point chain is built for (sinusoid table, LDS key blocks of 128)
-#define SB_GIN_LD 132  // per (point, half): 64 mean, 64 var, [mean weight | 1], pad
+// Per-point records handed between the view kernels and the point kernel are lane-coalesced for the point kernel: record i (a float4)
+// of the point at (ray, sample) sits at [tile = ray * TPR + sample / 32][i][lane = sample % 32 + 32 * half].  (A point-major layout
+// made every wave of the point kernel pull 64 distinct cache lines per load instruction and thrash its L1: 42 k cycles of prologue.)
+#define SB_GIN_RECS 33  // geometry_fc input per (point, half): 16 x mean, 16 x var, then [mean weight | 1], 0, 0, 0
+#define SB_HG_RECS 16   // point part of rgb_fc.0 per (point, half)
 
 static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   StaticWs w;
@@ -328,9 +332,9 @@ static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   size_t o = 0;
   w.off_x = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64 * 64;
   w.off_vis = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64;
-  w.off_gin = o; o += (size_t)w.n_pts * 2 * SB_GIN_LD;
+  w.off_gin = o; o += (size_t)w.n_tiles_b * SB_GIN_RECS * 256;
   w.off_nvalid = o; o += (size_t)((w.n_pts + 3) & ~3L);
-  w.off_hg = o; o += dynamic ? 0 : (size_t)w.n_pts * 128;
+  w.off_hg = o; o += dynamic ? 0 : (size_t)w.n_tiles_b * SB_HG_RECS * 256;
   w.off_ref = o; o += dynamic ? 64 : (size_t)R * 36;
   o = (o + 3) & ~(size_t)3;
   w.off_qkvg = o; o += w.TPR > 4 ? (size_t)w.n_tiles_b * 4 * 4096 : 0;
@@ -409,6 +413,12 @@ struct StaticArgs {
   float* ws;
   StaticWs o;
 };
+// float4 index of record 0 of (point, half) in a [tile][n_rec][64 lanes] buffer (see SB_GIN_RECS); record i is i * 64 further
+__device__ __forceinline__ long point_rec(const StaticArgs& p, long point, int h, int n_rec) {
+  const long ray = point / p.S;
+  const int smp = (int)(point - ray * p.S);
+  return ((ray * p.TPR + (smp >> 5)) * n_rec) * 64 + (smp & 31) + 32 * h;
+}
 
 // -------------------------------------------------------------------------------------------------------------------
 // base_fc.0 of the view chains.  Its input is [mean | var | x]: the weighted mean / variance over the views are per-POINT values,
@@ -423,6 +433,8 @@ struct StaticArgs {
 template <int VSEG, int NX>
 __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], float wgt, int V, int view, int p_local, float* pool,
                                          f32x16 (&a1)[8]) {
+  constexpr int PHASE_KID = 0;
+  (void)PHASE_KID;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
   if (VSEG >= 8) {
@@ -485,6 +497,8 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
 template <int VSEG, bool STORE_X>
 __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
                                            long tile, long point, bool valid, int view, int seg_base) {
+  constexpr int PHASE_KID = 0;
+  (void)PHASE_KID;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int V = p.V;
   f32x16 x[4];
@@ -542,7 +556,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
   const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
   const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
   const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
-  float* gin = p.ws + p.o.off_gin + (valid ? (point * 2 + h) * SB_GIN_LD : 0);
+  float4* gin = reinterpret_cast<float4*>(p.ws + p.o.off_gin) + (valid ? point_rec(p, point, h, SB_GIN_RECS) : 0);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -558,12 +572,12 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
       const int sel = g & (VSEG - 1);  // spread the 32 row groups over the segment's real lanes
       const bool mine = valid && (view == (sel < V ? sel : 0));
       if (mine) {
-        reinterpret_cast<float4*>(gin)[g] = make_float4(m[0], m[1], m[2], m[3]);
-        reinterpret_cast<float4*>(gin + 64)[g] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        gin[g * 64] = make_float4(m[0], m[1], m[2], m[3]);
+        gin[(16 + g) * 64] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       }
     }
   if (valid && view == 0) {
-    gin[128] = h == 0 ? wmean : 1.0f;
+    gin[32 * 64] = make_float4(h == 0 ? wmean : 1.0f, 0.f, 0.f, 0.f);
     if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
   }
 }
@@ -573,6 +587,8 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
 // ===================================================================================================================
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs p) {
+  constexpr int PHASE_KID = 0;
+  (void)PHASE_KID;
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -678,6 +694,9 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 constexpr int SB_CHUNKS_QKV = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 3 * net_layer_chunks(4, 64);
 template <bool DYN, int PHASE>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
+  constexpr int PHASE_KID = 1;
+  (void)PHASE_KID;
+  DYN_PHASE(0);
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SB_CT] / [DB_CT]
   float* Kl = ctab + (DYN ? DB_CT : SB_CT);
@@ -690,6 +709,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * NET_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds);
   else
     net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds);
+  DYN_PHASE_RING_KID(ring, 1);
 
   const int TPR = p.TPR;
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -719,13 +739,13 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     f32x16 a9[8];
     {
       float gin[129];
-      const float4* src = reinterpret_cast<const float4*>(p.ws + p.o.off_gin + (point * 2 + h) * SB_GIN_LD);
+      const float4* src = reinterpret_cast<const float4*>(p.ws + p.o.off_gin) + (tile < p.n_tiles_b ? tile : 0) * SB_GIN_RECS * 64 + lane;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const float4 v = valid ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = valid ? src[i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         gin[i * 4] = v.x; gin[i * 4 + 1] = v.y; gin[i * 4 + 2] = v.z; gin[i * 4 + 3] = v.w;
       }
-      gin[128] = valid ? reinterpret_cast<const float*>(src)[128] : (h == 1 ? 1.0f : 0.f);
+      gin[128] = valid ? src[32 * 64].x : (h == 1 ? 1.0f : 0.f);
       acc_zero(a9);
       net_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
     }
@@ -745,6 +765,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       }
   }
   // ---- multi-head self-attention over the samples of the ray (mlp_network.py:13-31, 56-104) ----
+  DYN_PHASE(1);  // geometry_fc done
   f32x16 att[4];
   const float inv_temp = 1.0f / 5.656854249492381f;  // d_k ** 0.5
   const bool q_ok = nvalid > 1.0f;                    // mask = (num_valid_obs > 1), applied along the query axis
@@ -854,6 +875,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       return;
     }
     const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
+    DYN_PHASE(2);  // Q, K, V projections done
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
       __syncthreads();  // the previous head's K/V images are no longer read
@@ -923,6 +945,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   {
     f32x16 o[4];
     acc_zero(o);
+    DYN_PHASE(3);  // attention heads done
     net_layer<4, 64>(ring, o, [&](int s) { return att[s / 16][s % 16]; });
     // residual + LayerNorm(eps = 1e-6) over the 128 features (64 here, 64 in the other half's lane)
     float s1 = 0.f;
@@ -952,6 +975,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[t][r] = (o[t][r] - mu) * rstd * gam[t * 16 + r] + bet[t * 16 + r];
   }
+  DYN_PHASE(4);  // fc + LayerNorm done
   if (!DYN) {
     f32x16 a[4];
     acc_zero(a);
@@ -963,11 +987,11 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     acc_zero(a);
     net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
     if (valid) {
-      float4* dst = reinterpret_cast<float4*>(p.ws + p.o.off_hg + (point * 2 + h) * 64);
+      float4* dst = reinterpret_cast<float4*>(p.ws + p.o.off_hg) + tile * SB_HG_RECS * 64 + lane;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[t * 4 + q] = make_float4(a[t][q * 4], a[t][q * 4 + 1], a[t][q * 4 + 2], a[t][q * 4 + 3]);
+        for (int q = 0; q < 4; ++q) dst[(t * 4 + q) * 64] = make_float4(a[t][q * 4], a[t][q * 4 + 1], a[t][q * 4 + 2], a[t][q * 4 + 3]);
     }
   } else {
     // ref_pts_fc([globalfeat, PE(pts)])   (mlp_network.py:289-290)
@@ -1021,6 +1045,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     }
     if (valid && h == 0) reinterpret_cast<float4*>(p.raw)[point] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   }
+  DYN_PHASE(20);
 }
 
 // ===================================================================================================================
@@ -1028,12 +1053,16 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 // ===================================================================================================================
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs p) {
+  constexpr int PHASE_KID = 2;
+  (void)PHASE_KID;
+  DYN_PHASE(0);
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SC_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
   NetRing ring;
   net_ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
+  DYN_PHASE_RING_KID(ring, 2);
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -1057,14 +1086,14 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
   {
     f32x16 x[4];
     const float4* xw = reinterpret_cast<const float4*>(p.ws + p.o.off_x) + (tile_ok ? tile : 0) * 16 * 64 + lane;
-    const float4* hg = reinterpret_cast<const float4*>(p.ws + p.o.off_hg + (point * 2 + h) * 64);
+    const float4* hg = reinterpret_cast<const float4*>(p.ws + p.o.off_hg) + (valid ? point_rec(p, point, h, SB_HG_RECS) : 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = tile_ok ? xw[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
-        const float4 b = valid ? hg[t * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = valid ? hg[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
       }
     const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
@@ -1085,6 +1114,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
     const float v = seg_sum<VSEG>(rgb_in[c] * bw, V, seg_base);
     if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
   }
+  DYN_PHASE(20);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -43,15 +43,23 @@ for _ in range(3):
   net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(LIB)
-buf = (ctypes.c_ulonglong * 128)()
+buf = (ctypes.c_ulonglong * (3 * 2 * 160))()
 assert raw.dyn_debug_phases(buf) == 0
-for b in range(2):
-  st = [buf[b * 64 + i] for i in range(32)]
-  waits = [buf[b * 64 + 32 + i] for i in range(32)]
-  print('workgroup', 'first' if b == 0 else 'middle', 'total cycles', st[20] - st[0])
-  prev = st[0]
-  for i in range(1, 21):
-    if i in NAMES and st[i]:
-      print('  %-44s %8d' % (NAMES[i], st[i] - prev))
-      prev = st[i]
-  print('  cycles waited at the ring acquire of each weight chunk (s_waitcnt vmcnt(0) + barrier):', waits, 'sum', sum(waits))
+PNAMES = {1: {0: 'start', 1: 'geometry_fc (2 layers)', 2: 'Q, K, V projections', 3: 'attention (4 heads)', 4: 'fc + LayerNorm', 20: 'out_geometry_fc, rgb point part'},
+          2: {0: 'start', 20: 'whole kernel'}}
+for kid, kname in enumerate(('view chain (k_static_views)', 'point chain (k_net_points)', 'blend (k_static_blend)')):
+  for b in range(2):
+    base = (kid * 2 + b) * 160
+    st = [buf[base + i] for i in range(32)]
+    waits = [buf[base + 32 + i] for i in range(64)]
+    print(kname, '| workgroup', 'first' if b == 0 else 'middle', '| total cycles', st[20] - st[0])
+    names = NAMES if kid == 0 else PNAMES[kid]
+    prev = st[0]
+    for i in range(1, 21):
+      if i in names and st[i]:
+        print('  %-44s %8d' % (names[i], st[i] - prev))
+        prev = st[i]
+    nz = [w for w in waits if w]
+    print('  cycles waited at each ring acquire (s_waitcnt vmcnt(0) + barrier):', nz, 'sum', sum(nz))
+    at = [buf[base + 96 + i] for i in range(64) if buf[base + 96 + i]]
+    print('  cycles between consecutive ring acquires (= per weight chunk):', [at[0] - st[0]] + [at[i + 1] - at[i] for i in range(len(at) - 1)])
