@@ -266,13 +266,14 @@ struct WeightRing6 {
   const float* gsrc;
   float* buf;
   int next, total;
+  int skip_at, skip_n;  // chunks [skip_at, skip_at + skip_n) of the stream are not ring traffic (their user reads them straight from global)
 #ifdef DYN_PHASE_TIMING
   int kid;
 #endif
 };
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
-  const float* g = R.gsrc + (long)chunk * B6_CHUNK;
+  const float* g = R.gsrc + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK;
   float* l = R.buf + (chunk & 1) * B6_CHUNK + (threadIdx.x >> 6) * 256;
   const int round = blockDim.x * 4;  // floats moved by the whole workgroup per instruction
 #pragma unroll
@@ -281,11 +282,13 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round),
                                        (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
 }
-__device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds) {
+__device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds, int skip_at = 1 << 30, int skip_n = 0) {
   R.gsrc = stream + threadIdx.x * 4;
   R.buf = lds;
   R.next = 0;
-  R.total = total;
+  R.total = total - skip_n;
+  R.skip_at = skip_at;
+  R.skip_n = skip_n;
   DYN_PHASE_RING_KID(R, 0);
   ring6_issue(R, 0);
 }
@@ -469,6 +472,40 @@ __device__ __forceinline__ void mlp_layer_b6_tile(WeightRing6& R, int my_tile, f
         }
       }
     }
+  }
+}
+
+// One output tile of an NT-tile layer whose packed chunks the wave reads straight from global memory into registers, no ring and no
+// barriers (the layer's rows are shared by the whole workgroup and every wave needs a different eighth of the weights, so staging
+// them through LDS would cost whole chunks of DMA and barriers for a handful of MFMAs per wave).  b6_tile_prefetch is issued early
+// (its latency hides under whatever follows), b6_tile_apply consumes the registers.
+template <int NSLOTS>
+struct B6TileW {
+  B6A a[(NSLOTS + 7) / 8];
+};
+template <int NT, int NSLOTS>
+__device__ __forceinline__ void b6_tile_prefetch(const float* layer_chunks, int my_tile, B6TileW<NSLOTS>& w) {
+  constexpr int NG = (NSLOTS + 7) / 8;
+  constexpr int GPC = B6_CHUNK_PAIRS / NT;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) w.a[g] = b6_load_a(layer_chunks + (g / GPC) * B6_CHUNK + ((g % GPC) * NT + my_tile) * B6_PAIR_FLOATS, lane);
+}
+template <int NSLOTS, class Feed>
+__device__ __forceinline__ void b6_tile_apply(const B6TileW<NSLOTS>& w, f32x16& acc, Feed&& feed) {
+  constexpr int NG = (NSLOTS + 7) / 8;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    u32x4v bh, bm, bl;
+    b6_split_pairs<NSLOTS, 0, 4>(feed, g, bh, bm, bl);
+#if DYN_SPLIT_TERMS == 6
+    acc = mfma_bf16(w.a[g].lo, bh, acc);
+    acc = mfma_bf16(w.a[g].hi, bl, acc);
+    acc = mfma_bf16(w.a[g].mid, bm, acc);
+#endif
+    acc = mfma_bf16(w.a[g].mid, bh, acc);
+    acc = mfma_bf16(w.a[g].hi, bm, acc);
+    acc = mfma_bf16(w.a[g].hi, bh, acc);
   }
 }
 

@@ -431,8 +431,8 @@ __device__ __forceinline__ long point_rec(const StaticArgs& p, long point, int h
 #define POOL_FLOATS(NX) (2 * (NX) * 2 * 32)
 #define RES_FLOATS (256 * 32)
 template <int VSEG, int NX>
-__device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], float wgt, int V, int view, int p_local, float* pool,
-                                         f32x16 (&a1)[8]) {
+__device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, const float (&xin)[NX], float wgt, int V, int view, int p_local,
+                                         float* pool, f32x16 (&a1)[8]) {
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -442,6 +442,11 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     constexpr int PT = 32 / VSEG;
     float* res = pool + POOL_FLOATS(NX);
     const int col = wave * PT + p_local;
+#if DYN_ENGINE_B6
+    // this wave's output tile of the per-point part: weights straight from the packed stream into registers, in flight during the statistics
+    B6TileW<2 * NX> pw;
+    b6_tile_prefetch<8, 2 * NX>(pooled_w, wave, pw);
+#endif
     // all statistics first, one predicated block of stores after: a branch per feature would split the DPP reductions into
     // basic blocks and keep their lane moves from folding into the adds
     float pm[NX], pvr[NX];
@@ -464,7 +469,11 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float (&xin)[NX], 
     __syncthreads();
     f32x16 accp[1];
     acc_zero(accp);
+#if DYN_ENGINE_B6
+    b6_tile_apply<2 * NX>(pw, accp[0], [&](int s) { return pool[(s * 2 + h) * 32 + j]; });
+#else
     net_layer_tile<8, 2 * NX, 1>(ring, wave, accp, [&](int, int s) { return pool[(s * 2 + h) * 32 + j]; });
+#endif
     DYN_PHASE(7);
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
@@ -595,7 +604,13 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
   NetRing ring;
   DYN_PHASE(0);
+  // the per-point part of base_fc.0 (VSEG >= 8) is read straight from the stream by each wave, not through the ring
+  constexpr int SA_POOLED_AT = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
+#if DYN_ENGINE_B6
+  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, VSEG >= 8 ? net_layer_chunks(8, SA_L3P_STEPS) : 0);
+#else
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
+#endif
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -673,7 +688,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
 
   DYN_PHASE(5);
-  base_fc0<VSEG, SA_NX>(ring, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
+  base_fc0<VSEG, SA_NX>(ring, p.blob + ST_OFF_A + (size_t)SA_POOLED_AT * NET_CHUNK, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
   DYN_PHASE(10);
   views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
   DYN_PHASE(20);
@@ -1304,7 +1319,11 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
+#if DYN_ENGINE_B6
+  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, VSEG >= 8 ? net_layer_chunks(8, DA_L3P_STEPS) : 0);
+#else
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
+#endif
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -1325,7 +1344,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   }
   const float wgt = msk / (seg_sum<VSEG>(msk, V, seg_base) + 1e-8f);
   f32x16 a1[8];
-  base_fc0<VSEG, DA_NX>(ring, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
+  base_fc0<VSEG, DA_NX>(ring, p.blob + DY_OFF_A, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
   views_tail<VSEG, false>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
 }
 
