@@ -2,6 +2,7 @@
 
   python tools/rocpd_summary.py stats <results.db>          # per-kernel calls / total / avg / min / max (what --stats reports)
   python tools/rocpd_summary.py pmc <results.db> [...]      # per-kernel mean of every collected counter
+  python tools/rocpd_summary.py traffic <out.json> <results.db> [...]   # FETCH_SIZE / WRITE_SIZE per launch of the network kernels (bench.py reads it)
 """
 import sqlite3
 import sys
@@ -37,8 +38,26 @@ def pmc(paths):
         print(f'{short(n):70s} {cn:28s} {c:10d} {v:16.1f} {d / 1e3:12.2f}')
 
 
+def traffic(out, paths):
+  import json
+  res = {}
+  for path in paths:
+    cur = sqlite3.connect(path).cursor()
+    for n, cn, c, v in cur.execute('select kernel_name, counter_name, count(*), avg(value) from counters_collection '
+                                   "where counter_name in ('FETCH_SIZE', 'WRITE_SIZE') group by kernel_name, counter_name"):
+      key = n.replace('void ', '').split('<')[0].split('(')[0]
+      res.setdefault(key, {'source': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 2 --cpu-rays 0 --no-x6'})
+      res[key][cn + '_KB'] = v
+      res[key][cn + '_dispatches'] = c
+  with open(out, 'w') as f:
+    json.dump(res, f, indent=1, sort_keys=True)
+  print(json.dumps(res.get('k_static_views'), indent=1))
+
+
 if __name__ == '__main__':
   if sys.argv[1] == 'stats':
     stats(sys.argv[2])
+  elif sys.argv[1] == 'traffic':
+    traffic(sys.argv[2], sys.argv[3:])
   else:
     pmc(sys.argv[2:])
