@@ -7,7 +7,7 @@ may be ``nn.Module``s (optionally ``DataParallel``-wrapped) or plain state dicts
 tiles once and re-packed only when a parameter's version counter changes.
 
 Scope: forward rendering.  The kernels have no backward pass yet, so the tensors returned here carry no
-autograd graph; ``render_rays_mono(is_train=True)``, whose only extra work is the cross-time supervision branch, raises.
+autograd graph (``render_rays_mono(is_train=True)`` returns the cross-time supervision outputs as forward values).
 """
 from __future__ import annotations
 
@@ -231,10 +231,9 @@ def render_rays_mv(frame_idx, time_embedding, time_offset, ray_batch, model, pro
 # ----------------------------------------------------------------------------------------------------------------------
 def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, featmaps, projector, N_samples, args, inv_uniform=False,
                      N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True, num_vv=2):
-  """Reference render_ray.py:870-1277 with is_train=False: outputs_coarse_ref, outputs_coarse_ref_dy, outputs_coarse_st."""
-  if is_train:
-    raise NotImplementedError('render_rays_mono(is_train=True) needs the cross-time supervision branch and autograd; '
-                              'the HIP kernels are forward-only in this release (SURVEY.md section 8f)')
+  """Reference render_ray.py:870-1277: outputs_coarse_ref, outputs_coarse_ref_dy, outputs_coarse_st and, with is_train=True, the
+  cross-time rendering at the anchor frame (outputs_coarse_anchor, outputs_coarse_anchor_dy; :1099-1270) -- forward values only:
+  the returned tensors carry no autograd graph (the backward kernels are SURVEY section 8f)."""
   ref_frame_idx, ref_time_embedding, ref_time_offset = frame_idx[0], time_embedding[0], time_offset[0]
   ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
   pts, z_vals, s_vals = sample_along_camera_ray(ray_o, ray_d, ray_batch['depth_range'], N_samples, inv_uniform, det)
@@ -248,7 +247,68 @@ def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, f
   out['s_vals'] = s_vals
   out['exp_sf'] = exp_sf
   ret = {'outputs_coarse': None, 'outputs_fine': None}
+  if is_train:
+    out_a, out_a_dy = _anchor_pass(model, names, args, projector, ray_batch, featmaps[1], stage, pts, z_vals, out, out_dy, frame_idx,
+                                   time_embedding[1], time_offset[1], num_vv)
+    ret['outputs_coarse_anchor'] = out_a
+    ret['outputs_coarse_anchor_dy'] = out_a_dy
   ret['outputs_coarse_ref'] = out
   ret['outputs_coarse_ref_dy'] = out_dy
   ret['outputs_coarse_st'] = out_st
   return ret
+
+
+def _anchor_pass(model, names, args, projector, ray_batch, featmaps_anchor, stage, pts, z_vals, out_ref, out_ref_dy, frame_idx,
+                 anchor_time_embedding, anchor_time_offset, num_vv):
+  """Cross-time rendering for temporal consistency (render_ray.py:1099-1270): the reference-time samples are moved to the anchor
+  frame along their own trajectories, the motion MLP is evaluated again there, the displaced points are projected into the anchor
+  frame's source views and rendered with the same dynamic net; disocclusion weights compare the two renderings' sample weights."""
+  dev = pts.device
+  R, S = z_vals.shape
+  basis = stage['basis']
+  nf, num_basis = basis.shape[0], basis.shape[1]
+  r, a = int(frame_idx[0]), int(frame_idx[1])
+  if not -3 <= a - r <= 3:
+    raise KeyError(a - r)  # the reference's trajectory dictionary holds offsets -3..3 only (render_ray.py:965-979, :1109-1112)
+  n_last = int(round(S * 0.1))
+  coeff = stage['coeff']
+  # scene flow between consecutive frames around the reference time (:1101-1105): differences of (traj[o] - traj[0]), o = -3..3
+  rel = ops.trajectory_points(coeff, basis, torch.zeros_like(pts), [(r + o) % nf for o in range(-3, 4)], r % nf)
+  sf_seq = rel[1:7] - rel[0:6]
+  pts_anchor = ops.trajectory_points(coeff, basis, pts, [a % nf], r % nf)[0]
+  time_a = anchor_time_embedding.reshape(-1)[:1].to(dev).float()
+  coeff_a = _motion_mlp(model, names['motion'], dev, num_basis)(pts_anchor, time_a, n_last if n_last > 0 else S)
+  rows_a = [(a + int(o)) % nf for o in anchor_time_offset] + [-1] * num_vv
+  pts_seq_a = ops.trajectory_points(coeff_a, basis, pts_anchor, rows_a, a % nf)
+  # the trajectory of the reference-time point and of its anchor-time correspondence at the frames both passes look at (:1147-1168)
+  both = [(i, a + int(o) - r) for i, o in enumerate(anchor_time_offset) if -3 <= a + int(o) - r <= 3]
+  pts_traj_anchor = torch.stack([pts_seq_a[i] for i, _ in both], 0)
+  pts_traj_ref = ops.trajectory_points(coeff, basis, pts, [(r + ro) % nf for _, ro in both], r % nf)
+  views_a = projector.source_views(ray_batch['camera'], ray_batch['anchor_src_rgbs'], ray_batch['anchor_src_cameras'], featmaps_anchor)
+  assert views_a.V == len(rows_a), 'one time offset (or virtual view) per anchor source view'
+  rgb_feat_a, _, mask_a = ops.project_gather(views_a, R, S, pts_st=pts, xyz=pts_seq_a)
+  pm_a = ops.sample_mask(mask_a, 0.0)  # one observation is enough here (:1197-1199)
+  raw_a = _dynamic_net(model, names['dy'], dev)(ray_batch['ray_d'], pts_anchor, rgb_feat_a, mask_a, time_a)
+  out_a = ops.composite(raw_a, z_vals, pm_a, stage['raw_st'], stage['pm_st'])
+  out_a['mask'] = out_a['mask'] > 0
+  out_a = _as_out(out_a, _KEYS2)
+  out_a_dy = _vanilla(raw_a, z_vals, pm_a)
+  occ_dy = out_ref_dy['weights'] - out_a_dy['weights']
+  mode = int(getattr(args, 'occ_weights_mode', 0))
+  if mode == 0:    # mix-mode: composite-dy weights when the anchor is more than one frame away, full weights otherwise
+    key = 'weights_dy' if abs(r - a) > 1 else 'weights'
+  elif mode == 1:  # composite-dy
+    key = 'weights_dy'
+  elif mode == 2:  # full
+    key = 'weights'
+  else:
+    raise NotImplementedError
+  occ = out_ref[key] - out_a[key]
+  out_a['occ_weights'] = 1.0 - occ.abs()
+  out_a['occ_weight_map'] = 1.0 - occ.sum(dim=1).abs()
+  out_a['pts_traj_ref'] = pts_traj_ref
+  out_a['pts_traj_anchor'] = pts_traj_anchor
+  out_a['sf_seq'] = sf_seq
+  out_a_dy['occ_weights'] = 1.0 - occ_dy.abs()
+  out_a_dy['occ_weight_map'] = 1.0 - occ_dy.sum(dim=1).abs()
+  return out_a, out_a_dy

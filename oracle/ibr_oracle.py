@@ -618,7 +618,7 @@ def dual_branch_stage(models, scene, featmaps_dy, featmaps_st, ray_o, ray_d, uv_
   sf_p = torch.sum(out['weights'][..., None] * (traj[sf_offsets[0]] - traj[0]), dim=-2)
   sf_m = torch.sum(out['weights'][..., None] * (traj[sf_offsets[1]] - traj[0]), dim=-2)
   out['exp_sf'] = torch.max(sf_p, sf_m)
-  return out, out_dy, out_st, dict(raw_dy=raw_dy, raw_st=raw_st, coeff=coeff, pts_seq=pts_seq)
+  return out, out_dy, out_st, dict(raw_dy=raw_dy, raw_st=raw_st, coeff=coeff, pts_seq=pts_seq, pm_dy=pm_dy, pm_st=pm_st)
 
 
 def render_rays_mv(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_embedding, time_offset, N_samples,
@@ -655,3 +655,71 @@ def render_rays_mono_eval(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_
                                              'coarse', num_frames, anti_alias_pooling, mask_rgb, num_vv=num_vv,
                                              time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1))
   return {'outputs_coarse_ref': out, 'outputs_coarse_ref_dy': out_dy, 'outputs_coarse_st': out_st}
+
+
+def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_embedding, time_offset, N_samples,
+                           inv_uniform=True, det=True, anti_alias_pooling=True, mask_rgb=False, num_vv=2, occ_weights_mode=0,
+                           t_rand=None):
+  """Monocular path with is_train=True, forward values (render_ray.py:870-1277): the reference-time pass plus the cross-time
+  rendering at the anchor time (:1099-1270).  frame_idx / time_embedding / time_offset are (ref, anchor) pairs; the anchor
+  sources are scene['anchor_src_rgbs'], scene['anchor_src_cameras'], scene['featmaps_anchor']."""
+  ref_idx, anc_idx = frame_idx
+  ref_temb, anc_temb = time_embedding
+  ref_off, anc_off = time_offset
+  num_frames = int(ref_idx / ref_temb)
+  pts, z_vals, s_vals = sample_along_camera_ray(ray_o, ray_d, scene['depth_range'], N_samples, inv_uniform, det, t_rand)
+  out, out_dy, out_st, st = dual_branch_stage(models, scene, scene['featmaps'], scene['static_featmaps'], ray_o, ray_d, uv_grid, pts,
+                                              z_vals, s_vals, ref_idx, ref_temb, ref_off, 'coarse', num_frames, anti_alias_pooling,
+                                              mask_rgb, num_vv=num_vv, time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1))
+  basis = models['trajectory_basis']
+  R, S = pts.shape[:2]
+  n_last = int(round(S * 0.1))
+  traj = trajectory_points(st['coeff'], basis, ref_idx)                      # ref_traj_pts_dict, offsets -3..3 (:965-979)
+  sf_seq = torch.stack([traj[o] - traj[o - 1] for o in (-2, -1, 0, 1, 2, 3)], 0)   # :1101-1105
+  pts_anchor = pts + (traj[anc_idx - ref_idx] - traj[0])                      # :1109-1112
+  t_anc = anc_temb[None, None, :].repeat(R, S, 1).float()
+  coeff_a = motion_mlp(models['motion_mlp'], torch.cat([pts_anchor, t_anc], -1).float())
+  coeff_a[:, -n_last:, :] *= 0.0
+  B = basis.shape[1]
+  cx, cy, cz = coeff_a[..., :B], coeff_a[..., B:2 * B], coeff_a[..., 2 * B:3 * B]
+  traj_a0 = compute_traj_pts(cx, cy, cz, basis[None, None, anc_idx, :])
+  seq, tr_ref, tr_anc = [], [], []
+  for off in anc_off:                                                          # :1147-1168
+    ref_offset = anc_idx + off - ref_idx
+    tp = pts_anchor + (compute_traj_pts(cx, cy, cz, basis[None, None, anc_idx + off, :]) - traj_a0)
+    seq.append(tp)
+    if ref_offset not in traj:
+      continue
+    tr_anc.append(tp)
+    tr_ref.append(pts + traj[ref_offset] - traj[0])
+  for _ in range(num_vv):
+    seq.append(pts_anchor)
+  pts_seq_a = torch.stack(seq, 0)
+  rf_a, rd_a, mk_a = compute_with_motions(pts, pts_seq_a, scene['camera'], scene['anchor_src_rgbs'], scene['anchor_src_cameras'],
+                                          scene['featmaps_anchor'])
+  tdiff = torch.from_numpy(np.array(anc_off))[None, None, :, None].expand(R, S, -1, -1)
+  pm_a = mk_a[..., 0].sum(dim=2) > 0                                           # :1197-1199 (one observation is enough here)
+  ray_dir = F.normalize(ray_d, dim=-1)
+  raw_a = dynamic_net(models['net_coarse_dy'], pts_anchor, rf_a, ray_dir, rd_a, tdiff, mk_a, t_anc)
+  out_a = raw2outputs(raw_a, st['raw_st'], z_vals, pm_a, st['pm_st'])
+  out_a_dy = raw2outputs_vanilla(raw_a, z_vals, pm_a)
+  occ_dy = out_dy['weights'] - out_a_dy['weights']
+  if occ_weights_mode == 0:
+    key = 'weights_dy' if abs(ref_idx - anc_idx) > 1 else 'weights'
+  elif occ_weights_mode == 1:
+    key = 'weights_dy'
+  elif occ_weights_mode == 2:
+    key = 'weights'
+  else:
+    raise NotImplementedError
+  occ = out[key] - out_a[key]
+  out_a['occ_weights'] = 1.0 - occ.abs()
+  out_a['occ_weight_map'] = 1.0 - occ.sum(dim=1).abs()
+  out_a['pts_traj_ref'] = torch.stack(tr_ref, 0)
+  out_a['pts_traj_anchor'] = torch.stack(tr_anc, 0)
+  out_a['sf_seq'] = sf_seq
+  out_a_dy['occ_weights'] = 1.0 - occ_dy.abs()
+  out_a_dy['occ_weight_map'] = 1.0 - occ_dy.sum(dim=1).abs()
+  return {'outputs_coarse_ref': out, 'outputs_coarse_ref_dy': out_dy, 'outputs_coarse_st': out_st,
+          'outputs_coarse_anchor': out_a, 'outputs_coarse_anchor_dy': out_a_dy}
+

@@ -53,6 +53,23 @@ def model_weights(seed=0):
   return m
 
 
+def anchor_case(scene, num_vv=2, anchor_shift=1):
+  """Anchor-time inputs of the monocular training path for a scene_case scene: the anchor frame's source set is the scene's own
+  source set rolled by two views (different images / cameras / feature maps per slot), its time offsets are a different list.
+  Returns (scene with anchor_* entries, (ref, anchor) frame indices, time embeddings, time offsets)."""
+  V = scene['src_rgbs'].shape[1]
+  fidx, temb, toff = time_args(V)
+  toff = toff[:V - num_vv]
+  aidx = fidx + anchor_shift
+  aoff = ([-2, -1, 1, 2, 3, -3, 0] * 3)[:V - num_vv]
+  sc = dict(scene)
+  sc['anchor_src_rgbs'] = torch.roll(scene['src_rgbs'], 2, dims=1).contiguous()
+  sc['anchor_src_cameras'] = torch.roll(scene['src_cameras'], 2, dims=1).contiguous()
+  sc['featmaps_anchor'] = torch.roll(scene['featmaps'], 2, dims=0).contiguous()
+  temb_a = torch.tensor([aidx / float(NUM_FRAMES)], dtype=torch.float32)
+  return sc, (fidx, aidx), (temb, temb_a), (toff, aoff)
+
+
 def time_args(n_views):
   """(frame_idx, time_embedding[1], time_offset list) like eval_nvidia.py:323-329."""
   offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else [((i * 5) % 7) - 3 for i in range(n_views)]

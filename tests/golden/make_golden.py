@@ -226,8 +226,29 @@ def stress_goldens():
   print(name, len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def mono_train_goldens():
+  """render_rays_mono(is_train=True): reference-time pass + cross-time rendering at the anchor (render_ray.py:1099-1270), forward
+  values, for an adjacent anchor (occ mode 0 -> full weights) and an anchor two frames away (-> composite-dy weights)."""
+  out = {}
+  scene, o, d, uv, pix = cases.scene_case('small')
+  model = build_ref_model(cases.model_weights(0), 64, 128, ref_args())
+  for tag, shift, mode in (('adj', 1, 0), ('far', -2, 0), ('mode1', 1, 1)):
+    sc, fi, te, to = cases.anchor_case(scene, 2, shift)
+    rb = ray_batch_of(sc, o, d, uv)
+    rb['anchor_src_rgbs'] = sc['anchor_src_rgbs']; rb['anchor_src_cameras'] = sc['anchor_src_cameras']
+    with torch.no_grad():
+      ret = RR.render_rays_mono(fi, te, to, rb, model, (sc['featmaps'], sc['featmaps_anchor'], sc['static_featmaps']), PJ.Projector('cpu'),
+                                64, ref_args(occ_weights_mode=mode), inv_uniform=True, N_importance=0, det=True, is_train=True, num_vv=2)
+    flat(f'{tag}/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+  np.savez_compressed(os.path.join(HERE, 'mono_train.npz'), **out)
+  print('mono_train', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
   import sys
+  if 'mono_train' in sys.argv[1:]:
+    mono_train_goldens()
+    sys.exit(0)
   if 'stress' in sys.argv[1:]:
     stress_goldens()
     sys.exit(0)

@@ -89,6 +89,12 @@ def test_render_rays_mono(dev, golden_dir, name):
   parity.check_render_rays_mono(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
 
 
+@pytest.mark.parametrize('tag,shift,mode', [('adj', 1, 0), ('far', -2, 0), ('mode1', 1, 1)])
+def test_render_rays_mono_train(dev, golden_dir, tag, shift, mode):
+  """render_rays_mono(is_train=True) forward values incl. the anchor-frame cross-time rendering, vs the real reference."""
+  parity.check_render_rays_mono_train(dev, _golden(golden_dir, 'mono_train.npz'), tag, shift, mode)
+
+
 def test_render_single_image_nvi(dev, golden_dir):
   parity.check_render_image_nvi(dev, _golden(golden_dir, 'image_nvi.npz'))
 

@@ -112,6 +112,19 @@ def test_stress_mv(golden_dir):
   assert n == sum(1 for k in g if k.startswith('mv/')), 'oracle mv output key set differs from the reference'
 
 
+@pytest.mark.parametrize('tag,shift,mode', [('adj', 1, 0), ('far', -2, 0), ('mode1', 1, 1)])
+def test_mono_train(golden_dir, tag, shift, mode):
+  """render_rays_mono(is_train=True) forward values (cross-time rendering at the anchor, render_ray.py:1099-1270)."""
+  g = load(golden_dir, 'mono_train.npz')
+  scene, o, d, uv, pix = cases.scene_case('small')
+  sc, fi, te, to = cases.anchor_case(scene, 2, shift)
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  ret = O.render_rays_mono_train(W, sc, o, d, uv, fi, te, to, 64, True, True, num_vv=2, occ_weights_mode=mode)
+  n = check_group(f'{tag}/', ret, g)
+  assert n == sum(1 for k in g if k.startswith(tag + '/')), 'oracle mono train output key set differs from the reference'
+
+
 def test_image_rays(golden_dir):
   g = load(golden_dir, 'sampler.npz')
   scene, *_ = cases.scene_case('small')
