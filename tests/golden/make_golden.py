@@ -226,6 +226,34 @@ def stress_goldens():
   print(name, len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def image_mono_goldens():
+  """render_single_image_mono on a tiny frame, 3 chunks, 5 time-offset views + 2 virtual views (render_image.py:220-439)."""
+  cfg = dict(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
+  from dynibar_amd import synthetic as syn
+  sc = syn.make_scene(**cfg)
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  data = dict(camera=scene['camera'], rgb_path='x', depth_range=scene['depth_range'], src_rgbs=scene['src_rgbs'],
+              src_cameras=scene['src_cameras'], static_src_rgbs=scene['static_src_rgbs'],
+              static_src_cameras=scene['static_src_cameras'])
+  smp = SR.RaySamplerSingleImage(data, 'cpu')
+  rb = smp.get_all()
+  args = ref_args()
+  model = build_ref_model(cases.model_weights(0), 64, 128, args)
+  fidx, temb, toff = cases.time_args(7)
+  with torch.no_grad():
+    ret = RI.render_single_image_mono((fidx, None), (temb, None), (toff[:5], None), smp, rb, model, PJ.Projector('cpu'), 80, 64, args,
+                                      inv_uniform=True, N_importance=0, det=True,
+                                      featmaps=(scene['featmaps'], None, scene['static_featmaps']), is_train=False, num_vv=2)
+  out = {}
+  for grp, d in ret.items():
+    if isinstance(d, dict):
+      for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+          out[f'{grp}/{k}'] = npy(v)
+  np.savez_compressed(os.path.join(HERE, 'image_mono.npz'), **out)
+  print('image_mono', {k: v.shape for k, v in out.items()})
+
+
 def mono_train_goldens():
   """render_rays_mono(is_train=True): reference-time pass + cross-time rendering at the anchor (render_ray.py:1099-1270), forward
   values, for an adjacent anchor (occ mode 0 -> full weights) and an anchor two frames away (-> composite-dy weights)."""
@@ -246,6 +274,9 @@ def mono_train_goldens():
 
 if __name__ == '__main__':
   import sys
+  if 'image_mono' in sys.argv[1:]:
+    image_mono_goldens()
+    sys.exit(0)
   if 'mono_train' in sys.argv[1:]:
     mono_train_goldens()
     sys.exit(0)

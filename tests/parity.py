@@ -485,6 +485,38 @@ def check_render_image_nvi(device, golden, chunk_size=80):
   return ret
 
 
+def check_render_image_mono(device, golden, chunk_size=80):
+  """render_single_image_mono on a 12x16 frame in 3 chunks (5 time-offset views + 2 virtual views) against the real reference's frame."""
+  import types
+  from dynibar_amd import projection, render_image, sample_ray
+  data, cfeat, _ = image_case(device)
+  smp = sample_ray.RaySamplerSingleImage(data, device)
+  rb = smp.get_all()
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  fidx, temb, toff = cases.time_args(7)
+  ret = render_image.render_single_image_mono((fidx, None), (temb.to(device), None), (toff[:5], None), smp, rb, model, projection.Projector(device),
+                                              chunk_size, 64, args, inv_uniform=True, N_importance=0, det=True, featmaps=cfeat, is_train=False,
+                                              num_vv=2)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_coarse_st', 'outputs_coarse_anchor'):
+    keys_ref = sorted(k[len(grp) + 1:] for k in golden if k.startswith(grp + '/'))
+    assert sorted(ret[grp].keys()) == keys_ref, f'{grp}: keys {sorted(ret[grp].keys())} vs reference {keys_ref}'
+    for k, v in ret[grp].items():
+      ref = torch.from_numpy(golden[f'{grp}/{k}'])
+      assert tuple(v.shape) == tuple(ref.shape), f'{grp}/{k}: shape {tuple(v.shape)} vs reference {tuple(ref.shape)}'
+      assert v.device.type == 'cpu', 'render_single_image_* returns host tensors like the reference'
+      if ref.dtype == torch.bool:
+        assert_bitexact(v, ref, f'{grp}/{k}')
+      else:
+        tol = _group_tol(k, 'small')
+        assert_close(v.float(), ref.float(), tol['atol'], tol['rtol'], f'{grp}/{k}')
+      n += 1
+  assert n == len(golden), 'render_single_image_mono output key set differs from the reference'
+  assert ret['outputs_fine'] is None
+  return ret
+
+
 def check_full_size_properties(device, R=4096, S=64, V=8, N_importance=64):
   """BASELINE configs[1] at its full size (4096 rays x 64 samples x 8 views, 288x512 sources), where the oracle would take minutes:
   size-independent properties + an oracle spot check on a few rays."""
