@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   // the per-point part of base_fc.0 (VSEG >= 8) is read straight from the stream by each wave, not through the ring
   constexpr int SA_POOLED_AT = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
 #if DYN_ENGINE_B6
-  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, VSEG >= 8 ? net_layer_chunks(8, SA_L3P_STEPS) : 0);
+  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, VSEG >= 8 ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
 #endif
@@ -739,9 +739,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   for (int i = tid; i < CT; i += DYN_NET_THREADS) ctab[i] = p.blob[(DYN ? DY_OFF_CTB : ST_OFF_CTB) + i];
   NetRing ring;
   if (PHASE == 2)
-    net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * NET_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds);
+    net_ring_init_t(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * NET_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds, DYN_NET_THREADS);
   else
-    net_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds);
+    net_ring_init_t(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds, DYN_NET_THREADS);
   DYN_PHASE_RING_KID(ring, 1);
 
   const int TPR = p.TPR;
@@ -1094,7 +1094,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SC_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
   NetRing ring;
-  net_ring_init(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds);
+  net_ring_init_t(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds, DYN_VIEW_THREADS);
   DYN_PHASE_RING_KID(ring, 2);
 
   const int V = p.V;
@@ -1338,7 +1338,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
 #if DYN_ENGINE_B6
-  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, VSEG >= 8 ? net_layer_chunks(8, DA_L3P_STEPS) : 0);
+  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, VSEG >= 8 ? net_layer_chunks(8, DA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
 #endif
@@ -1487,7 +1487,7 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   NetRing ring;
-  net_ring_init(ring, blob, MO_CHUNKS, lds);
+  net_ring_init_t(ring, blob, MO_CHUNKS, lds, DYN_NET_THREADS);
   const long point = ((long)blockIdx.x * 4 + wave) * 32 + j;
   const bool valid = point < n_pts;
   float c4[4] = {0.f, 0.f, 0.f, time[0]};
@@ -1571,7 +1571,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 2) k_selftest(const float* __
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   NetRing ring;
-  net_ring_init(ring, stream, 2 * net_layer_chunks(2, 33), lds);
+  net_ring_init_t(ring, stream, 2 * net_layer_chunks(2, 33), lds, DYN_NET_THREADS);
   const int row = (blockIdx.x * 4 + wave) * 32 + j;
   f32x16 in[2];
 #pragma unroll
