@@ -263,7 +263,7 @@ extern "C" int dyn_debug_phases(unsigned long long* out) {
 #endif
 
 struct WeightRing6 {
-  const float* gsrc;
+  const float* gbase;  // the packed stream (uniform)
   float* buf;
   int next, total;
   int skip_at, skip_n;  // chunks [skip_at, skip_at + skip_n) of the stream are not ring traffic (their user reads them straight from global)
@@ -274,20 +274,22 @@ struct WeightRing6 {
 };
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
-  const float* g = R.gsrc + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK;
+  // uniform (scalar) base + zero-extended 32-bit lane offset: the load takes its address as SGPR pair + VGPR offset, no 64-bit vector adds
+  const float* g = R.gbase + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK;
   float* l = R.buf + (chunk & 1) * B6_CHUNK + (threadIdx.x >> 6) * 256;
   const int round = R.round;
+  const unsigned lane_off = threadIdx.x * 4;
 #pragma unroll
   for (int i = 0; i < 12; ++i)
     if (i * round < B6_CHUNK)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round + lane_off),
                                        (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
 }
 // threads: the workgroup size.  Kernels pass their compile-time constant: the piece loop of ring6_issue then unrolls without branches
 // and the implicit blockDim load (a memory round trip, waited for with vmcnt(0)) disappears -- worth 10 % of the view kernel.
 __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds, int skip_at = 1 << 30, int skip_n = 0,
                                            int threads = 0) {
-  R.gsrc = stream + threadIdx.x * 4;
+  R.gbase = stream;
   R.buf = lds;
   R.next = 0;
   R.total = total - skip_n;
