@@ -274,16 +274,25 @@ struct WeightRing6 {
 };
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
-  // uniform (scalar) base + zero-extended 32-bit lane offset: the load takes its address as SGPR pair + VGPR offset, no 64-bit vector adds
-  const float* g = R.gbase + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK;
-  float* l = R.buf + (chunk & 1) * B6_CHUNK + (threadIdx.x >> 6) * 256;
-  const int round = R.round;
-  const unsigned lane_off = threadIdx.x * 4;
+  // Every wave moves one contiguous slice of the chunk (6 KiB at 8 waves, 12 KiB at 4) as 1 KiB pieces.  The instruction's immediate
+  // offset applies to the global and to the LDS address alike and the LDS image is the stream's own layout, so six pieces share one
+  // address pair (vector address + M0) set in the middle of their 6 KiB: offsets -2048 ... +3072 fit the 13-bit field.
+  const int waves = R.round / 256, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per_wave = B6_CHUNK / waves;  // floats
+  const float* g = R.gbase + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK + wave * per_wave + 512 + lane * 4;
+  float* l = R.buf + (chunk & 1) * B6_CHUNK + wave * per_wave + 512;
 #pragma unroll
-  for (int i = 0; i < 12; ++i)
-    if (i * round < B6_CHUNK)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round + lane_off),
-                                       (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
+  for (int grp = 0; grp < 2; ++grp)
+    if (grp * 1536 < per_wave) {
+      const auto* gg = (const __attribute__((address_space(1))) void*)(g + grp * 1536);
+      auto* ll = (__attribute__((address_space(3))) void*)(l + grp * 1536);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, -2048, 0);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, -1024, 0);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds(gg, ll, 16, 3072, 0);
+    }
 }
 // threads: the workgroup size.  Kernels pass their compile-time constant: the piece loop of ring6_issue then unrolls without branches
 // and the implicit blockDim load (a memory round trip, waited for with vmcnt(0)) disappears -- worth 10 % of the view kernel.
