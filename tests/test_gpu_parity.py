@@ -108,6 +108,12 @@ def test_full_size_properties(dev):
   parity.check_full_size_properties(dev)
 
 
+def test_full_size_properties_stress(dev):
+  """BASELINE configs[4] at full chunk size (8192 rays x 256 samples x 16 views: the two-launch long-ray point chain, 16-lane view
+  segments, ~25 GB of workspace): chunk invariance, compositing / resampling invariants, oracle spot check on 48 rays."""
+  parity.check_full_size_properties(dev, R=8192, S=256, V=16, N_importance=64)
+
+
 @pytest.mark.parametrize('name', ['few', 'many'])
 def test_networks_other_segment_widths(dev, name):
   """3 / 4 views (4-lane segments, unpooled base_fc.0) and 13 / 20 views (16- and 32-lane segments)."""
