@@ -158,8 +158,26 @@ __device__ __forceinline__ float seg_reduce(float v, Op op) {
   if (VSEG >= 32) v = op(v, __shfl_xor(v, 16));
   return v;
 }
+// v + (lane i <-> 7 - i)(v): the compiler folds the quad_perm lane moves into v_add_f32_dpp but leaves row_half_mirror as a separate
+// v_mov_b32_dpp; written out, with the two wait states a DPP read of a just-written VGPR needs
+__device__ __forceinline__ float add_half_mirror(float v) {
+#if defined(__AMDGCN__)
+  float r;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+  return r;
+#else
+  return v + dpp_get<DYN_DPP_HALF_MIRROR>(v);
+#endif
+}
 template <int VSEG>
 __device__ __forceinline__ float seg_sum(float v, int, int) {
+  if (VSEG == 8) {  // xor 1, xor 2 (folded by the compiler), then the hand-folded half mirror
+    v = seg_reduce<4>(v, [](float a, float b) {
+#pragma clang fp contract(off)
+      return a + b;
+    });
+    return add_half_mirror(v);
+  }
   // contraction off: "x * w + dpp(x * w)" fused into an fma cannot take the DPP operand, a plain add folds the lane move into v_add_f32_dpp
   return seg_reduce<VSEG>(v, [](float a, float b) {
 #pragma clang fp contract(off)
