@@ -84,9 +84,18 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank):
       continue
     local[k] = torch.cat(parts, dim=1 if parts[0].dim() == 3 else 0)
   full = gather_ray_outputs(local, n_rays, dist, world, rank)
+  # to the host like the reference (.cpu() per tensor, render_image.py:113-118), but as one batch of asynchronous copies into pinned
+  # memory and a single synchronisation: the per-sample arrays of a 288x512 frame are ~1 GB, 0.1 s of pageable copies one by one
+  host = OrderedDict()
+  try:
+    for k, t in full.items():
+      host[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) if t.is_cuda else t
+    if any(t.is_cuda for t in full.values()):
+      torch.cuda.current_stream().synchronize()
+  except RuntimeError:  # no pinned memory to be had: plain synchronous copies
+    host = OrderedDict((k, t.cpu()) for k, t in full.items())
   ret = OrderedDict()
-  for k, t in full.items():
-    t = t.cpu()
+  for k, t in host.items():
     if t.dim() == 3:
       ret[k] = t.reshape((t.shape[0], Hs, Ws, -1)).squeeze()
     else:
