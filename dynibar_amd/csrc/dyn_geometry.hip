@@ -267,6 +267,18 @@ extern "C" int dyn_points_from_z(const float* ray_o, const float* ray_d, const f
 #ifndef PG_STAGE
 #define PG_STAGE 1  /* assemble each wave's 64 output rows in LDS and store them as aligned, fully coalesced dwordx4 */
 #endif
+#ifdef DYN_PHASE_TIMING  /* developer instrumentation: cycle stamps of one wave of two workgroups (tools/phasebench.py) */
+__device__ unsigned long long g_pg_phase[2][8];
+#define PG_PHASE(i)                                                                                          \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && (blockIdx.x == 8 || blockIdx.x == gridDim.x / 2)) g_pg_phase[blockIdx.x != 8][i] = __builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int dyn_debug_pg_phases(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pg_phase), sizeof(g_pg_phase)) == hipSuccess ? 0 : 1;
+}
+#else
+#define PG_PHASE(i)
+#endif
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
@@ -345,10 +357,12 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #else
   if (local >= q.tasks_per_xcd || task >= q.ntask) return;  // whole wave leaves; no barriers below
 #endif
+  PG_PHASE(0);
   const long g0 = task * 64;
   const bool has = g0 + lane < q.N;
   const unsigned g = (unsigned)(has ? g0 + lane : q.N - 1);  // idle lanes shadow the last row (loads stay in bounds, stores are skipped)
 
+  PG_PHASE(1);
   // ---- phase 1 ----
   const unsigned rs = fast_div(g, (unsigned)q.V, q.mV);
   const int v = (int)(g - rs * q.V);
@@ -411,6 +425,7 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #endif
     }
   }
+  PG_PHASE(2);
   // feature-tap descriptors of this row as float4-element offsets into feat4 (one 128-byte line = F4 elements)
   const int F4 = q.F >> 2;
   const int vbase = v * q.Hf * q.Wf;
@@ -451,6 +466,7 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #endif
     }
   }
+  PG_PHASE(3);
 #if PG_STAGE
   __syncthreads();  // the wave's LDS writes are complete and visible (one barrier per workgroup; waves only share the barrier)
   {
@@ -463,6 +479,10 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
     for (int i = (nflt & ~3) + lane; i < nflt; i += 64) dst[i] = tile[i];
   }
 #endif
+#ifdef DYN_PHASE_TIMING
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left
+#endif
+  PG_PHASE(4);
 }
 
 extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {

@@ -21,7 +21,8 @@ if '--build' in sys.argv:
   hipcc = '/opt/rocm/bin/hipcc'
   common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
   subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG)])
-  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry.o'), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), '-o', LIB])
+  subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING', '-ffp-contract=off'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_geometry.hip'), '-o', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG)])
+  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), '-o', LIB])
   sys.exit(0)
 
 os.environ['DYNIBAR_HIP_LIB'] = LIB
@@ -43,6 +44,11 @@ for _ in range(3):
   net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(LIB)
+pg = (ctypes.c_ulonglong * 16)()
+if raw.dyn_debug_pg_phases(pg) == 0:
+  for b in range(2):
+    st = [pg[b * 8 + i] for i in range(5)]
+    print('project_gather | workgroup', 'early' if b == 0 else 'middle', '| one wave, cycles: setup %d, projection + RGB taps + ray_diff %d, feature taps %d, LDS -> global stores %d, total %d' % (st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[4] - st[0]))
 buf = (ctypes.c_ulonglong * (3 * 2 * 160))()
 assert raw.dyn_debug_phases(buf) == 0
 PNAMES = {1: {0: 'start', 1: 'geometry_fc (2 layers)', 2: 'Q, K, V projections', 3: 'attention (4 heads)', 4: 'fc + LayerNorm', 20: 'out_geometry_fc, rgb point part'},
