@@ -35,3 +35,41 @@ __device__ __forceinline__ float wave_inclusive_prod(float v, int lane) {
   }
   return v;
 }
+
+// Streaming accesses: data written once for a later kernel, or read exactly once, can go around the 4 MiB L2 slices (non-temporal) so
+// that the re-read working set (source maps, the packed weight stream) stays resident.
+typedef float dyn_f32x4 __attribute__((ext_vector_type(4)));
+// Measured inside the bench pipeline (two runs each): the view kernel's stores of the parked feature / point records and the point
+// kernel's loads of those records: view kernel -1 %, point kernel -6 %.  NOT the gather's outputs (its consumer starts right after it
+// and finds part of them in the 256 MB Infinity Cache: gather alone 131 -> 98 us, but in the pipeline 121 -> 129 us), not the view
+// kernel's gathered inputs (+6 %), not the blend kernel's loads of the parked feature (+2 %).
+#ifndef DYN_NT
+#define DYN_NT 4  /* bit 0: gather outputs, bit 1: view kernel's gathered inputs, bit 2: parked features / point records, bit 3: blend loads */
+#endif
+template <int GROUP>
+__device__ __forceinline__ void nt_store4(float4* p, float4 v) {
+  if (DYN_NT & GROUP) {
+    const dyn_f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<dyn_f32x4*>(p));
+  } else {
+    *p = v;
+  }
+}
+template <int GROUP>
+__device__ __forceinline__ void nt_store1(float* p, float v) {
+  if (DYN_NT & GROUP) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int GROUP>
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  if (DYN_NT & GROUP) {
+    const dyn_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const dyn_f32x4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return *p;
+}
+template <int GROUP>
+__device__ __forceinline__ float nt_load1(const float* p) {
+  return (DYN_NT & GROUP) ? __builtin_nontemporal_load(p) : *p;
+}
+

@@ -412,8 +412,8 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
     normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
     normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
     if (has) {
-      ray_diff[g] = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
-      mask[g] = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
+      nt_store4<1>(ray_diff + g, make_float4(dx, dy, dz, ax * bx + ay * by + az * bz));
+      nt_store1<1>(mask + g, (inb && (hz > 0.f)) ? 1.0f : 0.0f);
       f32x3u o3;
       o3.x = fmaf(d.x, t.w_se, fmaf(c.x, t.w_sw, fmaf(b.x, t.w_ne, a.x * t.w_nw)));
       o3.y = fmaf(d.y, t.w_se, fmaf(c.y, t.w_sw, fmaf(b.y, t.w_ne, a.y * t.w_nw)));
@@ -475,8 +475,9 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
     float* dst = rgb_feat + g0 * C;  // g0 * C * 4 bytes = task * 64 * C * 4: 16-byte aligned for any C
     const float4* src4 = reinterpret_cast<const float4*>(tile);
     float4* dst4 = reinterpret_cast<float4*>(dst);
-    for (int i = lane; i < (nflt >> 2); i += 64) dst4[i] = src4[i];
-    for (int i = (nflt & ~3) + lane; i < nflt; i += 64) dst[i] = tile[i];
+    // streaming output, never read again by this kernel: non-temporal stores keep the 4 MiB L2 slices for the source maps
+    for (int i = lane; i < (nflt >> 2); i += 64) nt_store4<1>(dst4 + i, src4[i]);
+    for (int i = (nflt & ~3) + lane; i < nflt; i += 64) nt_store1<1>(dst + i, tile[i]);
   }
 #endif
 #ifdef DYN_PHASE_TIMING

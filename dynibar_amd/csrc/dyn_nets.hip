@@ -576,8 +576,8 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xw[(t * 4 + q) * 64] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
-    p.ws[p.o.off_vis + tile * 64 + lane] = vis2;
+      for (int q = 0; q < 4; ++q) nt_store4<4>(xw + (t * 4 + q) * 64, make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]));
+    nt_store1<4>(p.ws + p.o.off_vis + tile * 64 + lane, vis2);
   }
   DYN_PHASE(18);
   const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
@@ -599,8 +599,8 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
       const int sel = g & (VSEG - 1);  // spread the 32 row groups over the segment's real lanes
       const bool mine = valid && (view == (sel < V ? sel : 0));
       if (mine) {
-        gin[g * 64] = make_float4(m[0], m[1], m[2], m[3]);
-        gin[(16 + g) * 64] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        nt_store4<4>(gin + g * 64, make_float4(m[0], m[1], m[2], m[3]));
+        nt_store4<4>(gin + (16 + g) * 64, make_float4(vv[0], vv[1], vv[2], vv[3]));
       }
     }
   if (valid && view == 0) {
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 #pragma unroll
         for (int q = 0; q < 18; ++q) {
           const int ch = h == 0 ? q : 18 + q;
-          xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] : 0.f;
+          xin[q] = (valid && ch < 35) ? nt_load1<2>(p.rgb_feat + pv * 35 + ch) : 0.f;
         }
       }
       return elu1(a1[s / 16][s % 16]);  // ELU of ray_dir_fc.0 where it is consumed
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       const float4* src = reinterpret_cast<const float4*>(p.ws + p.o.off_gin) + (tile < p.n_tiles_b ? tile : 0) * SB_GIN_RECS * 64 + lane;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const float4 v = valid ? src[i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = valid ? nt_load4<4>(src + i * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
         gin[i * 4] = v.x; gin[i * 4 + 1] = v.y; gin[i * 4 + 2] = v.z; gin[i * 4 + 3] = v.w;
       }
       gin[128] = valid ? src[32 * 64].x : (h == 1 ? 1.0f : 0.f);
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = tile_ok ? xw[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = tile_ok ? nt_load4<8>(xw + (t * 4 + q) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
         x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
         const float4 b = valid ? hg[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
@@ -1358,7 +1358,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
 #pragma unroll
   for (int q = 0; q < DA_NX; ++q) {
     const int ch = h == 0 ? q : 18 + q;
-    xin[q] = (valid && ch < 35) ? p.rgb_feat[pv * 35 + ch] + tf[ch] : 0.f;
+    xin[q] = (valid && ch < 35) ? nt_load1<2>(p.rgb_feat + pv * 35 + ch) + tf[ch] : 0.f;
   }
   const float wgt = msk / (seg_sum<VSEG>(msk, V, seg_base) + 1e-8f);
   f32x16 a1[8];
