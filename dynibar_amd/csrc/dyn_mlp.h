@@ -286,6 +286,8 @@ struct WeightRing6 {
   int next, total;
   int skip_at, skip_n;  // chunks [skip_at, skip_at + skip_n) of the stream are not ring traffic (their user reads them straight from global)
   int round;            // floats moved by the whole workgroup per DMA instruction (threads * 4)
+  int nbuf;             // 2: double buffer (chunk c + 1 streams in under chunk c); 1: one 48 KiB buffer (several small workgroups per CU
+                        // hide each other's exposed DMA instead)
 #ifdef DYN_PHASE_TIMING
   int kid;
 #endif
@@ -298,7 +300,7 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
   const int waves = R.round / 256, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per_wave = B6_CHUNK / waves;  // floats
   const float* g = R.gbase + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK + wave * per_wave + 512 + lane * 4;
-  float* l = R.buf + (chunk & 1) * B6_CHUNK + wave * per_wave + 512;
+  float* l = R.buf + (R.nbuf == 2 ? (chunk & 1) : 0) * B6_CHUNK + wave * per_wave + 512;
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp)
     if (grp * 1536 < per_wave) {
@@ -315,7 +317,7 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
 // threads: the workgroup size.  Kernels pass their compile-time constant: the piece loop of ring6_issue then unrolls without branches
 // and the implicit blockDim load (a memory round trip, waited for with vmcnt(0)) disappears -- worth 10 % of the view kernel.
 __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, int total, float* lds, int skip_at = 1 << 30, int skip_n = 0,
-                                           int threads = 0) {
+                                           int threads = 0, int nbuf = 2) {
   R.gbase = stream;
   R.buf = lds;
   R.next = 0;
@@ -323,11 +325,24 @@ __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, 
   R.skip_at = skip_at;
   R.skip_n = skip_n;
   R.round = (threads > 0 ? threads : (int)blockDim.x) * 4;
+  R.nbuf = nbuf;
   DYN_PHASE_RING_KID(R, 0);
   ring6_issue(R, 0);
 }
 __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   DYN_PHASE_T0
+  if (R.nbuf == 1) {
+    // single buffer: chunk c can only be fetched once every wave has left chunk c - 1 (chunk 0 was issued by ring6_init)
+    const int c = R.next++;
+    if (c > 0) {
+      __syncthreads();
+      ring6_issue(R, c);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    DYN_PHASE_WAIT(R, c);
+    return R.buf;
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   const int c = R.next++;
@@ -578,6 +593,7 @@ typedef WeightRing6 NetRing;
 #define NET_CHUNK B6_CHUNK
 #define net_ring_init ring6_init
 #define net_ring_init_t(R, stream, total, lds, threads) ring6_init(R, stream, total, lds, 1 << 30, 0, threads)
+#define net_ring_init_1(R, stream, total, lds, threads) ring6_init(R, stream, total, lds, 1 << 30, 0, threads, 1)
 #define net_layer mlp_layer_b6
 #define net_layer_tile mlp_layer_b6_tile
 __host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return b6_layer_chunks(NT, NSLOTS); }
@@ -586,6 +602,7 @@ typedef WeightRing NetRing;
 #define NET_CHUNK DYN_CHUNK
 #define net_ring_init ring_init
 #define net_ring_init_t(R, stream, total, lds, threads) ring_init(R, stream, total, lds)
+#define net_ring_init_1(R, stream, total, lds, threads) ring_init(R, stream, total, lds)
 #define net_layer mlp_layer
 #define net_layer_tile mlp_layer_tile
 __host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return dyn_layer_chunks(NT, NSLOTS); }

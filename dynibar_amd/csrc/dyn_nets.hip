@@ -1084,21 +1084,26 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 // ===================================================================================================================
 // C: rgb_fc over [globalfeat | x | vis | ray_diff], masked softmax over the views, colour blend
 // ===================================================================================================================
+// The blend kernel is a stream over the parked features (512 B per row) with a short MFMA chain per row.  A CU streams at ~10 B/cycle
+// and a load stalls its wave once the memory queue is full, so a workgroup's loads and layers do not overlap by themselves.  Small
+// workgroups (4 waves) with a single 48 KiB weight buffer fit three to a CU (LDS 146 KiB, 168 registers): independent barriers, so
+// one workgroup's loads run under another's layers, and the exposed DMA of the single buffer hides the same way.
+#define DYN_BLEND_THREADS 256
 template <int VSEG>
-__global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_blend(StaticArgs p) {
+__global__ void __launch_bounds__(DYN_BLEND_THREADS, 3) k_static_blend(StaticArgs p) {
   constexpr int PHASE_KID = 2;
   (void)PHASE_KID;
   DYN_PHASE(0);
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * NET_CHUNK;  // [SC_CT]
+  float* ctab = lds + NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  for (int i = tid; i < SC_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
+  for (int i = tid; i < SC_CT; i += DYN_BLEND_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
   NetRing ring;
-  net_ring_init_t(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds, DYN_VIEW_THREADS);
+  net_ring_init_1(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds, DYN_BLEND_THREADS);
   DYN_PHASE_RING_KID(ring, 2);
 
   const int V = p.V;
-  const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
+  const long tile = (long)blockIdx.x * (DYN_BLEND_THREADS / 64) + wave;
   const bool tile_ok = tile < p.n_tiles_a;
   // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
   const int p_local = j / VSEG;
@@ -1175,7 +1180,8 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  const size_t lds_c = (2 * NET_CHUNK + SC_CT) * sizeof(float);
+  const size_t lds_c = (NET_CHUNK + SC_CT) * sizeof(float);
+  const dim3 grid_c(dyn_cdiv(a.n_tiles_a, DYN_BLEND_THREADS / 64)), blk_c(DYN_BLEND_THREADS);
   if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);
@@ -1186,10 +1192,10 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
     DYN_LAUNCH(DYN_K_STATIC_POINTS_QKV, "k_static_points_qkv", (k_net_points<false, 1>), grid_b, blk, lds_b, stream, a);
     DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 2>), grid_b, blk, lds_b, stream, a);
   }
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_a, blk_v, lds_c, stream, a);
-  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_a, blk_v, lds_c, stream, a);
-  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_a, blk_v, lds_c, stream, a);
-  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_a, blk_v, lds_c, stream, a);
+  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_c, blk_c, lds_c, stream, a);
+  else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_c, blk_c, lds_c, stream, a);
+  else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_c, blk_c, lds_c, stream, a);
+  else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_c, blk_c, lds_c, stream, a);
   return 0;
 }
 
