@@ -76,11 +76,13 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank):
   """list of per-chunk output dicts -> full-frame dict, reshaped like render_image.py:137-188 and moved to the host."""
   keys = list(per_chunk[0].keys()) if per_chunk else []
   local = OrderedDict()
+  lists4 = OrderedDict()
   for k in keys:
     parts = [c[k] for c in per_chunk]
     if parts[0] is None or k == 'random_sigma':
       continue
     if parts[0].dim() == 4:
+      lists4[k] = [t.cpu() for t in parts]  # the reference leaves 4-D entries as its per-chunk list of host tensors (render_image.py:368-369)
       continue
     local[k] = torch.cat(parts, dim=1 if parts[0].dim() == 3 else 0)
   full = gather_ray_outputs(local, n_rays, dist, world, rank)
@@ -95,6 +97,9 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank):
   except RuntimeError:  # no pinned memory to be had: plain synchronous copies
     host = OrderedDict((k, t.cpu()) for k, t in full.items())
   ret = OrderedDict()
+  for k in keys:  # the reference's key order
+    if k in lists4:
+      ret[k] = lists4[k]
   for k, t in host.items():
     if t.dim() == 3:
       ret[k] = t.reshape((t.shape[0], Hs, Ws, -1)).squeeze()

@@ -254,6 +254,36 @@ def image_mono_goldens():
   print('image_mono', {k: v.shape for k, v in out.items()})
 
 
+def image_mono_train_goldens():
+  """render_single_image_mono(is_train=True) on the tiny frame: adds the anchor group (render_image.py:333-336, 412-437)."""
+  cfg = dict(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
+  from dynibar_amd import synthetic as syn
+  sc = syn.make_scene(**cfg)
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  scn, fi, te, to = cases.anchor_case(scene, 2, 1)
+  data = dict(camera=scn['camera'], rgb_path='x', depth_range=scn['depth_range'], src_rgbs=scn['src_rgbs'],
+              src_cameras=scn['src_cameras'], static_src_rgbs=scn['static_src_rgbs'], static_src_cameras=scn['static_src_cameras'],
+              anchor_src_rgbs=scn['anchor_src_rgbs'], anchor_src_cameras=scn['anchor_src_cameras'])
+  smp = SR.RaySamplerSingleImage(data, 'cpu')
+  rb = smp.get_all()
+  args = ref_args()
+  model = build_ref_model(cases.model_weights(0), 64, 128, args)
+  with torch.no_grad():
+    ret = RI.render_single_image_mono(fi, te, to, smp, rb, model, PJ.Projector('cpu'), 80, 64, args, inv_uniform=True, N_importance=0, det=True,
+                                      featmaps=(scn['featmaps'], scn['featmaps_anchor'], scn['static_featmaps']), is_train=True, num_vv=2)
+  out = {}
+  for grp, d in ret.items():
+    if isinstance(d, dict):
+      for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+          out[f'{grp}/{k}'] = npy(v)
+        elif isinstance(v, list):
+          for i, t in enumerate(v):
+            out[f'{grp}/{k}#{i}'] = npy(t)
+  np.savez_compressed(os.path.join(HERE, 'image_mono_train.npz'), **out)
+  print('image_mono_train', len(out), 'arrays')
+
+
 def mono_train_goldens():
   """render_rays_mono(is_train=True): reference-time pass + cross-time rendering at the anchor (render_ray.py:1099-1270), forward
   values, for an adjacent anchor (occ mode 0 -> full weights) and an anchor two frames away (-> composite-dy weights)."""
@@ -274,6 +304,9 @@ def mono_train_goldens():
 
 if __name__ == '__main__':
   import sys
+  if 'image_mono_train' in sys.argv[1:]:
+    image_mono_train_goldens()
+    sys.exit(0)
   if 'image_mono' in sys.argv[1:]:
     image_mono_goldens()
     sys.exit(0)

@@ -517,6 +517,45 @@ def check_render_image_mono(device, golden, chunk_size=80):
   return ret
 
 
+def check_render_image_mono_train(device, golden, chunk_size=80):
+  """render_single_image_mono(is_train=True): the anchor group is assembled too; 4-D entries stay per-chunk lists like the reference's."""
+  import types
+  from dynibar_amd import projection, render_image, sample_ray, synthetic as syn
+  sc = syn.make_scene(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  scn, fi, te, to = cases.anchor_case(scene, 2, 1)
+  data = dict(camera=scn['camera'], rgb_path='x', depth_range=scn['depth_range'], src_rgbs=scn['src_rgbs'], src_cameras=scn['src_cameras'],
+              static_src_rgbs=scn['static_src_rgbs'], static_src_cameras=scn['static_src_cameras'],
+              anchor_src_rgbs=scn['anchor_src_rgbs'], anchor_src_cameras=scn['anchor_src_cameras'])
+  smp = sample_ray.RaySamplerSingleImage(data, device)
+  rb = smp.get_all()
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
+  feat = (scn['featmaps'].to(device), scn['featmaps_anchor'].to(device), scn['static_featmaps'].to(device))
+  ret = render_image.render_single_image_mono(fi, (te[0].to(device), te[1].to(device)), to, smp, rb, model, projection.Projector(device), chunk_size,
+                                              64, args, inv_uniform=True, N_importance=0, det=True, featmaps=feat, is_train=True, num_vv=2)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_coarse_st', 'outputs_coarse_anchor'):
+    keys_ref = sorted({k[len(grp) + 1:].split('#')[0] for k in golden if k.startswith(grp + '/')})
+    assert sorted(ret[grp].keys()) == keys_ref, f'{grp}: keys {sorted(ret[grp].keys())} vs reference {keys_ref}'
+    for k, v in ret[grp].items():
+      parts = v if isinstance(v, list) else [v]
+      names = [f'{grp}/{k}#{i}' for i in range(len(parts))] if isinstance(v, list) else [f'{grp}/{k}']
+      assert all(nm in golden for nm in names) and (not isinstance(v, list) or f'{grp}/{k}#{len(parts)}' not in golden), f'{grp}/{k}: chunk list length'
+      for nm, t in zip(names, parts):
+        ref = torch.from_numpy(golden[nm])
+        assert tuple(t.shape) == tuple(ref.shape), f'{nm}: shape {tuple(t.shape)} vs reference {tuple(ref.shape)}'
+        assert t.device.type == 'cpu'
+        if ref.dtype == torch.bool:
+          assert_bitexact(t, ref, nm)
+        else:
+          tol = _group_tol(k, 'small')
+          assert_close(t.float(), ref.float(), tol['atol'], tol['rtol'], nm)
+        n += 1
+  assert n == len(golden), 'render_single_image_mono(is_train=True) output set differs from the reference'
+  return n
+
+
 def check_full_size_properties(device, R=4096, S=64, V=8, N_importance=64):
   """BASELINE configs[1] at its full size (4096 rays x 64 samples x 8 views, 288x512 sources), where the oracle would take minutes:
   size-independent properties + an oracle spot check on a few rays."""

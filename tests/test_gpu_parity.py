@@ -103,6 +103,10 @@ def test_render_single_image_mono(dev, golden_dir):
   parity.check_render_image_mono(dev, _golden(golden_dir, 'image_mono.npz'))
 
 
+def test_render_single_image_mono_train(dev, golden_dir):
+  parity.check_render_image_mono_train(dev, _golden(golden_dir, 'image_mono_train.npz'))
+
+
 def test_full_size_properties(dev):
   """BASELINE configs[1] at full size: chunk invariance (bit-exact), compositing / resampling invariants, oracle spot check."""
   parity.check_full_size_properties(dev)
