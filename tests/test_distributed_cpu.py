@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def fake_render(chunk):
-  """A per-ray function with the output structure of render_rays_mv: 1-D, 2-D, bool, [V,R,2] and 4-D (dropped) tensors."""
+  """A per-ray function with the output structure of render_rays_mv: 1-D, 2-D, bool, [V,R,2] and 4-D (kept as per-chunk lists) tensors."""
   o = chunk['ray_o']
   R = o.shape[0]
   s = torch.arange(5, dtype=torch.float32)[None, :]
@@ -45,7 +45,7 @@ def worker(rank, world, port, n_rays, chunk_size, q):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     out, seen = run_frame(n_rays, chunk_size)
-    q.put((rank, {g: {k: v.clone() for k, v in d.items()} for g, d in out.items()}, seen))
+    q.put((rank, {g: {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in d.items()} for g, d in out.items()}, seen))
   finally:
     dist.destroy_process_group()
 
@@ -78,8 +78,15 @@ def test_two_rank_frame_equals_single_process(n_rays, chunk):
     for grp in ref:
       assert list(out[grp].keys()) == list(ref[grp].keys())
       for k in ref[grp]:
+        if isinstance(ref[grp][k], list):
+          # 4-D entries stay per-chunk lists (as the reference leaves them); under tiling a rank holds the chunks of its own tile
+          assert isinstance(out[grp][k], list) and all(t.dim() == 4 for t in out[grp][k])
+          continue
         assert torch.equal(out[grp][k], ref[grp][k]), f'rank {rank} {grp}/{k} differs from the single-process frame'
-      assert 'dropme' not in out[grp]
+  assert isinstance(ref['outputs_coarse_ref']['dropme'], list), '4-D entries are kept as per-chunk lists, never assembled'
+  for grp in ('outputs_coarse_ref',):  # the two ranks' chunk lists together are the single-process list
+    both = [t for rank, out, _ in sorted(got, key=lambda g: g[0]) for t in out[grp]['dropme']]
+    assert torch.equal(torch.cat(both, dim=1), torch.cat(ref[grp]['dropme'], dim=1))
   # masked pixels are blanked after the gather, like render_image.py:186-188
   m = ref['outputs_coarse_ref']['mask']
   assert bool((ref['outputs_coarse_ref']['rgb'][m == 0] == 0).all())
