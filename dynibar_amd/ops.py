@@ -175,9 +175,44 @@ def _host_f32(t):
   return np.ascontiguousarray(t, dtype=np.float32)
 
 
-def _pack(fn_pack, fn_size, names, state_dict, F):
+def _expected_shapes(kind, F=32, num_basis=6):
+  """{state-dict key: shape} of the reference module the C packers are written for (they index with these strides and check nothing):
+  DynibarStatic / DynibarDynamic with input_dir=True and in_feat_ch=F (mlp_network.py:319-421, :129-215), MotionMLP (:558-603)."""
+  from . import synthetic
+  table = {'static': synthetic.static_layer_table, 'dynamic': synthetic.dynamic_layer_table}[kind](F) if kind != 'motion' else \
+      synthetic.motion_layer_table(num_basis)
+  shapes = {}
+  for name, nout, nin, has_bias in table:
+    shapes[name + '.weight'] = (nout, nin)
+    if has_bias:
+      shapes[name + '.bias'] = (nout,)
+  if kind != 'motion':
+    shapes['ray_attention.layer_norm.weight'] = (128,)
+    shapes['ray_attention.layer_norm.bias'] = (128,)
+  if kind == 'static':
+    shapes['s'] = ()
+  return shapes
+
+
+def _pack(fn_pack, fn_size, names, state_dict, F, kind, optional=()):
+  """Validates every tensor against the reference module's shapes, then hands raw host pointers to the C packer.  Entries listed in
+  ``optional`` may be absent (they are packed as zeros).  F: in_feat_ch (static / dynamic) or num_basis (motion), as the C packer takes it."""
   import numpy as np
-  arrs = [_host_f32(state_dict[n]).reshape(-1) for n in names]
+  shapes = _expected_shapes(kind, num_basis=F) if kind == 'motion' else _expected_shapes(kind, F=F)
+  arrs = []
+  for n in names:
+    if n not in state_dict:
+      if n in optional:
+        arrs.append(np.zeros(max(1, int(np.prod(shapes[n]))), dtype=np.float32))
+        continue
+      raise KeyError(f'{kind} network: state dict has no {n!r} (keys: {sorted(state_dict)[:6]}...)')
+    a = _host_f32(state_dict[n])
+    if tuple(a.shape) != tuple(shapes[n]) and not (shapes[n] == () and a.size == 1):  # ascontiguousarray promotes 0-d to (1,)
+      hint = ''
+      if n == 'rgb_fc.0.weight' and kind == 'static' and tuple(a.shape) == (32, 33):
+        hint = ' (a DynibarStatic built with input_dir=False; the kernels implement input_dir=True, as every shipped config sets)'
+      raise ValueError(f'{kind} network: {n} has shape {tuple(a.shape)}, the kernels are built for {tuple(shapes[n])}{hint}')
+    arrs.append(a.reshape(-1))
   ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
   n = int(getattr(_lib.lib(), fn_size)())
   blob = np.zeros(n, dtype=np.float32)
@@ -185,12 +220,27 @@ def _pack(fn_pack, fn_size, names, state_dict, F):
   return torch.from_numpy(blob)
 
 
+def _infer_F(state_dict, key='ray_dir_fc.2.weight'):
+  """in_feat_ch of a DynibarStatic / DynibarDynamic state dict: ray_dir_fc.2 maps 256 -> in_feat_ch + 3."""
+  w = state_dict.get(key)
+  if w is None:
+    raise KeyError(f'state dict has no {key!r}')
+  return int(w.shape[0]) - 3
+
+
 class StaticNet:
   """DynibarStatic (mlp_network.py:319-527) as packed MFMA operand tiles on one device.  ``state_dict``: the module's
   state dict (torch tensors or numpy arrays; a DataParallel 'module.' prefix is accepted)."""
 
-  def __init__(self, state_dict, device, anti_alias_pooling=True, mask_rgb=False, F=32):
-    self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, _strip_module(state_dict), F).to(device)
+  def __init__(self, state_dict, device, anti_alias_pooling=True, mask_rgb=False, F=None):
+    sd = _strip_module(state_dict)
+    F = _infer_F(sd) if F is None else F
+    # the module only owns the pooling temperature `s` when it was built with anti_alias_pooling (mlp_network.py:330-331); every
+    # monocular config ships anti_alias_pooling = 0 (configs/train_kid-running.txt:41), and the kernels never read it then
+    if anti_alias_pooling and 's' not in sd:
+      raise KeyError("DynibarStatic state dict has no 's' but anti_alias_pooling is on (mlp_network.py:330-331)")
+    self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, sd, F, 'static',
+                      optional=() if anti_alias_pooling else ('s',)).to(device)
     self.anti_alias_pooling, self.mask_rgb = int(bool(anti_alias_pooling)), int(bool(mask_rgb))
     self._ws = None
 
@@ -247,8 +297,10 @@ class _Workspace:
 class DynamicNet:
   """DynibarDynamic (mlp_network.py:129-316) on one device.  ``shift`` as passed to the module's constructor."""
 
-  def __init__(self, state_dict, device, shift=0.0, F=32):
-    self.blob = _pack('dyn_dynamic_net_pack', 'dyn_dynamic_net_blob_floats', DYNAMIC_TENSORS, _strip_module(state_dict), F).to(device)
+  def __init__(self, state_dict, device, shift=0.0, F=None):
+    sd = _strip_module(state_dict)
+    F = _infer_F(sd) if F is None else F
+    self.blob = _pack('dyn_dynamic_net_pack', 'dyn_dynamic_net_blob_floats', DYNAMIC_TENSORS, sd, F, 'dynamic').to(device)
     self.shift = float(shift)
     self._ws = _Workspace()
 
@@ -270,7 +322,12 @@ class MotionMLP:
   """MotionMLP (mlp_network.py:558-618) on one device."""
 
   def __init__(self, state_dict, device, num_basis=6, sf_mag_div=1.0):
-    self.blob = _pack('dyn_motion_mlp_pack', 'dyn_motion_mlp_blob_floats', MOTION_TENSORS, _strip_module(state_dict), num_basis).to(device)
+    sd = _strip_module(state_dict)
+    cw = sd.get('coeff_linear.weight')
+    if cw is not None and int(cw.shape[0]) != 3 * int(num_basis):
+      raise ValueError(f'MotionMLP: coeff_linear has {int(cw.shape[0])} outputs but the trajectory basis has {num_basis} columns '
+                       f'(expected {3 * int(num_basis)}; mlp_network.py:598-603)')
+    self.blob = _pack('dyn_motion_mlp_pack', 'dyn_motion_mlp_blob_floats', MOTION_TENSORS, sd, num_basis, 'motion').to(device)
     self.num_basis, self.sf_mag_div = int(num_basis), float(sf_mag_div)
 
   def __call__(self, pts, time, n_zero_last):

@@ -11,8 +11,7 @@ Pinning: ``tests/golden/make_golden.py`` runs the *real* reference modules
 (imported read-only from /root/reference in the build container) on seeded
 inputs and commits their outputs as ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` checks every function here against those
-fixtures, and ``tests/test_oracle_vs_reference.py`` re-checks live (bit-exact
-on the same torch build) whenever /root/reference is present.
+fixtures (bit-exact on the same torch build).
 
 Each function cites the reference lines it follows (paths under
 /root/reference/ibrnet/).  The arithmetic uses the same torch operators in the
@@ -206,6 +205,13 @@ def fine_z_vals(z_vals, weights, N_importance, inv_uniform, det, u=None, return_
 # ----------------------------------------------------------------------------
 
 
+# 'reference': K.inv(c2w) exactly as the reference forms it (fp32 LU inverse + fp32 bmm).  'double': the same product formed in
+# float64 and rounded once to fp32 -- what k_prepare_cameras does.  The two differ in the last bits of the matrix; running the oracle
+# in both modes measures how far the REFERENCE's own outputs move under that perturbation (the conditioning bound the parity tests
+# add to their tolerance on white-noise maps, tests/parity.py:projection_sensitivity).  Never changed outside a `with` block there.
+PROJECTION_MODE = 'reference'
+
+
 def compute_projections(xyz, train_cameras):
   """xyz [V,...,3], train_cameras [V,34] -> pixel_locations [V,...,2], in-front mask [V,...]
   (projection.py:32-59)."""
@@ -215,7 +221,11 @@ def compute_projections(xyz, train_cameras):
   K = train_cameras[:, 2:18].reshape(-1, 4, 4)
   c2w = train_cameras[:, -16:].reshape(-1, 4, 4)
   xyz_h = torch.cat([xyz, torch.ones_like(xyz[..., :1])], dim=-1)
-  proj = K.bmm(torch.inverse(c2w)).bmm(xyz_h.permute(0, 2, 1)).permute(0, 2, 1)
+  if PROJECTION_MODE == 'double':
+    P = K.double().bmm(torch.inverse(c2w.double())).float()
+    proj = P.bmm(xyz_h.permute(0, 2, 1)).permute(0, 2, 1)
+  else:
+    proj = K.bmm(torch.inverse(c2w)).bmm(xyz_h.permute(0, 2, 1)).permute(0, 2, 1)
   pix = proj[..., :2] / torch.clamp(proj[..., 2:3], min=1e-8)
   pix = torch.clamp(pix, min=-1e6, max=1e6)
   mask = proj[..., 2] > 0
@@ -573,7 +583,7 @@ def static_branch_pass(sd_static, scene, ray_o, ray_d, N_samples, inv_uniform=Tr
 def dual_branch_stage(models, scene, featmaps_dy, featmaps_st, ray_o, ray_d, uv_grid, pts, z_vals, s_vals,
                       ref_frame_idx, ref_time_embedding, ref_time_offset, which, num_frames,
                       anti_alias_pooling=True, mask_rgb=False, num_vv=0, time_diff_scaled=True,
-                      flow_views=None, sf_offsets=(2, -2)):
+                      flow_views=None, sf_offsets=(2, -2), dy_shift=0.0):
   """One dynamic+static evaluation at given sample points: the shared body of the coarse stage of
   render_rays_mv (render_ray.py:672-784), of fine_render_rays (:461-597) and of the reference-time pass
   of render_rays_mono (:948-1098).  ``which`` = 'coarse' | 'fine' selects the nets in ``models``."""
@@ -606,7 +616,7 @@ def dual_branch_stage(models, scene, featmaps_dy, featmaps_st, ray_o, ray_d, uv_
     tdiff = tdiff / float(num_frames)
   tdiff = tdiff[None, None, :, None].expand(R, S, -1, -1)
   ray_dir = F.normalize(ray_d, dim=-1)
-  raw_dy = dynamic_net(sd_dy, pts, rgb_feat_dy, ray_dir, ray_diff_dy, tdiff, mask_dy, t_emb)
+  raw_dy = dynamic_net(sd_dy, pts, rgb_feat_dy, ray_dir, ray_diff_dy, tdiff, mask_dy, t_emb, shift=dy_shift)
   raw_st = static_net(sd_st, pts, ref_plucker(ray_o, ray_d), src_plucker(pts, scene['static_src_cameras']),
                       rgb_feat_st, ray_dir, ray_diff_st, mask_st, anti_alias_pooling, mask_rgb)
   out = raw2outputs(raw_dy, raw_st, z_vals, pm_dy, pm_st)
@@ -645,7 +655,7 @@ def render_rays_mv(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_embeddi
 
 
 def render_rays_mono_eval(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_embedding, time_offset, N_samples,
-                          inv_uniform=True, det=True, anti_alias_pooling=True, mask_rgb=False, num_vv=2, t_rand=None):
+                          inv_uniform=True, det=True, anti_alias_pooling=True, mask_rgb=False, num_vv=2, t_rand=None, dy_shift=0.0):
   """Monocular path with is_train=False (render_ray.py:870-1098, 1272-1277): coarse only, time_diff unscaled
   (:1031-1036), flows on the first 6 views (:1077-1082), exp_sf from offsets +-1 (:1086-1096)."""
   num_frames = int(frame_idx / time_embedding)
@@ -653,7 +663,7 @@ def render_rays_mono_eval(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_
   out, out_dy, out_st, _ = dual_branch_stage(models, scene, scene['featmaps'], scene['static_featmaps'], ray_o, ray_d,
                                              uv_grid, pts, z_vals, s_vals, frame_idx, time_embedding, time_offset,
                                              'coarse', num_frames, anti_alias_pooling, mask_rgb, num_vv=num_vv,
-                                             time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1))
+                                             time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1), dy_shift=dy_shift)
   return {'outputs_coarse_ref': out, 'outputs_coarse_ref_dy': out_dy, 'outputs_coarse_st': out_st}
 
 

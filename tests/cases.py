@@ -26,6 +26,8 @@ def scene_case(name):
       'few': dict(seed=5, H=32, W=48, V=3, n_static=4, smooth=True, R=5),
       'many': dict(seed=6, H=32, W=48, V=13, n_static=20, smooth=True, R=3),
       # BASELINE configs[4] (stress): 16 views in both branches, rendered with 128 + 128 samples
+      # configs/train_kid-running.txt shape: 7 time-offset + num_vv = 3 virtual dynamic views, 15 static views (render_monocular_bt.py:113-201)
+      'kid': dict(seed=8, H=32, W=48, V=10, n_static=15, smooth=True, R=5),
       'stress': dict(seed=7, H=32, W=48, V=16, n_static=16, smooth=True, R=4),  # not 3 rays: torch.cross without dim (reference quirk)
   }[name]
   R = cfg.pop('R')

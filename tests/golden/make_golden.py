@@ -49,13 +49,14 @@ def ref_args(anti_alias_pooling=1, mask_rgb=0, occ_weights_mode=0):
                                occ_weights_mode=occ_weights_mode)
 
 
-def build_ref_model(weights, n_coarse, n_fine, args):
+def build_ref_model(weights, n_coarse, n_fine, args, shift=0.0):
   def load(mod, sd):
-    missing = mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    own = mod.state_dict()  # a DynibarStatic built with anti_alias_pooling=0 has no `s` (mlp_network.py:330-331)
+    missing = mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in own}, strict=True)
     return mod.eval()
   m = types.SimpleNamespace()
   m.net_coarse_st = load(NET.DynibarStatic(args, in_feat_ch=32, n_samples=n_coarse), weights['net_coarse_st'])
-  m.net_coarse_dy = load(NET.DynibarDynamic(args, in_feat_ch=32, n_samples=n_coarse), weights['net_coarse_dy'])
+  m.net_coarse_dy = load(NET.DynibarDynamic(args, in_feat_ch=32, n_samples=n_coarse, shift=shift), weights['net_coarse_dy'])
   m.net_fine_st = load(NET.DynibarStatic(args, in_feat_ch=32, n_samples=n_fine), weights['net_fine_st'])
   m.net_fine_dy = load(NET.DynibarDynamic(args, in_feat_ch=32, n_samples=n_fine), weights['net_fine_dy'])
   m.motion_mlp = load(NET.MotionMLP(num_basis=cases.NUM_BASIS), weights['motion_mlp'])
@@ -138,11 +139,29 @@ def stage_goldens(name, S=64):
       out[f'pdf/inv{int(inv)}/rand'] = npy(smp)
     # full eval paths
     rb = ray_batch_of(scene, o, d, uv)
-    ret = RR.render_rays_mv((fidx, None), (temb, None), (toff, None), rb, model, proj,
-                            (scene['featmaps'], None, scene['static_featmaps']),
-                            (scene['featmaps_fine'], None, scene['static_featmaps_fine']),
-                            S, args, inv_uniform=True, N_importance=S, det=True, is_train=False)
+    # chain-level index exactness (protocol b): record what the reference's own sample_pdf sees and returns INSIDE
+    # render_rays_mv (its own coarse weights), restate its index computation and prove the restatement on the recorded output
+    seen = {}
+    real_sample_pdf = RR.sample_pdf
+
+    def recording_sample_pdf(bins, weights, N_samples, det=False):
+      seen['bins'], seen['weights'] = bins.clone(), weights.clone()  # sample_pdf mutates `weights` in place (render_ray.py:23)
+      seen['out'] = real_sample_pdf(bins, weights, N_samples, det=det)
+      return seen['out']
+
+    RR.sample_pdf = recording_sample_pdf
+    try:
+      ret = RR.render_rays_mv((fidx, None), (temb, None), (toff, None), rb, model, proj,
+                              (scene['featmaps'], None, scene['static_featmaps']),
+                              (scene['featmaps_fine'], None, scene['static_featmaps_fine']),
+                              S, args, inv_uniform=True, N_importance=S, det=True, is_train=False)
+    finally:
+      RR.sample_pdf = real_sample_pdf
     flat('mv/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+    from oracle import ibr_oracle as O
+    smp, inds = O.sample_pdf(seen['bins'].clone(), seen['weights'].clone(), S, det=True, return_inds=True)
+    assert torch.equal(smp, seen['out']), 'index restatement does not reproduce the reference sample_pdf output bit for bit'
+    out['chain/mv_above_inds'] = npy(inds).astype(np.int32)
     ret = RR.render_rays_mono((fidx, None), (temb, None), (toff, None), rb, model,
                               (scene['featmaps'], None, scene['static_featmaps']), proj,
                               S, args, inv_uniform=True, N_importance=0, det=True, is_train=False, num_vv=0)
@@ -302,8 +321,29 @@ def mono_train_goldens():
   print('mono_train', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def mono_kid_goldens():
+  """render_rays_mono with the monocular configs' arguments (configs/train_kid-running.txt:41-42,69: anti_alias_pooling = 0, mask_rgb = 1,
+  num_vv = 3; DynibarMono builds the dynamic net with shift = 5.0, model.py:304-309): the real DynibarStatic then has no `s`."""
+  out = {}
+  scene, o, d, uv, pix = cases.scene_case('kid')
+  args = ref_args(anti_alias_pooling=0, mask_rgb=1)
+  model = build_ref_model(cases.model_weights(0), 64, 128, args, shift=5.0)
+  assert 's' not in model.net_coarse_st.state_dict()
+  fidx, temb, toff = cases.time_args(7)
+  with torch.no_grad():
+    ret = RR.render_rays_mono((fidx, None), (temb, None), (toff, None), ray_batch_of(scene, o, d, uv), model,
+                              (scene['featmaps'], None, scene['static_featmaps']), PJ.Projector('cpu'), 64, args, inv_uniform=True,
+                              N_importance=0, det=True, is_train=False, num_vv=3)
+  flat('mono/', {k: v for k, v in ret.items() if isinstance(v, dict)}, out)
+  np.savez_compressed(os.path.join(HERE, 'mono_kid.npz'), **out)
+  print('mono_kid', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
   import sys
+  if 'mono_kid' in sys.argv[1:]:
+    mono_kid_goldens()
+    sys.exit(0)
   if 'image_mono_train' in sys.argv[1:]:
     image_mono_train_goldens()
     sys.exit(0)
@@ -321,3 +361,7 @@ if __name__ == '__main__':
   stress_goldens()
   sampler_goldens()
   image_goldens()
+  image_mono_goldens()
+  image_mono_train_goldens()
+  mono_train_goldens()
+  mono_kid_goldens()

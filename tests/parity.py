@@ -3,8 +3,10 @@
 
 Tolerances (stated per check): integer / boolean / index outputs exact; depths, points and normalised distances bit-exact
 (the geometry TU is built with -ffp-contract=off); interpolated colours / features within 2e-5 on smooth maps (coordinate
-rounding times the map gradient) and 5e-4 on white-noise maps; network outputs and rendered colours within 1e-4
-(BASELINE.json north_star)."""
+rounding times the map gradient); network outputs and rendered colours within 1e-4 (BASELINE.json north_star).  Where the
+reference's own arithmetic is ill-conditioned (white-noise maps: a 1e-4 px shift of a tap is visible; anti-alias pooling weights: a
+cancellation) the allowance added is MEASURED on the oracle per element (projection_sensitivity, check_static_net's exp jitter), not
+a blanket factor.  Every check records the fraction of its limit it used (MARGINS, printed by tests/conftest.py)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -24,10 +26,29 @@ def cpu(x):
   return x.detach().cpu()
 
 
-def assert_close(a, b, atol, rtol=0.0, what=''):
+# Every tolerance check records how much of its limit it used: (label, max |err|, limit at that element, worst err / limit).
+# tests/conftest.py prints the table at the end of the session (and writes gpurun_out/parity_margins.json), so the GPU test record
+# shows the margins, not just "passed".
+MARGINS = []
+
+
+def record_margin(what, err, lim):
+  err, lim = torch.as_tensor(err).double().reshape(-1), torch.as_tensor(lim).double().reshape(-1)
+  if err.numel() == 0:
+    return
+  ratio = err / lim.clamp(min=1e-300)
+  i = int(torch.argmax(ratio))
+  MARGINS.append(dict(check=what, max_err=float(err.max()), err_at_worst=float(err[i]), limit_at_worst=float(lim[i]), used=float(ratio[i])))
+
+
+def assert_close(a, b, atol, rtol=0.0, what='', extra=None):
+  """|a - b| <= atol + rtol |b| (+ extra, a per-element conditioning allowance computed by the caller)."""
   a, b = cpu(a).double(), cpu(b).double()
   err = (a - b).abs()
   lim = atol + rtol * b.abs()
+  if extra is not None:
+    lim = lim + extra.double()
+  record_margin(what, err, lim.expand_as(err))
   if not bool((err <= lim).all()):
     i = int(torch.argmax(err - lim))
     raise AssertionError(f'{what}: max err {float(err.max()):.3e} (limit {atol:.1e}+{rtol:.1e}*|ref|) at flat index {i}: '
@@ -97,7 +118,7 @@ def check_ray_diff(rd, rd_ref, xyz_st, xyz, qcam, cams, what):
 
 def check_project_gather(device, name='small', S=64):
   scene, o, d, uv, _ = cases.scene_case(name)
-  atol = 5e-4 if name == 'noise' else 3e-5
+  atol = 3e-5  # + on white-noise maps the measured conditioning of the reference's own taps (projection_sensitivity)
   pts_r, z_r, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
   R = o.shape[0]
   sd = to_dev(scene, device)
@@ -111,7 +132,9 @@ def check_project_gather(device, name='small', S=64):
   margin = boundary_margin(xyz, scene['static_src_cameras'][0])
   nflip = _mask_check(mk, mk_r, margin, f'{name} static mask')
   keep = (~margin)[..., None].float()
-  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} static rgb_feat')
+  sens = projection_sensitivity(lambda: dict(rf=O.compute_with_motions(pts_r, xyz, scene['camera'], scene['static_src_rgbs'],
+                                                                          scene['static_src_cameras'], scene['static_featmaps'])[0]))['rf']
+  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} static rgb_feat', extra=SENS_FACTOR * sens * keep)
   check_ray_diff(rd, rd_r, pts_r, xyz, scene['camera'][0], scene['static_src_cameras'][0], f'{name} static ray_diff')
   # dynamic branch: explicit displaced points (Projector API form)
   g = torch.Generator().manual_seed(9)
@@ -123,7 +146,9 @@ def check_project_gather(device, name='small', S=64):
   margin = boundary_margin(xyz, scene['src_cameras'][0])
   nflip += _mask_check(mk, mk_r, margin, f'{name} dynamic mask')
   keep = (~margin)[..., None].float()
-  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} dynamic rgb_feat')
+  sens = projection_sensitivity(lambda: dict(rf=O.compute_with_motions(pts_r, xyz, scene['camera'], scene['src_rgbs'], scene['src_cameras'],
+                                                                          scene['featmaps'])[0]))['rf']
+  assert_close(cpu(rf) * keep, rf_r * keep, atol, 1e-5, f'{name} dynamic rgb_feat', extra=SENS_FACTOR * sens * keep)
   check_ray_diff(rd, rd_r, pts_r, xyz, scene['camera'][0], scene['src_cameras'][0], f'{name} dynamic ray_diff')
   pm = ops.sample_mask(mk, 1.0)
   assert_bitexact(pm, (cpu(mk)[..., 0].sum(dim=2) > 1).float(), 'sample_mask')
@@ -242,10 +267,12 @@ def check_static_pass(device, name='small', S=64, R=None, atol=1e-4):
   margin = boundary_margin(st['pts'][None].repeat(Vs, 1, 1, 1), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
   keep = ~margin
   assert int(keep.sum()) > 0
-  tol = 5e-4 if name == 'noise' else atol  # white-noise maps amplify the 1-ulp coordinate differences of the gather
-  assert_close(cpu(out['rgb'])[keep], out_ref['rgb'][keep], tol, 0.0, f'{name} static pass rgb')
-  assert_close(cpu(out['depth'])[keep], out_ref['depth'][keep], 0.0, 2e-4, f'{name} static pass depth')
-  assert_close(cpu(out['weights'])[keep], out_ref['weights'][keep], tol, 0.0, f'{name} static pass weights')
+  # white-noise maps amplify the last-bit differences of the projection matrices: measured on the oracle, per element
+  sens = projection_sensitivity(lambda: O.static_branch_pass(sd, scene, o, d, S, True, True, True, False))
+  ex = lambda k: SENS_FACTOR * sens[k][keep]
+  assert_close(cpu(out['rgb'])[keep], out_ref['rgb'][keep], atol, 0.0, f'{name} static pass rgb', extra=ex('rgb'))
+  assert_close(cpu(out['depth'])[keep], out_ref['depth'][keep], 0.0, 2e-4, f'{name} static pass depth', extra=ex('depth'))
+  assert_close(cpu(out['weights'])[keep], out_ref['weights'][keep], atol, 0.0, f'{name} static pass weights', extra=ex('weights'))
   assert_bitexact((cpu(out['mask']) > 0)[keep], out_ref['mask'][keep], f'{name} static pass ray mask')
   return float((cpu(out['rgb'])[keep] - out_ref['rgb'][keep]).abs().max())
 
@@ -336,25 +363,53 @@ def make_ray_batch(scene, o, d, uv, device):
   return b
 
 
-def _group_tol(key, name):
-  # per-sample probabilities and rendered colours: 1e-4 (north_star); depths scale with the scene; flows are pixel differences
-  loose = 5.0 if name == 'noise' else 1.0
+def _group_tol(key, name=None):
+  # per-sample probabilities and rendered colours: 1e-4 (north_star); depths scale with the scene; flows are pixel differences.
+  # No blanket loosening for ill-conditioned scenes: their allowance is measured per element (projection_sensitivity).
   if key in ('depth', 'z_vals', 's_vals'):
-    return dict(atol=2e-4 * loose, rtol=2e-4)
+    return dict(atol=2e-4, rtol=2e-4)
   if key in ('render_flows',):
-    return dict(atol=2e-2 * loose, rtol=1e-3)
+    return dict(atol=2e-2, rtol=1e-3)
   if key in ('exp_sf',):
-    return dict(atol=2e-5 * loose, rtol=1e-3)
-  return dict(atol=1e-4 * loose, rtol=1e-4)
+    return dict(atol=2e-5, rtol=1e-3)
+  return dict(atol=1e-4, rtol=1e-4)
 
 
-def check_group_vs_golden(prefix, out, golden, name, skip_rays=None):
+SENS_FACTOR = 3.0
+
+
+def projection_sensitivity(run):
+  """Conditioning of the REFERENCE algorithm with respect to the last bits of K.inv(c2w): the kernels form that matrix in double
+  (k_prepare_cameras), the reference with an fp32 LU inverse + fp32 bmm (projection.py:42-47); neither is "the" fp32 answer.  `run`
+  evaluates the oracle; it is evaluated once as the reference does and once with the double-formed matrix, and the per-element
+  difference of its outputs (nested dicts of tensors) is how far the reference's own result moves under that perturbation.  On smooth
+  maps it is ~1e-7; on white-noise maps (gradient ~1 per pixel) a 1e-4 px shift of a tap is visible.  Checks add SENS_FACTOR x this."""
+  base = run()
+  O.PROJECTION_MODE = 'double'
+  try:
+    pert = run()
+  finally:
+    O.PROJECTION_MODE = 'reference'
+
+  def diff(a, b):
+    if isinstance(a, dict):
+      return {k: diff(a[k], b[k]) for k in a if a[k] is not None}
+    if isinstance(a, torch.Tensor) and a.dtype.is_floating_point:
+      return (a.double() - b.double()).abs()
+    return None
+  return diff(base, pert)
+
+
+def check_group_vs_golden(prefix, out, golden, name, skip_rays=None, sens=None):
   n = 0
   for k, v in out.items():
     if v is None:
       continue
     ref = torch.from_numpy(golden[prefix + k])
     got = cpu(v)
+    extra = None
+    if sens is not None and sens.get(k) is not None:
+      extra = SENS_FACTOR * sens[k]
     if skip_rays is not None and skip_rays.any():
       ax = 1 if got.dim() == 3 and got.shape[1] == skip_rays.numel() else 0
       keep = ~skip_rays
@@ -363,9 +418,16 @@ def check_group_vs_golden(prefix, out, golden, name, skip_rays=None):
       assert_bitexact(got, ref, prefix + k)
     else:
       tol = _group_tol(k, name)
-      assert_close(got.float(), ref.float(), tol['atol'], tol['rtol'], prefix + k)
+      assert_close(got.float(), ref.float(), tol['atol'], tol['rtol'], f'{name}:{prefix}{k}', extra=extra)
     n += 1
   return n
+
+
+def oracle_models():
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  W['trajectory_basis_fine'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  return W
 
 
 def check_render_rays_mv(device, golden, name='small', S=64):
@@ -382,13 +444,45 @@ def check_render_rays_mv(device, golden, name='small', S=64):
   ffeat = (scene['featmaps_fine'].to(device), None, scene['static_featmaps_fine'].to(device))
   ret = render_ray.render_rays_mv((fidx, None), (temb.to(device), None), (toff, None), batch, model, proj, cfeat, ffeat, S, args,
                                   inv_uniform=True, N_importance=S, det=True, is_train=False)
-  # rays whose coarse or fine samples touch a frustum edge within fp32 rounding may flip a mask bit (see _mask_check): skipped
+  sens = {}
+  if name == 'noise':  # white-noise maps: the reference's own conditioning w.r.t. the projection matrices' last bits, per element
+    W = oracle_models()
+    sens = projection_sensitivity(lambda: O.render_rays_mv(W, dict(scene), o, d, uv, fidx, temb, toff, S, S))
   n = 0
   for grp in ('outputs_coarse_ref', 'outputs_fine_ref', 'outputs_fine_ref_dy'):
-    n += check_group_vs_golden(f'mv/{grp}/', ret[grp], golden, name)
+    n += check_group_vs_golden(f'mv/{grp}/', ret[grp], golden, name, sens=sens.get(grp))
   assert n == sum(1 for k in golden if k.startswith('mv/')), 'render_rays_mv output key set differs from the reference'
   assert ret['outputs_fine_anchor'] is None and ret['outputs_fine_anchor_dy'] is None
+  # chain-level index exactness (protocol b): the inverse-CDF indices the HIP chain derives from ITS OWN coarse
+  # weights against the indices the real reference derived from its own (recorded inside the reference's render_rays_mv)
+  if 'chain/mv_above_inds' in golden:
+    c = ret['outputs_coarse_ref']
+    _, _, inds = ops.fine_samples(c['z_vals'], c['weights'], S, True, None, want_inds=True)
+    ref_inds = torch.from_numpy(golden['chain/mv_above_inds']).long()
+    mism = cpu(inds).long() != ref_inds
+    n_mis = int(mism.sum())
+    CHAIN_INDEX_REPORT.append(dict(case=name, samples=int(ref_inds.numel()), mismatches=n_mis))
+    if n_mis:
+      # A flip is legitimate only where u sits within the cdf's own uncertainty of every knot it jumped: the reference's index is then
+      # decided by the last bits of ITS coarse weights, which carry the network round-off of either implementation.
+      w_ref = torch.from_numpy(golden['mv/outputs_coarse_ref/weights'])
+      w_err = float((cpu(c['weights']) - w_ref).abs().max())
+      ww = torch.flip(w_ref[:, 1:-1], dims=[1])  # inv_uniform=True ordering (render_ray.py:793-797)
+      cdf = O.pdf_to_cdf(ww.clone())
+      bound = 4e-7 + 2.0 * w_err * ww.shape[1] / float((ww + 1e-5).sum(dim=1).min())
+      u = torch.linspace(0.0, 1.0, S)
+      got = cpu(inds).long()
+      unexplained = 0
+      for r, k in zip(*torch.nonzero(mism, as_tuple=True)):
+        lo, hi = sorted((int(got[r, k]), int(ref_inds[r, k])))
+        if float((cdf[r, lo:hi] - u[k]).abs().max()) > bound:
+          unexplained += 1
+      CHAIN_INDEX_REPORT[-1].update(knot_ties=n_mis - unexplained, tie_bound=bound)
+      assert unexplained == 0, f'{name}: {unexplained} inverse-CDF index flips that are not knot ties (of {n_mis} flips, {ref_inds.numel()} samples)'
   return n
+
+
+CHAIN_INDEX_REPORT = []
 
 
 def check_render_rays_mono(device, golden, name='small', S=64):
@@ -403,10 +497,50 @@ def check_render_rays_mono(device, golden, name='small', S=64):
   feat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
   ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, proj, S, args, inv_uniform=True,
                                     det=True, is_train=False, num_vv=0)
+  sens = {}
+  if name == 'noise':
+    W = oracle_models()
+    sens = projection_sensitivity(lambda: O.render_rays_mono_eval(W, dict(scene), o, d, uv, fidx, temb, toff, S, True, True, num_vv=0))
   n = 0
   for grp in ('outputs_coarse_ref', 'outputs_coarse_ref_dy', 'outputs_coarse_st'):
-    n += check_group_vs_golden(f'mono/{grp}/', ret[grp], golden, name)
+    n += check_group_vs_golden(f'mono/{grp}/', ret[grp], golden, name, sens=sens.get(grp))
   assert n == sum(1 for k in golden if k.startswith('mono/')), 'render_rays_mono output key set differs from the reference'
+  return n
+
+
+def make_module_model(device, args, shift=5.0, wrap=True):
+  """A DynibarMono-shaped model whose nets are real nn.Modules on `device`, DataParallel-wrapped like model.py:382-397, with the
+  conditional parameter set of the reference's constructors for `args` (no `s` when anti_alias_pooling = 0)."""
+  import types
+  import refmodules
+  W = cases.model_weights(0)
+  dp = (lambda m: torch.nn.DataParallel(m.to(device))) if wrap else (lambda m: m.to(device))
+  m = types.SimpleNamespace()
+  m.net_coarse_st = dp(refmodules.load_numpy_state(refmodules.like_reference('static', args), W['net_coarse_st']))
+  m.net_coarse_dy = dp(refmodules.load_numpy_state(refmodules.like_reference('dynamic', args, shift=shift), W['net_coarse_dy']))
+  m.motion_mlp = dp(refmodules.load_numpy_state(refmodules.like_reference('motion', args, num_basis=cases.NUM_BASIS), W['motion_mlp']))
+  m.trajectory_basis = torch.nn.parameter.Parameter(O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)).float().to(device).detach().requires_grad_(True)
+  return m
+
+
+def check_render_rays_mono_kid(device, golden, S=64):
+  """render_rays_mono with the arguments every monocular config ships (configs/train_kid-running.txt:41-42,69: anti_alias_pooling=0,
+  mask_rgb=1, num_vv=3) on DataParallel-wrapped nn.Modules WITHOUT an `s` parameter, against the real reference's outputs."""
+  import types
+  from dynibar_amd import projection, render_ray
+  scene, o, d, uv, _ = cases.scene_case('kid')
+  fidx, temb, toff = cases.time_args(7)
+  args = types.SimpleNamespace(anti_alias_pooling=0, mask_rgb=1, input_dir=True, input_xyz=False, occ_weights_mode=0)
+  model = make_module_model(device, args, shift=5.0)
+  assert not any(k.endswith('s') and '.' not in k.replace('module.', '') for k in model.net_coarse_st.state_dict()), 'stand-in must not own `s`'
+  batch = make_ray_batch(scene, o, d, uv, device)
+  feat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
+  ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, projection.Projector(device), S, args,
+                                    inv_uniform=True, det=True, is_train=False, num_vv=3)
+  n = 0
+  for grp in ('outputs_coarse_ref', 'outputs_coarse_ref_dy', 'outputs_coarse_st'):
+    n += check_group_vs_golden(f'mono/{grp}/', ret[grp], golden, 'kid')
+  assert n == len(golden), 'render_rays_mono (kid-running arguments) output key set differs from the reference'
   return n
 
 

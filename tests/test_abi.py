@@ -42,11 +42,11 @@ def test_invalid_arguments_are_reported():
 def test_weight_packing_runs_on_the_host():
   """Packing is host code: it must work (and validate its input) without a GPU."""
   from dynibar_amd import ops, synthetic as syn
-  blob = ops._pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', ops.STATIC_TENSORS, syn.make_weights('static', 0), 32)
+  blob = ops._pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', ops.STATIC_TENSORS, syn.make_weights('static', 0), 32, 'static')
   assert blob.shape[0] == _lib.lib().dyn_static_net_blob_floats() and bool(torch.isfinite(blob).all())
   assert float(blob.abs().sum()) > 0
   with pytest.raises(RuntimeError, match='32 feature channels'):
-    ops._pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', ops.STATIC_TENSORS, syn.make_weights('static', 0), 16)
+    ops._pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', ops.STATIC_TENSORS, syn.make_weights('static', 0, F=16), 16, 'static')
 
 
 def test_no_cpu_fallback():

@@ -89,6 +89,11 @@ def test_render_rays_mono(dev, golden_dir, name):
   parity.check_render_rays_mono(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
 
 
+def test_render_rays_mono_kid_running_config(dev, golden_dir):
+  """BASELINE configs[3] arguments on real nn.Modules: anti_alias_pooling=0 / mask_rgb=1 / num_vv=3, DataParallel-wrapped nets without `s`."""
+  parity.check_render_rays_mono_kid(dev, _golden(golden_dir, 'mono_kid.npz'))
+
+
 @pytest.mark.parametrize('tag,shift,mode', [('adj', 1, 0), ('far', -2, 0), ('mode1', 1, 1)])
 def test_render_rays_mono_train(dev, golden_dir, tag, shift, mode):
   """render_rays_mono(is_train=True) forward values incl. the anchor-frame cross-time rendering, vs the real reference."""

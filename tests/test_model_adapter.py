@@ -1,0 +1,129 @@
+"""The drop-in must accept the reference's own model objects: nn.Modules, DataParallel-wrapped (model.py:134-159, :382-397), for BOTH
+argument sets the reference ships -- Nvidia eval (anti_alias_pooling=1, mask_rgb=0: configs_nvidia/eval_balloon1_long.txt:21-22) and
+the monocular configs (anti_alias_pooling=0, mask_rgb=1: configs/train_kid-running.txt:41-42, where DynibarStatic has NO `s`
+parameter, mlp_network.py:330-331).  Packing is host code, so all of this runs without a GPU."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import refimport
+import refmodules
+from dynibar_amd import ops, render_ray, synthetic as syn
+
+ARG_SETS = {'nvidia_eval': dict(anti_alias_pooling=1, mask_rgb=0), 'kid_running': dict(anti_alias_pooling=0, mask_rgb=1)}
+
+
+def _args(name):
+  return types.SimpleNamespace(input_dir=True, input_xyz=False, occ_weights_mode=0, **ARG_SETS[name])
+
+
+def _model(mods, args, wrap):
+  """A DynibarMono / DynibarFF shaped holder: nets DataParallel-wrapped like model.py:382-397 when wrap is set."""
+  W = cases.model_weights(0)
+  w = (lambda m: torch.nn.DataParallel(m)) if wrap else (lambda m: m)
+  m = types.SimpleNamespace()
+  m.net_coarse_st = w(refmodules.load_numpy_state(mods('static', args), W['net_coarse_st']))
+  m.net_coarse_dy = w(refmodules.load_numpy_state(mods('dynamic', args, shift=5.0), W['net_coarse_dy']))
+  m.motion_mlp = w(refmodules.load_numpy_state(mods('motion', args), W['motion_mlp']))
+  m.trajectory_basis = torch.nn.parameter.Parameter(torch.zeros(cases.NUM_FRAMES, cases.NUM_BASIS)).detach().requires_grad_(True)
+  return m
+
+
+def _standin(kind, args, shift=0.0):
+  return refmodules.like_reference(kind, args, num_basis=cases.NUM_BASIS, shift=shift)
+
+
+def _real(kind, args, shift=0.0):
+  NET = refimport.import_reference().mlp_network
+  if kind == 'static':
+    return NET.DynibarStatic(args, in_feat_ch=32, n_samples=64)
+  if kind == 'dynamic':
+    return NET.DynibarDynamic(args, in_feat_ch=32, n_samples=64, shift=shift)
+  return NET.MotionMLP(num_basis=cases.NUM_BASIS)
+
+
+def _check_adapter(mods, cfg, wrap):
+  args = _args(cfg)
+  model = _model(mods, args, wrap)
+  W = cases.model_weights(0)
+  aa, mr = bool(args.anti_alias_pooling), bool(args.mask_rgb)
+  if not aa:
+    assert 's' not in render_ray._state_dict(model.net_coarse_st) and 'module.s' not in render_ray._state_dict(model.net_coarse_st)
+  st = render_ray._static_net(model, 'net_coarse_st', args, 'cpu')
+  assert (st.anti_alias_pooling, st.mask_rgb) == (int(aa), int(mr))
+  want = dict(W['net_coarse_st'])
+  if not aa:
+    want.pop('s')
+  assert torch.equal(st.blob, ops.StaticNet(want, 'cpu', aa, mr).blob), 'module and dict pack to different blobs'
+  dy = render_ray._dynamic_net(model, 'net_coarse_dy', 'cpu')
+  assert dy.shift == 5.0 and torch.equal(dy.blob, ops.DynamicNet(W['net_coarse_dy'], 'cpu').blob)
+  mo = render_ray._motion_mlp(model, 'motion_mlp', 'cpu', cases.NUM_BASIS)
+  assert torch.equal(mo.blob, ops.MotionMLP(W['motion_mlp'], 'cpu', cases.NUM_BASIS).blob)
+  # packed once, re-packed when a parameter changes in place (an optimizer step bumps _version)
+  assert render_ray._static_net(model, 'net_coarse_st', args, 'cpu') is st
+  with torch.no_grad():
+    dict(render_ray._unwrap(model.net_coarse_st).named_parameters())['base_fc.0.weight'].mul_(1.5)
+  st2 = render_ray._static_net(model, 'net_coarse_st', args, 'cpu')
+  assert st2 is not st and not torch.equal(st2.blob, st.blob)
+
+
+@pytest.mark.parametrize('cfg', sorted(ARG_SETS))
+@pytest.mark.parametrize('wrap', [False, True])
+def test_adapter_accepts_modules(cfg, wrap):
+  _check_adapter(_standin, cfg, wrap)
+
+
+@pytest.mark.skipif(not refimport.have_reference(), reason='needs /root/reference (build container only)')
+@pytest.mark.parametrize('cfg', sorted(ARG_SETS))
+@pytest.mark.parametrize('wrap', [False, True])
+def test_adapter_accepts_the_real_reference_modules(cfg, wrap):
+  _check_adapter(_real, cfg, wrap)
+
+
+@pytest.mark.skipif(not refimport.have_reference(), reason='needs /root/reference (build container only)')
+@pytest.mark.parametrize('cfg', sorted(ARG_SETS))
+def test_standins_mirror_the_real_modules(cfg):
+  """tests/refmodules.py is what the GPU box feeds the adapter: its state dicts must be the reference's, key for key."""
+  args = _args(cfg)
+  for kind in ('static', 'dynamic', 'motion'):
+    real, mine = _real(kind, args).state_dict(), _standin(kind, args).state_dict()
+    assert list(real.keys()) == list(mine.keys()) or sorted(real.keys()) == sorted(mine.keys()), kind
+    for k in real:
+      assert tuple(real[k].shape) == tuple(mine[k].shape), (kind, k)
+  assert ('s' in _real('static', args).state_dict()) == bool(args.anti_alias_pooling)
+
+
+def test_missing_s_is_an_error_only_with_anti_alias_pooling():
+  W = dict(syn.make_weights('static', 0))
+  W.pop('s')
+  ops.StaticNet(W, 'cpu', anti_alias_pooling=False, mask_rgb=True)
+  with pytest.raises(KeyError, match="no 's'"):
+    ops.StaticNet(W, 'cpu', anti_alias_pooling=True)
+
+
+def test_unsupported_module_variants_are_rejected_by_shape():
+  """The C packers index with fixed strides: every tensor is shape-checked first."""
+  W = dict(syn.make_weights('static', 0))
+  bad = dict(W)
+  bad['rgb_fc.0.weight'] = np.zeros((32, 33), np.float32)  # DynibarStatic(input_dir=False), mlp_network.py:396-403
+  with pytest.raises(ValueError, match='input_dir=False'):
+    ops.StaticNet(bad, 'cpu')
+  with pytest.raises(RuntimeError, match='32 feature channels'):
+    ops.StaticNet(syn.make_weights('static', 0, F=16), 'cpu')
+  bad = dict(W)
+  bad['base_fc.0.weight'] = W['base_fc.0.weight'][:, :100]
+  with pytest.raises(ValueError, match='base_fc.0.weight'):
+    ops.StaticNet(bad, 'cpu')
+  bad = dict(W)
+  bad.pop('vis_fc.2.bias')
+  with pytest.raises(KeyError, match='vis_fc.2.bias'):
+    ops.StaticNet(bad, 'cpu')
+  with pytest.raises(ValueError, match='coeff_linear'):
+    ops.MotionMLP(syn.make_weights('motion', 0, num_basis=4), 'cpu', num_basis=6)
+  D = dict(syn.make_weights('dynamic', 0))
+  D['ref_pts_fc.0.weight'] = D['ref_pts_fc.0.weight'][:, :128]
+  with pytest.raises(ValueError, match='ref_pts_fc.0.weight'):
+    ops.DynamicNet(D, 'cpu')

@@ -125,6 +125,31 @@ def test_mono_train(golden_dir, tag, shift, mode):
   assert n == sum(1 for k in g if k.startswith(tag + '/')), 'oracle mono train output key set differs from the reference'
 
 
+def test_mono_kid_config(golden_dir):
+  """The monocular configs' arguments (configs/train_kid-running.txt: anti_alias_pooling=0, mask_rgb=1, num_vv=3; dynamic net shift 5.0,
+  model.py:304-309), 7 + 3 dynamic and 15 static views, against the real reference's render_rays_mono."""
+  g = load(golden_dir, 'mono_kid.npz')
+  scene, o, d, uv, pix = cases.scene_case('kid')
+  W = {k: O.tdict(v) for k, v in cases.model_weights(0).items()}
+  W['trajectory_basis'] = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES)
+  fidx, temb, toff = cases.time_args(7)
+  ret = O.render_rays_mono_eval(W, dict(scene), o, d, uv, fidx, temb, toff, 64, True, True, anti_alias_pooling=False, mask_rgb=True, num_vv=3,
+                                dy_shift=5.0)
+  n = check_group('mono/', ret, g)
+  assert n == len(g), 'oracle mono (kid-running arguments) output key set differs from the reference'
+
+
+def test_chain_level_indices(golden_dir):
+  """The inverse-CDF indices recorded INSIDE the reference's render_rays_mv (from its own coarse weights) are what the oracle derives
+  from the golden coarse weights: pins the index restatement the GPU chain test compares against."""
+  for name in ('small', 'harsh', 'noise'):
+    g = load(golden_dir, f'stages_{name}.npz')
+    z = torch.from_numpy(g['mv/outputs_coarse_ref/z_vals'])
+    w = torch.from_numpy(g['mv/outputs_coarse_ref/weights'])
+    _, inds = O.fine_z_vals(z, w, 64, True, True, None, return_inds=True)
+    np.testing.assert_array_equal(inds.numpy(), g['chain/mv_above_inds'])
+
+
 def test_image_rays(golden_dir):
   g = load(golden_dir, 'sampler.npz')
   scene, *_ = cases.scene_case('small')
