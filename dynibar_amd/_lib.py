@@ -124,7 +124,11 @@ def ptr(t, dtype=torch.float32):
 
 
 def stream_of(t):
+  """torch's current stream on the tensor's device; that device is made current first (kernels launch on the current device, and the
+  C side refuses a stream of another device)."""
   if t is not None and t.is_cuda:
+    if torch.cuda.current_device() != t.device.index:
+      torch.cuda.set_device(t.device)
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
   return ctypes.c_void_p(0)
 

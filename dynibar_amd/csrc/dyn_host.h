@@ -35,17 +35,28 @@ enum DynKernelSlot {
 void dyn_prof_begin(int slot, hipStream_t stream);
 void dyn_prof_end(int slot, hipStream_t stream);
 
+// Dynamic LDS beyond 64 KiB must be opted into per kernel AND per device, and the opt-in is a maximum: a call site whose LDS size
+// varies (k_fine_samples: 72-144 KiB with S + N) raises it again whenever a launch needs more than any earlier one on that device.
+// The launch goes to the CURRENT device; a stream that belongs to another device is refused instead of launched wrongly.
+#define DYN_MAX_DEVICES 16
 #define DYN_LAUNCH(slot, name, kernel, grid, block, shmem, stream, ...)              \
   do {                                                                              \
-    if ((size_t)(shmem) > 65536) { /* dynamic LDS beyond 64 KiB must be opted into, once per kernel */ \
-      static bool attr_done_ = false;                                               \
-      if (!attr_done_) {                                                            \
+    int dev_ = 0, sdev_ = -1;                                                       \
+    (void)hipGetDevice(&dev_);                                                      \
+    if ((stream) != nullptr && hipStreamGetDevice((stream), &sdev_) == hipSuccess && sdev_ != dev_) { \
+      dyn_set_error("%s: the stream belongs to device %d but the current device is %d (select the tensors' device first)", name, sdev_, dev_); \
+      return DYN_E_INVALID;                                                         \
+    }                                                                               \
+    if ((size_t)(shmem) > 65536) {                                                  \
+      static int attr_max_[DYN_MAX_DEVICES] = {0};                                  \
+      const int slot_ = (dev_ >= 0 && dev_ < DYN_MAX_DEVICES) ? dev_ : 0;           \
+      if ((int)(shmem) > attr_max_[slot_] || dev_ >= DYN_MAX_DEVICES) {             \
         hipError_t ea_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shmem)); \
         if (ea_ != hipSuccess) {                                                    \
           dyn_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, (size_t)(shmem), hipGetErrorString(ea_)); \
           return DYN_E_LAUNCH;                                                      \
         }                                                                           \
-        attr_done_ = true;                                                          \
+        attr_max_[slot_] = (int)(shmem);                                            \
       }                                                                             \
     }                                                                               \
     dyn_prof_begin(slot, stream);                                                   \

@@ -1,18 +1,22 @@
-// Register-resident MLP chain engine for gfx950 (fp32-in / fp32-accumulate MFMA, v_mfma_f32_32x32x2_f32).
+// Register-resident MLP chain engine for gfx950.
 //
 // Every Linear layer of the per-point networks (reference ibrnet/mlp_network.py) is evaluated TRANSPOSED:
 //     out^T [features x rows] = W [features x K] . act^T [K x rows]
 // so the weights are the MFMA A operand and the activations the B operand.  One wavefront owns a tile of 32 rows
 // (point-views or points): lane l = (j = l & 31 : the row, h = l >> 5 : the half).  The MFMA result layout
 // ("D layout": register r of lane (j,h) holds feature (r&3) + 8*(r>>2) + 4*h of the 32-feature output tile, for row j) is
-// exactly what the next layer's B operand wants when its k-steps are enumerated in that same order, so activations never
+// exactly what the next layer's B operand wants when its k-slots are enumerated in that same order, so activations never
 // leave the register file between layers: no LDS round trip, no transposes.  The summation order over K is a
 // pack-time permutation of the reference's (results agree to fp32 round-off, not bitwise; tolerance 1e-4 per north_star).
 //
-// Weights are pre-packed on the host (dyn_nets.hip: pack_layer) into a stream of 16 KiB chunks in consumption order and
-// DMA'd global->LDS (global_load_lds_dwordx4) into a 2-deep ring shared by the 4 waves of a workgroup: chunk c+1 is in
-// flight while chunk c feeds the MFMAs; one workgroup barrier per chunk (4096 MFMA-cycles per wave).
-// Bias is folded into K as one extra k-slot whose activation is the constant 1.
+// Two engines share that structure (selected at build time, DYN_ENGINE_B6):
+//  * the shipped one ("B6", second half of this file): fp32 operands split exactly into bf16 parts, products on the bf16 matrix pipe
+//    (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, 3 or 6 partial products per product (DYN_SPLIT_TERMS).  Weights are split and
+//    packed on the host (dyn_nets.hip: pack_layer_b6) into a stream of 48 KiB chunks in consumption order and DMA'd global->LDS
+//    (global_load_lds_dwordx4) into a ring shared by the 4 or 8 waves of a workgroup: chunk c+1 in flight while chunk c feeds the
+//    MFMAs, one workgroup barrier per chunk.  Biases are accumulator initial values (LDS tables) or one extra k-slot fed with 1.
+//  * the first one (kept for A/B builds, -DDYN_ENGINE_B6=0; first half of this file): native fp32 MFMA (v_mfma_f32_32x32x2_f32),
+//    16 KiB chunks (DYN_CHUNK) in a 2-deep ring, bias folded into K as one extra k-step.
 #pragma once
 #include "dyn_device.h"
 

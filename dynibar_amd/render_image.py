@@ -1,14 +1,25 @@
 """Drop-in for the reference's ``ibrnet/render_image.py``: ``render_single_image_nvi`` / ``render_single_image_mono`` with the
 reference signatures and return structure (reference render_image.py:9-217, :220-439).
 
-Multi-GPU: rays are independent, so when ``torch.distributed`` is initialised (one process per GPU, RCCL) the H*W rays of the
-target view are split into ``world_size`` contiguous, equally padded tiles; every rank renders its own tile chunk by chunk and
-the tiles are concatenated with ONE all-gather per output tensor (reference: ``nn.DataParallel`` scatter/gather inside every
-module call, model.py:134-159).  Every rank returns the full frame.  With world_size == 1 no collective is issued.
-Chunk results stay on the device until the frame is assembled (the reference copies every tensor of every chunk to the host).
+Multi-GPU.  Rays are independent, so when ``torch.distributed`` is initialised (one process per GPU, RCCL) the H*W rays of the target
+view are split into ``world_size`` contiguous tiles of equal size (+-1 ray); every rank renders its own tile chunk by chunk and every
+rank returns the full frame (the callers are SPMD scripts).  The reference's counterpart is ``nn.DataParallel`` scatter / gather inside
+every module call (model.py:134-159).
+
+Output contract.  The reference copies EVERY tensor of EVERY chunk to the host (render_image.py:123-135): per 288x512 frame about
+1 GB of per-sample arrays (weights, alpha, z_vals ... [H,W,S]) that ``eval_nvidia.py:380-381`` never reads.  Here a frame group is a
+``FrameOutputs`` mapping with the reference's keys, order, shapes and dtypes, in which
+  * the pixels every caller reads -- ``rgb``, ``depth``, ``mask`` of the frame's primary group -- are assembled eagerly: ONE packed
+    ``[rays, 5]`` all-gather per frame (<= 3 MB at 288x512) and one device-to-host copy;
+  * every other entry is resolved on first access (``ret['outputs_coarse_ref']['weights']`` gathers and copies that tensor then, and
+    caches it).  A caller that reads an entry gets exactly what the reference returns; a caller that does not pays nothing.
+    With world_size > 1 the access issues a collective, so ranks must read the same entries in the same order (SPMD callers do).
+``FRAME_OUTPUTS = 'all'`` (or ``args.frame_outputs`` / env ``DYNIBAR_FRAME_OUTPUTS``) restores the eager behaviour: everything is
+assembled before the call returns, with one packed collective per group.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
@@ -18,19 +29,24 @@ from .render_ray import render_rays_mono, render_rays_mv
 _PER_VIEW_KEYS = ('camera', 'anchor_camera', 'render_camera', 'depth_range', 'src_rgbs', 'src_cameras', 'anchor_src_rgbs', 'anchor_src_cameras', 'static_src_rgbs',
                   'static_src_cameras')
 
+FRAME_OUTPUTS = 'lazy'       # 'lazy' | 'all'
+TILE_ACROSS_RANKS = True     # False: every rank renders the whole frame by itself (no collective), e.g. when only one rank calls in
+_EAGER_KEYS = ('rgb', 'depth', 'mask')
+
 
 def _dist():
   import torch.distributed as dist
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+  if TILE_ACROSS_RANKS and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
     return dist, dist.get_world_size(), dist.get_rank()
   return None, 1, 0
 
 
 def ray_tile(n_rays, world, rank):
-  """Contiguous tile [lo, hi) of rank ``rank``; all tiles have the padded size ``tile`` except that the last ones may be short/empty."""
-  tile = (n_rays + world - 1) // world
-  lo = min(rank * tile, n_rays)
-  return lo, min(lo + tile, n_rays), tile
+  """Contiguous tile [lo, hi) of rank ``rank`` and the padded tile size: a balanced split, tile sizes differ by at most one ray
+  (ranks beyond n_rays get an empty tile and still take part in the collectives)."""
+  lo = (n_rays * rank) // world
+  hi = (n_rays * (rank + 1)) // world
+  return lo, hi, (n_rays + world - 1) // world
 
 
 def slice_ray_batch(ray_batch, lo, hi, per_view_keys=_PER_VIEW_KEYS):
@@ -49,78 +65,218 @@ def slice_ray_batch(ray_batch, lo, hi, per_view_keys=_PER_VIEW_KEYS):
   return chunk
 
 
-def gather_ray_outputs(local, n_rays, dist, world, rank):
-  """local: {key: tensor} covering this rank's tile (ray axis 0, or 1 for 3-D [V,N,c] tensors; 4-D tensors are dropped like the
-  reference drops them).  Returns {key: full tensor over all n_rays} on every rank, via one all_gather per key of equal padded tiles."""
-  lo, hi, tile = ray_tile(n_rays, world, rank)
-  out = OrderedDict()
+# ----------------------------------------------------------------------------------------------------------------------
+# tile -> frame
+# ----------------------------------------------------------------------------------------------------------------------
+def _rows(t):
+  """[N, ...] or [V, N, c] tensor -> ([N, cols] float32 rows, restore(rows) -> original layout)."""
+  dtype = t.dtype
+  if t.dim() == 3:
+    V, N, c = t.shape
+    rows = t.permute(1, 0, 2).reshape(N, V * c)
+    back = lambda r: r.reshape(r.shape[0], V, c).permute(1, 0, 2).contiguous()
+  else:
+    shape = tuple(t.shape[1:])
+    rows = t.reshape(t.shape[0], -1)
+    back = lambda r: r.reshape((r.shape[0],) + shape)
+  if dtype != torch.float32:
+    rows = rows.float()  # the ray masks (bool) travel as 0 / 1
+    inner = back
+    back = lambda r: inner(r).to(dtype)
+  return rows, back
+
+
+def gather_rows(local, n_rays, dist, world, rank, count=None):
+  """local: {key: tensor over this rank's tile (ray axis 0; axis 1 for 3-D [V,N,c] tensors)} -> {key: tensor over all n_rays} on every
+  rank: the entries are packed side by side into ONE [tile, C] buffer and reassembled with ONE all_gather_into_tensor.
+  ``count``: valid rays of the local tile (default: all rows; 0 for a rank whose tile is empty and that rendered a placeholder ray)."""
+  if not local:
+    return OrderedDict()
+  packed, restore, widths = [], [], []
   for k, t in local.items():
-    if t is None or t.dim() == 4:
-      continue
-    axis = 1 if t.dim() == 3 else 0
-    if world == 1:
-      out[k] = t
-      continue
-    tt = t.transpose(0, axis) if axis else t
-    pad_shape = (tile,) + tuple(tt.shape[1:])
-    send = torch.zeros(pad_shape, dtype=tt.dtype, device=tt.device)
-    send[: hi - lo] = tt
-    recv = torch.empty((world,) + pad_shape, dtype=tt.dtype, device=tt.device)
-    dist.all_gather_into_tensor(recv.view((world * tile,) + pad_shape[1:]), send.contiguous())
-    full = recv.view((world * tile,) + pad_shape[1:])[:n_rays]
-    out[k] = full.transpose(0, axis).contiguous() if axis else full
+    rows, back = _rows(t)
+    packed.append(rows)
+    restore.append(back)
+    widths.append(rows.shape[1])
+  n_local = packed[0].shape[0] if count is None else count
+  buf = packed[0] if len(packed) == 1 else torch.cat(packed, dim=1)
+  if world > 1:
+    lo, hi, tile = ray_tile(n_rays, world, rank)
+    assert hi - lo == n_local, 'a rank renders exactly its own tile'
+    send = torch.zeros((tile, buf.shape[1]), dtype=torch.float32, device=buf.device)
+    send[:n_local] = buf[:n_local]
+    recv = torch.empty((world * tile, buf.shape[1]), dtype=torch.float32, device=buf.device)
+    dist.all_gather_into_tensor(recv, send)
+    spans = [ray_tile(n_rays, world, r) for r in range(world)]
+    if all(h - l == tile for l, h, _ in spans):
+      buf = recv
+    else:
+      buf = torch.cat([recv[r * tile: r * tile + (h - l)] for r, (l, h, _) in enumerate(spans)], dim=0)
+  else:
+    buf = buf[:n_local]
+  out = OrderedDict()
+  c0 = 0
+  for (k, _), back, w in zip(local.items(), restore, widths):
+    out[k] = back(buf[:, c0:c0 + w])
+    c0 += w
   return out
 
 
-def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank):
-  """list of per-chunk output dicts -> full-frame dict, reshaped like render_image.py:137-188 and moved to the host."""
+def _to_host(tensors):
+  """{key: device tensor} -> {key: host tensor}: one batch of asynchronous copies into pinned memory and a single synchronisation
+  (the reference: one blocking .cpu() per tensor per chunk, render_image.py:113-118)."""
+  host = OrderedDict()
+  try:
+    for k, t in tensors.items():
+      host[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) if t.is_cuda else t
+    if any(t.is_cuda for t in tensors.values()):
+      torch.cuda.current_stream().synchronize()
+  except RuntimeError:  # no pinned memory to be had: plain synchronous copies
+    host = OrderedDict((k, t.cpu()) for k, t in tensors.items())
+  return host
+
+
+class FrameOutputs(OrderedDict):
+  """One output group of a frame: the reference's keys in the reference's order.  Entries not yet assembled are resolved (gathered
+  across ranks, copied to the host, reshaped to [H, W, ...]) by the first read and cached."""
+
+  def __init__(self):
+    super().__init__()
+    self._pending = {}
+
+  def _defer(self, key, thunk):
+    super().__setitem__(key, None)
+    self._pending[key] = thunk
+
+  def _resolve(self, key):
+    thunk = self._pending.pop(key, None)
+    if thunk is not None:
+      super().__setitem__(key, thunk())
+
+  def pending(self):
+    return list(self._pending)
+
+  def resolve_all(self):
+    for k in list(self._pending):
+      self._resolve(k)
+    return self
+
+  def __getitem__(self, key):
+    self._resolve(key)
+    return super().__getitem__(key)
+
+  def get(self, key, default=None):
+    return self[key] if key in self else default
+
+  def __setitem__(self, key, value):
+    self._pending.pop(key, None)
+    super().__setitem__(key, value)
+
+  def items(self):
+    self.resolve_all()
+    return super().items()
+
+  def values(self):
+    self.resolve_all()
+    return super().values()
+
+  def pop(self, key, *default):
+    if key in self:
+      self._resolve(key)
+    return super().pop(key, *default)
+
+  def __reduce__(self):  # pickling / copying a frame materialises it
+    self.resolve_all()
+    return (OrderedDict, (list(super().items()),))
+
+
+def _frame_mode(args):
+  mode = getattr(args, 'frame_outputs', None) or os.environ.get('DYNIBAR_FRAME_OUTPUTS') or FRAME_OUTPUTS
+  if mode not in ('lazy', 'all'):
+    raise ValueError(f"frame_outputs must be 'lazy' or 'all', got {mode!r}")
+  return mode
+
+
+def _shape_frame(t, Hs, Ws):
+  """render_image.py:137-188: 3-D [V,N,c] entries -> [V,H,W,c], others -> [H,W,...], singleton axes squeezed."""
+  if t.dim() == 3:
+    return t.reshape((t.shape[0], Hs, Ws, -1)).squeeze()
+  return t.reshape((Hs, Ws, -1)).squeeze()
+
+
+def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank, count=None, eager=None):
+  """list of per-chunk output dicts of this rank's tile -> FrameOutputs of the full frame.  eager: keys assembled now (None: all)."""
+  frame = FrameOutputs()
   keys = list(per_chunk[0].keys()) if per_chunk else []
   local = OrderedDict()
-  lists4 = OrderedDict()
   for k in keys:
     parts = [c[k] for c in per_chunk]
     if parts[0] is None or k == 'random_sigma':
       continue
     if parts[0].dim() == 4:
-      lists4[k] = [t.cpu() for t in parts]  # the reference leaves 4-D entries as its per-chunk list of host tensors (render_image.py:368-369)
+      # the reference leaves 4-D entries as its per-chunk list of host tensors (render_image.py:368-369); under tiling: this rank's chunks
+      n_keep = len(parts) if count is None or count > 0 else 0
+      frame._defer(k, (lambda ps=parts[:n_keep]: [t.cpu() for t in ps]))
       continue
-    local[k] = torch.cat(parts, dim=1 if parts[0].dim() == 3 else 0)
-  full = gather_ray_outputs(local, n_rays, dist, world, rank)
-  # to the host like the reference (.cpu() per tensor, render_image.py:113-118), but as one batch of asynchronous copies into pinned
-  # memory and a single synchronisation: the per-sample arrays of a 288x512 frame are ~1 GB, 0.1 s of pageable copies one by one
-  host = OrderedDict()
-  try:
-    for k, t in full.items():
-      host[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) if t.is_cuda else t
-    if any(t.is_cuda for t in full.values()):
-      torch.cuda.current_stream().synchronize()
-  except RuntimeError:  # no pinned memory to be had: plain synchronous copies
-    host = OrderedDict((k, t.cpu()) for k, t in full.items())
-  ret = OrderedDict()
-  for k in keys:  # the reference's key order
-    if k in lists4:
-      ret[k] = lists4[k]
-  for k, t in host.items():
-    if t.dim() == 3:
-      ret[k] = t.reshape((t.shape[0], Hs, Ws, -1)).squeeze()
-    else:
-      ret[k] = t.reshape((Hs, Ws, -1)).squeeze()
-  if 'rgb' in ret and 'mask' in ret:
-    ret['rgb'][ret['mask'] == 0] = 0.0
-  return ret
+    local[k] = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1 if parts[0].dim() == 3 else 0)
+    frame._defer(k, None)
+  now = [k for k in local if eager is None or k in eager]
+
+  def fetch(ks):
+    full = gather_rows(OrderedDict((k, local[k]) for k in ks), n_rays, dist, world, rank, count)
+    return OrderedDict((k, _shape_frame(t, Hs, Ws)) for k, t in _to_host(full).items())
+
+  def blank(rgb, mask):
+    rgb[mask == 0] = 0.0  # render_image.py:162-164, :186-188: pixels whose ray mask is off are zeroed, in every group
+    return rgb
+
+  for k, t in fetch(now).items():
+    frame[k] = t
+  if 'rgb' in now and 'mask' in now:
+    blank(OrderedDict.__getitem__(frame, 'rgb'), OrderedDict.__getitem__(frame, 'mask'))
+
+  def late(k):
+    if k == 'rgb' and 'mask' in local:  # the blanking needs the ray mask: both travel together
+      got = fetch(['rgb', 'mask'] if 'mask' in frame._pending else ['rgb'])
+      if 'mask' in got:
+        frame['mask'] = got['mask']
+      return blank(got['rgb'], frame['mask'])
+    return fetch([k])[k]
+
+  for k in local:
+    if k not in now:
+      frame._defer(k, (lambda kk=k: late(kk)))
+  if eager is None:
+    frame.resolve_all()
+  return frame
 
 
 def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
   dist, world, rank = _dist()
   n_rays = ray_batch['ray_o'].shape[0]
   lo, hi, _ = ray_tile(n_rays, world, rank)
+  count = hi - lo
+  if count == 0:
+    lo, hi = 0, 1  # an empty tile still joins the collectives: render one placeholder ray for the key / shape structure, contribute none
   chunks = {g: [] for g in group_names}
   for i in range(lo, hi, chunk_size):
     ret = render_chunk(slice_ray_batch(ray_batch, i, min(i + chunk_size, hi)))
     for g in group_names:
       if ret.get(g) is not None:
         chunks[g].append(ret[g])
-  return chunks, n_rays, dist, world, rank
+  return chunks, n_rays, dist, world, rank, count
+
+
+def _frame(chunks, groups, primary, n_rays, Hs, Ws, dist, world, rank, count, mode):
+  all_ret = OrderedDict()
+  for g in groups:
+    if not chunks[g]:
+      all_ret[g] = OrderedDict()
+      continue
+    eager = None if mode == 'all' else (_EAGER_KEYS if g == primary else ())
+    all_ret[g] = _assemble(chunks[g], n_rays, Hs, Ws, dist, world, rank, count, eager)
+  all_ret['outputs_fine'] = None
+  return all_ret
 
 
 def render_single_image_nvi(frame_idx, time_embedding, time_offset, ray_sampler, ray_batch, model, projector, chunk_size, N_samples, args,
@@ -134,14 +290,10 @@ def render_single_image_nvi(frame_idx, time_embedding, time_offset, ray_sampler,
                           is_train=is_train)
 
   groups = ('outputs_fine_anchor', 'outputs_fine_ref', 'outputs_coarse_ref')
-  chunks, n_rays, dist, world, rank = _render_tiles(ray_batch, chunk_size, render_chunk, groups)
+  chunks, n_rays, dist, world, rank, count = _render_tiles(ray_batch, chunk_size, render_chunk, groups)
   Hs = len(range(0, ray_sampler.H, render_stride))
   Ws = len(range(0, ray_sampler.W, render_stride))
-  all_ret = OrderedDict()
-  for g in groups:
-    all_ret[g] = _assemble(chunks[g], n_rays, Hs, Ws, dist, world, rank) if chunks[g] else OrderedDict()
-  all_ret['outputs_fine'] = None
-  return all_ret
+  return _frame(chunks, groups, 'outputs_fine_ref', n_rays, Hs, Ws, dist, world, rank, count, _frame_mode(args))
 
 
 def render_single_image_mono(frame_idx, time_embedding, time_offset, ray_sampler, ray_batch, model, projector, chunk_size, N_samples, args,
@@ -154,11 +306,7 @@ def render_single_image_mono(frame_idx, time_embedding, time_offset, ray_sampler
                             N_importance=N_importance, raw_noise_std=0.0, det=det, white_bkgd=white_bkgd, is_train=is_train, num_vv=num_vv)
 
   groups = ('outputs_coarse_ref', 'outputs_coarse_st', 'outputs_coarse_anchor')
-  chunks, n_rays, dist, world, rank = _render_tiles(ray_batch, chunk_size, render_chunk, groups)
+  chunks, n_rays, dist, world, rank, count = _render_tiles(ray_batch, chunk_size, render_chunk, groups)
   Hs = len(range(0, ray_sampler.H, render_stride))
   Ws = len(range(0, ray_sampler.W, render_stride))
-  all_ret = OrderedDict()
-  for g in groups:
-    all_ret[g] = _assemble(chunks[g], n_rays, Hs, Ws, dist, world, rank) if chunks[g] else OrderedDict()
-  all_ret['outputs_fine'] = None
-  return all_ret
+  return _frame(chunks, groups, 'outputs_coarse_ref', n_rays, Hs, Ws, dist, world, rank, count, _frame_mode(args))

@@ -56,6 +56,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 constexpr int hipMemcpyHostToDevice = 1;
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamGetDevice(hipStream_t, int* d) { *d = 0; return hipSuccess; }
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 
 namespace emu {

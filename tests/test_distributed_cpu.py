@@ -1,52 +1,72 @@
-"""world_size-2 gloo tests (CPU) of the N > 1 path: ray-tile partitioning, the reference's chunk slicing rules and the
-all-gather that reassembles a frame must reproduce the single-process result exactly (tiling must not change any per-ray value)."""
+"""world_size-2 gloo tests (CPU) of the N > 1 path.  The REAL ``render_single_image_nvi`` / ``_mono`` run in every rank -- ray-tile
+partitioning, the reference's chunk slicing rules, the packed all-gather, the deferred per-sample entries, empty tiles -- over a stub
+of the kernel layer (``render_rays_mv`` replaced by a cheap per-ray function with the same output structure); the tiled frame must equal
+the single-process frame bit for bit (tiling must not change any per-ray value).  Results travel back as numpy arrays: a torch tensor on
+an mp.Queue is a file-descriptor handle that dies with its producer."""
 import os
 import socket
 import sys
+import types
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLS = []
 
 
-def fake_render(chunk):
+def stub_render_rays_mv(frame_idx, time_embedding, time_offset, ray_batch, model, projector, coarse_featmaps, fine_featmaps, N_samples, args,
+                        inv_uniform=False, N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True):
   """A per-ray function with the output structure of render_rays_mv: 1-D, 2-D, bool, [V,R,2] and 4-D (kept as per-chunk lists) tensors."""
+  chunk = ray_batch
+  assert chunk['camera'].shape == (1, 34) and chunk['flows'].shape[1] == chunk['ray_o'].shape[0] and chunk['rgb'] is None
   o = chunk['ray_o']
   R = o.shape[0]
+  CALLS.append(R)
   s = torch.arange(5, dtype=torch.float32)[None, :]
-  return {'outputs_coarse_ref': {'rgb': o * 2.0 + 1.0, 'depth': o.sum(dim=1), 'weights': o[:, :1] * s, 'mask': o[:, 0] > 0.3,
-                                 'render_flows': torch.stack([o[:, :2], -o[:, :2]], dim=0), 'dropme': torch.zeros(2, R, 3, 1)},
-          'outputs_fine_ref': {'rgb': o * 3.0, 'mask': o[:, 1] > 0.5, 'depth': o[:, 2]}}
+  coarse = {'rgb': o * 2.0 + 1.0, 'depth': o.sum(dim=1), 'weights': o[:, :1] * s, 'mask': o[:, 0] > 0.3,
+            'render_flows': torch.stack([o[:, :2], -o[:, :2]], dim=0), 'dropme': torch.zeros(2, R, 3, 1) + o[None, :, :, None]}
+  fine = {'rgb': o * 3.0, 'mask': o[:, 1] > 0.5, 'depth': o[:, 2], 'alpha': o[:, 1:2] * s}
+  return {'outputs_coarse_ref': coarse, 'outputs_fine_ref': fine, 'outputs_fine_anchor': None, 'outputs_fine_anchor_dy': None}
 
 
-def run_frame(n_rays, chunk_size):
+def run_frame(H, W, chunk_size, mode, read=('weights', 'render_flows', 'rgb', 'dropme')):
   from dynibar_amd import render_image as RI
+  RI.render_rays_mv = stub_render_rays_mv
+  n_rays = H * W
   g = torch.Generator().manual_seed(5)
   batch = {'ray_o': torch.rand(n_rays, 3, generator=g), 'camera': torch.zeros(1, 34), 'flows': torch.rand(6, n_rays, 2, generator=g), 'rgb': None}
-  seen = []
+  del CALLS[:]
+  args = types.SimpleNamespace(frame_outputs=mode)
+  ret = RI.render_single_image_nvi((0, None), (None, None), ([0], None), types.SimpleNamespace(H=H, W=W), batch, None, None, chunk_size, 4, args,
+                                   N_importance=4, det=True, is_train=False)
+  assert ret['outputs_fine'] is None and len(ret['outputs_fine_anchor']) == 0
+  pend = {g_: list(ret[g_].pending()) for g_ in ('outputs_coarse_ref', 'outputs_fine_ref')}
+  out = {}
+  for g_ in ('outputs_coarse_ref', 'outputs_fine_ref'):
+    keys = list(ret[g_].keys())
+    # lazy mode: read a subset (SPMD: the same entries in the same order on every rank); 'all': everything is already there
+    want = keys if mode == 'all' else [k for k in keys if k in read or k in ('rgb', 'depth', 'mask')]
+    out[g_] = {'__keys__': keys}
+    for k in want:
+      v = ret[g_][k]
+      out[g_][k] = [t.numpy().copy() for t in v] if isinstance(v, list) else v.numpy().copy()
+  return out, list(CALLS), pend
 
-  def render_chunk(chunk):
-    assert chunk['camera'].shape == (1, 34) and chunk['flows'].shape[1] == chunk['ray_o'].shape[0] and chunk['rgb'] is None
-    seen.append(chunk['ray_o'].shape[0])
-    return fake_render(chunk)
 
-  chunks, n, d, world, rank = RI._render_tiles(batch, chunk_size, render_chunk, ('outputs_coarse_ref', 'outputs_fine_ref'))
-  H, W = 7, n_rays // 7
-  out = {g_: RI._assemble(chunks[g_], n, H, W, d, world, rank) for g_ in chunks}
-  return out, seen
-
-
-def worker(rank, world, port, n_rays, chunk_size, q):
+def worker(rank, world, port, H, W, chunk_size, mode, q):
   sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
-    out, seen = run_frame(n_rays, chunk_size)
-    q.put((rank, {g: {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in d.items()} for g, d in out.items()}, seen))
+    out, seen, pend = run_frame(H, W, chunk_size, mode)
+    q.put((rank, out, seen, pend))
   finally:
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -58,45 +78,80 @@ def free_port():
   return p
 
 
-@pytest.mark.parametrize('n_rays,chunk', [(7 * 9, 10), (7 * 13, 64)])
-def test_two_rank_frame_equals_single_process(n_rays, chunk):
-  sys.path.insert(0, ROOT)
-  ref, seen1 = run_frame(n_rays, chunk)
-  assert sum(seen1) == n_rays
+def run_ranks(world, H, W, chunk, mode):
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   port = free_port()
-  procs = [ctx.Process(target=worker, args=(r, 2, port, n_rays, chunk, q)) for r in range(2)]
+  procs = [ctx.Process(target=worker, args=(r, world, port, H, W, chunk, mode, q)) for r in range(world)]
   for p in procs:
     p.start()
-  got = [q.get(timeout=120) for _ in procs]
+  got = [q.get(timeout=180) for _ in procs]
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
-  assert sum(sum(s) for _, _, s in got) == n_rays, 'every ray is rendered exactly once across the ranks'
-  for rank, out, _ in got:
+  return sorted(got, key=lambda g: g[0])
+
+
+@pytest.mark.parametrize('H,W,chunk,mode', [(7, 9, 10, 'lazy'), (7, 13, 64, 'all'), (7, 9, 10, 'all'), (1, 1, 8, 'lazy'), (1, 3, 2, 'all')])
+def test_two_rank_frame_equals_single_process(H, W, chunk, mode):
+  sys.path.insert(0, ROOT)
+  n_rays = H * W
+  ref, seen1, pend1 = run_frame(H, W, chunk, mode)
+  assert sum(seen1) == n_rays
+  got = run_ranks(2, H, W, chunk, mode)
+  rendered = sum(sum(s) for _, _, s, _ in got)
+  assert rendered == max(n_rays, 2) if n_rays < 2 else rendered == n_rays, 'every ray is rendered exactly once across the ranks (+ one placeholder per empty tile)'
+  for rank, out, _, pend in got:
     for grp in ref:
-      assert list(out[grp].keys()) == list(ref[grp].keys())
+      assert out[grp]['__keys__'] == ref[grp]['__keys__'], 'key set / order of the tiled frame differs'
       for k in ref[grp]:
+        if k == '__keys__':
+          continue
         if isinstance(ref[grp][k], list):
           # 4-D entries stay per-chunk lists (as the reference leaves them); under tiling a rank holds the chunks of its own tile
-          assert isinstance(out[grp][k], list) and all(t.dim() == 4 for t in out[grp][k])
+          assert isinstance(out[grp][k], list) and all(t.ndim == 4 for t in out[grp][k])
           continue
-        assert torch.equal(out[grp][k], ref[grp][k]), f'rank {rank} {grp}/{k} differs from the single-process frame'
+        a, b = out[grp][k], ref[grp][k]
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), f'rank {rank} {grp}/{k} differs from the single-process frame'
+    if mode == 'lazy':
+      # only the primary group's rgb / depth / mask were assembled by the call itself: one packed [rays, 5] all-gather
+      assert sorted(set(out['outputs_fine_ref']['__keys__']) - set(pend['outputs_fine_ref'])) == ['depth', 'mask', 'rgb']
+      assert sorted(pend['outputs_coarse_ref']) == sorted(out['outputs_coarse_ref']['__keys__'])
+    else:
+      assert pend['outputs_fine_ref'] == [] and pend['outputs_coarse_ref'] == []
   assert isinstance(ref['outputs_coarse_ref']['dropme'], list), '4-D entries are kept as per-chunk lists, never assembled'
-  for grp in ('outputs_coarse_ref',):  # the two ranks' chunk lists together are the single-process list
-    both = [t for rank, out, _ in sorted(got, key=lambda g: g[0]) for t in out[grp]['dropme']]
-    assert torch.equal(torch.cat(both, dim=1), torch.cat(ref[grp]['dropme'], dim=1))
-  # masked pixels are blanked after the gather, like render_image.py:186-188
-  m = ref['outputs_coarse_ref']['mask']
-  assert bool((ref['outputs_coarse_ref']['rgb'][m == 0] == 0).all())
+  both = [t for _, out, _, _ in got for t in out['outputs_coarse_ref']['dropme']]
+  assert np.array_equal(np.concatenate(both, axis=1), np.concatenate(ref['outputs_coarse_ref']['dropme'], axis=1))
+  # masked pixels are blanked after the gather, like render_image.py:186-188 -- also for a group whose rgb was resolved late
+  for grp in ref:
+    m = ref[grp]['mask']
+    assert bool((ref[grp]['rgb'].reshape(-1, 3)[m.reshape(-1) == 0] == 0).all())
 
 
 def test_ray_tiles_partition():
   from dynibar_amd.render_image import ray_tile
-  for n in (1, 7, 64, 147456, 147457):
-    for world in (1, 2, 3, 8):
+  for n in (1, 5, 7, 64, 147456, 147457):
+    for world in (1, 2, 3, 4, 8):
       spans = [ray_tile(n, world, r) for r in range(world)]
       assert spans[0][0] == 0 and spans[-1][1] == n
       assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
-      assert all(hi - lo <= tile for lo, hi, tile in spans)
+      sizes = [hi - lo for lo, hi, _ in spans]
+      assert max(sizes) - min(sizes) <= 1 and all(sz <= tile for sz, (_, _, tile) in zip(sizes, spans)), 'balanced tiles'
+
+
+def test_collective_payload_of_a_frame():
+  """What the call itself moves between ranks by default: rgb + depth + mask of the primary group, 20 B per ray (2.9 MB at 288x512)."""
+  from dynibar_amd import render_image as RI
+  sent = []
+
+  class FakeDist:
+    @staticmethod
+    def all_gather_into_tensor(recv, send):
+      sent.append(send.numel() * 4)
+      recv.view(2, -1)[:] = send.reshape(1, -1)
+
+  n = 288 * 512
+  local = {'rgb': torch.zeros(n // 2, 3), 'depth': torch.zeros(n // 2), 'mask': torch.zeros(n // 2, dtype=torch.bool)}
+  out = RI.gather_rows(local, n, FakeDist, 2, 0)
+  assert len(sent) == 1 and sent[0] * 2 == n * 20 and n * 20 <= 3 * 1024 * 1024
+  assert out['mask'].dtype == torch.bool and out['rgb'].shape == (n, 3) and out['depth'].shape == (n,)
