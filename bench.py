@@ -4,7 +4,7 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the static-branch hot path over one batch of R = 4096 rays per GPU (64 coarse samples, 8 source
-views): sample_along_ray -> project_gather -> DynibarStatic (views / points / blend kernels) -> sample_mask -> composite,
+views): sample_along_ray -> project_gather -> DynibarStatic (views / points / blend kernels) -> composite,
 all through the C-ABI of libdynibar_hip.so with inputs resident in HBM.  With N > 1 every rank renders its own tile of rays
 (weak scaling: rays are independent) and each step ends with the RCCL all-gather of the rendered pixels.
 Prints ONE JSON line (rank 0).  The CPU leg times the oracle (the reference algorithm restated on torch-CPU) on a bounded
@@ -85,9 +85,8 @@ def main():
 
   def step():
     pts, z, _ = ops.sample_along_ray(ray_o, ray_d, scene['depth_range'], S, True, want_s=False)
-    rgb_feat, ray_diff, mask = ops.project_gather(views, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z)
+    rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z, pix_mask_thresh=1.0)
     raw = net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
-    pm = ops.sample_mask(mask, 1.0)
     out = ops.composite(raw, z, pm, per_sample=False)
     if world > 1:
       dist.all_gather_into_tensor(gathered, torch.cat([out['rgb'], out['depth'][:, None]], dim=1))

@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
   subprocess.check_call(cmd)
   # the same library with the fp32-class 6-term split engine: used by the precision A/B test and bench leg
   obj6 = os.path.join(CSRC, 'dyn_nets_x6.o')
-  cmd = [hipcc] + COMMON + ['-DDYN_SPLIT_TERMS=6', '-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', obj6]
+  cmd = [hipcc] + COMMON + ['-DDYN_SPLIT_TERMS=6', '-DDYN_SPLIT_F16=0', '-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', obj6]
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)

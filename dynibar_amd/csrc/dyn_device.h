@@ -39,12 +39,14 @@ __device__ __forceinline__ float wave_inclusive_prod(float v, int lane) {
 // Streaming accesses: data written once for a later kernel, or read exactly once, can go around the 4 MiB L2 slices (non-temporal) so
 // that the re-read working set (source maps, the packed weight stream) stays resident.
 typedef float dyn_f32x4 __attribute__((ext_vector_type(4)));
-// Measured inside the bench pipeline (two runs each): the view kernel's stores of the parked feature / point records and the point
-// kernel's loads of those records: view kernel -1 %, point kernel -6 %.  NOT the gather's outputs (its consumer starts right after it
-// and finds part of them in the 256 MB Infinity Cache: gather alone 131 -> 98 us, but in the pipeline 121 -> 129 us), not the view
-// kernel's gathered inputs (+6 %), not the blend kernel's loads of the parked feature (+2 %).
+// Measured inside the bench pipeline: the view kernel's stores of the parked feature / point records and the point kernel's loads of
+// those records (group 4): view kernel -1 %, point kernel -6 %.  The gather's outputs (group 1): 335 MB of plain stores push the source
+// maps out of the L2s and the memory-side cache while the taps still need them: with non-temporal stores (and the map prefetch of
+// k_project_gather_tile) the gather runs 86 us instead of 102 us inside the pipeline; its consumer then finds less of them in the
+// 256 MB Infinity Cache (view kernel +2 %).  Not the view kernel's gathered inputs (+6 %), not the blend kernel's loads of the parked
+// feature (+2 %).
 #ifndef DYN_NT
-#define DYN_NT 4  /* bit 0: gather outputs, bit 1: view kernel's gathered inputs, bit 2: parked features / point records, bit 3: blend loads */
+#define DYN_NT 5  /* bit 0: gather outputs, bit 1: view kernel's gathered inputs, bit 2: parked features / point records, bit 3: blend loads */
 #endif
 template <int GROUP>
 __device__ __forceinline__ void nt_store4(float4* p, float4 v) {

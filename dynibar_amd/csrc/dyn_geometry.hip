@@ -486,21 +486,226 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
   PG_PHASE(4);
 }
 
-extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {
-  DYN_REQUIRE(p, "dyn_project_gather: null params");
-  DYN_REQUIRE(p->R > 0 && p->S > 0 && p->V > 0, "dyn_project_gather: empty problem");
-  DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 256, "dyn_project_gather: F must be a multiple of 4 (<=256)");
-  DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->ray_diff && p->mask,
-              "dyn_project_gather: null pointer");
-  DYN_REQUIRE(p->pts_st != nullptr || (p->ray_o && p->ray_d && p->z_vals), "dyn_project_gather: need pts_st or (ray_o, ray_d, z_vals)");
-  DYN_REQUIRE(p->H > 1 && p->W > 1 && p->Hf > 1 && p->Wf > 1, "dyn_project_gather: maps must be at least 2x2");
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1, tile form (the shipped one): one workgroup = P consecutive sample points x all V views, one wavefront = 64 / P views.
+//
+// Why: in row order (point-major, view-minor) the 64 rows of a wave are 8 points x 8 views, i.e. eight different source maps per
+// tap instruction and a working set of ~48 cache lines per wave: with 16 waves on a CU the 32 KiB vector L1 thrashes (PMC: the
+// texture addresser is busy 84 % of the time, half of it waiting on pending misses).  Here a wave walks ONE epipolar line: its
+// lanes are consecutive samples of a ray seen from one source view, so the eight rows of a tap instruction fall into one or two
+// neighbouring bilinear cells (a few cache lines, mostly L1 hits) and the wave's working set is ~1 KiB.
+// The output tile [P][V][3+F] is assembled in LDS in its final memory order and leaves as ONE contiguous, 16-byte aligned burst
+// (P = 64, V = 8: 70 KiB); ray_diff and mask reuse the same LDS afterwards and leave the same way.  With all views of a point in
+// one workgroup the per-point observation count (render_ray.py:736-741, the former k_sample_mask launch, which re-read the mask
+// this kernel had just written) is a by-product.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PGT_UNROLL
+#define PGT_UNROLL 4
+#endif
+#ifndef PGT_EXP
+#define PGT_EXP 0  /* developer decomposition builds (tools/build_variant.py): 1 no feature-tap loads, 2 no rgb_feat stores, 3 all taps from one line, 4 no RGB taps */
+#endif
+struct PGTile {
+  int R, S, V, H, W, Hf, Wf, F;
+  float img_h, img_w, inv_wm1, inv_hm1, mask_thresh;
+  unsigned mS;          // fast_div multiplier for S
+  long n_pts;           // R * S
+  long ntile, tiles_per_xcd;
+  int pref_wgs;         // workgroups that stream the source maps into the memory-side cache before their tile
+};
+
+template <int P>
+__global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ z_vals,
+                                      const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
+                                      const float* __restrict__ query_center, const float* __restrict__ src_rgb, const float4* __restrict__ feat4,
+                                      float* __restrict__ rgb_feat, float4* __restrict__ ray_diff, float* __restrict__ mask,
+                                      float* __restrict__ pix_mask) {
+  constexpr int VPW = 64 / P;  // views per wave
+  float* tile = reinterpret_cast<float*>(dyn_smem);
+  const int lane = dyn_lane(), wave = dyn_wave();
+  const int V = q.V, C = 3 + q.F;
+#ifndef PGT_PREFETCH
+#define PGT_PREFETCH 1
+#endif
+#if PGT_PREFETCH
+  // In the rendering pipeline the source maps (24 MB at 8 views) have long left the memory-side cache when this kernel starts (the
+  // network kernels stream gigabytes in between), and a gather whose every first touch of a cell goes to HBM runs 30 % slower
+  // (measured: 122 us cold, 92 us warm).  The first workgroups therefore stream the maps once, coalesced, at full HBM rate, into the
+  // Infinity Cache (~5 us chip-wide, overlapped with their own first taps); the values are not used.
+  if (blockIdx.x < (unsigned)q.pref_wgs) {
+    const long n4a = (long)V * q.Hf * q.Wf * (q.F >> 2);            // float4 elements of the feature maps
+    const long n4b = ((long)V * q.H * q.W * 3) >> 2;                 // ... of the colour images (16-byte aligned base)
+    const long per = (n4a + n4b + q.pref_wgs - 1) / q.pref_wgs;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < n4a + n4b ? lo + per : n4a + n4b;
+    const float4* rgb4 = reinterpret_cast<const float4*>(src_rgb);
+    float sink = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      const float4 t = i < n4a ? feat4[i] : rgb4[i - n4a];
+      sink += t.x;
+    }
+    asm volatile("" ::"v"(sink));
+  }
+#endif
+  // XCD-aware tile id: workgroup b runs on XCD b % 8; XCD x owns the x-th contiguous eighth of the tiles (neighbouring rays share an L2)
+  const long wg = blockIdx.x;
+  const long local = wg >> 3;
+  const long t = (wg & 7) * q.tiles_per_xcd + local;
+  const bool tile_live = local < q.tiles_per_xcd && t < q.ntile;
+  const long p0 = t * P;                       // first point of the tile
+  const int pl = lane & (P - 1);               // point within the tile
+  const int v = wave * VPW + (lane / P);       // this lane's view
+  const long pt = p0 + pl;
+  const int vv = v < V ? v : V - 1;            // idle lanes shadow a real row: their loads stay in bounds, their results are dropped
+  const unsigned rs = (unsigned)(tile_live ? (pt < q.n_pts ? pt : q.n_pts - 1) : 0);
+
+  // ---- phase 1: lane = (point, view) ----
+  const unsigned r = fast_div(rs, (unsigned)q.S, q.mS);
+  float sx, sy, sz;
+  if (pts_st != nullptr) {
+    sx = pts_st[rs * 3 + 0]; sy = pts_st[rs * 3 + 1]; sz = pts_st[rs * 3 + 2];
+  } else {
+    const float z = z_vals[rs];
+    sx = z * ray_d[r * 3 + 0] + ray_o[r * 3 + 0];
+    sy = z * ray_d[r * 3 + 1] + ray_o[r * 3 + 1];
+    sz = z * ray_d[r * 3 + 2] + ray_o[r * 3 + 2];
+  }
+  float x = sx, y = sy, z3 = sz;
+  if (xyz != nullptr) {
+    const long o = ((long)vv * q.n_pts + rs) * 3;
+    x = xyz[o]; y = xyz[o + 1]; z3 = xyz[o + 2];
+  }
+  const float4 P0 = proj4[vv * 4], P1 = proj4[vv * 4 + 1], P2 = proj4[vv * 4 + 2], P3 = proj4[vv * 4 + 3];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  const float izc = __builtin_amdgcn_rcpf(zc);
+  float px = hx * izc, py = hy * izc;
+  px = fminf(fmaxf(px, -1e6f), 1e6f);
+  py = fminf(fmaxf(py, -1e6f), 1e6f);
+  const float wm1 = q.img_w - 1.0f, hm1 = q.img_h - 1.0f;
+  const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
+  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
+  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const Taps tf = make_taps(nx, ny, q.Wf, q.Hf);
+  const int row = pl * V + vv;  // row of the tile in its final order
+  float4 rd;
+  float mk;
+  {
+    const Taps tt = make_taps(nx, ny, q.W, q.H);
+    const float* img = src_rgb + (long)vv * q.H * q.W * 3;
+#if PGT_EXP == 4
+    const f32x3u a = {nx, ny, nx}, b = a, c = a, d = a;
+#else
+    const f32x3u a = *reinterpret_cast<const f32x3u*>(img + (tt.y0 * q.W + tt.x0) * 3);
+    const f32x3u b = *reinterpret_cast<const f32x3u*>(img + (tt.y0 * q.W + tt.x1) * 3);
+    const f32x3u c = *reinterpret_cast<const f32x3u*>(img + (tt.y1 * q.W + tt.x0) * 3);
+    const f32x3u d = *reinterpret_cast<const f32x3u*>(img + (tt.y1 * q.W + tt.x1) * 3);
+#endif
+    float ax, ay, az, bx, by, bz, dx, dy, dz;
+    normalize3(query_center[0] - sx, query_center[1] - sy, query_center[2] - sz, ax, ay, az);
+    normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
+    normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
+    rd = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
+    mk = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
+    if (v < V) {
+      tile[row * C + 0] = fmaf(d.x, tt.w_se, fmaf(c.x, tt.w_sw, fmaf(b.x, tt.w_ne, a.x * tt.w_nw)));
+      tile[row * C + 1] = fmaf(d.y, tt.w_se, fmaf(c.y, tt.w_sw, fmaf(b.y, tt.w_ne, a.y * tt.w_nw)));
+      tile[row * C + 2] = fmaf(d.z, tt.w_se, fmaf(c.z, tt.w_sw, fmaf(b.z, tt.w_ne, a.z * tt.w_nw)));
+    }
+  }
+  const int F4 = q.F >> 2;
+  const int vbase = vv * q.Hf * q.Wf;
+  const int o_nw = (vbase + tf.y0 * q.Wf + tf.x0) * F4, o_ne = (vbase + tf.y0 * q.Wf + tf.x1) * F4;
+  const int o_sw = (vbase + tf.y1 * q.Wf + tf.x0) * F4, o_se = (vbase + tf.y1 * q.Wf + tf.x1) * F4;
+
+  // ---- phase 2: F4 lanes per row, RPI consecutive rows (= consecutive samples of one view) per tap instruction ----
+  const int RPI = 64 / F4;
+  const int rsub = lane / F4, c4 = lane - rsub * F4;
+  const bool lane_on = rsub < RPI;
+  for (int it0 = 0; it0 * RPI < 64; it0 += PGT_UNROLL) {
+    float4 ta[PGT_UNROLL], tb[PGT_UNROLL], tc[PGT_UNROLL], td[PGT_UNROLL];
+    float w0[PGT_UNROLL], w1[PGT_UNROLL], w2[PGT_UNROLL], w3[PGT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PGT_UNROLL; ++u) {
+      const int src = (it0 + u) * RPI + rsub < 63 ? (it0 + u) * RPI + rsub : 63;
+#if PGT_EXP == 1
+      const float zz = __shfl(tf.w_nw, src) * 1e-30f;
+      ta[u] = tb[u] = tc[u] = td[u] = make_float4(zz, zz, zz, zz);
+#elif PGT_EXP == 3
+      ta[u] = feat4[(__shfl(o_nw, src) & 7) + c4];
+      tb[u] = feat4[(__shfl(o_ne, src) & 7) + c4];
+      tc[u] = feat4[(__shfl(o_sw, src) & 7) + c4];
+      td[u] = feat4[(__shfl(o_se, src) & 7) + c4];
+#else
+      ta[u] = feat4[__shfl(o_nw, src) + c4];
+      tb[u] = feat4[__shfl(o_ne, src) + c4];
+      tc[u] = feat4[__shfl(o_sw, src) + c4];
+      td[u] = feat4[__shfl(o_se, src) + c4];
+#endif
+      w0[u] = __shfl(tf.w_nw, src); w1[u] = __shfl(tf.w_ne, src); w2[u] = __shfl(tf.w_sw, src); w3[u] = __shfl(tf.w_se, src);
+    }
+#pragma unroll
+    for (int u = 0; u < PGT_UNROLL; ++u) {
+      const int src = (it0 + u) * RPI + rsub;  // owning lane: (point src % P, view wave * VPW + src / P)
+      const int sv = wave * VPW + src / P;
+      if (lane_on && src < 64 && sv < V) {
+        float* o = tile + ((src & (P - 1)) * V + sv) * C + 3 + c4 * 4;
+        o[0] = fmaf(td[u].x, w3[u], fmaf(tc[u].x, w2[u], fmaf(tb[u].x, w1[u], ta[u].x * w0[u])));
+        o[1] = fmaf(td[u].y, w3[u], fmaf(tc[u].y, w2[u], fmaf(tb[u].y, w1[u], ta[u].y * w0[u])));
+        o[2] = fmaf(td[u].z, w3[u], fmaf(tc[u].z, w2[u], fmaf(tb[u].z, w1[u], ta[u].z * w0[u])));
+        o[3] = fmaf(td[u].w, w3[u], fmaf(tc[u].w, w2[u], fmaf(tb[u].w, w1[u], ta[u].w * w0[u])));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the tile leaves as one contiguous burst (p0 * V * C * 4 bytes: 16-byte aligned since P is a multiple of 4) ----
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const long npt = !tile_live ? 0 : ((q.n_pts - p0 < P) ? (q.n_pts - p0) : P);
+  {
+    const int nflt = (int)npt * V * C;
+    float* dst = rgb_feat + p0 * V * C;
+    const float4* src4 = reinterpret_cast<const float4*>(tile);
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+#if PGT_EXP == 2
+    for (int i = tid; i < (nflt >> 2); i += nthr) if (src4[i].x == 1.2345e-33f) nt_store4<1>(dst4 + i, src4[i]);
+#else
+    for (int i = tid; i < (nflt >> 2); i += nthr) nt_store4<1>(dst4 + i, src4[i]);
+    for (int i = (nflt & ~3) + tid; i < nflt; i += nthr) nt_store1<1>(dst + i, tile[i]);
+#endif
+  }
+  __syncthreads();
+  // ---- ray_diff [P][V] float4 and mask [P][V] through the same LDS ----
+  float4* rdt = reinterpret_cast<float4*>(tile);
+  float* mkt = tile + P * V * 4;
+  if (v < V) {
+    rdt[row] = rd;
+    mkt[row] = (pt < q.n_pts) ? mk : 0.0f;
+  }
+  __syncthreads();
+  {
+    const int nrow = (int)npt * V;
+    float4* dst4 = ray_diff + p0 * V;
+    for (int i = tid; i < nrow; i += nthr) nt_store4<1>(dst4 + i, rdt[i]);
+    float* dm = mask + p0 * V;  // p0 * V * 4 bytes: 16-byte aligned
+    const float4* m4 = reinterpret_cast<const float4*>(mkt);
+    for (int i = tid; i < (nrow >> 2); i += nthr) nt_store4<1>(reinterpret_cast<float4*>(dm) + i, m4[i]);
+    for (int i = (nrow & ~3) + tid; i < nrow; i += nthr) nt_store1<1>(dm + i, mkt[i]);
+    if (pix_mask != nullptr && tid < npt) {
+      float cnt = 0.f;
+      for (int k = 0; k < V; ++k) cnt += mkt[tid * V + k];  // 0/1 addends: exact in any order
+      pix_mask[p0 + tid] = cnt > q.mask_thresh ? 1.0f : 0.0f;
+    }
+  }
+}
+
+static int project_gather_rows(const DynProjectGatherParams* p, void* stream) {
   PGShape q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
   q.img_h = p->img_h; q.img_w = p->img_w;
   q.inv_wm1 = 1.0f / (p->img_w - 1.0f); q.inv_hm1 = 1.0f / (p->img_h - 1.0f);
   q.N = (long)p->R * p->S * p->V;
-  DYN_REQUIRE(q.N < (1L << 31) && (long)p->V * p->H * p->W * 3 < (1L << 31) && (long)p->V * p->Hf * p->Wf * p->F < (1L << 31),
-              "dyn_project_gather: R*S*V and the map sizes must stay below 2^31 elements (split the ray batch)");
   q.mV = (unsigned)(((1ULL << 32) + p->V - 1) / p->V);
   q.mS = (unsigned)(((1ULL << 32) + p->S - 1) / p->S);
   q.ntask = (q.N + 63) / 64;
@@ -511,6 +716,49 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
              PG_STAGE ? (size_t)(PG_THREADS / 64) * 64 * (3 + p->F) * sizeof(float) : 0, (hipStream_t)stream, q,
              p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
              reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask);
+  if (p->pix_mask != nullptr) return dyn_sample_mask(p->mask, p->R * p->S, p->V, p->pix_mask_thresh, p->pix_mask, stream);
+  return 0;
+}
+
+extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream) {
+  DYN_REQUIRE(p, "dyn_project_gather: null params");
+  DYN_REQUIRE(p->R > 0 && p->S > 0 && p->V > 0, "dyn_project_gather: empty problem");
+  DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 256, "dyn_project_gather: F must be a multiple of 4 (<=256)");
+  DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->ray_diff && p->mask,
+              "dyn_project_gather: null pointer");
+  DYN_REQUIRE(p->pts_st != nullptr || (p->ray_o && p->ray_d && p->z_vals), "dyn_project_gather: need pts_st or (ray_o, ray_d, z_vals)");
+  DYN_REQUIRE(p->H > 1 && p->W > 1 && p->Hf > 1 && p->Wf > 1, "dyn_project_gather: maps must be at least 2x2");
+  const long N = (long)p->R * p->S * p->V;
+  DYN_REQUIRE(N < (1L << 31) && (long)p->V * p->H * p->W * 3 < (1L << 31) && (long)p->V * p->Hf * p->Wf * p->F < (1L << 31),
+              "dyn_project_gather: R*S*V and the map sizes must stay below 2^31 elements (split the ray batch)");
+  static const int legacy = getenv("DYN_PG_ROWS") != nullptr;  // developer A/B: the row-order kernel of round 1
+  const int C = 3 + p->F;
+  // points per tile: 64 (one view per wave) while the [P][V][C] tile leaves room for two workgroups per CU, else 32 (two views per wave)
+  static const int force_p = getenv("DYN_PG_P") ? atoi(getenv("DYN_PG_P")) : 0;  // developer A/B
+  const int P = force_p ? force_p : (((size_t)64 * p->V * C * 4 <= 72 * 1024 && p->V <= 16) ? 64 : 32);
+  const int waves = (p->V * P + 63) / 64;
+  const size_t lds = (size_t)P * p->V * C * sizeof(float);
+  if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);
+  PGTile q;
+  q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
+  q.img_h = p->img_h; q.img_w = p->img_w;
+  q.inv_wm1 = 1.0f / (p->img_w - 1.0f); q.inv_hm1 = 1.0f / (p->img_h - 1.0f);
+  q.mask_thresh = p->pix_mask_thresh;
+  q.mS = (unsigned)(((1ULL << 32) + p->S - 1) / p->S);
+  q.n_pts = (long)p->R * p->S;
+  q.ntile = (q.n_pts + P - 1) / P;
+  q.tiles_per_xcd = (q.ntile + 7) / 8;
+  const long nblocks = 8 * q.tiles_per_xcd;
+  static const int no_pref = getenv("DYN_PG_NOPREF") != nullptr;  // developer A/B
+  q.pref_wgs = no_pref ? 0 : (int)(nblocks < 512 ? nblocks : 512);  // the first resident generation of workgroups (2 per CU)
+  if (P == 64)
+    DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<64>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
+               p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+  else
+    DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<32>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
+               p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
   return 0;
 }
 

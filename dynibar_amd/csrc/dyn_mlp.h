@@ -236,6 +236,19 @@ __device__ __forceinline__ float row_dot(const f32x16 (&act)[NTI], const float* 
 #ifndef DYN_SPLIT_TERMS
 #define DYN_SPLIT_TERMS 3
 #endif
+// DYN_SPLIT_F16 = 1: the two parts of the 3-term engine are IEEE half floats instead of bf16 (v_mfma_f32_32x32x16_f16: same shape, same
+// rate).  Two halves carry 22 mantissa bits where two bf16 carry 16, so the kept products hi.hi + hi.mid + mid.hi are good to ~2^-20
+// of |x w| (activation parts by truncation, weight parts by round-to-nearest on the host; dropped mid.mid <= 2^-22): fp32-class
+// products at the cost of the 3-term engine.  Range: a half holds |x| < 65504 (beyond, the truncating convert saturates and the
+// second part absorbs up to another 65504: graceful, not silent inf) and residuals below 6e-5 are subnormal halves, an ABSOLUTE
+// error floor of 2^-24 per operand -- fp32's own epsilon at O(1), which is the scale of every activation and weight of these nets
+// (weights outside the half range are refused at pack time).
+#ifndef DYN_SPLIT_F16
+#define DYN_SPLIT_F16 1
+#endif
+#if DYN_SPLIT_F16 && DYN_SPLIT_TERMS != 3
+#error "the half-float split engine has two parts per operand (DYN_SPLIT_TERMS == 3)"
+#endif
 #if DYN_SPLIT_TERMS == 3
 #define DYN_SPLIT_PARTS 2
 #define B6_CHUNK_PAIRS 24
@@ -247,6 +260,7 @@ __device__ __forceinline__ float row_dot(const f32x16 (&act)[NTI], const float* 
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
@@ -357,6 +371,23 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
 
 // exact three-way bf16 split of two fp32 values, each part packed as (first in the low half, second in the high half)
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+#if DYN_SPLIT_F16
+  // truncating pack-convert (one instruction per pair), exact residuals (<= 13 significant bits), truncating pack-convert again
+  const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  hi = __builtin_bit_cast(unsigned, h);
+#if defined(__AMDGCN__)
+  // three instructions per pair: the mixed-precision fma reads the half part, subtracts it from the fp32 value exactly and writes the
+  // residual as a half (round to nearest) straight into its slot of the packed register
+  unsigned m;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(hi), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(hi), "v"(b));
+  mid = m;
+#else
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  mid = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+#endif
+  lo = 0u;
+#else
   f32x2v v = {a, b};
   hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
   f32x2v hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
@@ -369,10 +400,15 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 #else
   lo = 0u;
 #endif
+#endif
 }
 
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {  // the split engine's MFMA (bf16 or half parts)
+#if DYN_SPLIT_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 __host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS) {

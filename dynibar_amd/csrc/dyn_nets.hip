@@ -55,6 +55,42 @@ float bf16_to_f32(unsigned short b) {
   return f;
 }
 
+// round-to-nearest-even IEEE half bits of an fp32 value (subnormal halves included; |x| >= 65520 -> inf, refused by the packer)
+unsigned short f16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);  // >= 65520: rounds to inf
+  if (u < 0x38800000u) {                                          // < 2^-14: subnormal half = round(|x| * 2^24)
+    float a;
+    memcpy(&a, &u, 4);
+    const float scaled = a * 16777216.0f;                          // exact
+    const float r = nearbyintf(scaled);                            // default rounding mode: to nearest even
+    return (unsigned short)(sign | (unsigned)r);
+  }
+  u += 0xc8000000u;                                               // rebias exponent 127 -> 15
+  u += 0x0fffu + ((u >> 13) & 1u);
+  return (unsigned short)(sign | (u >> 13));
+}
+float f16_to_f32(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+  const unsigned e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = (float)m * (1.0f / 16777216.0f);
+  } else {
+    const unsigned u = ((e + 112u) << 23) | (m << 13);
+    memcpy(&f, &u, 4);
+  }
+  unsigned u2;
+  memcpy(&u2, &f, 4);
+  u2 |= sign;
+  memcpy(&f, &u2, 4);
+  return f;
+}
+static bool g_pack_range_error = false;  // set by pack_layer_b6 when a weight does not fit the half-float range
+
 // B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
 void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
   const int NG = (NSLOTS + 7) / 8, GPC = B6_CHUNK_PAIRS / NT, NCH = (NG + GPC - 1) / GPC;
@@ -71,10 +107,18 @@ void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn
             const int s = g * 8 + e;
             if (s >= NSLOTS) continue;
             const float w = fn(t, lane & 31, s, lane >> 5);
+#if DYN_SPLIT_F16
+            if (!(fabsf(w) < 65504.0f)) g_pack_range_error = true;
+            const unsigned short hi = f16_rne(w);
+            const float r1 = w - f16_to_f32(hi);
+            const unsigned short mid = f16_rne(r1);
+            const unsigned short lo = 0;
+#else
             const unsigned short hi = bf16_rne(w);
             const float r1 = w - bf16_to_f32(hi);
             const unsigned short mid = bf16_rne(r1);
             const unsigned short lo = bf16_rne(r1 - bf16_to_f32(mid));
+#endif
             const size_t pair = (size_t)c * B6_CHUNK * 2 + (size_t)(gi * NT + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
             img[pair + 0 * 512 + lane * 8 + e] = hi;
             img[pair + 1 * 512 + lane * 8 + e] = mid;
@@ -212,6 +256,7 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   DYN_REQUIRE(blob_floats >= ST_BLOB_FLOATS, "dyn_static_net_pack: blob too small");
   for (int i = 0; i < ST_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_static_net_pack: tensor %d is NULL", i);
   std::vector<float> o;
+  g_pack_range_error = false;
   o.reserve(ST_BLOB_FLOATS);
   // ---- A ----
   {
@@ -301,6 +346,7 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   for (int i = 0; i < 35 * 66; ++i) o.push_back(T[ST_REFFEAT_W][i]);
   for (int i = 0; i < 35; ++i) o.push_back(T[ST_REFFEAT_B][i]);
   o.resize(ST_BLOB_FLOATS, 0.f);
+  DYN_REQUIRE(!g_pack_range_error, "dyn_static_net_pack: a weight is outside the half-float range of the split engine (|w| >= 65504 or not finite)");
   for (size_t i = 0; i < ST_BLOB_FLOATS; ++i) blob[i] = o[i];
   return 0;
 }
@@ -1210,6 +1256,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   DYN_REQUIRE(blob_floats >= DY_BLOB_FLOATS, "dyn_dynamic_net_pack: blob too small");
   for (int i = 0; i < DT_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_dynamic_net_pack: tensor %d is NULL", i);
   std::vector<float> o;
+  g_pack_range_error = false;
   o.reserve(DY_BLOB_FLOATS);
   {
     const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];  // input [mean | var | x]  (mlp_network.py:262-266)
@@ -1297,6 +1344,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   for (int i = 0; i < 35 * 256; ++i) o.push_back(T[DT_RAYDIR2_W][i]);
   for (int i = 0; i < 35; ++i) o.push_back(T[DT_RAYDIR2_B][i]);
   o.resize(DY_BLOB_FLOATS, 0.f);
+  DYN_REQUIRE(!g_pack_range_error, "dyn_dynamic_net_pack: a weight is outside the half-float range of the split engine (|w| >= 65504 or not finite)");
   for (size_t i = 0; i < DY_BLOB_FLOATS; ++i) blob[i] = o[i];
   return 0;
 }
@@ -1434,6 +1482,7 @@ extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* 
   DYN_REQUIRE(blob_floats >= MO_BLOB_FLOATS, "dyn_motion_mlp_pack: blob too small");
   for (int i = 0; i < MT_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_motion_mlp_pack: tensor %d is NULL", i);
   std::vector<float> o;
+  g_pack_range_error = false;
   o.reserve(MO_BLOB_FLOATS);
   {
     const float *W = T[MT_L0_W], *b = T[MT_L0_B];
@@ -1463,6 +1512,7 @@ extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* 
     const float step = (17.0f - 1.0f) / 15.0f;
     for (int i = 0; i < 16; ++i) o.push_back(i < 8 ? 1.0f + (float)i * step : 17.0f - (float)(15 - i) * step);
   }
+  DYN_REQUIRE(!g_pack_range_error, "dyn_motion_mlp_pack: a weight is outside the half-float range of the split engine (|w| >= 65504 or not finite)");
   for (size_t i = 0; i < MO_BLOB_FLOATS; ++i) blob[i] = o[i];
   return 0;
 }
@@ -1566,6 +1616,15 @@ extern "C" int dyn_mlp_split_terms(void) {
   return DYN_SPLIT_TERMS;
 #else
   return 0;  // native fp32 MFMA engine
+#endif
+}
+extern "C" int dyn_mlp_split_kind(void) {  // 0: native fp32 MFMA, 1: bf16 parts, 2: half-float parts
+#if !DYN_ENGINE_B6
+  return 0;
+#elif DYN_SPLIT_F16
+  return 2;
+#else
+  return 1;
 #endif
 }
 

@@ -91,19 +91,24 @@ def points_from_z(ray_o, ray_d, z_vals, depth_range=None, want_pts=True):
   return pts, s
 
 
-def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None):
-  """k_project_gather -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]."""
+def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None, pix_mask_thresh=None):
+  """k_project_gather_tile -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]; with pix_mask_thresh also the per-sample
+  observation mask ``mask[..., 0].sum(dim=2) > thresh`` [R,S] (render_ray.py:736-741) as a fourth result, from the same launch."""
   k = _Keep()
   dev = views.proj.device
   V, C = views.V, 3 + views.F
   rgb_feat = torch.empty((R, S, V, C), dtype=torch.float32, device=dev)
   ray_diff = torch.empty((R, S, V, 4), dtype=torch.float32, device=dev)
   mask = torch.empty((R, S, V, 1), dtype=torch.float32, device=dev)
+  pix = torch.empty((R, S), dtype=torch.float32, device=dev) if pix_mask_thresh is not None else None
   p = params('DynProjectGatherParams', R=R, S=S, V=V, H=views.H, W=views.W, Hf=views.Hf, Wf=views.Wf, F=views.F,
              img_h=views.img_h, img_w=views.img_w, ray_o=k(ray_o), ray_d=k(ray_d), z_vals=k(z_vals),
              pts_st=k(pts_st), xyz=k(xyz), proj=ptr(views.proj), query_center=ptr(views.query_center),
-             src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask))
+             src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask),
+             pix_mask=ptr(pix), pix_mask_thresh=float(pix_mask_thresh) if pix_mask_thresh is not None else 0.0)
   call('dyn_project_gather', ctypes.byref(p), stream_of(rgb_feat))
+  if pix_mask_thresh is not None:
+    return rgb_feat, ray_diff, mask, pix
   return rgb_feat, ray_diff, mask
 
 

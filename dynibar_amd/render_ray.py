@@ -149,10 +149,9 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
   views_dy = projector.source_views(ray_batch['camera'], ray_batch['src_rgbs'], ray_batch['src_cameras'], featmaps_dy)
   views_st = projector.source_views(ray_batch['camera'], ray_batch['static_src_rgbs'], ray_batch['static_src_cameras'], featmaps_st)
   assert views_dy.V == len(rows), 'one time offset (or virtual view) per dynamic source view'
-  rgb_feat_dy, _, mask_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq)
-  rgb_feat_st, ray_diff_st, mask_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals)
-  pm_dy = ops.sample_mask(mask_dy, 1.0)  # at least 2 observations (render_ray.py:736-741)
-  pm_st = ops.sample_mask(mask_st, 1.0)
+  # sample masks: at least 2 observations (render_ray.py:736-741), counted by the gather kernel itself
+  rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
+  rgb_feat_st, ray_diff_st, mask_st, pm_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals, pix_mask_thresh=1.0)
   raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
   raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
   return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis)
@@ -286,8 +285,7 @@ def _anchor_pass(model, names, args, projector, ray_batch, featmaps_anchor, stag
   pts_traj_ref = ops.trajectory_points(coeff, basis, pts, [(r + ro) % nf for _, ro in both], r % nf)
   views_a = projector.source_views(ray_batch['camera'], ray_batch['anchor_src_rgbs'], ray_batch['anchor_src_cameras'], featmaps_anchor)
   assert views_a.V == len(rows_a), 'one time offset (or virtual view) per anchor source view'
-  rgb_feat_a, _, mask_a = ops.project_gather(views_a, R, S, pts_st=pts, xyz=pts_seq_a)
-  pm_a = ops.sample_mask(mask_a, 0.0)  # one observation is enough here (:1197-1199)
+  rgb_feat_a, _, mask_a, pm_a = ops.project_gather(views_a, R, S, pts_st=pts, xyz=pts_seq_a, pix_mask_thresh=0.0)  # one observation is enough here (:1197-1199)
   raw_a = _dynamic_net(model, names['dy'], dev)(ray_batch['ray_d'], pts_anchor, rgb_feat_a, mask_a, time_a)
   out_a = ops.composite(raw_a, z_vals, pm_a, stage['raw_st'], stage['pm_st'])
   out_a['mask'] = out_a['mask'] > 0

@@ -158,9 +158,11 @@ def motion_layer_table(num_basis=6, W=256, D=8, input_ch=4, num_freqs=16, skips=
   return tab
 
 
-def make_weights(kind, seed=0, F=32, num_basis=6, gain=1.0):
+def make_weights(kind, seed=0, F=32, num_basis=6, gain=1.0, bias=0.1, head_gain=1.0, ln_gain=1.0):
   """Seeded state-dict (numpy float32) for 'static' | 'dynamic' | 'motion'.
 
+  ``gain`` scales every weight matrix, ``bias`` the bias range, ``head_gain`` the density head, ``ln_gain`` the LayerNorm gains:
+  the "trained-scale" test weights use them to reach activations of tens and density logits of +-30..50.
   Kaiming-uniform-like scale so activations stay O(1) through ~20 layers; biases
   are non-zero and the MotionMLP head is non-zero (the reference zero-inits it,
   mlp_network.py:602-603, which would make scene motion a no-op in tests).
@@ -175,9 +177,10 @@ def make_weights(kind, seed=0, F=32, num_basis=6, gain=1.0):
     bound = gain * np.sqrt(3.0 / nin)
     sd[name + '.weight'] = rng.uniform(-bound, bound, (nout, nin)).astype(np.float32)
     if has_bias:
-      sd[name + '.bias'] = rng.uniform(-0.1, 0.1, (nout,)).astype(np.float32)
+      sd[name + '.bias'] = rng.uniform(-bias, bias, (nout,)).astype(np.float32)
   if kind in ('static', 'dynamic'):
-    sd['ray_attention.layer_norm.weight'] = (1.0 + 0.1 * rng.standard_normal(128)).astype(np.float32)
+    sd['ray_attention.layer_norm.weight'] = (ln_gain * (1.0 + 0.1 * rng.standard_normal(128))).astype(np.float32)
+    sd['out_geometry_fc.2.weight'] *= np.float32(head_gain)  # the density head: trained nets reach logits of +-30..50
     sd['ray_attention.layer_norm.bias'] = (0.05 * rng.standard_normal(128)).astype(np.float32)
   if kind == 'static':
     sd['s'] = np.array(0.2, np.float32)  # anti-alias pooling temperature (mlp_network.py:331)

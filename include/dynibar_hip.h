@@ -75,6 +75,8 @@ typedef struct {
   float* rgb_feat;          /* [R,S,V,3+F] */
   float* ray_diff;          /* [R,S,V,4] */
   float* mask;              /* [R,S,V] (the reference's trailing singleton dim is a view) */
+  float* pix_mask;          /* [R,S] or NULL: 1 where more than pix_mask_thresh views see the sample (render_ray.py:736-741), else 0 */
+  float pix_mask_thresh;
 } DynProjectGatherParams;
 int dyn_project_gather(const DynProjectGatherParams* p, void* stream);
 
@@ -207,9 +209,11 @@ int dyn_expected_scene_flow(const float* weights, const float* coeff, const floa
 /* ---- a2 RaySamplerSingleImage.get_rays_single_image (sample_ray.py:143-163): camera DEVICE [34]; rays_o, rays_d [(H/stride)*(W/stride),3] */
 int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream);
 
-/* ---- how the network kernels of this build multiply: 3 or 6 = bf16 split-product terms kept per fp32 product (csrc/dyn_mlp.h;
- * 6 is fp32-class, 3 keeps 16 mantissa bits per operand), 0 = native fp32 MFMA engine ------------------------------------------- */
+/* ---- how the network kernels of this build multiply (csrc/dyn_mlp.h): split terms = partial products kept per fp32 product (3 or 6;
+ * 0 = native fp32 MFMA engine); split kind = what the operand parts are: 0 none (fp32 MFMA), 1 bf16 (3 terms: 16 mantissa bits per
+ * operand; 6 terms: fp32-class), 2 IEEE half (3 terms: 22 mantissa bits per operand, fp32-class; the shipped engine) --------------- */
 int dyn_mlp_split_terms(void);
+int dyn_mlp_split_kind(void);
 
 /* ---- self-test of the MFMA chain engine: y = elu(W elu(W x + b) + b), W [64,64], b [64] HOST; x, y [rows,64] DEVICE;
  * stream_buf: DEVICE scratch of 2 * 3 * 4096 floats ------------------------------------------------------------------- */

@@ -55,6 +55,22 @@ def model_weights(seed=0):
   return m
 
 
+def model_weights_trained(seed=3):
+  """Weights at the scale of a trained model rather than of an initialisation: every matrix 1.4x Kaiming, biases up to +-1, LayerNorm
+  gains around 3, density heads 5x: density logits spanning -40..+25 on the test scenes (what the split-product engine must hold
+  1e-4 (+1e-4 relative) on)."""
+  kw = dict(gain=1.4, bias=1.0, head_gain=5.0, ln_gain=3.0)
+  m = {
+      'net_coarse_st': syn.make_weights('static', seed, **kw),
+      'net_coarse_dy': syn.make_weights('dynamic', seed, **kw),
+      'net_fine_st': syn.make_weights('static', seed + 100, **kw),
+      'net_fine_dy': syn.make_weights('dynamic', seed + 100, **kw),
+      'motion_mlp': syn.make_weights('motion', seed, num_basis=NUM_BASIS, gain=1.3, bias=0.5),
+      'motion_mlp_fine': syn.make_weights('motion', seed + 100, num_basis=NUM_BASIS, gain=1.3, bias=0.5),
+  }
+  return m
+
+
 def anchor_case(scene, num_vv=2, anchor_shift=1):
   """Anchor-time inputs of the monocular training path for a scene_case scene: the anchor frame's source set is the scene's own
   source set rolled by two views (different images / cameras / feature maps per slot), its time offsets are a different list.

@@ -232,6 +232,42 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, e
   return c;
 }
 
+// v_mfma_f32_32x32x16_f16: same operand layout as the bf16 form, IEEE half elements
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 emu_f16x2 __attribute__((ext_vector_type(2)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, int, int, int) {
+  uint64_t aw[2], bw[2];
+  memcpy(aw, &a, 16);
+  memcpy(bw, &b, 16);
+  auto s = emu::exchange(aw[0], aw[1], bw[0], bw[1]);
+  auto elem = [&](int lane, int which, int e) -> float {
+    uint64_t w = s[lane][which * 2 + (e >> 2)];
+    unsigned short bits = (unsigned short)((w >> (16 * (e & 3))) & 0xffffu);
+    _Float16 h; memcpy(&h, &bits, 2); return (float)h;
+  };
+  int l = emu::tc.lane, j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(elem(row + 32 * (k >> 3), 0, k & 7), elem(j + 32 * (k >> 3), 1, k & 7), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+// v_cvt_pkrtz_f16_f32: two fp32 -> packed halves, rounded toward zero (finite overflow saturates at 65504)
+static inline _Float16 emu_f16_rtz(float x) {
+  _Float16 h = (_Float16)x;                       // round to nearest even
+  if (__builtin_isnan(x)) return h;
+  if (__builtin_isinf((float)h) && !__builtin_isinf(x)) { h = (_Float16)65504.0f; return x < 0 ? -h : h; }
+  if (__builtin_fabsf((float)h) > __builtin_fabsf(x)) {  // step one ulp toward zero
+    unsigned short b; memcpy(&b, &h, 2); b -= 1; memcpy(&h, &b, 2);
+  }
+  return h;
+}
+static inline emu_f16x2 __builtin_amdgcn_cvt_pkrtz(float a, float b) {
+  emu_f16x2 r; r[0] = emu_f16_rtz(a); r[1] = emu_f16_rtz(b); return r;
+}
+
 // v_mov_b32_dpp for the lane selects used by csrc: quad_perm (ctrl < 0x100), row_half_mirror (0x141), row_mirror (0x140)
 static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) {
   auto s = emu::exchange(emu::bits(v), 0);

@@ -56,6 +56,16 @@ def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
 
 
+@pytest.mark.parametrize('name', ['small', 'harsh'])
+def test_trained_scale_weights(dev, name):
+  """The split-product engine at the scale of a trained model (activations of tens, density logits -40..+25, LayerNorm gains ~3):
+  network outputs within 1e-4 (+1e-4 relative), rendered colours within 1e-4; the achieved fractions are in the margin report."""
+  parity.check_static_net(dev, name, S=64, weights='trained')
+  parity.check_dynamic_net(dev, name, S=64, shift=5.0, weights='trained')
+  parity.check_motion(dev, name, S=64, weights='trained')
+  parity.check_static_pass(dev, name, weights='trained')
+
+
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64, shift=5.0), dict(name='noise', S=128), dict(name='small', S=32, R=3), dict(name='small', S=256, R=6), dict(name='harsh', S=160, R=5, shift=2.0)])
 def test_dynamic_net(dev, kw):
   parity.check_dynamic_net(dev, **kw)
