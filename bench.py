@@ -4,16 +4,20 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the static-branch hot path over one batch of R = 4096 rays per GPU (64 coarse samples, 8 source
-views): sample_along_ray -> project_gather -> DynibarStatic (views / points / blend kernels) -> composite,
-all through the C-ABI of libdynibar_hip.so with inputs resident in HBM.  With N > 1 every rank renders its own tile of rays
-(weak scaling: rays are independent) and each step ends with the RCCL all-gather of the rendered pixels.
+views): sample_along_ray -> project_gather -> DynibarStatic (views / points / blend kernels) -> composite, all through the
+C-ABI of libdynibar_hip.so with inputs resident in HBM.  With N > 1 every rank renders its own tile of rays (weak scaling: rays
+are independent) and each step ends with the RCCL all-gather of the rendered pixels.
 Prints ONE JSON line (rank 0).  The CPU leg times the oracle (the reference algorithm restated on torch-CPU) on a bounded
-sample of the same workload; it is a reported baseline, not the target.
+sample of the same workload (median of 3); it is a reported baseline, not the target.  Extra legs in the same line (`extra`): the
+same step at the Nvidia eval's real static view count (11), one full 288x512 frame through render_single_image_nvi (on N > 1 GPUs:
+ray-tiled across the ranks -- a strong-scaling number next to the weak-scaling headline), and the HBM traffic of the network and
+gather kernels measured by rocprofv3 --pmc children of this same command.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,24 +26,117 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 H, W, F = 288, 512, 32
 # algorithmic FLOPs (2 x MAC of the reference's Linear layers, mlp_network.py:333-405) per point-view of k_static_views:
 # ray_dir_fc 103x256+256x35, base_fc 210x256+256x128, vis_fc 128x128+128x129, vis_fc2 128x128+128x1
 FLOP_VIEWS_PER_PV = 2 * (103 * 256 + 256 * 35 + 210 * 256 + 256 * 128 + 128 * 128 + 128 * 129 + 128 * 128 + 128)
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
-# The network kernels run fp32-accurate products on the bf16 matrix pipe: every fp32 operand is split exactly into three bf16 parts and a
-# product keeps 3 (default build) or 6 (fp32-class build) partial products (csrc/dyn_mlp.h), so the matrix-pipe ceiling for ALGORITHMIC
-# fp32 FLOPs is the bf16 peak / terms.
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HALF_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA (v_mfma_f32_32x32x16_{bf16,f16})
+HBM_PEAK_GBPS = 8000.0
+KIND = {0: 'native fp32 MFMA', 1: 'bf16', 2: 'f16'}
+
+
 def split_peak(terms):
-  """matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs: bf16 dense peak / partial products kept (0 = native fp32 MFMA engine)."""
-  return FP32_MFMA_PEAK_TFLOPS if terms == 0 else BF16_MFMA_PEAK_TFLOPS / terms
+  """Matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs: the network kernels multiply fp32 operands as exact sums of 16-bit parts and keep
+  `terms` partial products per product on the 16-bit matrix pipe (csrc/dyn_mlp.h), so the ceiling is the dense 16-bit peak / terms
+  (0 = the native fp32 MFMA engine)."""
+  return FP32_MFMA_PEAK_TFLOPS if terms == 0 else HALF_MFMA_PEAK_TFLOPS / terms
 
 
 def static_net_flops_per_point(S, V):
   """Linear layers + attention matmuls of DynibarStatic, per sample point."""
   return 0.361e6 + 0.033e6 * (S / 64.0) + 0.4305e6 * V
+
+
+def gather_bytes(R, S, V):
+  """compulsory bytes of the fused projection/gather per launch."""
+  return R * S * V * 160 + V * ((H // 4) * (W // 4) * F + H * W * 3) * 4 + R * (24 + 4 * S)
+
+
+def read_kernels(lib):
+  nk = lib.dyn_profile_count()
+  ms = (ctypes.c_float * nk)()
+  cnt = (ctypes.c_int * nk)()
+  lib.dyn_profile_read(ms, cnt)
+  return {lib.dyn_profile_name(i).decode(): {'launches': cnt[i], 'avg_ms': ms[i] / cnt[i]} for i in range(nk) if cnt[i] > 0}
+
+
+class StaticStep:
+  """The bench workload on one device: everything resident in HBM; step() launches one pass of the hot path."""
+
+  def __init__(self, dev, R, S, V, rank=0):
+    from dynibar_amd import ops, synthetic as syn
+    self.ops, self.R, self.S, self.V = ops, R, S, V
+    self.sc = syn.make_scene(seed=0, H=H, W=W, V=V, F=F, n_static=V)
+    T = lambda x: torch.from_numpy(x).to(dev)
+    self.scene = {k: T(v) for k, v in self.sc.items()}
+    pix = syn.sample_pixels(100 + rank, H, W, R)  # each rank renders its own tile of rays
+    self.o_np, self.d_np, _ = syn.pixel_rays(self.sc['camera'], pix)
+    self.ray_o, self.ray_d = T(self.o_np), T(self.d_np)
+    self.weights = syn.make_weights('static', 0, F)
+    self.net = ops.StaticNet(self.weights, dev, anti_alias_pooling=True, mask_rgb=False)
+    self.views = ops.SourceViews(self.scene['camera'], self.scene['static_src_rgbs'], self.scene['static_src_cameras'], self.scene['static_featmaps'])
+
+  def step(self):
+    ops, R, S = self.ops, self.R, self.S
+    pts, z, _ = ops.sample_along_ray(self.ray_o, self.ray_d, self.scene['depth_range'], S, True, want_s=False)
+    rgb_feat, ray_diff, mask, pm = ops.project_gather(self.views, R, S, ray_o=self.ray_o, ray_d=self.ray_d, z_vals=z, pix_mask_thresh=1.0)
+    raw = self.net(self.views, self.ray_o, self.ray_d, pts, rgb_feat, ray_diff, mask)
+    return ops.composite(raw, z, pm, per_sample=False)
+
+
+def timed(lib, step, steps, warmup, fence):
+  for _ in range(warmup):
+    out = step()
+  fence()
+  lib.dyn_profile_enable(1)
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    out = step()
+  fence()
+  dt = time.perf_counter() - t0
+  lib.dyn_profile_enable(0)
+  return out, dt, read_kernels(lib)
+
+
+def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE')):
+  """HBM-side bytes per launch of every kernel of this bench, by rocprofv3 --pmc children of this same command (one counter per pass, as
+  MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950: wide coalesced reads are tallied at half their bytes)."""
+  import glob
+  import shutil
+  import sqlite3
+  import tempfile
+  exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+  if not os.path.exists(exe):
+    return None, 'rocprofv3 not found'
+  res = {}
+  for c in counters:
+    d = tempfile.mkdtemp(prefix='dynibar_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
+    try:
+      cmd = [exe, '--kernel-trace', '--pmc', c, '-d', d, '--', sys.executable, os.path.abspath(__file__), '--child', '--steps', '4', '--warmup', '1',
+             '--rays', str(a.rays), '--samples', str(a.samples), '--views', str(a.views)]
+      r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=d, env=dict(os.environ, TMPDIR=d))
+      dbs = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
+      if not dbs:
+        return None, f'rocprofv3 --pmc {c}: no database written (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}'
+      cur = sqlite3.connect(dbs[0]).cursor()
+      for name, n, v in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (c,)):
+        key = name.replace('void ', '').split('<')[0].split('(')[0]
+        res.setdefault(key, {})[c + '_KB'] = v
+        res[key]['dispatches'] = n
+    except Exception as e:  # the profiler leg must never cost the main line
+      return None, f'rocprofv3 --pmc {c} failed: {str(e)[:200]}'
+    finally:
+      shutil.rmtree(d, ignore_errors=True)
+  out = {}
+  for k, v in res.items():
+    if k.startswith('k_') and 'FETCH_SIZE_KB' in v and 'WRITE_SIZE_KB' in v:
+      out[k] = {'bytes': 2 * v['FETCH_SIZE_KB'] * 1024 + v['WRITE_SIZE_KB'] * 1024, 'fetch_kb_raw': v['FETCH_SIZE_KB'], 'write_kb': v['WRITE_SIZE_KB'],
+                'dispatches': v['dispatches']}
+  return out, ('bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, rocprofv3 --kernel-trace --pmc <one counter per pass> '
+               'children of this command (4 steps each)')
 
 
 def main():
@@ -51,8 +148,14 @@ def main():
   ap.add_argument('--samples', type=int, default=64)
   ap.add_argument('--views', type=int, default=8)
   ap.add_argument('--cpu-rays', type=int, default=256, help='rays of the same workload timed on the host oracle (0 = skip)')
-  ap.add_argument('--no-x6', action='store_true', help='skip the extra leg that times the fp32-class (6-term split) engine build')
+  ap.add_argument('--no-x6', action='store_true', help='(kept for old command lines; the bf16 6-term leg is off unless --x6)')
+  ap.add_argument('--x6', action='store_true', help='also time the bf16 6-term split engine build (libdynibar_hip_x6.so)')
+  ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (11 views, full frame)')
+  ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc child runs that measure HBM traffic per launch')
+  ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
   a = ap.parse_args()
+  if a.child:
+    a.cpu_rays, a.no_extra, a.no_traffic, a.x6 = 0, True, True, False
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -68,26 +171,15 @@ def main():
     import torch.distributed as dist
     dist.init_process_group('nccl', device_id=dev)
 
-  from dynibar_amd import _lib, ops, synthetic as syn
+  from dynibar_amd import _lib
   lib = _lib.lib()
 
   R, S, V = a.rays, a.samples, a.views
-  sc = syn.make_scene(seed=0, H=H, W=W, V=V, F=F, n_static=V)
-  T = lambda x: torch.from_numpy(x).to(dev)
-  scene = {k: T(v) for k, v in sc.items()}
-  pix = syn.sample_pixels(100 + rank, H, W, R)  # each rank renders its own tile of rays
-  o_np, d_np, _ = syn.pixel_rays(sc['camera'], pix)
-  ray_o, ray_d = T(o_np), T(d_np)
-  weights = syn.make_weights('static', 0, F)
-  net = ops.StaticNet(weights, dev, anti_alias_pooling=True, mask_rgb=False)
-  views = ops.SourceViews(scene['camera'], scene['static_src_rgbs'], scene['static_src_cameras'], scene['static_featmaps'])
+  wl = StaticStep(dev, R, S, V, rank)
   gathered = torch.empty((world * R, 4), dtype=torch.float32, device=dev) if world > 1 else None
 
   def step():
-    pts, z, _ = ops.sample_along_ray(ray_o, ray_d, scene['depth_range'], S, True, want_s=False)
-    rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z, pix_mask_thresh=1.0)
-    raw = net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
-    out = ops.composite(raw, z, pm, per_sample=False)
+    out = wl.step()
     if world > 1:
       dist.all_gather_into_tensor(gathered, torch.cat([out['rgb'], out['depth'][:, None]], dim=1))
     return out
@@ -98,26 +190,52 @@ def main():
       dist.barrier()
       torch.cuda.synchronize()
 
-  for _ in range(a.warmup):
-    out = step()
-  fence()
-  lib.dyn_profile_enable(1)
-  t0 = time.perf_counter()
-  for _ in range(a.steps):
-    out = step()
-  fence()
-  dt = time.perf_counter() - t0
-  lib.dyn_profile_enable(0)
-  if world > 1:
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+  def max_over_ranks(x):
+    if world == 1:
+      return x
+    tt = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    return float(tt.item())
 
-  nk = lib.dyn_profile_count()
-  ms = (ctypes.c_float * nk)()
-  cnt = (ctypes.c_int * nk)()
-  lib.dyn_profile_read(ms, cnt)
-  kernels = {lib.dyn_profile_name(i).decode(): {'launches': cnt[i], 'avg_ms': ms[i] / cnt[i]} for i in range(nk) if cnt[i] > 0}
+  out, dt, kernels = timed(lib, step, a.steps, a.warmup, fence)
+  dt = max_over_ranks(dt)
+
+  # ---- extra legs (every rank takes part in the frame leg: the ray tiles are a collective effort) ----
+  extra = {}
+  if not a.no_extra:
+    try:
+      from frame_case import FrameCase
+      fc = FrameCase(dev)
+      smp, rb = fc.sampler()
+      fc.render(smp, rb)  # warm-up: packs the six networks, prepares the source views
+      fence()
+      lib.dyn_profile_enable(1)
+      t0 = time.perf_counter()
+      ret = fc.render(smp, rb)
+      fence()
+      fdt = max_over_ranks(time.perf_counter() - t0)
+      lib.dyn_profile_enable(0)
+      fk = read_kernels(lib)
+      extra['frame_nvi_288x512'] = {
+          'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
+                  + ('rays tiled over %d ranks, one packed [rays,5] all-gather: strong scaling' % world if world > 1 else 'one GPU'),
+          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': H * W / fdt,
+          'kernel_ms_per_frame_rank0': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},
+          'pixels_check': [float(ret['outputs_fine_ref']['rgb'].mean()), float(ret['outputs_fine_ref']['depth'].mean())]}
+      del fc, smp, rb, ret
+    except Exception as e:
+      extra['frame_nvi_288x512'] = {'error': str(e)[:300]}
+    if world == 1:
+      try:
+        wl11 = StaticStep(dev, R, S, 11, rank)
+        _, dt11, k11 = timed(lib, wl11.step, max(5, a.steps // 2), 2, fence)
+        n11 = max(5, a.steps // 2)
+        extra['views_11'] = {'what': 'the same step at the 11 static source views of the Nvidia eval (eval_nvidia.py:92-119)', 'value': R * n11 / dt11, 'unit': 'rays/s',
+                             'ms_per_step': dt11 / n11 * 1e3, 'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in k11.items()},
+                             'k_static_views_vs_8_views': k11['k_static_views']['avg_ms'] / kernels['k_static_views']['avg_ms'], 'rows_vs_8_views': 11 / 8}
+        del wl11
+      except Exception as e:
+        extra['views_11'] = {'error': str(e)[:300]}
 
   if rank != 0:
     if world > 1:
@@ -125,59 +243,54 @@ def main():
     return
 
   value = world * R * a.steps / dt
-  terms = int(lib.dyn_mlp_split_terms())
-  B6_PEAK_TFLOPS = split_peak(terms)
+  terms, kind = int(lib.dyn_mlp_split_terms()), int(lib.dyn_mlp_split_kind())
+  peak = split_peak(terms)
   dom = kernels['k_static_views']
   flops_launch = FLOP_VIEWS_PER_PV * R * S * V
   achieved = flops_launch / (dom['avg_ms'] * 1e-3) / 1e12
   net_ms = sum(kernels[k]['avg_ms'] for k in ('k_static_ref_feat', 'k_static_views', 'k_static_points', 'k_static_blend'))
   net_tflops = static_net_flops_per_point(S, V) * R * S / (net_ms * 1e-3) / 1e12
-  # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are collected with
-  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this same command and stored by tools/rocpd_summary.py traffic
-  traffic, traffic_note = None, 'no PMC summary for this build (profiles/r01_traffic.json)'
-  tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-  if os.path.exists(tpath) and (R, S, V) == (4096, 64, 8) and terms == 3:
-    try:
-      with open(tpath) as f:
-        tj = json.load(f)['k_static_views']
-      # gfx950 rocprofv3: FETCH_SIZE counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM section)
-      traffic = 2 * tj['FETCH_SIZE_KB'] * 1024 + tj['WRITE_SIZE_KB'] * 1024
-      traffic_note = (f"bytes per launch from {tj['source']}: 2 x FETCH_SIZE ({tj['FETCH_SIZE_KB']:.0f} KB, gfx950 half-count correction) + "
-                      f"WRITE_SIZE ({tj['WRITE_SIZE_KB']:.0f} KB); collected on the same bench command, not in this run")
-    except Exception as e:
-      traffic_note = f'profiles/r01_traffic.json unreadable: {e}'
   pg = kernels['k_project_gather']
-  pg_bytes = R * S * V * 160 + V * ((H // 4) * (W // 4) * F + H * W * 3) * 4 + R * (24 + 4 * S)
+  pg_bytes = gather_bytes(R, S, V)
+  engine = 'f32' if terms == 0 else f'f32 ({KIND[kind]}x{terms} split-product MFMA: fp32 operands as exact sums of {KIND[kind]} parts, f32 accumulate)'
+
+  traffic, traffic_note = None, 'skipped (--no-traffic)'
+  if not a.no_traffic and world == 1:
+    traffic, traffic_note = pmc_traffic(a)
+  tr = lambda k: (traffic[k]['bytes'] if traffic and k in traffic else None)
+
   res = {
       'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps,
       'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-      'dtype': 'f32' if terms == 0 else f'f32 (bf16x{terms} split-product MFMA, f32 accumulate)', 'data': 'synthetic',
+      'dtype': engine, 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: Nvidia Balloon1 eval shape, static branch only '
                              '(sample -> project/gather -> DynibarStatic -> composite)',
                  'rays_per_step_per_gpu': R, 'samples': S, 'src_views': V, 'src_image': [H, W], 'feature_map': [F, H // 4, W // 4],
                  'sharding': 'ray tiles per rank + RCCL all-gather of rendered pixels' if world > 1 else 'single GPU'},
-      'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': achieved, 'peak': B6_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                   'frac': achieved / B6_PEAK_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note, 'avg_launch_ms': dom['avg_ms'],
+      'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                   'frac': achieved / peak, 'traffic': tr('k_static_views'), 'traffic_note': traffic_note, 'avg_launch_ms': dom['avg_ms'],
                    'algorithmic_flops_per_launch': flops_launch,
-                   'peak_note': f'fp32 operands as exact bf16 splits, {terms} partial products per product on the bf16 matrix pipe, fp32 '
-                                f'accumulation: peak = 2500 TFLOP/s dense bf16 MFMA / {terms}; the native fp32 MFMA peak is 157.3 TFLOP/s',
-                   'vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS},
-      'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': B6_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': net_tflops / B6_PEAK_TFLOPS, 'avg_ms': net_ms, 'vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS},
-      'roofline_project_gather': {'bound': 'hbm', 'achieved': pg_bytes / (pg['avg_ms'] * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                                  'frac': pg_bytes / (pg['avg_ms'] * 1e-3) / 8e12, 'avg_launch_ms': pg['avg_ms'],
-                                  'algorithmic_bytes_per_launch': pg_bytes},
+                   'peak_note': f'fp32 operands as exact sums of two {KIND[kind]} parts, {terms} partial products per product on the 16-bit matrix pipe, fp32 '
+                                f'accumulation: peak = 2500 TFLOP/s dense / {terms}; against the native fp32 MFMA peak (157.3 TFLOP/s) see frac_vs_fp32_mfma_peak',
+                   'frac_vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS},
+      'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': net_tflops / peak, 'avg_ms': net_ms,
+                              'frac_vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS},
+      'roofline_project_gather': {'kernel': 'k_project_gather_tile', 'bound': 'hbm', 'achieved': pg_bytes / (pg['avg_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
+                                  'unit': 'GB/s', 'frac': pg_bytes / (pg['avg_ms'] * 1e-3) / (HBM_PEAK_GBPS * 1e9), 'avg_launch_ms': pg['avg_ms'],
+                                  'algorithmic_bytes_per_launch': pg_bytes, 'traffic': tr('k_project_gather_tile')},
       'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()},
+      'traffic_per_launch': traffic,
+      'extra': extra,
   }
 
   if a.cpu_rays > 0 and world == 1:
     # the oracle (test infrastructure) is used here ONLY as the timed CPU baseline and as the checker of this run's pixels
     from oracle import ibr_oracle as O
     n = min(a.cpu_rays, R)
-    cpu_scene = {k: torch.from_numpy(v) for k, v in sc.items()}
-    sd = O.tdict(weights)
-    co, cd = torch.from_numpy(o_np[:n]), torch.from_numpy(d_np[:n])
-    # torch-CPU oversubscribes on these small per-ray tensors: pick the best thread count on a 32-ray probe, then time the sample
+    cpu_scene = {k: torch.from_numpy(v) for k, v in wl.sc.items()}
+    sd = O.tdict(wl.weights)
+    co, cd = torch.from_numpy(wl.o_np[:n]), torch.from_numpy(wl.d_np[:n])
+    # torch-CPU oversubscribes on these small per-ray tensors: pick the best thread count on a 32-ray probe, then time the sample 3 times
     best = None
     with torch.no_grad():
       for th in sorted({8, 32, min(64, os.cpu_count() or 1), os.cpu_count() or 1}):
@@ -190,27 +303,29 @@ def main():
           best = (th, tp)
       cores = best[0]
       torch.set_num_threads(cores)
-      t1 = time.perf_counter()
-      ref = O.static_branch_pass(sd, cpu_scene, co, cd, S, True, True)
-      cpu_dt = time.perf_counter() - t1
+      runs = []
+      for _ in range(3):
+        t1 = time.perf_counter()
+        ref = O.static_branch_pass(sd, cpu_scene, co, cd, S, True, True)
+        runs.append(time.perf_counter() - t1)
+    cpu_dt = float(np.median(runs))
     res['cpu_baseline'] = {'value': n / cpu_dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-                           'sample': f'{n} of the {R} rays of one step, same scene/weights, torch-CPU oracle, {cores} threads (best of 8/32/64/all on a 32-ray probe; host has {os.cpu_count()} hardware threads), 1 run after warm-up'}
+                           'sample': f'{n} of the {R} rays of one step, same scene/weights, torch-CPU oracle, {cores} threads (best of 8/32/64/all on a 32-ray probe; '
+                                     f'host has {os.cpu_count()} hardware threads), median of 3 runs after warm-up ({", ".join("%.2f s" % r for r in runs)})'}
     err = (out['rgb'][:n].cpu() - ref['rgb']).abs()
     mse = float((err ** 2).mean())
     res['check_vs_oracle'] = {'rays': n, 'max_abs_rgb_err': float(err.max()), 'psnr_db': (10 * np.log10(1.0 / mse)) if mse > 0 else float('inf')}
   x6 = os.path.join(ROOT, 'dynibar_amd', 'csrc', 'libdynibar_hip_x6.so')
-  if world == 1 and not a.no_x6 and terms == 3 and os.path.exists(x6) and not os.environ.get('DYNIBAR_HIP_LIB'):
-    # the same bench on the fp32-class build (6 partial products), as a second reported number
-    import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', str(max(5, a.steps // 2)), '--warmup', '2', '--cpu-rays', '0', '--no-x6',
+  if world == 1 and a.x6 and os.path.exists(x6) and not os.environ.get('DYNIBAR_HIP_LIB'):
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', '--steps', str(max(5, a.steps // 2)), '--warmup', '2',
                         '--rays', str(R), '--samples', str(S), '--views', str(V)], env=dict(os.environ, DYNIBAR_HIP_LIB=x6),
                        capture_output=True, text=True, timeout=600)
     try:
       d6 = json.loads(r.stdout.strip().splitlines()[-1])
-      res['fp32_class_engine'] = {'value': d6['value'], 'unit': 'rays/s', 'ms_per_step': d6['ms_per_step'], 'dtype': d6['dtype'],
-                                  'k_static_views_ms': d6['kernels_avg_ms']['k_static_views']}
+      res['bf16x6_engine'] = {'value': d6['value'], 'unit': 'rays/s', 'ms_per_step': d6['ms_per_step'], 'dtype': d6['dtype'],
+                              'k_static_views_ms': d6['kernels_avg_ms']['k_static_views']}
     except Exception as e:  # the extra leg must never cost the main line
-      res['fp32_class_engine'] = {'error': str(e)[:200]}
+      res['bf16x6_engine'] = {'error': str(e)[:200]}
   print(json.dumps(res))
   if world > 1:
     dist.destroy_process_group()
