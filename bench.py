@@ -237,6 +237,47 @@ def main():
       except Exception as e:
         extra['views_11'] = {'error': str(e)[:300]}
 
+    if world == 1:
+      try:
+        # section 8(f)1: the feature encoder on the 18 source images of one Balloon1 target view (7 dynamic + 11 static, eval_nvidia.py:335-358)
+        from dynibar_amd import feature_network, synthetic as syn
+        n_img = 18
+        imgs = torch.rand(n_img, H, W, 3, device=dev)
+        ew = syn.make_encoder_weights(0)
+        enc = feature_network.ResNet.from_module(ew)
+        x = imgs.permute(0, 3, 1, 2)
+        enc(x); fence()
+        lib.dyn_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(5):
+          xc, xf = enc(x)
+        fence()
+        edt = (time.perf_counter() - t0) / 5
+        lib.dyn_profile_enable(0)
+        ek = read_kernels(lib)
+        h1, w1, h2, w2 = H // 2, W // 2, H // 4, W // 4
+        eflops = n_img * 2.0 * (h1 * w1 * 64 * 147 + h2 * w2 * 64 * (6 * 576 + 2 * 64))
+        extra['feature_encoder'] = {'what': 'ResNet feature encoder (feature_network.py:179-311) on 18 source images 288x512 -> 2 x [18,32,72,128], channels-last, HIP implicit-GEMM '
+                                            'convolutions on the split-product MFMA engine', 'ms': edt * 1e3, 'algorithmic_tflops': eflops / edt / 1e12,
+                                    'frac_of_split_mfma_peak': eflops / edt / 1e12 / split_peak(int(lib.dyn_mlp_split_terms())),
+                                    'kernel_ms': {k: round(v['avg_ms'] * v['launches'] / 5, 4) for k, v in ek.items()}}
+        try:  # the reference's own route on this GPU: the same convolutions as PyTorch eager ops (MIOpen), via the oracle's restatement
+          from oracle import ibr_oracle as O
+          sd_dev = {k: torch.from_numpy(v).to(dev) for k, v in ew.items()}
+          with torch.no_grad():
+            rc, rf = O.resnet_encoder(sd_dev, x.contiguous()); fence()
+            t0 = time.perf_counter()
+            for _ in range(3):
+              rc, rf = O.resnet_encoder(sd_dev, x.contiguous())
+            fence()
+          extra['feature_encoder']['pytorch_eager_same_gpu_ms'] = (time.perf_counter() - t0) / 3 * 1e3
+          extra['feature_encoder']['max_abs_diff_vs_pytorch_eager'] = float((xc - rc).abs().max())
+        except Exception as e:
+          extra['feature_encoder']['pytorch_eager_same_gpu_ms'] = 'failed: ' + str(e)[:120]
+        del imgs, enc, x
+      except Exception as e:
+        extra['feature_encoder'] = {'error': str(e)[:300]}
+
   if rank != 0:
     if world > 1:
       dist.destroy_process_group()

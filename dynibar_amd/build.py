@@ -1,7 +1,7 @@
 """Build libdynibar_hip.so for gfx950 in-tree (dynibar_amd/csrc/).   python -m dynibar_amd.build [--force]
 
-Two translation units: the geometry/compositing kernels are compiled with -ffp-contract=off (bit-exact sample depths,
-points and indices versus the reference's un-fused fp32 ops), the MFMA network kernels with default contraction.
+Three translation units: the geometry/compositing kernels are compiled with -ffp-contract=off (bit-exact sample depths,
+points and indices versus the reference's un-fused fp32 ops), the MFMA network kernels and the feature encoder with default contraction.
 """
 from __future__ import annotations
 
@@ -16,6 +16,7 @@ OUT_X6 = os.path.join(CSRC, 'libdynibar_hip_x6.so')
 UNITS = [
     ('dyn_geometry.hip', ['-ffp-contract=off']),
     ('dyn_nets.hip', []),
+    ('dyn_encoder.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -48,7 +49,7 @@ def build(force=False, verbose=True):
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)
-  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6, '-o', OUT_X6]
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6] + objs[2:] + ['-o', OUT_X6]
   subprocess.check_call(cmd)
   return OUT
 

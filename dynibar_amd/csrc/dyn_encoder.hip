@@ -1,0 +1,417 @@
+// The 2-D feature encoder that runs right before the per-ray path (reference ibrnet/feature_network.py:179-311): the part of
+// ResNet.forward that is executed -- conv 7x7 / 2 (3 -> 64, reflect padding) -> InstanceNorm -> ReLU -> layer1 (three BasicBlocks of
+// 3x3 convolutions, the first with stride 2 and a 1x1 / 2 shortcut, InstanceNorm after every convolution) -> 1x1 convolution with
+// bias -> 32 coarse + 32 fine channels at 1/4 resolution.
+//
+// MI355X form.  Activations are channels-last fp32 ([N,H,W,64]: one pixel = 256 contiguous bytes), so the outputs ARE the
+// [V,Hf,Wf,32] maps the gather kernel taps (no NCHW -> NHWC repack) and the source images are consumed as the data loader
+// stores them ([V,H,W,3]).  Every convolution is an implicit GEMM on the split-product MFMA engine of dyn_mlp.h (fp32 operands
+// as exact sums of two half floats, 3 MFMAs per K = 16, fp32 accumulate: fp32-class products), evaluated transposed like the
+// networks: out^T [channels x pixels] = W [channels x K] . patch^T [K x pixels], K = (ky, kx, input channel).  One wavefront owns
+// 32 consecutive output pixels of one row and all 64 output channels; the lane of a pixel gathers its own K-slices (8 consecutive
+// input channels = 32 bytes) straight from L1/L2 -- a 72x128x64 map is 2.4 MB -- with reflect padding folded into the index.
+// The whole weight set of a convolution (3x3x64x64 as half-float hi | mid images: 144 KiB) sits in LDS for the lifetime of a
+// workgroup, which walks a strip of output rows of one image.
+// InstanceNorm needs per-(image, channel) statistics of a convolution's whole output: every convolution adds per-channel sums and
+// sums of squares of what it writes to a small fp64 table, and the CONSUMER of a tensor applies normalisation + affine + ReLU
+// (+ residual) while it loads it (one fma + one max per value).  Block outputs are materialised once by a small elementwise kernel.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dyn_host.h"
+#include "dyn_mlp.h"
+#include "dyn_pack.h"
+
+#define ENC_C 64            // channels of every activation
+#define ENC_THREADS 512     // 8 waves = 8 tiles of 32 output pixels per workgroup iteration
+#define ENC_EPS 1e-5        // nn.InstanceNorm2d default
+
+// state-dict order of the tensors handed to dyn_encoder_pack
+enum {
+  EN_CONV1_W, EN_BN1_G, EN_BN1_B,
+  EN_B0_C1_W, EN_B0_N1_G, EN_B0_N1_B, EN_B0_C2_W, EN_B0_N2_G, EN_B0_N2_B, EN_B0_DS_W, EN_B0_DS_G, EN_B0_DS_B,
+  EN_B1_C1_W, EN_B1_N1_G, EN_B1_N1_B, EN_B1_C2_W, EN_B1_N2_G, EN_B1_N2_B,
+  EN_B2_C1_W, EN_B2_N1_G, EN_B2_N1_B, EN_B2_C2_W, EN_B2_N2_G, EN_B2_N2_B,
+  EN_OUT_W, EN_OUT_B, EN_NUM_TENSORS
+};
+
+// k-groups (16 K values each) of the three convolution shapes
+#define K7_ROW 24                        /* conv 7x7: one kernel row = 7 px x 3 ch = 21 floats, padded to 24 */
+#define K7_GROUPS ((7 * K7_ROW + 15) / 16)  /* 11 */
+#define K3_GROUPS (9 * 4)
+#define K1_GROUPS 4
+constexpr size_t enc_image_floats(int groups) { return (size_t)groups * 2 * B6_PAIR_FLOATS; }  // 2 output tiles
+// blob layout (floats): packed weight images, then the affine / bias tables
+constexpr size_t EN_OFF_CONV1 = 0;
+constexpr size_t EN_OFF_C3 = EN_OFF_CONV1 + enc_image_floats(K7_GROUPS);            // six 3x3 convolutions: b0c1 b0c2 b1c1 b1c2 b2c1 b2c2
+constexpr size_t EN_OFF_DS = EN_OFF_C3 + 6 * enc_image_floats(K3_GROUPS);
+constexpr size_t EN_OFF_OUT = EN_OFF_DS + enc_image_floats(K1_GROUPS);
+constexpr size_t EN_OFF_AFFINE = EN_OFF_OUT + enc_image_floats(K1_GROUPS);          // 8 norms x [gamma 64 | beta 64]
+constexpr size_t EN_OFF_BIAS = EN_OFF_AFFINE + 8 * 128;
+constexpr size_t EN_BLOB_FLOATS = EN_OFF_BIAS + 64;
+enum { NORM_BN1, NORM_B0N1, NORM_B0N2, NORM_B0DS, NORM_B1N1, NORM_B1N2, NORM_B2N1, NORM_B2N2 };
+
+namespace {
+
+// one convolution -> the engine's A images: pair (g, t) = [hi 1 KiB | mid 1 KiB], lane (n = l & 31, h = l >> 5), element e: W[32 t + n][k = 16 g + 8 h + e]
+template <class KFn>
+void pack_conv(float* dst, int groups, KFn&& w_of) {
+  unsigned short* img = reinterpret_cast<unsigned short*>(dst);
+  for (int g = 0; g < groups; ++g)
+    for (int t = 0; t < 2; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const float w = w_of(32 * t + (lane & 31), 16 * g + 8 * (lane >> 5) + e);
+          unsigned short hi, mid, lo;
+          split_weight(w, hi, mid, lo);
+          const size_t pair = (size_t)(g * 2 + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
+          img[pair + lane * 8 + e] = hi;
+          img[pair + 512 + lane * 8 + e] = mid;
+#if DYN_SPLIT_PARTS == 3
+          img[pair + 1024 + lane * 8 + e] = lo;
+#endif
+        }
+}
+
+}  // namespace
+
+extern "C" size_t dyn_encoder_blob_floats(void) { return EN_BLOB_FLOATS; }
+
+extern "C" int dyn_encoder_pack(const float* const* T, float* blob, size_t blob_floats) {
+  DYN_REQUIRE(T && blob, "dyn_encoder_pack: null pointer");
+  DYN_REQUIRE(blob_floats >= EN_BLOB_FLOATS, "dyn_encoder_pack: blob too small");
+  for (int i = 0; i < EN_NUM_TENSORS; ++i) DYN_REQUIRE(T[i] != nullptr, "dyn_encoder_pack: tensor %d is NULL", i);
+  g_pack_range_error = false;
+  memset(blob, 0, EN_BLOB_FLOATS * sizeof(float));
+  {
+    const float* W = T[EN_CONV1_W];  // [64, 3, 7, 7]
+    pack_conv(blob + EN_OFF_CONV1, K7_GROUPS, [=](int oc, int k) -> float {
+      const int ky = k / K7_ROW, j = k % K7_ROW;
+      if (ky >= 7 || j >= 21) return 0.f;
+      const int kx = j / 3, ic = j % 3;
+      return W[((oc * 3 + ic) * 7 + ky) * 7 + kx];
+    });
+  }
+  const int c3[6] = {EN_B0_C1_W, EN_B0_C2_W, EN_B1_C1_W, EN_B1_C2_W, EN_B2_C1_W, EN_B2_C2_W};
+  for (int c = 0; c < 6; ++c) {
+    const float* W = T[c3[c]];  // [64, 64, 3, 3]
+    pack_conv(blob + EN_OFF_C3 + c * enc_image_floats(K3_GROUPS), K3_GROUPS, [=](int oc, int k) -> float {
+      const int tap = k / 64, ic = k % 64;
+      return W[((oc * 64 + ic) * 3 + tap / 3) * 3 + tap % 3];
+    });
+  }
+  {
+    const float* W = T[EN_B0_DS_W];  // [64, 64, 1, 1]
+    pack_conv(blob + EN_OFF_DS, K1_GROUPS, [=](int oc, int k) -> float { return W[oc * 64 + k]; });
+    const float* Wo = T[EN_OUT_W];
+    pack_conv(blob + EN_OFF_OUT, K1_GROUPS, [=](int oc, int k) -> float { return Wo[oc * 64 + k]; });
+  }
+  const int norms[8][2] = {{EN_BN1_G, EN_BN1_B}, {EN_B0_N1_G, EN_B0_N1_B}, {EN_B0_N2_G, EN_B0_N2_B}, {EN_B0_DS_G, EN_B0_DS_B},
+                           {EN_B1_N1_G, EN_B1_N1_B}, {EN_B1_N2_G, EN_B1_N2_B}, {EN_B2_N1_G, EN_B2_N1_B}, {EN_B2_N2_G, EN_B2_N2_B}};
+  for (int n = 0; n < 8; ++n)
+    for (int c = 0; c < 64; ++c) {
+      blob[EN_OFF_AFFINE + n * 128 + c] = T[norms[n][0]][c];
+      blob[EN_OFF_AFFINE + n * 128 + 64 + c] = T[norms[n][1]][c];
+    }
+  for (int c = 0; c < 64; ++c) blob[EN_OFF_BIAS + c] = T[EN_OUT_B][c];
+  DYN_REQUIRE(!g_pack_range_error, "dyn_encoder_pack: a weight is outside the half-float range of the split engine (|w| >= 65504 or not finite)");
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// device side
+// -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // padding_mode='reflect': -1 -> 1, n -> n - 2
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// how a convolution reads its input: 0 the tensor as stored; 1 relu(IN(in)); 2 relu(IN(in) + in2) with in2 stored as is
+enum { LOAD_PLAIN = 0, LOAD_NORM_RELU = 1, LOAD_NORM_ADD_RELU = 2 };
+
+struct ConvArgs {
+  const float* in;         // [N, Hin, Win, CIN] channels-last
+  const float* in2;        // [N, Hin, Win, 64] or NULL (LOAD_NORM_ADD_RELU)
+  const double* stats_in;  // [N][64][2] sum, sum of squares of `in` (modes 1, 2)
+  const float* affine_in;  // [gamma 64 | beta 64] of the norm applied to `in`
+  const float* wimg;       // packed weight images
+  const float* bias;       // [64] or NULL
+  float* out;              // [N, Hout, Wout, 64] channels-last, or (split outputs) the first 32 channels [N, Hout, Wout, 32]
+  float* out_hi;           // NULL, or the last 32 channels [N, Hout, Wout, 32]
+  double* stats_out;       // [N][64][2] accumulated here, or NULL
+  int N, Hin, Win, Hout, Wout;
+  int rows_per_wg;
+};
+
+// statistics of one (image, channel) -> the fused multiply-add of InstanceNorm + affine: y = x * sc + sh
+__device__ __forceinline__ void norm_coeff(const double* st, float gamma, float beta, double inv_n, float& sc, float& sh) {
+  const double mean = st[0] * inv_n;
+  double var = st[1] * inv_n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const double rstd = 1.0 / sqrt(var + ENC_EPS);
+  sc = (float)(rstd * (double)gamma);
+  sh = (float)((double)beta - mean * rstd * (double)gamma);
+}
+
+template <int KH, int KW, int STRIDE, int CIN, int MODE>
+__global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
+  constexpr int PAD = KH / 2;
+  constexpr int GROUPS = CIN == 3 ? K7_GROUPS : KH * KW * 4;
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* wl = lds;                                     // weight images
+  float* coef = lds + enc_image_floats(GROUPS);        // [sc 64 | sh 64] of the input norm
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  const int n = blockIdx.y;
+  // weights -> LDS (lane-linear images, 16 bytes per thread per step)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wimg);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int i = tid; i < (int)(enc_image_floats(GROUPS) / 4); i += ENC_THREADS) dst[i] = src[i];
+  }
+  if (MODE != LOAD_PLAIN && tid < 64) {
+    float sc, sh;
+    norm_coeff(p.stats_in + ((long)n * 64 + tid) * 2, p.affine_in[tid], p.affine_in[64 + tid], 1.0 / ((double)p.Hin * p.Win), sc, sh);
+    coef[tid] = sc;
+    coef[64 + tid] = sh;
+  }
+  __syncthreads();
+
+  const int tiles_x = (p.Wout + 31) / 32;
+  const int row0 = blockIdx.x * p.rows_per_wg;
+  const int row1 = row0 + p.rows_per_wg < p.Hout ? row0 + p.rows_per_wg : p.Hout;
+  const int n_tiles = (row1 - row0) * tiles_x;
+  float s1[2][16], s2[2][16];  // this lane's running per-channel sums of what it wrote (channel 32 t + fi(r, h))
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+
+  const float* inb = p.in + (long)n * p.Hin * p.Win * CIN;
+  const float* in2b = MODE == LOAD_NORM_ADD_RELU ? p.in2 + (long)n * p.Hin * p.Win * 64 : nullptr;
+  for (int tile = wave; tile < n_tiles; tile += ENC_THREADS / 64) {
+    const int oy = row0 + tile / tiles_x, ox = (tile % tiles_x) * 32 + j;
+    const bool live = ox < p.Wout;
+    const int oxc = live ? ox : p.Wout - 1;  // idle lanes shadow the last pixel (loads stay in bounds, nothing is stored)
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = p.bias != nullptr ? p.bias[32 * t + dyn_fi(r, h)] : 0.f;
+    constexpr int G_UNROLL = CIN == 3 ? 1 : 2;
+#pragma unroll G_UNROLL
+    for (int g = 0; g < GROUPS; ++g) {
+      float v[8];
+      if (CIN == 3) {
+        // K = (ky, [kx, ic] padded to 24): this lane's 8 values are k = 16 g + 8 h + e, i.e. 8-float chunk c = 2 g + h of the padded rows:
+        // kernel row ky = c / 3, floats [8 (c % 3), + 8) of that row's 21 (+ 3 zero-weight) floats
+        const int c = 2 * g + h;
+        const int ky = (c * 11) >> 5;          // c / 3 for c < 32
+        const int j0 = (c - 3 * ky) * 8;
+        const int iy = reflect_idx(oy * STRIDE + (ky < 7 ? ky : 6) - PAD, p.Hin);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int jj = j0 + e;
+          const int kx = (jj * 11) >> 5;        // jj / 3 for jj < 32
+          const int ic = jj - 3 * kx;
+          const int ix = reflect_idx(oxc * STRIDE + (kx < 7 ? kx : 6) - PAD, p.Win);
+          const float x = inb[((long)iy * p.Win + ix) * 3 + ic];
+          v[e] = (ky < 7 && jj < 21) ? x : 0.f;
+        }
+      } else {
+        const int tap = g >> 2, cg = g & 3;
+        const int ky = tap / KW, kx = tap - ky * KW;
+        const int iy = reflect_idx(oy * STRIDE + ky - PAD, p.Hin), ix = reflect_idx(oxc * STRIDE + kx - PAD, p.Win);
+        const long off = ((long)iy * p.Win + ix) * 64 + cg * 16 + h * 8;
+        const float4 a = *reinterpret_cast<const float4*>(inb + off), b = *reinterpret_cast<const float4*>(inb + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (MODE != LOAD_PLAIN) {
+          const float4 sa = *reinterpret_cast<const float4*>(coef + cg * 16 + h * 8), sb = *reinterpret_cast<const float4*>(coef + cg * 16 + h * 8 + 4);
+          const float4 ha = *reinterpret_cast<const float4*>(coef + 64 + cg * 16 + h * 8), hb = *reinterpret_cast<const float4*>(coef + 64 + cg * 16 + h * 8 + 4);
+          const float scv[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w}, shv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+          float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (MODE == LOAD_NORM_ADD_RELU) {
+            const float4 ra = *reinterpret_cast<const float4*>(in2b + off), rb = *reinterpret_cast<const float4*>(in2b + off + 4);
+            add[0] = ra.x; add[1] = ra.y; add[2] = ra.z; add[3] = ra.w; add[4] = rb.x; add[5] = rb.y; add[6] = rb.z; add[7] = rb.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]) + add[e], 0.f);
+        }
+      }
+      u32x4v bh, bm, bl;
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        unsigned h_, m_, l_;
+        split3_pair(v[2 * p2], v[2 * p2 + 1], h_, m_, l_);
+        bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const B6A a = b6_load_a(wl + (size_t)(g * 2 + t) * B6_PAIR_FLOATS, lane);
+#if DYN_SPLIT_TERMS == 6
+        acc[t] = mfma_bf16(a.lo, bh, acc[t]);
+        acc[t] = mfma_bf16(a.hi, bl, acc[t]);
+        acc[t] = mfma_bf16(a.mid, bm, acc[t]);
+#endif
+        acc[t] = mfma_bf16(a.mid, bh, acc[t]);
+        acc[t] = mfma_bf16(a.hi, bm, acc[t]);
+        acc[t] = mfma_bf16(a.hi, bh, acc[t]);
+      }
+    }
+    if (live) {
+      const long pix = ((long)n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float* o = p.out_hi == nullptr ? p.out + pix * 64 + 32 * t : (t == 0 ? p.out : p.out_hi) + pix * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // registers 4 q .. 4 q + 3 are channels 8 q + 4 h + (0..3) of the tile
+          *reinterpret_cast<float4*>(o + 8 * q + 4 * h) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[t][r] += acc[t][r]; s2[t][r] = fmaf(acc[t][r], acc[t][r], s2[t][r]); }
+      }
+    }
+  }
+  if (p.stats_out != nullptr) {
+    // the 32 pixel-lanes of a half hold partial sums of the same 32 channels: butterfly over the lanes, then one fp64 atomic per channel
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (j == 0) {
+          double* st = p.stats_out + ((long)n * 64 + 32 * t + dyn_fi(r, h)) * 2;
+          atomicAdd(st, (double)a);
+          atomicAdd(st + 1, (double)b);
+        }
+      }
+  }
+}
+
+// block output: out = relu(IN(a) + (IN(b) | b))   (BasicBlock.forward, feature_network.py:66-85)
+__global__ void __launch_bounds__(256) k_enc_block_out(const float* __restrict__ a, const double* __restrict__ stats_a, const float* __restrict__ aff_a,
+                                                       const float* __restrict__ b, const double* __restrict__ stats_b, const float* __restrict__ aff_b,
+                                                       long hw, float* __restrict__ out) {
+  float* coef = reinterpret_cast<float*>(dyn_smem);  // [4][64]
+  const int n = blockIdx.y;
+  if (threadIdx.x < 64) {
+    float sc, sh;
+    norm_coeff(stats_a + ((long)n * 64 + threadIdx.x) * 2, aff_a[threadIdx.x], aff_a[64 + threadIdx.x], 1.0 / (double)hw, sc, sh);
+    coef[threadIdx.x] = sc; coef[64 + threadIdx.x] = sh;
+    if (stats_b != nullptr) {
+      norm_coeff(stats_b + ((long)n * 64 + threadIdx.x) * 2, aff_b[threadIdx.x], aff_b[64 + threadIdx.x], 1.0 / (double)hw, sc, sh);
+      coef[128 + threadIdx.x] = sc; coef[192 + threadIdx.x] = sh;
+    }
+  }
+  __syncthreads();
+  const long total4 = hw * 16;  // float4 elements per image
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 15) * 4;
+    const float4 x = reinterpret_cast<const float4*>(a)[(long)n * total4 + i];
+    float4 y = reinterpret_cast<const float4*>(b)[(long)n * total4 + i];
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    float ys[4] = {y.x, y.y, y.z, y.w}, o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (stats_b != nullptr) ys[e] = fmaf(ys[e], coef[128 + c + e], coef[192 + c + e]);
+      o[e] = fmaxf(fmaf(xs[e], coef[c + e], coef[64 + c + e]) + ys[e], 0.f);
+    }
+    reinterpret_cast<float4*>(out)[(long)n * total4 + i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// host
+// -------------------------------------------------------------------------------------------------------------------
+struct EncWs {
+  int H1, W1, H2, W2;
+  size_t off_c1, off_t[4], off_stats, total;  // c1: [N,H1,W1,64]; t[0..3]: [N,H2,W2,64] scratch maps; stats: 9 tables of [N][64][2] doubles
+};
+static EncWs enc_ws(int N, int H, int W) {
+  EncWs w;
+  w.H1 = (H + 2 * 3 - 7) / 2 + 1; w.W1 = (W + 2 * 3 - 7) / 2 + 1;
+  w.H2 = (w.H1 + 2 - 3) / 2 + 1; w.W2 = (w.W1 + 2 - 3) / 2 + 1;
+  size_t o = 0;
+  w.off_c1 = o; o += (size_t)N * w.H1 * w.W1 * 64;
+  for (int i = 0; i < 4; ++i) { w.off_t[i] = o; o += (size_t)N * w.H2 * w.W2 * 64; }
+  o = (o + 3) & ~(size_t)3;
+  w.off_stats = o; o += (size_t)9 * N * 64 * 2 * 2;  // doubles counted as 2 floats
+  w.total = o;
+  return w;
+}
+extern "C" size_t dyn_encoder_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H < 16 || W < 16) return 0;
+  return enc_ws(N, H, W).total * sizeof(float);
+}
+extern "C" int dyn_encoder_out_size(int H, int W, int* Hf, int* Wf) {
+  DYN_REQUIRE(Hf && Wf && H >= 16 && W >= 16, "dyn_encoder_out_size: bad argument");
+  const EncWs w = enc_ws(1, H, W);
+  *Hf = w.H2; *Wf = w.W2;
+  return 0;
+}
+
+template <int KH, int KW, int STRIDE, int CIN, int MODE>
+static int launch_conv(int slot, const char* name, ConvArgs a, hipStream_t stream) {
+  constexpr int GROUPS = CIN == 3 ? K7_GROUPS : KH * KW * 4;
+  const size_t lds = (enc_image_floats(GROUPS) + 128) * sizeof(float);
+  // about one workgroup per CU over the whole batch: strips of output rows per image
+  int strips = (256 + a.N - 1) / a.N;
+  strips = strips < 1 ? 1 : (strips > a.Hout ? a.Hout : strips);
+  a.rows_per_wg = (a.Hout + strips - 1) / strips;
+  const dim3 grid((a.Hout + a.rows_per_wg - 1) / a.rows_per_wg, a.N);
+  DYN_LAUNCH(slot, name, (k_enc_conv<KH, KW, STRIDE, CIN, MODE>), grid, dim3(ENC_THREADS), lds, stream, a);
+  return 0;
+}
+
+extern "C" int dyn_encoder_forward(const DynEncoderParams* q, void* stream_) {
+  DYN_REQUIRE(q, "dyn_encoder_forward: null params");
+  DYN_REQUIRE(q->blob && q->images && q->coarse && q->fine && q->workspace, "dyn_encoder_forward: null pointer");
+  DYN_REQUIRE(q->N > 0 && q->H >= 16 && q->W >= 16, "dyn_encoder_forward: need N > 0 and images of at least 16 x 16");
+  const EncWs w = enc_ws(q->N, q->H, q->W);
+  DYN_REQUIRE(q->workspace_bytes >= w.total * sizeof(float), "dyn_encoder_forward: workspace too small (%zu < %zu bytes)", q->workspace_bytes,
+              w.total * sizeof(float));
+  hipStream_t stream = (hipStream_t)stream_;
+  float* ws = (float*)q->workspace;
+  const float* B = q->blob;
+  double* stats = reinterpret_cast<double*>(ws + w.off_stats);
+  auto st = [&](int i) { return stats + (size_t)i * q->N * 64 * 2; };
+  auto aff = [&](int n) { return B + EN_OFF_AFFINE + n * 128; };
+  auto c3 = [&](int c) { return B + EN_OFF_C3 + c * enc_image_floats(K3_GROUPS); };
+  if (hipMemsetAsync(stats, 0, (size_t)9 * q->N * 64 * 2 * sizeof(double), stream) != hipSuccess) {
+    dyn_set_error("dyn_encoder_forward: hipMemsetAsync failed");
+    return DYN_E_LAUNCH;
+  }
+  float *c1 = ws + w.off_c1, *t0 = ws + w.off_t[0], *t1 = ws + w.off_t[1], *t2 = ws + w.off_t[2], *t3 = ws + w.off_t[3];
+  const long hw2 = (long)w.H2 * w.W2;
+  const dim3 ew_grid(64, q->N), ew_blk(256);
+  ConvArgs a;
+  int rc;
+  // conv1 7x7 / 2 on the images as stored ([N,H,W,3]); its norm + ReLU is applied by its two consumers
+  a = ConvArgs{q->images, nullptr, nullptr, nullptr, B + EN_OFF_CONV1, nullptr, c1, nullptr, st(0), q->N, q->H, q->W, w.H1, w.W1, 0};
+  if ((rc = launch_conv<7, 7, 2, 3, LOAD_PLAIN>(DYN_K_ENC_CONV7, "k_enc_conv7", a, stream))) return rc;
+  // layer1.0: conv3x3 / 2 and the 1x1 / 2 shortcut, both on relu(IN(c1))
+  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), c3(0), nullptr, t0, nullptr, st(1), q->N, w.H1, w.W1, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 2, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3s2", a, stream))) return rc;
+  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), B + EN_OFF_DS, nullptr, t1, nullptr, st(3), q->N, w.H1, w.W1, w.H2, w.W2, 0};
+  if ((rc = launch_conv<1, 1, 2, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV1, "k_enc_conv1s2", a, stream))) return rc;
+  a = ConvArgs{t0, nullptr, st(1), aff(NORM_B0N1), c3(1), nullptr, t2, nullptr, st(2), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
+  // out0 = relu(IN(conv2) + IN(shortcut)) -> t3
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "k_enc_block_out", k_enc_block_out, ew_grid, ew_blk, 1024, stream, t2, st(2), aff(NORM_B0N2), t1, st(3), aff(NORM_B0DS), hw2, t3);
+  // layer1.1 on out0 (t3): conv1 -> t0, conv2 -> t1, out1 = relu(IN(conv2) + out0) -> t2
+  a = ConvArgs{t3, nullptr, nullptr, nullptr, c3(2), nullptr, t0, nullptr, st(4), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 1, 64, LOAD_PLAIN>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
+  a = ConvArgs{t0, nullptr, st(4), aff(NORM_B1N1), c3(3), nullptr, t1, nullptr, st(5), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "k_enc_block_out", k_enc_block_out, ew_grid, ew_blk, 1024, stream, t1, st(5), aff(NORM_B1N2), t3, (const double*)nullptr, (const float*)nullptr, hw2, t2);
+  // layer1.2 on out1 (t2): conv1 -> t0, conv2 -> t1; out2 = relu(IN(conv2) + out1) is formed by the 1x1 output convolution as it loads
+  a = ConvArgs{t2, nullptr, nullptr, nullptr, c3(4), nullptr, t0, nullptr, st(6), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 1, 64, LOAD_PLAIN>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
+  a = ConvArgs{t0, nullptr, st(6), aff(NORM_B2N1), c3(5), nullptr, t1, nullptr, st(7), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
+  a = ConvArgs{t1, t2, st(7), aff(NORM_B2N2), B + EN_OFF_OUT, B + EN_OFF_BIAS, q->coarse, q->fine, nullptr, q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  if ((rc = launch_conv<1, 1, 1, 64, LOAD_NORM_ADD_RELU>(DYN_K_ENC_CONV1, "k_enc_out_conv", a, stream))) return rc;
+  return 0;
+}

@@ -35,7 +35,7 @@ static const char* const g_prof_names[DYN_K_COUNT] = {
     "k_prepare_cameras", "k_nchw_to_nhwc", "k_sample_along_ray", "k_points_from_z", "k_project_gather", "k_sample_mask", "k_composite",
     "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest", "k_dynamic_time_feat",
     "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points", "k_render_flows", "k_expected_scene_flow", "k_image_rays",
-    "k_static_points_qkv", "k_dynamic_points_qkv"};
+    "k_static_points_qkv", "k_dynamic_points_qkv", "k_enc_conv7", "k_enc_conv3", "k_enc_conv1", "k_enc_block_out"};
 
 static void prof_flush(int slot) {
   for (int i = 0; i < g_prof.used[slot]; ++i) {

@@ -1,0 +1,73 @@
+"""Drop-in for the reference's ``ibrnet/feature_network.py`` encoder: ``ResNet(...)(x) -> (x_coarse, x_fine)`` (reference
+feature_network.py:179-311), executed by the HIP convolution kernels of csrc/dyn_encoder.hip.
+
+Only the part of ``ResNet.forward`` the reference executes exists here (conv1 -> bn1 -> relu -> layer1 -> out_conv; the decoder
+layers the reference constructs are never run, :302-311).  Forward only: the returned maps carry no autograd graph.
+
+Layout: the reference's callers pass ``src_rgbs.squeeze(0).permute(0, 3, 1, 2)`` (eval_nvidia.py:335-358), i.e. an NCHW *view* of
+channels-last memory; the kernels read that memory as it is.  The returned ``x_coarse`` / ``x_fine`` are NCHW views ([N,32,Hf,Wf],
+what the callers index) of channels-last storage, which is exactly the layout the gather kernel taps: ``Projector`` /
+``ops.SourceViews`` recognise it and skip the per-target-view NCHW -> NHWC repack.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _unwrap(net):
+  return net.module if hasattr(net, 'module') and not isinstance(net, dict) else net
+
+
+class ResNet(object):
+  """``ResNet.from_module(model.feature_net)`` wraps the reference's (optionally DataParallel-wrapped) module or a state dict; the
+  weights are packed once and re-packed when a parameter's version counter changes."""
+
+  def __init__(self, encoder='resnet34', coarse_out_ch=32, fine_out_ch=32, norm_layer=None, coarse_only=False, state_dict=None):
+    assert encoder in ['resnet18', 'resnet34'], 'the HIP encoder implements the BasicBlock variants the reference instantiates (model.py:56-66)'
+    if coarse_only or coarse_out_ch != 32 or fine_out_ch != 32:
+      raise NotImplementedError('the HIP encoder is built for coarse_out_ch = fine_out_ch = 32 (every shipped config)')
+    self.coarse_out_ch, self.fine_out_ch = coarse_out_ch, fine_out_ch
+    self._source = state_dict
+    self._packed = {}
+
+  @classmethod
+  def from_module(cls, module_or_state_dict):
+    return cls(state_dict=module_or_state_dict)
+
+  def load_state_dict(self, state_dict, strict=True):
+    self._source = state_dict
+    self._packed = {}
+
+  def eval(self):
+    return self
+
+  def _state(self):
+    src = _unwrap(self._source)
+    if src is None:
+      raise RuntimeError('dynibar_amd.feature_network.ResNet has no weights: construct it with from_module(...) or load_state_dict(...)')
+    if hasattr(src, 'state_dict'):
+      ver = tuple((p.data_ptr(), p._version) for p in src.parameters())
+      return src.state_dict(), ver
+    return src, id(src)
+
+  def _encoder(self, device):
+    sd, ver = self._state()
+    key = (str(device), ver)
+    enc = self._packed.get('enc')
+    if enc is None or enc[0] != key:
+      enc = (key, ops.Encoder(sd, device))
+      self._packed['enc'] = enc
+    return enc[1]
+
+  def forward(self, x):
+    """x [N,3,H,W] -> (x_coarse [N,32,Hf,Wf], x_fine [N,32,Hf,Wf])."""
+    assert x.dim() == 4 and x.shape[1] == 3
+    img = x.permute(0, 2, 3, 1)
+    if img.dtype != torch.float32 or not img.is_contiguous():
+      img = img.float().contiguous()
+    coarse, fine = self._encoder(x.device)(img)
+    return coarse.permute(0, 3, 1, 2), fine.permute(0, 3, 1, 2)
+
+  __call__ = forward

@@ -37,6 +37,15 @@ class _Keep:
     return ptr(t, dtype)
 
 
+def _channels_last_view(fm):
+  """[V,F,Hf,Wf] tensor whose memory is already [V,Hf,Wf,F] (what dynibar_amd.feature_network returns) -> that contiguous tensor, else None."""
+  if fm.dim() == 4 and fm.dtype == torch.float32:
+    cl = fm.permute(0, 2, 3, 1)
+    if cl.is_contiguous():
+      return cl
+  return None
+
+
 class SourceViews:
   """Per-target-view prepared source data for one branch: projection matrices, camera centres, channels-last maps.
 
@@ -51,12 +60,17 @@ class SourceViews:
     self.cams = _f32c(src_cameras[0])           # [V,34]
     self.query = _f32c(query_camera[0])         # [34]
     self.V, self.H, self.W = self.src_rgbs.shape[:3]
-    fm = _f32c(featmaps)
-    assert fm.shape[0] == self.V
-    self.F, self.Hf, self.Wf = fm.shape[1:]
-    self.feat_cl = torch.empty((self.V, self.Hf, self.Wf, self.F), dtype=torch.float32, device=dev)
-    st = stream_of(fm)
-    call('dyn_nchw_to_nhwc', ptr(fm), ptr(self.feat_cl), self.V, self.F, self.Hf, self.Wf, st)
+    assert featmaps.shape[0] == self.V
+    self.F, self.Hf, self.Wf = featmaps.shape[1:]
+    cl = _channels_last_view(featmaps)
+    if cl is not None:   # maps from the HIP encoder are channels-last in memory already: tapped in place
+      self.feat_cl = cl
+      st = stream_of(cl)
+    else:                # maps from a PyTorch encoder (NCHW): one repack per target view
+      fm = _f32c(featmaps)
+      self.feat_cl = torch.empty((self.V, self.Hf, self.Wf, self.F), dtype=torch.float32, device=dev)
+      st = stream_of(fm)
+      call('dyn_nchw_to_nhwc', ptr(fm), ptr(self.feat_cl), self.V, self.F, self.Hf, self.Wf, st)
     self.proj = torch.empty((self.V, 16), dtype=torch.float32, device=dev)
     self.query_center = torch.empty((4,), dtype=torch.float32, device=dev)
     call('dyn_prepare_cameras', ptr(self.cams), self.V, ptr(self.query), ptr(self.proj), ptr(self.query_center), st)
@@ -354,3 +368,47 @@ def trajectory_points(coeff, basis, pts, rows, row_ref):
   arr = (ctypes.c_int * len(rows))(*[int(r) for r in rows])
   call('dyn_trajectory_points', k(coeff), k(basis), k(pts), R * S, B, arr, len(rows), int(row_ref), ptr(out), stream_of(out))
   return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# feature encoder
+# ----------------------------------------------------------------------------------------------------------------------
+class Encoder:
+  """The executed part of the reference's ResNet (feature_network.py:179-311) as packed convolution images on one device."""
+
+  def __init__(self, state_dict, device):
+    import numpy as np
+    from . import synthetic
+    sd = _strip_module(state_dict)
+    arrs = []
+    for name, shape in synthetic.ENCODER_TENSORS:
+      if name not in sd:
+        raise KeyError(f'encoder: state dict has no {name!r}')
+      a = _host_f32(sd[name])
+      if tuple(a.shape) != tuple(shape):
+        raise ValueError(f'encoder: {name} has shape {tuple(a.shape)}, the kernels are built for {tuple(shape)} '
+                         "(resnet34-style BasicBlock encoder with coarse_out_ch + fine_out_ch = 64)")
+      arrs.append(a.reshape(-1))
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    n = int(_lib.lib().dyn_encoder_blob_floats())
+    blob = np.zeros(n, dtype=np.float32)
+    call('dyn_encoder_pack', ptrs, ctypes.c_void_p(blob.ctypes.data), n)
+    self.blob = torch.from_numpy(blob).to(device)
+    self._ws = _Workspace()
+
+  def __call__(self, images):
+    """images [N,H,W,3] channels-last fp32 on the device -> (coarse [N,Hf,Wf,32], fine [N,Hf,Wf,32]) channels-last."""
+    images = _f32c(images)
+    N, H, W, C = images.shape
+    assert C == 3
+    dev = images.device
+    hf, wf = ctypes.c_int(0), ctypes.c_int(0)
+    call('dyn_encoder_out_size', H, W, ctypes.byref(hf), ctypes.byref(wf))
+    coarse = torch.empty((N, hf.value, wf.value, 32), dtype=torch.float32, device=dev)
+    fine = torch.empty_like(coarse)
+    need = int(_lib.lib().dyn_encoder_workspace_bytes(N, H, W))
+    ws = self._ws.get(need, dev)
+    p = params('DynEncoderParams', N=N, H=H, W=W, blob=ptr(self.blob), images=ptr(images), coarse=ptr(coarse), fine=ptr(fine),
+               workspace=ptr(ws), workspace_bytes=need)
+    call('dyn_encoder_forward', ctypes.byref(p), stream_of(images))
+    return coarse, fine

@@ -158,6 +158,35 @@ def motion_layer_table(num_basis=6, W=256, D=8, input_ch=4, num_freqs=16, skips=
   return tab
 
 
+ENCODER_TENSORS = (
+    ('conv1.weight', (64, 3, 7, 7)), ('bn1.weight', (64,)), ('bn1.bias', (64,)),
+    ('layer1.0.conv1.weight', (64, 64, 3, 3)), ('layer1.0.bn1.weight', (64,)), ('layer1.0.bn1.bias', (64,)),
+    ('layer1.0.conv2.weight', (64, 64, 3, 3)), ('layer1.0.bn2.weight', (64,)), ('layer1.0.bn2.bias', (64,)),
+    ('layer1.0.downsample.0.weight', (64, 64, 1, 1)), ('layer1.0.downsample.1.weight', (64,)), ('layer1.0.downsample.1.bias', (64,)),
+    ('layer1.1.conv1.weight', (64, 64, 3, 3)), ('layer1.1.bn1.weight', (64,)), ('layer1.1.bn1.bias', (64,)),
+    ('layer1.1.conv2.weight', (64, 64, 3, 3)), ('layer1.1.bn2.weight', (64,)), ('layer1.1.bn2.bias', (64,)),
+    ('layer1.2.conv1.weight', (64, 64, 3, 3)), ('layer1.2.bn1.weight', (64,)), ('layer1.2.bn1.bias', (64,)),
+    ('layer1.2.conv2.weight', (64, 64, 3, 3)), ('layer1.2.bn2.weight', (64,)), ('layer1.2.bn2.bias', (64,)),
+    ('out_conv.weight', (64, 64, 1, 1)), ('out_conv.bias', (64,)),
+)
+
+
+def make_encoder_weights(seed=0):
+  """Seeded state dict (numpy float32) of the executed part of the reference's ResNet (feature_network.py:179-311; names and shapes
+  of ENCODER_TENSORS): Kaiming-uniform-like convolutions, InstanceNorm gains around 1 and non-zero shifts, non-zero output bias."""
+  rng = np.random.default_rng([seed, 7])
+  sd = {}
+  for name, shape in ENCODER_TENSORS:
+    if len(shape) == 4:
+      bound = np.sqrt(3.0 / (shape[1] * shape[2] * shape[3]))
+      sd[name] = rng.uniform(-bound, bound, shape).astype(np.float32)
+    elif name.endswith('.weight'):
+      sd[name] = (1.0 + 0.2 * rng.standard_normal(shape)).astype(np.float32)
+    else:
+      sd[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+  return sd
+
+
 def make_weights(kind, seed=0, F=32, num_basis=6, gain=1.0, bias=0.1, head_gain=1.0, ln_gain=1.0):
   """Seeded state-dict (numpy float32) for 'static' | 'dynamic' | 'motion'.
 

@@ -209,6 +209,31 @@ int dyn_expected_scene_flow(const float* weights, const float* coeff, const floa
 /* ---- a2 RaySamplerSingleImage.get_rays_single_image (sample_ray.py:143-163): camera DEVICE [34]; rays_o, rays_d [(H/stride)*(W/stride),3] */
 int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream);
 
+/* ---- section 8(f)1: the 2-D feature encoder that feeds the path (feature_network.py:179-311, the executed part of ResNet.forward:
+ * conv 7x7/2 -> InstanceNorm -> ReLU -> layer1 (3 BasicBlocks, reflect padding) -> 1x1 conv; 32 coarse + 32 fine channels at 1/4 resolution).
+ * Channels-last throughout: images [N,H,W,3] as the data loader stores them, outputs [N,Hf,Wf,32] = the gather kernel's feat_cl layout.
+ * dyn_encoder_pack: HOST pointers to the row-major fp32 tensors in this order (state-dict names of ibrnet.feature_network.ResNet):
+ *   conv1.weight bn1.weight bn1.bias
+ *   layer1.0.conv1.weight layer1.0.bn1.weight .bias layer1.0.conv2.weight layer1.0.bn2.weight .bias
+ *   layer1.0.downsample.0.weight layer1.0.downsample.1.weight .bias
+ *   layer1.1.conv1.weight layer1.1.bn1.weight .bias layer1.1.conv2.weight layer1.1.bn2.weight .bias
+ *   layer1.2.conv1.weight layer1.2.bn1.weight .bias layer1.2.conv2.weight layer1.2.bn2.weight .bias
+ *   out_conv.weight out_conv.bias */
+size_t dyn_encoder_blob_floats(void);
+int dyn_encoder_pack(const float* const* tensors, float* blob, size_t blob_floats);
+size_t dyn_encoder_workspace_bytes(int N, int H, int W);
+int dyn_encoder_out_size(int H, int W, int* Hf, int* Wf);
+typedef struct {
+  int N, H, W;              /* images */
+  const float* blob;        /* DEVICE copy of the packed encoder */
+  const float* images;      /* [N,H,W,3] */
+  float* coarse;            /* [N,Hf,Wf,32]: channels 0..31 of out_conv (x_coarse) */
+  float* fine;              /* [N,Hf,Wf,32]: channels 32..63 (x_fine) */
+  void* workspace;
+  size_t workspace_bytes;
+} DynEncoderParams;
+int dyn_encoder_forward(const DynEncoderParams* p, void* stream);
+
 /* ---- how the network kernels of this build multiply (csrc/dyn_mlp.h): split terms = partial products kept per fp32 product (3 or 6;
  * 0 = native fp32 MFMA engine); split kind = what the operand parts are: 0 none (fp32 MFMA), 1 bf16 (3 terms: 16 mantissa bits per
  * operand; 6 terms: fp32-class), 2 IEEE half (3 terms: 22 mantissa bits per operand, fp32-class; the shipped engine) --------------- */

@@ -271,6 +271,38 @@ def compute_with_motions(xyz_st, xyz, query_camera, train_imgs, train_cameras, f
 
 
 # ----------------------------------------------------------------------------
+# section 8(f)1  feature encoder     (feature_network.py:13-85, 179-311)
+# ----------------------------------------------------------------------------
+
+
+def _conv_reflect(x, w, stride, pad, bias=None):
+  """nn.Conv2d(..., padding=pad, padding_mode='reflect', bias=...) (feature_network.py:13-38, 240-249)."""
+  if pad > 0:
+    x = F.pad(x, (pad, pad, pad, pad), mode='reflect')
+  return F.conv2d(x, w, bias, stride=stride)
+
+
+def _inorm(sd, name, x):
+  """nn.InstanceNorm2d(C, track_running_stats=False, affine=True) (feature_network.py:60-63)."""
+  return F.instance_norm(x, weight=sd[name + '.weight'], bias=sd[name + '.bias'], eps=1e-5)
+
+
+def resnet_encoder(sd, x, coarse_out_ch=32, fine_out_ch=32):
+  """The executed part of ResNet.forward (feature_network.py:302-311): x [N,3,H,W] -> (x_coarse, x_fine) [N,32,H/4,W/4]."""
+  x = F.relu(_inorm(sd, 'bn1', _conv_reflect(x, sd['conv1.weight'], 2, 3)))
+  for b in range(3):
+    pre = 'layer1.%d.' % b
+    identity = x
+    out = F.relu(_inorm(sd, pre + 'bn1', _conv_reflect(x, sd[pre + 'conv1.weight'], 2 if b == 0 else 1, 1)))
+    out = _inorm(sd, pre + 'bn2', _conv_reflect(out, sd[pre + 'conv2.weight'], 1, 1))
+    if b == 0:
+      identity = _inorm(sd, pre + 'downsample.1', _conv_reflect(x, sd[pre + 'downsample.0.weight'], 2, 0))
+    x = F.relu(out + identity)
+  x_out = F.conv2d(x, sd['out_conv.weight'], sd['out_conv.bias'])
+  return x_out[:, :coarse_out_ch], x_out[:, -fine_out_ch:]
+
+
+# ----------------------------------------------------------------------------
 # a12  Pluecker coordinates          (render_ray.py:372-396)
 # ----------------------------------------------------------------------------
 

@@ -88,6 +88,21 @@ def anchor_case(scene, num_vv=2, anchor_shift=1):
   return sc, (fidx, aidx), (temb, temb_a), (toff, aoff)
 
 
+def encoder_case(name='small'):
+  """Seeded image batch [N,H,W,3] in [0,1] for the feature encoder (the data loaders' source images) and the encoder weights."""
+  cfg = {'small': dict(seed=11, N=2, H=40, W=56), 'odd': dict(seed=12, N=3, H=37, W=50), 'wide': dict(seed=13, N=1, H=64, W=160)}[name]
+  rng = np.random.default_rng([cfg['seed'], 5])
+  yy, xx = np.meshgrid(np.linspace(0, 1, cfg['H']), np.linspace(0, 1, cfg['W']), indexing='ij')
+  imgs = []
+  for n in range(cfg['N']):
+    ph = rng.uniform(0, 6.28, (3, 4))
+    fr = rng.uniform(2, 9, (3, 4))
+    img = np.stack([0.5 + 0.25 * np.sin(fr[c, 0] * xx + ph[c, 0]) * np.cos(fr[c, 1] * yy + ph[c, 1]) + 0.2 * np.sin(fr[c, 2] * (xx + yy) + ph[c, 2])
+                    for c in range(3)], -1) + 0.05 * rng.standard_normal((cfg['H'], cfg['W'], 3))
+    imgs.append(np.clip(img, 0.0, 1.0))
+  return t(np.stack(imgs, 0).astype(np.float32)), syn.make_encoder_weights(cfg['seed'])
+
+
 def time_args(n_views):
   """(frame_idx, time_embedding[1], time_offset list) like eval_nvidia.py:323-329."""
   offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else [((i * 5) % 7) - 3 for i in range(n_views)]

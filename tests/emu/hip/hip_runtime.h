@@ -289,6 +289,11 @@ static inline float atomicAdd(float* p, float v) {
   return old;
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline double atomicAdd(double* p, double v) {
+  double old = *p, want;
+  do { want = old + v; } while (!__atomic_compare_exchange(p, &old, &want, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+  return old;
+}
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 namespace emu {

@@ -321,6 +321,23 @@ def mono_train_goldens():
   print('mono_train', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def encoder_goldens():
+  """The reference's ResNet feature encoder (feature_network.py:179-311) on seeded image batches, incl. odd sizes (reflect padding, strides)."""
+  FN = ref.feature_network
+  out = {}
+  for name in ('small', 'odd', 'wide'):
+    imgs, sd = cases.encoder_case(name)
+    net = FN.ResNet(coarse_out_ch=32, fine_out_ch=32, coarse_only=False)
+    own = net.state_dict()
+    assert all(k in own and tuple(own[k].shape) == tuple(v.shape) for k, v in sd.items())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)  # the decoder layers the forward never runs keep their init
+    with torch.no_grad():
+      xc, xf = net.eval()(imgs.permute(0, 3, 1, 2))
+    out[f'{name}/coarse'] = npy(xc); out[f'{name}/fine'] = npy(xf)
+  np.savez_compressed(os.path.join(HERE, 'encoder.npz'), **out)
+  print('encoder', {k: v.shape for k, v in out.items()})
+
+
 def mono_kid_goldens():
   """render_rays_mono with the monocular configs' arguments (configs/train_kid-running.txt:41-42,69: anti_alias_pooling = 0, mask_rgb = 1,
   num_vv = 3; DynibarMono builds the dynamic net with shift = 5.0, model.py:304-309): the real DynibarStatic then has no `s`."""
@@ -341,6 +358,9 @@ def mono_kid_goldens():
 
 if __name__ == '__main__':
   import sys
+  if 'encoder' in sys.argv[1:]:
+    encoder_goldens()
+    sys.exit(0)
   if 'mono_kid' in sys.argv[1:]:
     mono_kid_goldens()
     sys.exit(0)
@@ -365,3 +385,4 @@ if __name__ == '__main__':
   image_mono_train_goldens()
   mono_train_goldens()
   mono_kid_goldens()
+  encoder_goldens()

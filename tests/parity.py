@@ -559,6 +559,48 @@ def check_render_rays_mono_kid(device, golden, S=64):
   return n
 
 
+def check_encoder(device, golden, name='small', atol=1e-4):
+  """dynibar_amd.feature_network.ResNet (HIP convolutions, channels-last) against the real reference's ResNet outputs: 1e-4 (+1e-4
+  relative); returned maps are NCHW views of channels-last storage that SourceViews taps in place."""
+  from dynibar_amd import feature_network
+  imgs, sd = cases.encoder_case(name)
+  net = feature_network.ResNet.from_module(sd)
+  x = imgs.to(device).permute(0, 3, 1, 2)  # what eval_nvidia.py:335-358 passes: an NCHW view of [N,H,W,3]
+  xc, xf = net(x)
+  for got, key in ((xc, 'coarse'), (xf, 'fine')):
+    ref = torch.from_numpy(golden[f'{name}/{key}'])
+    assert tuple(got.shape) == tuple(ref.shape), f'{key}: shape {tuple(got.shape)} vs reference {tuple(ref.shape)}'
+    assert ops._channels_last_view(got) is not None, 'encoder outputs must be channels-last in memory'
+    assert_close(got, ref, atol, 1e-4, f'encoder {name} {key} (|ref| up to {float(ref.abs().max()):.1f})')
+  # the oracle's restatement on the same inputs (pinned to the same golden by tests/test_oracle_golden.py)
+  oc, of = O.resnet_encoder(O.tdict(sd), imgs.permute(0, 3, 1, 2))
+  assert_close(xc, oc, atol, 1e-4, f'encoder {name} coarse vs oracle')
+  return float((cpu(xc) - torch.from_numpy(golden[f'{name}/coarse'])).abs().max())
+
+
+def check_encoder_feeds_gather(device):
+  """Maps produced by the HIP encoder are tapped in place (no repack): the gather on them equals the gather on an NCHW copy."""
+  from dynibar_amd import feature_network
+  scene, o, d, uv, _ = cases.scene_case('small')
+  sd = to_dev(scene, device)
+  enc = feature_network.ResNet.from_module(syn_encoder())
+  _, fine = enc(sd['static_src_rgbs'][0].permute(0, 3, 1, 2))
+  assert fine.shape[1] == 32
+  pts_r, z_r, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], 16, True, True)
+  va = ops.SourceViews(sd['camera'], sd['static_src_rgbs'], sd['static_src_cameras'], fine)
+  assert va.feat_cl.data_ptr() == fine.data_ptr(), 'channels-last maps must be used without a copy'
+  vb = ops.SourceViews(sd['camera'], sd['static_src_rgbs'], sd['static_src_cameras'], fine.contiguous())
+  assert vb.feat_cl.data_ptr() != fine.data_ptr()
+  ra = ops.project_gather(va, o.shape[0], 16, ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
+  rb = ops.project_gather(vb, o.shape[0], 16, ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
+  assert_bitexact(ra[0], rb[0], 'gather on in-place channels-last maps')
+
+
+def syn_encoder():
+  from dynibar_amd import synthetic
+  return synthetic.make_encoder_weights(0)
+
+
 def sampler_data():
   """The seeded `data` dict of tests/golden/make_golden.py:sampler_goldens."""
   scene, o, d, uv, pix = cases.scene_case('small')

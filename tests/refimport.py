@@ -34,7 +34,7 @@ def import_reference():
     sys.path.insert(0, REF_ROOT)
   import importlib
   mods = types.SimpleNamespace()
-  for name in ('sample_ray', 'projection', 'render_ray', 'mlp_network', 'render_image'):
+  for name in ('sample_ray', 'projection', 'render_ray', 'mlp_network', 'render_image', 'feature_network'):
     setattr(mods, name, importlib.import_module('ibrnet.' + name))
   mods.init_dct_basis = importlib.import_module('ibrnet.model').init_dct_basis
   return mods

@@ -146,6 +146,16 @@ def test_render_rays_mono_virtual_views(dev):
   parity.check_render_rays_mono_vv(dev)
 
 
+@pytest.mark.parametrize('name', ['small', 'odd', 'wide'])
+def test_feature_encoder(dev, golden_dir, name):
+  """Section 8(f)1: the ResNet feature encoder as HIP implicit-GEMM convolutions vs the real reference's feature maps."""
+  parity.check_encoder(dev, _golden(golden_dir, 'encoder.npz'), name)
+
+
+def test_feature_encoder_feeds_the_gather_in_place(dev):
+  parity.check_encoder_feeds_gather(dev)
+
+
 def test_fp32_class_engine_build(dev):
   """libdynibar_hip_x6.so (6-term bf16 split, fp32-class products): engine self-test at 2e-6 and static net parity, in a subprocess
   because a process binds one library."""

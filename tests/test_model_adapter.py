@@ -127,3 +127,21 @@ def test_unsupported_module_variants_are_rejected_by_shape():
   D['ref_pts_fc.0.weight'] = D['ref_pts_fc.0.weight'][:, :128]
   with pytest.raises(ValueError, match='ref_pts_fc.0.weight'):
     ops.DynamicNet(D, 'cpu')
+
+
+@pytest.mark.skipif(not refimport.have_reference(), reason='needs /root/reference (build container only)')
+def test_encoder_packs_the_real_reference_module():
+  """dynibar_amd.feature_network.ResNet.from_module takes the reference's ResNet (DataParallel-wrapped like model.py:142-151); the
+  decoder layers its state dict also carries are ignored like its forward ignores them."""
+  from dynibar_amd import feature_network
+  FN = refimport.import_reference().feature_network
+  net = FN.ResNet(coarse_out_ch=32, fine_out_ch=32, coarse_only=False)
+  sd = {k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(2).items()}
+  net.load_state_dict(sd, strict=False)
+  enc = feature_network.ResNet.from_module(torch.nn.DataParallel(net))
+  a = enc._encoder('cpu').blob
+  b = ops.Encoder(syn.make_encoder_weights(2), 'cpu').blob
+  assert torch.equal(a, b)
+  with pytest.raises(ValueError, match='conv1.weight'):
+    bad = dict(syn.make_encoder_weights(2)); bad['conv1.weight'] = bad['conv1.weight'][:, :, :5, :5]
+    ops.Encoder(bad, 'cpu')

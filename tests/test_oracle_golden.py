@@ -150,6 +150,15 @@ def test_chain_level_indices(golden_dir):
     np.testing.assert_array_equal(inds.numpy(), g['chain/mv_above_inds'])
 
 
+@pytest.mark.parametrize('name', ['small', 'odd', 'wide'])
+def test_encoder(golden_dir, name):
+  """Section 8(f)1: the oracle's restatement of the executed part of ResNet.forward against the real reference's feature maps."""
+  g = load(golden_dir, 'encoder.npz')
+  imgs, sd = cases.encoder_case(name)
+  xc, xf = O.resnet_encoder(O.tdict(sd), imgs.permute(0, 3, 1, 2))
+  close(xc, g[f'{name}/coarse'], rtol=1e-5, atol=1e-5); close(xf, g[f'{name}/fine'], rtol=1e-5, atol=1e-5)
+
+
 def test_image_rays(golden_dir):
   g = load(golden_dir, 'sampler.npz')
   scene, *_ = cases.scene_case('small')

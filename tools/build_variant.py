@@ -12,7 +12,7 @@ for a in rest:
   elif a == '--nets': cur = nets
   else: cur.append(a)
 objs = []
-for src, base, extra in (('dyn_geometry.hip', ['-ffp-contract=off'], geom), ('dyn_nets.hip', [], nets)):
+for src, base, extra in (('dyn_geometry.hip', ['-ffp-contract=off'], geom), ('dyn_nets.hip', [], nets), ('dyn_encoder.hip', [], [])):
   obj = os.path.join(CSRC, src.replace('.hip', '.o'))
   if extra:
     obj = os.path.join(CSRC, src.replace('.hip', f'_{tag}.o'))
