@@ -142,7 +142,6 @@ struct ConvArgs {
   float* out_hi;           // NULL, or the last 32 channels [N, Hout, Wout, 32]
   double* stats_out;       // [N][64][2] accumulated here, or NULL
   int N, Hin, Win, Hout, Wout;
-  int rows_per_wg;
 };
 
 // statistics of one (image, channel) -> the fused multiply-add of InstanceNorm + affine: y = x * sc + sh
@@ -163,35 +162,61 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
   float* wl = lds;                                     // weight images
   float* coef = lds + enc_image_floats(GROUPS);        // [sc 64 | sh 64] of the input norm
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  const int n = blockIdx.y;
   // weights -> LDS (lane-linear images, 16 bytes per thread per step)
   {
     const float4* src = reinterpret_cast<const float4*>(p.wimg);
     float4* dst = reinterpret_cast<float4*>(wl);
     for (int i = tid; i < (int)(enc_image_floats(GROUPS) / 4); i += ENC_THREADS) dst[i] = src[i];
   }
-  if (MODE != LOAD_PLAIN && tid < 64) {
+  // This workgroup's share of the batch: a contiguous run of the N * Hout output rows (one workgroup per CU: no tail generation of
+  // workgroups).  The run may cross an image boundary: the per-image norm coefficients are tabulated for both images it can touch.
+  const long rows_total = (long)p.N * p.Hout;
+  const long r_lo = rows_total * blockIdx.x / gridDim.x, r_hi = rows_total * (blockIdx.x + 1) / gridDim.x;
+  const int n_first = (int)(r_lo / p.Hout);
+  if (MODE != LOAD_PLAIN && tid < 128) {
+    const int which = tid >> 6, c = tid & 63;
+    const int n = n_first + which < p.N ? n_first + which : p.N - 1;
     float sc, sh;
-    norm_coeff(p.stats_in + ((long)n * 64 + tid) * 2, p.affine_in[tid], p.affine_in[64 + tid], 1.0 / ((double)p.Hin * p.Win), sc, sh);
-    coef[tid] = sc;
-    coef[64 + tid] = sh;
+    norm_coeff(p.stats_in + ((long)n * 64 + c) * 2, p.affine_in[c], p.affine_in[64 + c], 1.0 / ((double)p.Hin * p.Win), sc, sh);
+    coef[which * 128 + c] = sc;
+    coef[which * 128 + 64 + c] = sh;
   }
   __syncthreads();
 
   const int tiles_x = (p.Wout + 31) / 32;
-  const int row0 = blockIdx.x * p.rows_per_wg;
-  const int row1 = row0 + p.rows_per_wg < p.Hout ? row0 + p.rows_per_wg : p.Hout;
-  const int n_tiles = (row1 - row0) * tiles_x;
-  float s1[2][16], s2[2][16];  // this lane's running per-channel sums of what it wrote (channel 32 t + fi(r, h))
+  const long n_tiles = (r_hi - r_lo) * tiles_x;
+  float s1[2][16], s2[2][16];  // this lane's running per-channel sums of what it wrote (channel 32 t + fi(r, h)) for image n_cur
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+  int n_cur = -1;
+  // the 32 pixel-lanes of a half hold partial sums of the same 32 channels: butterfly over the lanes, then one fp64 atomic per channel
+  auto flush_stats = [&]() {
+    if (p.stats_out == nullptr || n_cur < 0) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (j == 0) {
+          double* st = p.stats_out + ((long)n_cur * 64 + 32 * t + dyn_fi(r, h)) * 2;
+          atomicAdd(st, (double)a);
+          atomicAdd(st + 1, (double)b);
+        }
+        s1[t][r] = 0.f; s2[t][r] = 0.f;
+      }
+  };
 
-  const float* inb = p.in + (long)n * p.Hin * p.Win * CIN;
-  const float* in2b = MODE == LOAD_NORM_ADD_RELU ? p.in2 + (long)n * p.Hin * p.Win * 64 : nullptr;
-  for (int tile = wave; tile < n_tiles; tile += ENC_THREADS / 64) {
-    const int oy = row0 + tile / tiles_x, ox = (tile % tiles_x) * 32 + j;
+  for (long tile = wave; tile < n_tiles; tile += ENC_THREADS / 64) {
+    const long grow = r_lo + tile / tiles_x;  // row of the flattened (image, output row) list
+    const int n = (int)(grow / p.Hout), oy = (int)(grow - (long)n * p.Hout), ox = (int)(tile % tiles_x) * 32 + j;
+    if (n != n_cur) { flush_stats(); n_cur = n; }
+    const float* cf = coef + (n - n_first) * 128;
+    const float* inb = p.in + (long)n * p.Hin * p.Win * CIN;
+    const float* in2b = MODE == LOAD_NORM_ADD_RELU ? p.in2 + (long)n * p.Hin * p.Win * 64 : nullptr;
     const bool live = ox < p.Wout;
     const int oxc = live ? ox : p.Wout - 1;  // idle lanes shadow the last pixel (loads stay in bounds, nothing is stored)
     f32x16 acc[2];
@@ -199,46 +224,8 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = p.bias != nullptr ? p.bias[32 * t + dyn_fi(r, h)] : 0.f;
-    constexpr int G_UNROLL = CIN == 3 ? 1 : 2;
-#pragma unroll G_UNROLL
-    for (int g = 0; g < GROUPS; ++g) {
-      float v[8];
-      if (CIN == 3) {
-        // K = (ky, [kx, ic] padded to 24): this lane's 8 values are k = 16 g + 8 h + e, i.e. 8-float chunk c = 2 g + h of the padded rows:
-        // kernel row ky = c / 3, floats [8 (c % 3), + 8) of that row's 21 (+ 3 zero-weight) floats
-        const int c = 2 * g + h;
-        const int ky = (c * 11) >> 5;          // c / 3 for c < 32
-        const int j0 = (c - 3 * ky) * 8;
-        const int iy = reflect_idx(oy * STRIDE + (ky < 7 ? ky : 6) - PAD, p.Hin);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int jj = j0 + e;
-          const int kx = (jj * 11) >> 5;        // jj / 3 for jj < 32
-          const int ic = jj - 3 * kx;
-          const int ix = reflect_idx(oxc * STRIDE + (kx < 7 ? kx : 6) - PAD, p.Win);
-          const float x = inb[((long)iy * p.Win + ix) * 3 + ic];
-          v[e] = (ky < 7 && jj < 21) ? x : 0.f;
-        }
-      } else {
-        const int tap = g >> 2, cg = g & 3;
-        const int ky = tap / KW, kx = tap - ky * KW;
-        const int iy = reflect_idx(oy * STRIDE + ky - PAD, p.Hin), ix = reflect_idx(oxc * STRIDE + kx - PAD, p.Win);
-        const long off = ((long)iy * p.Win + ix) * 64 + cg * 16 + h * 8;
-        const float4 a = *reinterpret_cast<const float4*>(inb + off), b = *reinterpret_cast<const float4*>(inb + off + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if (MODE != LOAD_PLAIN) {
-          const float4 sa = *reinterpret_cast<const float4*>(coef + cg * 16 + h * 8), sb = *reinterpret_cast<const float4*>(coef + cg * 16 + h * 8 + 4);
-          const float4 ha = *reinterpret_cast<const float4*>(coef + 64 + cg * 16 + h * 8), hb = *reinterpret_cast<const float4*>(coef + 64 + cg * 16 + h * 8 + 4);
-          const float scv[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w}, shv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
-          float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (MODE == LOAD_NORM_ADD_RELU) {
-            const float4 ra = *reinterpret_cast<const float4*>(in2b + off), rb = *reinterpret_cast<const float4*>(in2b + off + 4);
-            add[0] = ra.x; add[1] = ra.y; add[2] = ra.z; add[3] = ra.w; add[4] = rb.x; add[5] = rb.y; add[6] = rb.z; add[7] = rb.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]) + add[e], 0.f);
-        }
-      }
+    // one K-group (16 K values: this lane's 8) through the split engine against both output tiles
+    auto mma_group = [&](int g, const float (&v)[8]) {
       u32x4v bh, bm, bl;
 #pragma unroll
       for (int p2 = 0; p2 < 4; ++p2) {
@@ -258,6 +245,79 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
         acc[t] = mfma_bf16(a.hi, bm, acc[t]);
         acc[t] = mfma_bf16(a.hi, bh, acc[t]);
       }
+    };
+    if constexpr (CIN == 3) {
+      // K = (ky, [kx, ic] padded to 24): this lane's 8 values of group g are k = 16 g + 8 h + e, i.e. 8-float chunk c = 2 g + h of the padded
+      // rows: kernel row ky = c / 3, floats [8 (c % 3), + 8) of that row's 21 (+ 3 zero-weight) floats.  Group g + 1 is in flight under group g.
+      auto load_group = [&](int g, float (&v)[8]) {
+        const int c = 2 * g + h;
+        const int ky = (c * 11) >> 5;          // c / 3 for c < 32
+        const int j0 = (c - 3 * ky) * 8;
+        const int iy = reflect_idx(oy * STRIDE + (ky < 7 ? ky : 6) - PAD, p.Hin);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int jj = j0 + e;
+          const int kx = (jj * 11) >> 5;        // jj / 3 for jj < 32
+          const int ic = jj - 3 * kx;
+          const int ix = reflect_idx(oxc * STRIDE + (kx < 7 ? kx : 6) - PAD, p.Win);
+          const float x = inb[((long)iy * p.Win + ix) * 3 + ic];
+          v[e] = (ky < 7 && jj < 21) ? x : 0.f;
+        }
+      };
+      float cur[8], nxt[8];
+      load_group(0, cur);
+#pragma unroll 1
+      for (int g = 0; g < GROUPS; ++g) {
+        if (g + 1 < GROUPS) load_group(g + 1, nxt);
+        mma_group(g, cur);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
+      }
+    } else {
+      // K order of the weight images: k-group g = tap * 4 + cg.  The channel group is the OUTER loop, so that the 16 norm coefficients of
+      // the lane's 8 channels sit in registers for all taps; operand fetches (2 float4 = this lane's 8 channels of one input pixel) run
+      // PF (tap, cg) steps ahead of the MFMAs that consume them.
+      constexpr int TAPS = KH * KW, STEPS = 4 * TAPS, PF = 4;
+      struct Op { float4 a, b, ra, rb; };
+      auto load_op = [&](int step, Op& o) {
+        const int cg = step / TAPS, tap = step - cg * TAPS;
+        const int ky = tap / KW, kx = tap - ky * KW;
+        const int iy = reflect_idx(oy * STRIDE + ky - PAD, p.Hin), ix = reflect_idx(oxc * STRIDE + kx - PAD, p.Win);
+        const long off = ((long)iy * p.Win + ix) * 64 + cg * 16 + h * 8;
+        o.a = *reinterpret_cast<const float4*>(inb + off);
+        o.b = *reinterpret_cast<const float4*>(inb + off + 4);
+        if (MODE == LOAD_NORM_ADD_RELU) {
+          o.ra = *reinterpret_cast<const float4*>(in2b + off);
+          o.rb = *reinterpret_cast<const float4*>(in2b + off + 4);
+        }
+      };
+      Op ring[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        if (i < STEPS) load_op(i, ring[i]);
+      float scv[8], shv[8];
+#pragma unroll
+      for (int step = 0; step < STEPS; ++step) {
+        const int cg = step / TAPS, tap = step - cg * TAPS;
+        if (MODE != LOAD_PLAIN && tap == 0) {
+          const float4 sa = *reinterpret_cast<const float4*>(cf + cg * 16 + h * 8), sb = *reinterpret_cast<const float4*>(cf + cg * 16 + h * 8 + 4);
+          const float4 ha = *reinterpret_cast<const float4*>(cf + 64 + cg * 16 + h * 8), hb = *reinterpret_cast<const float4*>(cf + 64 + cg * 16 + h * 8 + 4);
+          scv[0] = sa.x; scv[1] = sa.y; scv[2] = sa.z; scv[3] = sa.w; scv[4] = sb.x; scv[5] = sb.y; scv[6] = sb.z; scv[7] = sb.w;
+          shv[0] = ha.x; shv[1] = ha.y; shv[2] = ha.z; shv[3] = ha.w; shv[4] = hb.x; shv[5] = hb.y; shv[6] = hb.z; shv[7] = hb.w;
+        }
+        const Op o = ring[step % PF];
+        if (step + PF < STEPS) load_op(step + PF, ring[step % PF]);
+        float v[8] = {o.a.x, o.a.y, o.a.z, o.a.w, o.b.x, o.b.y, o.b.z, o.b.w};
+        if (MODE != LOAD_PLAIN) {
+          float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (MODE == LOAD_NORM_ADD_RELU) {
+            add[0] = o.ra.x; add[1] = o.ra.y; add[2] = o.ra.z; add[3] = o.ra.w; add[4] = o.rb.x; add[5] = o.rb.y; add[6] = o.rb.z; add[7] = o.rb.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]) + add[e], 0.f);
+        }
+        mma_group(tap * 4 + cg, v);
+      }
     }
     if (live) {
       const long pix = ((long)n * p.Hout + oy) * p.Wout + ox;
@@ -272,22 +332,7 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
       }
     }
   }
-  if (p.stats_out != nullptr) {
-    // the 32 pixel-lanes of a half hold partial sums of the same 32 channels: butterfly over the lanes, then one fp64 atomic per channel
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = s1[t][r], b = s2[t][r];
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-        if (j == 0) {
-          double* st = p.stats_out + ((long)n * 64 + 32 * t + dyn_fi(r, h)) * 2;
-          atomicAdd(st, (double)a);
-          atomicAdd(st + 1, (double)b);
-        }
-      }
-  }
+  flush_stats();
 }
 
 // block output: out = relu(IN(a) + (IN(b) | b))   (BasicBlock.forward, feature_network.py:66-85)
@@ -355,12 +400,17 @@ extern "C" int dyn_encoder_out_size(int H, int W, int* Hf, int* Wf) {
 template <int KH, int KW, int STRIDE, int CIN, int MODE>
 static int launch_conv(int slot, const char* name, ConvArgs a, hipStream_t stream) {
   constexpr int GROUPS = CIN == 3 ? K7_GROUPS : KH * KW * 4;
-  const size_t lds = (enc_image_floats(GROUPS) + 128) * sizeof(float);
-  // about one workgroup per CU over the whole batch: strips of output rows per image
-  int strips = (256 + a.N - 1) / a.N;
-  strips = strips < 1 ? 1 : (strips > a.Hout ? a.Hout : strips);
-  a.rows_per_wg = (a.Hout + strips - 1) / strips;
-  const dim3 grid((a.Hout + a.rows_per_wg - 1) / a.rows_per_wg, a.N);
+  const size_t lds = (enc_image_floats(GROUPS) + 256) * sizeof(float);
+  // one workgroup per CU (the weight images take the LDS of a CU), each a contiguous share of the batch's output rows
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const long rows_total = (long)a.N * a.Hout;
+  const long want = n_cu > a.N ? n_cu : a.N;  // a share never spans more than two images (the kernel tabulates the norm coefficients of two)
+  const dim3 grid((unsigned)(rows_total < want ? rows_total : want));
   DYN_LAUNCH(slot, name, (k_enc_conv<KH, KW, STRIDE, CIN, MODE>), grid, dim3(ENC_THREADS), lds, stream, a);
   return 0;
 }
@@ -389,29 +439,29 @@ extern "C" int dyn_encoder_forward(const DynEncoderParams* q, void* stream_) {
   ConvArgs a;
   int rc;
   // conv1 7x7 / 2 on the images as stored ([N,H,W,3]); its norm + ReLU is applied by its two consumers
-  a = ConvArgs{q->images, nullptr, nullptr, nullptr, B + EN_OFF_CONV1, nullptr, c1, nullptr, st(0), q->N, q->H, q->W, w.H1, w.W1, 0};
+  a = ConvArgs{q->images, nullptr, nullptr, nullptr, B + EN_OFF_CONV1, nullptr, c1, nullptr, st(0), q->N, q->H, q->W, w.H1, w.W1};
   if ((rc = launch_conv<7, 7, 2, 3, LOAD_PLAIN>(DYN_K_ENC_CONV7, "k_enc_conv7", a, stream))) return rc;
   // layer1.0: conv3x3 / 2 and the 1x1 / 2 shortcut, both on relu(IN(c1))
-  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), c3(0), nullptr, t0, nullptr, st(1), q->N, w.H1, w.W1, w.H2, w.W2, 0};
+  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), c3(0), nullptr, t0, nullptr, st(1), q->N, w.H1, w.W1, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 2, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3s2", a, stream))) return rc;
-  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), B + EN_OFF_DS, nullptr, t1, nullptr, st(3), q->N, w.H1, w.W1, w.H2, w.W2, 0};
+  a = ConvArgs{c1, nullptr, st(0), aff(NORM_BN1), B + EN_OFF_DS, nullptr, t1, nullptr, st(3), q->N, w.H1, w.W1, w.H2, w.W2};
   if ((rc = launch_conv<1, 1, 2, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV1, "k_enc_conv1s2", a, stream))) return rc;
-  a = ConvArgs{t0, nullptr, st(1), aff(NORM_B0N1), c3(1), nullptr, t2, nullptr, st(2), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t0, nullptr, st(1), aff(NORM_B0N1), c3(1), nullptr, t2, nullptr, st(2), q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
   // out0 = relu(IN(conv2) + IN(shortcut)) -> t3
   DYN_LAUNCH(DYN_K_ENC_BLOCK, "k_enc_block_out", k_enc_block_out, ew_grid, ew_blk, 1024, stream, t2, st(2), aff(NORM_B0N2), t1, st(3), aff(NORM_B0DS), hw2, t3);
   // layer1.1 on out0 (t3): conv1 -> t0, conv2 -> t1, out1 = relu(IN(conv2) + out0) -> t2
-  a = ConvArgs{t3, nullptr, nullptr, nullptr, c3(2), nullptr, t0, nullptr, st(4), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t3, nullptr, nullptr, nullptr, c3(2), nullptr, t0, nullptr, st(4), q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 1, 64, LOAD_PLAIN>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
-  a = ConvArgs{t0, nullptr, st(4), aff(NORM_B1N1), c3(3), nullptr, t1, nullptr, st(5), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t0, nullptr, st(4), aff(NORM_B1N1), c3(3), nullptr, t1, nullptr, st(5), q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
   DYN_LAUNCH(DYN_K_ENC_BLOCK, "k_enc_block_out", k_enc_block_out, ew_grid, ew_blk, 1024, stream, t1, st(5), aff(NORM_B1N2), t3, (const double*)nullptr, (const float*)nullptr, hw2, t2);
   // layer1.2 on out1 (t2): conv1 -> t0, conv2 -> t1; out2 = relu(IN(conv2) + out1) is formed by the 1x1 output convolution as it loads
-  a = ConvArgs{t2, nullptr, nullptr, nullptr, c3(4), nullptr, t0, nullptr, st(6), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t2, nullptr, nullptr, nullptr, c3(4), nullptr, t0, nullptr, st(6), q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 1, 64, LOAD_PLAIN>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
-  a = ConvArgs{t0, nullptr, st(6), aff(NORM_B2N1), c3(5), nullptr, t1, nullptr, st(7), q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t0, nullptr, st(6), aff(NORM_B2N1), c3(5), nullptr, t1, nullptr, st(7), q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<3, 3, 1, 64, LOAD_NORM_RELU>(DYN_K_ENC_CONV3, "k_enc_conv3", a, stream))) return rc;
-  a = ConvArgs{t1, t2, st(7), aff(NORM_B2N2), B + EN_OFF_OUT, B + EN_OFF_BIAS, q->coarse, q->fine, nullptr, q->N, w.H2, w.W2, w.H2, w.W2, 0};
+  a = ConvArgs{t1, t2, st(7), aff(NORM_B2N2), B + EN_OFF_OUT, B + EN_OFF_BIAS, q->coarse, q->fine, nullptr, q->N, w.H2, w.W2, w.H2, w.W2};
   if ((rc = launch_conv<1, 1, 1, 64, LOAD_NORM_ADD_RELU>(DYN_K_ENC_CONV1, "k_enc_out_conv", a, stream))) return rc;
   return 0;
 }

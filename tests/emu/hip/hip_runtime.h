@@ -57,6 +57,8 @@ constexpr int hipMemcpyHostToDevice = 1;
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; int clockRate; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 7; p->clockRate = 1000000; return hipSuccess; }
 static inline hipError_t hipStreamGetDevice(hipStream_t, int* d) { *d = 0; return hipSuccess; }
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 
