@@ -145,3 +145,58 @@ def test_encoder_packs_the_real_reference_module():
   with pytest.raises(ValueError, match='conv1.weight'):
     bad = dict(syn.make_encoder_weights(2)); bad['conv1.weight'] = bad['conv1.weight'][:, :, :5, :5]
     ops.Encoder(bad, 'cpu')
+
+
+def _checkpoint_files(tmp_path, modules=None):
+  """Files in the reference's two checkpoint formats (model.py:424-441 coarse / monocular, :177-190 fine), from seeded weights."""
+  W = cases.model_weights(0)
+  T = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+  basis = torch.nn.parameter.Parameter(torch.arange(cases.NUM_FRAMES * cases.NUM_BASIS, dtype=torch.float32).reshape(cases.NUM_FRAMES, cases.NUM_BASIS) * 1e-2)
+  if modules is not None:  # state dicts taken from the reference's own modules, de-parallelised like model.py:13-15
+    st = lambda kind, sd, **kw: refmodules.load_numpy_state(modules(kind, _args('nvidia_eval'), **kw), sd).state_dict()
+    W = {k: {n: t.numpy() for n, t in st('static' if '_st' in k else ('dynamic' if '_dy' in k else 'motion'), v).items()} for k, v in W.items()}
+  coarse = {'optimizer': {'state': {}, 'param_groups': []}, 'scheduler': {'last_epoch': 3}, 'net_coarse_st': T(W['net_coarse_st']), 'net_coarse_dy': T(W['net_coarse_dy']),
+            'feature_net': T(syn.make_encoder_weights(1)), 'feature_net_st': T(syn.make_encoder_weights(2)), 'motion_mlp': T(W['motion_mlp']), 'traj_basis': basis,
+            'global_step': 1234}
+  fine = {'optimizer': {}, 'scheduler': {}, 'net_fine_st': T(W['net_fine_st']), 'net_fine_dy': T(W['net_fine_dy']), 'feature_net_fine': T(syn.make_encoder_weights(3)),
+          'motion_mlp_fine': T(W['motion_mlp_fine']), 'traj_basis_fine': basis.detach() * 2.0, 'global_step': 99}
+  pc, pf = str(tmp_path / 'model_coarse.pth'), str(tmp_path / 'model_fine.pth')
+  torch.save(coarse, pc)
+  torch.save(fine, pf)
+  return pc, pf, W
+
+
+def test_checkpoint_files_load_into_the_adapter(tmp_path):
+  """Section 8(f)4: torch.save dictionaries in the reference's checkpoint formats -> a model the renderer packs."""
+  from dynibar_amd import checkpoint
+  pc, pf, W = _checkpoint_files(tmp_path)
+  m = checkpoint.load_model(pc, pf, device='cpu')
+  assert m.global_step == 99 and tuple(m.trajectory_basis.shape) == (cases.NUM_FRAMES, cases.NUM_BASIS) and not m.trajectory_basis.requires_grad
+  assert float(m.trajectory_basis_fine[1, 1]) == 2.0 * float(m.trajectory_basis[1, 1])
+  args = _args('nvidia_eval')
+  for name in ('net_coarse_st', 'net_fine_st'):
+    assert torch.equal(render_ray._static_net(m, name, args, 'cpu').blob, ops.StaticNet(W[name], 'cpu', True, False).blob)
+  dy = render_ray._dynamic_net(m, 'net_coarse_dy', 'cpu')
+  assert dy.shift == 5.0, 'a file with feature_net_st is a monocular checkpoint: DynibarMono builds the dynamic net with shift 5 (model.py:304-309)'
+  assert torch.equal(dy.blob, ops.DynamicNet(W['net_coarse_dy'], 'cpu').blob)
+  assert torch.equal(render_ray._motion_mlp(m, 'motion_mlp_fine', 'cpu', cases.NUM_BASIS).blob, ops.MotionMLP(W['motion_mlp_fine'], 'cpu', cases.NUM_BASIS).blob)
+  for name, seed in (('feature_net', 1), ('feature_net_st', 2), ('feature_net_fine', 3)):
+    assert torch.equal(getattr(m, name)._encoder('cpu').blob, ops.Encoder(syn.make_encoder_weights(seed), 'cpu').blob)
+  m0 = checkpoint.load_model(torch.load(pc, weights_only=False), device='cpu', dynamic_shift=0.0)  # an already-loaded dictionary, explicit shift
+  assert render_ray._dynamic_net(m0, 'net_coarse_dy', 'cpu').shift == 0.0 and not hasattr(m0, 'net_fine_st')
+  with pytest.raises(KeyError, match='net_coarse_st'):
+    checkpoint.load_model({'net_fine_st': {}}, device='cpu')
+
+
+@pytest.mark.skipif(not refimport.have_reference(), reason='needs /root/reference (build container only)')
+def test_checkpoint_of_the_real_reference_modules(tmp_path):
+  """The same through state dicts produced by the reference's own nn.Modules (what de_parallel(net).state_dict() saves)."""
+  from dynibar_amd import checkpoint
+  pc, pf, W = _checkpoint_files(tmp_path, modules=_real)
+  m = checkpoint.load_model(pc, pf, device='cpu')
+  assert torch.equal(render_ray._static_net(m, 'net_coarse_st', _args('nvidia_eval'), 'cpu').blob, ops.StaticNet(cases.model_weights(0)['net_coarse_st'], 'cpu', True, False).blob)
+  FN = refimport.import_reference().feature_network
+  net = FN.ResNet(coarse_out_ch=32, fine_out_ch=32)
+  torch.save({'net_coarse_st': m.net_coarse_st, 'feature_net': net.state_dict()}, str(tmp_path / 'x.pth'))  # incl. the decoder layers forward never runs
+  m2 = checkpoint.load_model(str(tmp_path / 'x.pth'), device='cpu')
+  assert m2.feature_net._encoder('cpu').blob.numel() == ops.Encoder(syn.make_encoder_weights(0), 'cpu').blob.numel()
