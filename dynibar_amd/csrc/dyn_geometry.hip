@@ -1023,7 +1023,7 @@ __global__ void k_fine_samples(DynFineSampleParams p, int T) {
   const int S = p.S, N = p.N, M = S - 2, NB = S - 1;
   float* cdf = lds;                 // [NB][T]   cdf_0..cdf_M
   float* bins = lds + (long)NB * T; // [NB][T]
-  float* outz = bins + (long)NB * T;  // [S+N][T]
+  float* news = bins + (long)NB * T;  // [N][T] the new depths, kept ascending in z
   if (r >= p.R) return;  // no barrier in this kernel
   const float* z = p.z_vals + (long)r * S;
   const float* w = p.weights + (long)r * S;
@@ -1054,8 +1054,6 @@ __global__ void k_fine_samples(DynFineSampleParams p, int T) {
     c += (double)(wj / total);
     cdf[(j + 1) * T + t] = (float)c;
   }
-  for (int i = 0; i < S; ++i) outz[i * T + t] = z[i];
-  int filled = S;
   for (int n = 0; n < N; ++n) {
     float u;
     if (p.u != nullptr) {
@@ -1065,8 +1063,14 @@ __global__ void k_fine_samples(DynFineSampleParams p, int T) {
       float step = 1.0f / (float)(N - 1);
       u = (n < N / 2) ? ((float)n * step) : (1.0f - step * (float)(N - 1 - n));
     }
-    int above = 0;
-    for (int j = 0; j < M; ++j) above += (u >= cdf[j * T + t]) ? 1 : 0;
+    // above = #{j < M : cdf_j <= u}  (render_ray.py:38-39 counts with a loop of M compares).  The cdf is non-decreasing (prefix sums of
+    // non-negative terms, rounded monotonically), so the count is an upper bound found by bisection: same integer, log2(M) probes.
+    int lo_i = 0, hi_i = M;
+    while (lo_i < hi_i) {
+      const int mid = (lo_i + hi_i) >> 1;
+      if (u >= cdf[mid * T + t]) lo_i = mid + 1; else hi_i = mid;
+    }
+    const int above = lo_i;
     int below = above - 1 < 0 ? 0 : above - 1;
     float c0 = cdf[below * T + t], c1 = cdf[above * T + t];
     float b0 = bins[below * T + t], b1 = bins[above * T + t];
@@ -1077,23 +1081,35 @@ __global__ void k_fine_samples(DynFineSampleParams p, int T) {
     if (p.inv_uniform) smp = 1.0f / smp;
     if (p.inds) p.inds[(long)r * N + n] = above;
     if (p.z_samples) p.z_samples[(long)r * N + n] = smp;
-    // insertion into the sorted union (values only, so any correct sort equals torch.sort's values)
-    int k = filled;
-    while (k > 0 && outz[(k - 1) * T + t] > smp) {
-      outz[k * T + t] = outz[(k - 1) * T + t];
+    news[(p.inv_uniform ? N - 1 - n : n) * T + t] = smp;  // ascending u is ascending 1/z: descending z
+  }
+  // sorted union (values only, so any correct sort equals torch.sort's values): the new depths are insertion-sorted among themselves
+  // (already ascending for det=True, where u is a ramp and the map u -> depth is monotone up to rounding), then merged with the coarse ones
+  for (int n = 1; n < N; ++n) {
+    const float v = news[n * T + t];
+    int k = n;
+    while (k > 0 && news[(k - 1) * T + t] > v) {
+      news[k * T + t] = news[(k - 1) * T + t];
       --k;
     }
-    outz[k * T + t] = smp;
-    ++filled;
+    news[k * T + t] = v;
   }
-  float* zo = p.z_out + (long)r * (S + N);
-  for (int i = 0; i < S + N; ++i) zo[i] = outz[i * T + t];
+  {
+    float* zo = p.z_out + (long)r * (S + N);
+    int a = 0, b = 0;
+    for (int i = 0; i < S + N; ++i) {
+      const bool take_a = b >= N || (a < S && z[a] <= news[b * T + t]);
+      zo[i] = take_a ? z[a] : news[b * T + t];
+      a += take_a ? 1 : 0;
+      b += take_a ? 0 : 1;
+    }
+  }
 }
 
 extern "C" int dyn_fine_samples(const DynFineSampleParams* p, void* stream) {
   DYN_REQUIRE(p && p->z_vals && p->weights && p->z_out, "dyn_fine_samples: null pointer");
   DYN_REQUIRE(p->R > 0 && p->S > 2 && p->N > 1, "dyn_fine_samples: need R>0, S>2, N>1");
-  const size_t per_thread = (size_t)(2 * (p->S - 1) + p->S + p->N) * 4;
+  const size_t per_thread = (size_t)(2 * (p->S - 1) + p->N) * 4;
   int T = 64;
   while (T > 1 && per_thread * T > 144 * 1024) T >>= 1;
   DYN_REQUIRE(per_thread * T <= 144 * 1024, "dyn_fine_samples: S+N too large for LDS");
