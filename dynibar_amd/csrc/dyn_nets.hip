@@ -7,6 +7,7 @@
 //   C  k_static_blend : per point-view  rgb_fc -> masked softmax over views -> blend of the source colours
 // Between A and C the 128-wide per-view feature x is parked in HBM in the lanes' own register order (512 B per point-view).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -295,7 +296,16 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
 // -------------------------------------------------------------------------------------------------------------------
 // workspace layout (floats) of one dyn_static_net call
 // -------------------------------------------------------------------------------------------------------------------
+static bool dense_views(int V) {
+  static const int mode = getenv("DYN_DENSE_VIEWS") ? atoi(getenv("DYN_DENSE_VIEWS")) : -1;  // developer A/B: 0 never, 1 whenever V >= 9
+  if (mode == 0) return false;
+  if (mode == 1) return V >= 9;
+  // measured (4096/2048 rays x 64 samples, k_static_views + k_static_blend): dense rows win where the lane segments would be more than a
+  // quarter padding -- 9..12 views (vs 16 lanes) and 17..26 views (vs 32 lanes); 13..15 and 27..31 views keep the segments
+  return (V >= 9 && V <= 12) || (V >= 17 && V <= 26);
+}
 struct StaticWs {
+  bool dense;
   long n_pts, n_tiles_a, n_tiles_b;
   int PT, TPR;  // points per A tile; B tiles per ray (1, 2, 4 or -- rays of more than 128 samples -- a multiple of 4)
   size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;  // dynamic net: off_x/off_vis/off_hg unused, off_ref = time feature
@@ -311,8 +321,11 @@ struct StaticWs {
 static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   StaticWs w;
   w.n_pts = (long)R * S;
-  w.PT = 32 / (V <= 4 ? 4 : (V <= 8 ? 8 : (V <= 16 ? 16 : 32)));  // points per wave: views are padded to a power-of-two lane segment
-  w.n_tiles_a = (w.n_pts + w.PT - 1) / w.PT;
+  // points per wave: views are padded to a power-of-two lane segment; or (dense rows: view counts from 9 that are not a power of two)
+  // points per 256-row workgroup, whose 8 waves are 8 tiles of the parked-feature buffer
+  w.dense = dense_views(V);
+  w.PT = w.dense ? 256 / V : 32 / (V <= 4 ? 4 : (V <= 8 ? 8 : (V <= 16 ? 16 : 32)));
+  w.n_tiles_a = w.dense ? ((w.n_pts + w.PT - 1) / w.PT) * 8 : (w.n_pts + w.PT - 1) / w.PT;
   int tpr = (S + 31) / 32;
   w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : ((tpr + 3) / 4) * 4);
   w.n_tiles_b = (long)R * w.TPR;
@@ -435,14 +448,147 @@ __device__ __forceinline__ long point_rec(const StaticArgs& p, long point, int h
 // -------------------------------------------------------------------------------------------------------------------
 #define POOL_FLOATS(NX) (2 * (NX) * 2 * 32)
 #define RES_FLOATS (256 * 32)
+
+// ---- dense rows (VSEG == 0): any number of views without padding ------------------------------------------------------------------
+// The lane segments above want the views of a point in a power-of-two group of lanes, so 11 views occupy 16 lanes and 31 % of the
+// matrix work is padding.  In the dense flavour the 256 rows of a view workgroup are simply the first PTW * V point-views of its
+// PTW = 256 / V points, in order: a point's rows sit at arbitrary lanes and may straddle two waves.  Cross-view reductions then go
+// through LDS: rows deposit their terms in a [slot][row] table, a barrier, and (point, slot) tasks spread over the 512 threads add up the
+// V rows of their point.  More barriers than the DPP butterflies (about 18 per pass of the view chain), none of the padding.
+#define DENSE_STRIDE 258   /* row stride of a slot in the reduction tables (256 rows + 2: the two halves of a wave land on different banks) */
+#define DENSE_SCALARS 512  /* floats at the end of the workgroup's LDS for scalar rounds: [2][256] */
+#define DENSE_EXTRA 2304   /* floats added to the view kernels' LDS in the dense flavour (table space behind `res`) */
+struct DenseRows {
+  int V, PTW, rw, p_local, view, base;  // base: first row of this row's point (clamped for the idle tail rows)
+  float* scal;                          // [2][256]
+};
+__device__ __forceinline__ DenseRows dense_rows(int V, int PTW, float* scal) {
+  DenseRows d;
+  d.V = V; d.PTW = PTW; d.scal = scal;
+  d.rw = (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+  d.p_local = d.rw / V;
+  d.view = d.rw - d.p_local * V;
+  d.base = (d.p_local < PTW ? d.p_local : PTW - 1) * V;
+  return d;
+}
+// all-reduce of one value per row over the rows of the row's point (two values per round with the second table)
+template <class Op>
+__device__ __forceinline__ float dense_all(const DenseRows& d, float v, float ident, Op op) {
+  if ((threadIdx.x & 32) == 0) d.scal[d.rw] = v;
+  __syncthreads();
+  // four loads in flight per step: the trip count is a run-time value, and one dependent LDS round trip per view would cost ~100 cycles each
+  const float* src = d.scal + d.base;
+  float a0 = ident, a1 = ident, a2 = ident, a3 = ident;
+  int k = 0;
+  for (; k + 4 <= d.V; k += 4) { a0 = op(a0, src[k]); a1 = op(a1, src[k + 1]); a2 = op(a2, src[k + 2]); a3 = op(a3, src[k + 3]); }
+  for (; k < d.V; ++k) a0 = op(a0, src[k]);
+  __syncthreads();
+  return op(op(a0, a1), op(a2, a3));
+}
+__device__ __forceinline__ void dense_all2(const DenseRows& d, float v0, float v1, float& s0, float& s1) {
+  if ((threadIdx.x & 32) == 0) { d.scal[d.rw] = v0; d.scal[256 + d.rw] = v1; }
+  __syncthreads();
+  const float* src = d.scal + d.base;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  int k = 0;
+  for (; k + 2 <= d.V; k += 2) { a0 += src[k]; a1 += src[k + 1]; b0 += src[256 + k]; b1 += src[256 + k + 1]; }
+  for (; k < d.V; ++k) { a0 += src[k]; b0 += src[256 + k]; }
+  __syncthreads();
+  s0 = a0 + a1; s1 = b0 + b1;
+}
+template <int VSEG>
+__device__ __forceinline__ float views_sum(const DenseRows& d, float v) {
+  if constexpr (VSEG == 0) return dense_all(d, v, 0.f, [](float a, float b) { return a + b; });
+  else return seg_sum<VSEG>(v, 0, 0);
+}
+template <int VSEG>
+__device__ __forceinline__ float views_min(const DenseRows& d, float v) {
+  if constexpr (VSEG == 0) return dense_all(d, v, 3.0e38f, [](float a, float b) { return fminf(a, b); });
+  else return seg_min<VSEG>(v, 0, 0);
+}
+template <int VSEG>
+__device__ __forceinline__ float views_max(const DenseRows& d, float v) {
+  if constexpr (VSEG == 0) return dense_all(d, v, -3.0e38f, [](float a, float b) { return fmaxf(a, b); });
+  else return seg_max<VSEG>(v, 0, 0);
+}
+
+// base_fc.0's per-point statistics in the dense flavour: weighted mean and variance of the NX x 2 per-view slots over the views of
+// each point, into `pool` (the B operand of the per-point MFMA).  One-pass variance (sum w x^2 - mean^2 (2 - sum w)) of O(1) inputs;
+// four rounds of (NX + 1) / 2 slots x 2 halves through the table behind `pool`.
+template <int NX>
+__device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float (&xin)[NX], float wgt, float wsum, float* pool, float* tab) {
+  constexpr int NH = (NX + 1) / 2;
+  constexpr int MAXT = 3;  // (point, slot) tasks per thread and round: PTW * 2 NH <= 28 * 38 = 1064 over 512 threads
+  const int tid = threadIdx.x, h = (tid >> 5) & 1;
+  float* wtab = d.scal;    // sum of the pooling weights per point (0 or ~1); published by the first barrier below
+  if (d.view == 0 && h == 0 && d.p_local < d.PTW) wtab[d.p_local] = wsum;
+  float means[2][MAXT];    // [half of the slot list][task]: the means of rounds 0 / 1, consumed by rounds 2 / 3
+#pragma unroll
+  for (int round = 0; round < 4; ++round) {
+    const int stat = round >> 1, half = round & 1, q0 = half * NH;
+#pragma unroll
+    for (int qq = 0; qq < NH; ++qq) {
+      const int q = q0 + qq;
+      if (q < NX) {
+        const float wx = wgt * xin[q];
+        tab[(qq * 2 + h) * DENSE_STRIDE + d.rw] = stat ? wx * xin[q] : wx;
+      }
+    }
+    __syncthreads();
+    const int ns = (q0 + NH <= NX ? NH : NX - q0) * 2, total = d.PTW * ns;
+#pragma unroll
+    for (int it = 0; it < MAXT; ++it) {
+      const int task = tid + it * DYN_VIEW_THREADS;
+      if (task < total) {
+        const int pnt = task / ns, slot = task - pnt * ns;
+        const float* src = tab + slot * DENSE_STRIDE + pnt * d.V;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= d.V; k += 4) { c0 += src[k]; c1 += src[k + 1]; c2 += src[k + 2]; c3 += src[k + 3]; }
+        for (; k < d.V; ++k) c0 += src[k];
+        const float acc = (c0 + c1) + (c2 + c3);
+        if (stat == 0) {
+          means[half][it] = acc;
+        } else {
+          const float m = means[half][it], W = wtab[pnt];
+          const int q = q0 + (slot >> 1), hh = slot & 1;
+          pool[(q * 2 + hh) * 32 + pnt] = m;
+          pool[((NX + q) * 2 + hh) * 32 + pnt] = acc - m * m * (2.0f - W);  // sum w (x - m)^2 with sum w = W
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int VSEG, int NX>
 __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, const float (&xin)[NX], float wgt, int V, int view, int p_local,
-                                         float* pool, f32x16 (&a1)[8]) {
+                                         float* pool, f32x16 (&a1)[8], const DenseRows* dr = nullptr, float wsum = 0.f) {
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
-  if (VSEG >= 8) {
+  if constexpr (VSEG == 0) {
+    // dense rows: the statistics come through the LDS tables, the rest is the pooled form below with col = the point's index in the workgroup
+    float* res = pool + POOL_FLOATS(NX);
+    B6TileW<2 * NX> pw;
+    b6_tile_prefetch<8, 2 * NX>(pooled_w, wave, pw);
+    dense_pool_stats<NX>(*dr, xin, wgt, wsum, pool, res);
+    if (threadIdx.x < 2 * 2 * NX)
+      for (int c = dr->PTW; c < 32; ++c) pool[threadIdx.x * 32 + c] = 0.f;
+    __syncthreads();
+    f32x16 accp[1];
+    acc_zero(accp);
+    b6_tile_apply<2 * NX>(pw, accp[0], [&](int s) { return pool[(s * 2 + h) * 32 + j]; });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
+    __syncthreads();
+    const int col = dr->p_local < dr->PTW ? dr->p_local : dr->PTW - 1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[t][r] = res[(t * 32 + dyn_fi(r, h)) * 32 + col];
+  } else if (VSEG >= 8) {
     static_assert(DYN_VIEW_THREADS / 64 == 8, "one output tile of base_fc.0 per wave");
     constexpr int PT = 32 / VSEG;
     float* res = pool + POOL_FLOATS(NX);
@@ -510,7 +656,8 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
 // -------------------------------------------------------------------------------------------------------------------
 template <int VSEG, bool STORE_X>
 __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
-                                           long tile, long point, bool valid, int view, int seg_base) {
+                                           long tile, long point, bool valid, int view, int seg_base, const DenseRows* dr = nullptr,
+                                           float* lds_base = nullptr) {
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -567,6 +714,68 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     nt_store1<4>(p.ws + p.o.off_vis + tile * 64 + lane, vis2);
   }
   DYN_PHASE(18);
+  if constexpr (VSEG == 0) {
+    // ---- dense rows: visibility-weighted statistics through LDS tables (the whole workgroup LDS is free now: no weights are left to stream) ----
+    const DenseRows& d = *dr;
+    const int tid = threadIdx.x;
+    float vsum, nvalid;
+    dense_all2(d, vis2, msk, vsum, nvalid);
+    const float w2 = vis2 / (vsum + 1e-8f);
+    const float wmean = (vsum / (vsum + 1e-8f)) / (float)V;  // mean over the views of w2 (its sum, over V)
+    constexpr int FS = 257;                 // row stride of a feature slot (odd: the reducers below walk consecutive features conflict-free)
+    float* tab = lds_base;                  // [128 features][FS]
+    float* mt = lds_base + 128 * FS + 3;    // means [PTW][128] in the lanes' own order: p * 128 + h * 64 + t * 16 + r   (16-byte aligned)
+    const long point0 = (long)blockIdx.x * d.PTW;
+    // (the last dense_all2 barrier also retired every wave's reads of the constant tables and of the weight ring)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tab[(32 * t + dyn_fi(r, h)) * FS + d.rw] = x[t][r] * w2;
+      } else {
+        const float4* mu = reinterpret_cast<const float4*>(mt + (d.p_local < d.PTW ? d.p_local : d.PTW - 1) * 128 + h * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 m4 = mu[t * 4 + q];
+            const float ms[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dd = x[t][q * 4 + e] - ms[e];
+              tab[(32 * t + dyn_fi(q * 4 + e, h)) * FS + d.rw] = w2 * (dd * dd);
+            }
+          }
+      }
+      __syncthreads();
+      // tasks: (point, feature), the feature running fastest over the threads: consecutive threads read consecutive slots (stride FS, odd)
+      for (int task = tid; task < d.PTW * 128; task += DYN_VIEW_THREADS) {
+        const int pnt = task >> 7, f = task & 127;
+        const float* src = tab + f * FS + pnt * V;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= V; k += 4) { c0 += src[k]; c1 += src[k + 1]; c2 += src[k + 2]; c3 += src[k + 3]; }
+        for (; k < V; ++k) c0 += src[k];
+        const float acc = (c0 + c1) + (c2 + c3);
+        // feature f = 32 t + w sits in record g = 4 t + (w >> 3) of half hh = (w >> 2) & 1, component w & 3; register r = (w & 3) + 4 (w >> 3)
+        const int t = f >> 5, w = f & 31, hh = (w >> 2) & 1;
+        const long pt = point0 + pnt;
+        if (pt < p.n_pts) {
+          float* gin = p.ws + p.o.off_gin + (point_rec(p, pt, hh, SB_GIN_RECS) + (long)(pass * 16 + t * 4 + (w >> 3)) * 64) * 4 + (w & 3);
+          nt_store1<4>(gin, acc);
+        }
+        if (pass == 0) mt[pnt * 128 + hh * 64 + t * 16 + (w & 3) + 4 * (w >> 3)] = acc;
+      }
+      __syncthreads();
+    }
+    if (valid && view == 0) {
+      float4* gin = reinterpret_cast<float4*>(p.ws + p.o.off_gin) + point_rec(p, point, h, SB_GIN_RECS);
+      gin[32 * 64] = make_float4(h == 0 ? wmean : 1.0f, 0.f, 0.f, 0.f);
+      if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
+    }
+  } else {
   const float w2 = vis2 / (seg_sum<VSEG>(vis2, V, seg_base) + 1e-8f);
   const float wmean = seg_sum<VSEG>(w2, V, seg_base) / (float)V;
   const float nvalid = seg_sum<VSEG>(msk, V, seg_base);
@@ -594,6 +803,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     gin[32 * 64] = make_float4(h == 0 ? wmean : 1.0f, 0.f, 0.f, 0.f);
     if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
   }
+  }
 }
 
 // ===================================================================================================================
@@ -612,18 +822,21 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   // the per-point part of base_fc.0 (VSEG >= 8) is read straight from the stream by each wave, not through the ring
   constexpr int SA_POOLED_AT = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
 #if DYN_ENGINE_B6
-  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, VSEG >= 8 ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
+  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
 #endif
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
-  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
-  const int p_local = j / VSEG;
-  const int view = j & (VSEG - 1);
-  const long point = tile * p.PT + p_local;
-  const bool valid = (view < V) && (point < p.n_pts);
+  // VSEG > 0: views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding.
+  // VSEG == 0 (dense rows): the workgroup's 256 rows are the point-views of its PT = 256 / V points in order, no padding between points.
+  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
+  const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
+  const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
+  const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
+  const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
 
@@ -685,17 +898,19 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   // ---- pooling weights (mlp_network.py:462-471) ----
   float wgt;
   if (p.anti_alias) {
-    const float e = (view < V) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;  // padding lanes never set the minimum over the views
-    wgt = (e - seg_min<VSEG>(e, V, seg_base)) * msk;
+    // padding lanes (and, in the dense flavour, the idle tail rows, which shadow the last point) never set the minimum over the views
+    const float e = ((VSEG == 0 ? p_local < p.PT : view < V)) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;
+    wgt = (e - views_min<VSEG>(dr, e)) * msk;
   } else {
     wgt = msk;
   }
-  wgt = wgt / (seg_sum<VSEG>(wgt, V, seg_base) + 1e-8f);
+  const float wraw = views_sum<VSEG>(dr, wgt);
+  wgt = wgt / (wraw + 1e-8f);
 
   DYN_PHASE(5);
-  base_fc0<VSEG, SA_NX>(ring, p.blob + ST_OFF_A + (size_t)SA_POOLED_AT * NET_CHUNK, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
+  base_fc0<VSEG, SA_NX>(ring, p.blob + ST_OFF_A + (size_t)SA_POOLED_AT * NET_CHUNK, xin, wgt, V, view, p_local, ctab + SA_CT, a1, &dr, wraw / (wraw + 1e-8f));
   DYN_PHASE(10);
-  views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
+  views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base, &dr, lds);
   DYN_PHASE(20);
 }
 
@@ -1076,27 +1291,30 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
 // workgroups (4 waves) with a single 48 KiB weight buffer fit three to a CU (LDS 146 KiB, 168 registers): independent barriers, so
 // one workgroup's loads run under another's layers, and the exposed DMA of the single buffer hides the same way.
 #define DYN_BLEND_THREADS 256
-template <int VSEG>
-__global__ void __launch_bounds__(DYN_BLEND_THREADS, 3) k_static_blend(StaticArgs p) {
+// THREADS: 256 (lane segments: three workgroups per CU) or 512 (dense rows: the same 256-row partition as the view kernel, since a point's
+// rows must sit in one workgroup)
+template <int VSEG, int THREADS>
+__device__ __forceinline__ void static_blend_body(StaticArgs p) {
   constexpr int PHASE_KID = 2;
   (void)PHASE_KID;
   DYN_PHASE(0);
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + NET_CHUNK;  // [SC_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  for (int i = tid; i < SC_CT; i += DYN_BLEND_THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
+  for (int i = tid; i < SC_CT; i += THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
   NetRing ring;
-  net_ring_init_1(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds, DYN_BLEND_THREADS);
+  net_ring_init_1(ring, p.blob + ST_OFF_C, SC_CHUNKS, lds, THREADS);
   DYN_PHASE_RING_KID(ring, 2);
 
   const int V = p.V;
-  const long tile = (long)blockIdx.x * (DYN_BLEND_THREADS / 64) + wave;
+  const long tile = (long)blockIdx.x * (THREADS / 64) + wave;
   const bool tile_ok = tile < p.n_tiles_a;
-  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
-  const int p_local = j / VSEG;
-  const int view = j & (VSEG - 1);
-  const long point = tile * p.PT + p_local;
-  const bool valid = (view < V) && (point < p.n_pts);
+  // row -> (point, view) exactly as in the view kernel that parked x: lane segments (VSEG > 0) or dense rows (VSEG == 0)
+  const DenseRows dr = dense_rows(V, p.PT, ctab + SC_CT);
+  const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
+  const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
+  const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
+  const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
 
@@ -1130,17 +1348,21 @@ __global__ void __launch_bounds__(DYN_BLEND_THREADS, 3) k_static_blend(StaticArg
   acc_elu(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;
-  if (view >= V) logit = -3.0e38f;  // padding lanes take no share even when every real view is masked (uniform 1/V then)
-  const float mx = seg_max<VSEG>(logit, V, seg_base);
-  const float e = __expf(logit - mx);
-  const float bw = e / seg_sum<VSEG>(e, V, seg_base);
+  if (VSEG == 0 ? p_local >= p.PT : view >= V) logit = -3.0e38f;  // padding rows take no share even when every real view is masked (uniform 1/V then)
+  const float mx = views_max<VSEG>(dr, logit);
+  const float e = (VSEG == 0 && p_local >= p.PT) ? 0.f : __expf(logit - mx);
+  const float bw = e / views_sum<VSEG>(dr, e);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v = seg_sum<VSEG>(rgb_in[c] * bw, V, seg_base);
+    const float v = views_sum<VSEG>(dr, rgb_in[c] * bw);
     if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
   }
   DYN_PHASE(20);
 }
+template <int VSEG>
+__global__ void __launch_bounds__(DYN_BLEND_THREADS, 3) k_static_blend(StaticArgs p) { static_blend_body<VSEG, DYN_BLEND_THREADS>(p); }
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense(StaticArgs p) { static_blend_body<0, DYN_VIEW_THREADS>(p); }
+
 
 // -------------------------------------------------------------------------------------------------------------------
 extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
@@ -1169,7 +1391,8 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (NET_CHUNK + SC_CT) * sizeof(float);
   const dim3 grid_c(dyn_cdiv(a.n_tiles_a, DYN_BLEND_THREADS / 64)), blk_c(DYN_BLEND_THREADS);
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
+  if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  else if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk_v, lds_a, stream, a);
@@ -1179,7 +1402,8 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
     DYN_LAUNCH(DYN_K_STATIC_POINTS_QKV, "k_static_points_qkv", (k_net_points<false, 1>), grid_b, blk, lds_b, stream, a);
     DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 2>), grid_b, blk, lds_b, stream, a);
   }
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_c, blk_c, lds_c, stream, a);
+  if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense, grid_a, blk_v, lds_c + DENSE_SCALARS * sizeof(float), stream, a);
+  else if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_c, blk_c, lds_c, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_c, blk_c, lds_c, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<16>, grid_c, blk_c, lds_c, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<32>, grid_c, blk_c, lds_c, stream, a);
@@ -1333,18 +1557,20 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
 #if DYN_ENGINE_B6
-  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, VSEG >= 8 ? net_layer_chunks(8, DA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
+  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, DA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
 #endif
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
-  // views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding
-  const int p_local = j / VSEG;
-  const int view = j & (VSEG - 1);
-  const long point = tile * p.PT + p_local;
-  const bool valid = (view < V) && (point < p.n_pts);
+  // row -> (point, view): power-of-two lane segments (VSEG > 0) or dense rows (VSEG == 0), as in k_static_views
+  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
+  const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
+  const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
+  const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
+  const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
   const float msk = valid ? p.mask[pv] : 0.f;
@@ -1355,10 +1581,11 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
     const int ch = h == 0 ? q : 18 + q;
     xin[q] = (valid && ch < 35) ? nt_load1<2>(p.rgb_feat + pv * 35 + ch) + tf[ch] : 0.f;
   }
-  const float wgt = msk / (seg_sum<VSEG>(msk, V, seg_base) + 1e-8f);
+  const float wraw = views_sum<VSEG>(dr, msk);
+  const float wgt = msk / (wraw + 1e-8f);
   f32x16 a1[8];
-  base_fc0<VSEG, DA_NX>(ring, p.blob + DY_OFF_A, xin, wgt, V, view, p_local, ctab + SA_CT, a1);
-  views_tail<VSEG, false>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base);
+  base_fc0<VSEG, DA_NX>(ring, p.blob + DY_OFF_A, xin, wgt, V, view, p_local, ctab + SA_CT, a1, &dr, wraw / (wraw + 1e-8f));
+  views_tail<VSEG, false>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base, &dr, lds);
 }
 
 extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
@@ -1384,7 +1611,8 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
   const size_t lds_b = (2 * NET_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
+  if (a.o.dense) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  else if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk_v, lds_a, stream, a);

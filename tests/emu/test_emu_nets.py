@@ -25,3 +25,9 @@ def test_dynamic_net(emu):
 
 def test_motion_mlp(emu):
   parity.check_motion(emu, 'small', S=32, R=1)
+
+
+def test_dense_rows_dynamic_and_static(emu):
+  """View counts from 9 that are not powers of two run the dense-row flavour (cross-view reductions through LDS tables): 13 dynamic and 20 static views."""
+  parity.check_dynamic_net(emu, 'many', S=32, R=1)
+  parity.check_static_net(emu, 'many', S=32, R=1)

@@ -22,7 +22,7 @@ if '--build' in sys.argv:
   common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
   subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG)])
   subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING', '-ffp-contract=off'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_geometry.hip'), '-o', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG)])
-  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), '-o', LIB])
+  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_encoder.o'), '-o', LIB])
   sys.exit(0)
 
 os.environ['DYNIBAR_HIP_LIB'] = LIB
@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from dynibar_amd import ops, synthetic as syn  # noqa: E402
 
-R, S, V, dev = 4096, 64, 8, 'cuda:0'
+R, S, V, dev = 4096, 64, int(os.environ.get("PB_V", "8")), "cuda:0"
 sc = syn.make_scene(seed=0, H=288, W=512, V=V, F=32, n_static=V)
 T = lambda x: torch.from_numpy(x).to(dev)
 scene = {k: T(v) for k, v in sc.items()}
