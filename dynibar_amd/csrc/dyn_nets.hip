@@ -1111,6 +1111,107 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     }
     const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
     DYN_PHASE(2);  // Q, K, V projections done
+#if DYN_ENGINE_B6
+    // The attention matmuls on the split engine too (round 2; the native fp32 MFMA needs 16 instructions of 64 cycles per 32 x 32 x 32 block,
+    // the split engine 6 of 32).  scores^T [key x query] = K . q^T: A = a key tile's K in ITS lanes' register order (feature of slot e of group
+    // m = fi(8 m + e, h): the same enumeration on both operands), deposited in LDS as hi | mid half-float images; B = this wave's q.
+    // out^T [feature x query] = V^T . P: A = V^T rows read from the [feature][key] table and split on the fly, B = the probabilities.
+    auto split8 = [&](const float (&v)[8], u32x4v& hi, u32x4v& mid) {
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        unsigned h_, m_, l_;
+        split3_pair(v[2 * p2], v[2 * p2 + 1], h_, m_, l_);
+        hi[p2] = h_; mid[p2] = m_;
+      }
+    };
+    u32x4v* Kimg = reinterpret_cast<u32x4v*>(Kl);  // [key tile (wave)][group m][hi | mid][64 lanes]
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      __syncthreads();  // the previous head's K/V images are no longer read
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float kv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = kh[hd][8 * m + e];
+        u32x4v khi, kmid;
+        split8(kv, khi, kmid);
+        Kimg[((wave * 2 + m) * 2 + 0) * 64 + lane] = khi;
+        Kimg[((wave * 2 + m) * 2 + 1) * 64 + lane] = kmid;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Vl[dyn_fi(r, h) * SB_VL_LD + wave * 32 + j] = vh[hd][r];
+      u32x4v qhi[2], qmid[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = qh[hd][8 * m + e] * inv_temp;
+        split8(qv, qhi[m], qmid[m]);
+      }
+      __syncthreads();
+      f32x16 sc[4];
+      acc_zero(sc);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const u32x4v ahi = Kimg[(((wave0 + kt) * 2 + m) * 2 + 0) * 64 + lane], amid = Kimg[(((wave0 + kt) * 2 + m) * 2 + 1) * 64 + lane];
+            sc[kt] = mfma_bf16(amid, qhi[m], sc[kt]);
+            sc[kt] = mfma_bf16(ahi, qmid[m], sc[kt]);
+            sc[kt] = mfma_bf16(ahi, qhi[m], sc[kt]);
+          }
+        }
+      // softmax over the keys; register r of half h is key kt*32 + fi(r,h)
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool key_ok = (kt < TPR) && (kt * 32 + dyn_fi(r, h) < p.S);
+          float v = q_ok ? sc[kt][r] : -1e9f;
+          v = key_ok ? v : -3.0e38f;
+          sc[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
+          sc[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      f32x16 oh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oh[r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            // slot e of group m is key kt * 32 + fi(8 m + e, h) = 16 m + 4 h + (e & 3) + 8 (e >> 2): two float4 of this lane's feature row of V^T
+            const float* vrow = Vl + j * SB_VL_LD + (wave0 + kt) * 32 + 16 * m + 4 * h;
+            const float4 v0 = *reinterpret_cast<const float4*>(vrow), v1 = *reinterpret_cast<const float4*>(vrow + 8);
+            const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = sc[kt][8 * m + e] * inv;
+            u32x4v ahi, amid, phi, pmid;
+            split8(vv, ahi, amid);
+            split8(pv, phi, pmid);
+            oh = mfma_bf16(amid, phi, oh);
+            oh = mfma_bf16(ahi, pmid, oh);
+            oh = mfma_bf16(ahi, phi, oh);
+          }
+        }
+      att[hd] = oh;
+    }
+#else
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
       __syncthreads();  // the previous head's K/V images are no longer read
@@ -1176,6 +1277,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
         }
       att[hd] = oh;
     }
+#endif
   }
   {
     f32x16 o[4];
