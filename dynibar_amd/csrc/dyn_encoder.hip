@@ -164,9 +164,18 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   // weights -> LDS (lane-linear images, 16 bytes per thread per step)
   {
-    const float4* src = reinterpret_cast<const float4*>(p.wimg);
-    float4* dst = reinterpret_cast<float4*>(wl);
-    for (int i = tid; i < (int)(enc_image_floats(GROUPS) / 4); i += ENC_THREADS) dst[i] = src[i];
+    // global -> LDS DMA (no register round trip, all pieces in flight at once): each wave moves contiguous 1 KiB pieces, the LDS image is the
+    // packed stream's own layout
+    constexpr int PIECES = (int)(enc_image_floats(GROUPS) / 256);  // 1 KiB pieces
+    const float* g = p.wimg + lane * 4;
+#pragma unroll
+    for (int i = 0; i < (PIECES + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64); ++i) {
+      const int piece = i * (ENC_THREADS / 64) + wave;
+      if (piece < PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 256),
+                                         (__attribute__((address_space(3))) void*)(wl + piece * 256), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
   // This workgroup's share of the batch: a contiguous run of the N * Hout output rows (one workgroup per CU: no tail generation of
   // workgroups).  The run may cross an image boundary: the per-image norm coefficients are tabulated for both images it can touch.
@@ -277,13 +286,19 @@ __global__ void __launch_bounds__(ENC_THREADS, 2) k_enc_conv(ConvArgs p) {
       // K order of the weight images: k-group g = tap * 4 + cg.  The channel group is the OUTER loop, so that the 16 norm coefficients of
       // the lane's 8 channels sit in registers for all taps; operand fetches (2 float4 = this lane's 8 channels of one input pixel) run
       // PF (tap, cg) steps ahead of the MFMAs that consume them.
-      constexpr int TAPS = KH * KW, STEPS = 4 * TAPS, PF = 4;
+      constexpr int TAPS = KH * KW, STEPS = 4 * TAPS, PF = MODE == LOAD_NORM_ADD_RELU ? 4 : 8;
       struct Op { float4 a, b, ra, rb; };
-      auto load_op = [&](int step, Op& o) {
-        const int cg = step / TAPS, tap = step - cg * TAPS;
+      // element offsets of the lane's half of each tap's input pixel (reflect padding resolved once per tile, not once per fetch)
+      int tap_off[TAPS];
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
         const int ky = tap / KW, kx = tap - ky * KW;
         const int iy = reflect_idx(oy * STRIDE + ky - PAD, p.Hin), ix = reflect_idx(oxc * STRIDE + kx - PAD, p.Win);
-        const long off = ((long)iy * p.Win + ix) * 64 + cg * 16 + h * 8;
+        tap_off[tap] = (iy * p.Win + ix) * 64 + h * 8;
+      }
+      auto load_op = [&](int step, Op& o) {
+        const int cg = step / TAPS, tap = step - cg * TAPS;
+        const int off = tap_off[tap] + cg * 16;
         o.a = *reinterpret_cast<const float4*>(inb + off);
         o.b = *reinterpret_cast<const float4*>(inb + off + 4);
         if (MODE == LOAD_NORM_ADD_RELU) {
