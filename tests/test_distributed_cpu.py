@@ -155,3 +155,31 @@ def test_collective_payload_of_a_frame():
   out = RI.gather_rows(local, n, FakeDist, 2, 0)
   assert len(sent) == 1 and sent[0] * 2 == n * 20 and n * 20 <= 3 * 1024 * 1024
   assert out['mask'].dtype == torch.bool and out['rgb'].shape == (n, 3) and out['depth'].shape == (n,)
+
+
+def test_frame_outputs_mapping_semantics():
+  """FrameOutputs looks like the reference's OrderedDict of host tensors: same keys and order whether or not an entry has been
+  resolved; deferred entries are produced once, on first read; dict-style access paths all resolve."""
+  import pickle
+  from dynibar_amd.render_image import FrameOutputs
+  calls = []
+  f = FrameOutputs()
+  f['rgb'] = torch.ones(2, 3)
+  f._defer('weights', lambda: calls.append('weights') or torch.zeros(2, 5))
+  f._defer('alpha', lambda: calls.append('alpha') or torch.full((2, 5), 2.0))
+  assert list(f.keys()) == ['rgb', 'weights', 'alpha'] and len(f) == 3 and 'alpha' in f and f.pending() == ['weights', 'alpha']
+  assert calls == []
+  assert float(f['weights'].sum()) == 0.0 and calls == ['weights']
+  assert f['weights'] is f['weights'] and calls == ['weights'], 'resolved once, cached'
+  assert float(f.get('alpha')[0, 0]) == 2.0 and f.get('nope', 7) == 7 and calls == ['weights', 'alpha']
+  g = FrameOutputs()
+  g._defer('a', lambda: torch.zeros(1))
+  g._defer('b', lambda: torch.ones(1))
+  assert [k for k, v in g.items()] == ['a', 'b'] and all(isinstance(v, torch.Tensor) for v in g.values()) and g.pending() == []
+  h = FrameOutputs()
+  h._defer('a', lambda: torch.arange(3.0))
+  back = pickle.loads(pickle.dumps(h))
+  assert list(back.keys()) == ['a'] and torch.equal(back['a'], torch.arange(3.0))
+  k = FrameOutputs()
+  k._defer('a', lambda: torch.ones(1))
+  assert float(k.pop('a')) == 1.0 and 'a' not in k
