@@ -1117,3 +1117,104 @@ extern "C" int dyn_fine_samples(const DynFineSampleParams* p, void* stream) {
   DYN_LAUNCH(DYN_K_FINE_SAMPLES, "dyn_fine_samples", k_fine_samples, dim3(dyn_cdiv(p->R, T)), dim3(T), shmem, (hipStream_t)stream, *p, T);
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Helper exports of the reference's module surface (render_ray.py:19-64 sample_pdf, :372-396 Pluecker coordinates).  The render functions
+// do not call these (k_fine_samples fuses sample_pdf with the merge, the network kernels form the Pluecker coordinates in registers); they
+// exist so that code importing the helpers from ibrnet.render_ray finds them with the same semantics.
+// ---------------------------------------------------------------------------------------------------------------
+// sample_pdf: bins [R, M+1], weights [R, M] (1e-5 is added IN PLACE like the reference does, render_ray.py:23), u [R, N] or NULL (det=True) -> samples [R, N]
+__global__ void k_sample_pdf(const float* __restrict__ bins, float* __restrict__ weights, const float* __restrict__ u_in, int R, int M, int N,
+                             float* __restrict__ samples, int T) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  const int t = threadIdx.x;
+  const int r = blockIdx.x * T + t;
+  if (r >= R) return;
+  float* cdf = lds;  // [M + 1][T]
+  float* w = weights + (long)r * M;
+  const float* b = bins + (long)r * (M + 1);
+  double total_d = 0.0;
+  for (int j = 0; j < M; ++j) {
+    const float wj = w[j] + 1e-5f;
+    w[j] = wj;
+    total_d += (double)wj;
+  }
+  const float total = (float)total_d;
+  double c = 0.0;
+  cdf[t] = 0.f;
+  for (int j = 0; j < M; ++j) {
+    c += (double)(w[j] / total);
+    cdf[(j + 1) * T + t] = (float)c;
+  }
+  for (int n = 0; n < N; ++n) {
+    float u;
+    if (u_in != nullptr) {
+      u = u_in[(long)r * N + n];
+    } else {
+      const float step = 1.0f / (float)(N - 1);
+      u = (n < N / 2) ? ((float)n * step) : (1.0f - step * (float)(N - 1 - n));
+    }
+    int lo_i = 0, hi_i = M;
+    while (lo_i < hi_i) {
+      const int mid = (lo_i + hi_i) >> 1;
+      if (u >= cdf[mid * T + t]) lo_i = mid + 1; else hi_i = mid;
+    }
+    const int above = lo_i, below = above - 1 < 0 ? 0 : above - 1;
+    const float c0 = cdf[below * T + t], c1 = cdf[above * T + t];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;
+    const float tt = (u - c0) / denom;
+    samples[(long)r * N + n] = b[below] + tt * (b[above] - b[below]);
+  }
+}
+extern "C" int dyn_sample_pdf(const float* bins, float* weights, const float* u, int R, int M, int N, float* samples, void* stream) {
+  DYN_REQUIRE(bins && weights && samples && R > 0 && M > 0 && N > 1, "dyn_sample_pdf: bad argument");
+  const size_t per_thread = (size_t)(M + 1) * 4;
+  int T = 64;
+  while (T > 1 && per_thread * T > 144 * 1024) T >>= 1;
+  DYN_REQUIRE(per_thread * T <= 144 * 1024, "dyn_sample_pdf: too many bins for LDS");
+  DYN_LAUNCH(DYN_K_FINE_SAMPLES, "dyn_sample_pdf", k_sample_pdf, dim3(dyn_cdiv(R, T)), dim3(T), (per_thread * T + 15) & ~(size_t)15, (hipStream_t)stream, bins,
+             weights, u, R, M, N, samples, T);
+  return 0;
+}
+
+// [normalize(d), o x normalize(d)] per target ray (render_ray.py:372-377) and per (sample, source view) (:380-396, output [R,S,V,6])
+__global__ void k_plucker_ref(const float* __restrict__ ray_o, const float* __restrict__ ray_d, int R, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float dx, dy, dz;
+  const float x = ray_d[r * 3], y = ray_d[r * 3 + 1], z = ray_d[r * 3 + 2];
+  const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  dx = x / n; dy = y / n; dz = z / n;
+  const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+  float* o = out + (long)r * 6;
+  o[0] = dx; o[1] = dy; o[2] = dz;
+  o[3] = oy * dz - oz * dy; o[4] = oz * dx - ox * dz; o[5] = ox * dy - oy * dx;
+}
+__global__ void k_plucker_src(const float* __restrict__ pts, long pts_view_stride, const float* __restrict__ cams, long n_pts, int V, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts * V) return;
+  const long pnt = i / V;
+  const int v = (int)(i - pnt * V);
+  const float* c = cams + (long)v * 34 + 18;  // c2w
+  const float cx = c[3], cy = c[7], cz = c[11];
+  const float* q = pts + (long)v * pts_view_stride + pnt * 3;
+  const float x = q[0] - cx, y = q[1] - cy, z = q[2] - cz;
+  const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  const float dx = x / n, dy = y / n, dz = z / n;
+  float* o = out + i * 6;
+  o[0] = dx; o[1] = dy; o[2] = dz;
+  o[3] = cy * dz - cz * dy; o[4] = cz * dx - cx * dz; o[5] = cx * dy - cy * dx;
+}
+extern "C" int dyn_plucker_ref(const float* ray_o, const float* ray_d, int R, float* out, void* stream) {
+  DYN_REQUIRE(ray_o && ray_d && out && R > 0, "dyn_plucker_ref: bad argument");
+  DYN_LAUNCH(DYN_K_IMAGE_RAYS, "dyn_plucker_ref", k_plucker_ref, dim3(dyn_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, R, out);
+  return 0;
+}
+extern "C" int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, long n_pts, int V, float* out, void* stream) {
+  DYN_REQUIRE(pts && cams && out && n_pts > 0 && V > 0, "dyn_plucker_src: bad argument");
+  DYN_LAUNCH(DYN_K_IMAGE_RAYS, "dyn_plucker_src", k_plucker_src, dim3(dyn_cdiv(n_pts * V, 256)), dim3(256), 0, (hipStream_t)stream, pts,
+             per_view_pts ? n_pts * 3 : 0L, cams, n_pts, V, out);
+  return 0;
+}

@@ -57,6 +57,22 @@ class _Packed:
     return ent[1]
 
 
+_NET_CACHE = OrderedDict()  # explicit nets handed to fine_render_rays: (id(net), device) -> (version, packed, net)
+
+
+def _packed_net(net, device, build):
+  """Like _Packed.get for a network that does not hang off a model object; the entry keeps `net` alive so its id cannot be recycled."""
+  key = (id(net), str(device))
+  ver = _version(net)
+  ent = _NET_CACHE.get(key)
+  if ent is None or ent[0] != ver:
+    ent = (ver, build(_state_dict(net)), net)
+    _NET_CACHE[key] = ent
+    while len(_NET_CACHE) > 32:
+      _NET_CACHE.popitem(last=False)
+  return ent[1]
+
+
 def _packed(model):
   p = getattr(model, '_dynibar_amd_packed', None)
   if p is None:
@@ -109,6 +125,60 @@ def fine_z_vals(z_vals, weights, N_importance, inv_uniform, det):
   """Coarse weights -> sorted coarse+fine depths: sample_pdf + cat + sort of render_ray.py:790-821 in one kernel."""
   u = None if det else torch.rand(z_vals.shape[0], N_importance, device=z_vals.device)
   return ops.fine_samples(z_vals, weights, N_importance, inv_uniform, u)[0]
+
+
+def sample_pdf(bins, weights, N_samples, det=False):
+  """(render_ray.py:19-64) bins [R,M+1], weights [R,M] -> samples [R,N_samples].  Like the reference it adds 1e-5 to `weights` IN PLACE."""
+  assert weights.dtype == torch.float32 and weights.is_contiguous(), 'sample_pdf updates `weights` in place: pass a contiguous fp32 tensor'
+  k = ops._Keep()
+  R, M = weights.shape
+  u = None if det else torch.rand(R, N_samples, device=weights.device)
+  out = torch.empty((R, N_samples), dtype=torch.float32, device=weights.device)
+  ops.call('dyn_sample_pdf', k(bins), ops.ptr(weights), k(u), R, M, int(N_samples), ops.ptr(out), ops.stream_of(out))
+  return out
+
+
+def compute_traj_pts(raw_coeff_x, raw_coeff_y, raw_coeff_z, trajectory_basis_i):
+  """(render_ray.py:361-369) sum_b coeff_{x,y,z}[..., b] * basis_i[b] -> [..., 3]."""
+  B = raw_coeff_x.shape[-1]
+  shp = raw_coeff_x.shape[:-1]
+  coeff = torch.cat([raw_coeff_x, raw_coeff_y, raw_coeff_z], dim=-1).reshape(-1, 1, 3 * B)
+  basis = torch.cat([trajectory_basis_i.reshape(1, B).float(), torch.zeros(1, B, device=coeff.device)], dim=0)  # row 1 = zeros: the "reference" row
+  zero = torch.zeros((coeff.shape[0], 1, 3), dtype=torch.float32, device=coeff.device)
+  return ops.trajectory_points(coeff, basis, zero, [0], 1)[0].reshape(tuple(shp) + (3,))
+
+
+def compute_optical_flow(outputs_coarse, raw_pts_3d_seq, src_cameras, uv_grid):
+  """(render_ray.py:333-358) expected 2-D flow into every source view: [V,R,2]."""
+  k = ops._Keep()
+  w = outputs_coarse['weights']
+  V, R, S = raw_pts_3d_seq.shape[:3]
+  cams = src_cameras.squeeze(0)
+  proj = torch.empty((V, 16), dtype=torch.float32, device=w.device)
+  ops.call('dyn_prepare_cameras', k(cams), V, None, ops.ptr(proj), None, ops.stream_of(proj))
+  flows = torch.empty((V, R, 2), dtype=torch.float32, device=w.device)
+  ops.call('dyn_render_flows', k(w), k(raw_pts_3d_seq), ops.ptr(proj), k(uv_grid), R, S, V, ops.ptr(flows), ops.stream_of(flows))
+  return flows
+
+
+def compute_ref_plucker_coordinate(ray_o, ray_d):
+  """(render_ray.py:372-377) [R,6] = [normalize(d), o x normalize(d)]."""
+  k = ops._Keep()
+  out = torch.empty((ray_o.shape[0], 6), dtype=torch.float32, device=ray_o.device)
+  ops.call('dyn_plucker_ref', k(ray_o), k(ray_d), ray_o.shape[0], ops.ptr(out), ops.stream_of(out))
+  return out
+
+
+def compute_src_plucker_coordinate(pts, src_cameras):
+  """(render_ray.py:380-396) pts [R,S,3] or [V,R,S,3], src_cameras [1,V,34] -> [R,S,V,6] (always crossing over xyz: DESIGN.md section 7)."""
+  k = ops._Keep()
+  cams = src_cameras[0]
+  V = cams.shape[0]
+  per_view = pts.dim() == 4
+  R, S = pts.shape[-3], pts.shape[-2]
+  out = torch.empty((R, S, V, 6), dtype=torch.float32, device=pts.device)
+  ops.call('dyn_plucker_src', k(pts), int(per_view), k(cams), R * S, V, ops.ptr(out), ops.stream_of(out))
+  return out
 
 
 def _as_out(d, keys):
@@ -189,6 +259,30 @@ def _motion_outputs(out, stage, ray_batch, ref_frame_idx, sf_off, flow_views=Non
            (int(ref_frame_idx) + sf_off) % basis.shape[0], (int(ref_frame_idx) - sf_off) % basis.shape[0], int(ref_frame_idx) % basis.shape[0],
            ops.ptr(exp_sf), ops.stream_of(exp_sf))
   return exp_sf
+
+
+def fine_render_rays(projector, ray_batch, featmaps, pts_ref, z_vals, s_vals, ref_time_embedding, anchor_time_embedding, ref_frame_idx,
+                     anchor_frame_idx, ref_time_offset, anchor_time_offset, net_dy, net_st, motion_mlp, trajectory_basis, occ_weights_mode,
+                     is_train):
+  """Reference render_ray.py:407-597: the fine pass of the Nvidia path on explicit networks -> (outputs_ref, outputs_ref_dy, None, None)."""
+  import types
+  holder = types.SimpleNamespace(dy=net_dy, st=net_st, motion=motion_mlp, basis=trajectory_basis, _dynibar_amd_packed=_ExplicitNets())
+  names = dict(dy='dy', st='st', motion='motion', basis='basis')
+  stage = _dual_branch(holder, names, None, projector, ray_batch, featmaps[0], featmaps[2], pts_ref, z_vals, ref_frame_idx, ref_time_embedding,
+                       ref_time_offset)
+  out = _finish(stage, z_vals, _KEYS2, _KEYS1)
+  out_dy = _vanilla(stage['raw_dy'], z_vals, stage['pm_dy'])
+  exp_sf = _motion_outputs(out, stage, ray_batch, ref_frame_idx, 2)
+  out['s_vals'] = s_vals
+  out['exp_sf'] = exp_sf
+  return out, out_dy, None, None
+
+
+class _ExplicitNets:
+  """_Packed look-alike whose entries live in the module-level cache keyed by the network objects themselves."""
+
+  def get(self, model, name, device, build):
+    return _packed_net(getattr(model, name), device, build)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

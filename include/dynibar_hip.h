@@ -209,6 +209,14 @@ int dyn_expected_scene_flow(const float* weights, const float* coeff, const floa
 /* ---- a2 RaySamplerSingleImage.get_rays_single_image (sample_ray.py:143-163): camera DEVICE [34]; rays_o, rays_d [(H/stride)*(W/stride),3] */
 int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* rays_o, float* rays_d, void* stream);
 
+/* ---- helper exports of the reference's module surface (not on the render functions' own path, which fuses them) -------------------
+ * sample_pdf (render_ray.py:19-64): bins [R,M+1], weights [R,M] (+1e-5 IN PLACE like the reference), u [R,N] or NULL (det) -> samples [R,N];
+ * compute_ref_plucker_coordinate (:372-377): [R,6]; compute_src_plucker_coordinate (:380-396): pts [n_pts,3] (per_view_pts = 0) or
+ * [V,n_pts,3] (per_view_pts = 1), cams [V,34] -> [n_pts,V,6]. */
+int dyn_sample_pdf(const float* bins, float* weights, const float* u, int R, int M, int N, float* samples, void* stream);
+int dyn_plucker_ref(const float* ray_o, const float* ray_d, int R, float* out, void* stream);
+int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, long n_pts, int V, float* out, void* stream);
+
 /* ---- section 8(f)1: the 2-D feature encoder that feeds the path (feature_network.py:179-311, the executed part of ResNet.forward:
  * conv 7x7/2 -> InstanceNorm -> ReLU -> layer1 (3 BasicBlocks, reflect padding) -> 1x1 conv; 32 coarse + 32 fine channels at 1/4 resolution).
  * Channels-last throughout: images [N,H,W,3] as the data loader stores them, outputs [N,Hf,Wf,32] = the gather kernel's feat_cl layout.

@@ -27,3 +27,8 @@ def test_composite(emu):
 def test_fine_samples(emu, golden_dir):
   g = dict(np.load(os.path.join(golden_dir, 'stages_small.npz')))
   parity.check_fine_samples(emu, g)
+
+
+def test_module_helper_exports(emu, golden_dir):
+  g = dict(np.load(os.path.join(golden_dir, 'stages_small.npz')))
+  parity.check_module_helpers(emu, g, 'small', with_fine=False)

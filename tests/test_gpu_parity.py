@@ -156,6 +156,12 @@ def test_feature_encoder_feeds_the_gather_in_place(dev):
   parity.check_encoder_feeds_gather(dev)
 
 
+@pytest.mark.parametrize('name', ['small', 'harsh'])
+def test_module_helper_exports(dev, golden_dir, name):
+  """sample_pdf, compute_traj_pts, compute_optical_flow, compute_*_plucker_coordinate, fine_render_rays with the reference's signatures."""
+  parity.check_module_helpers(dev, _golden(golden_dir, f'stages_{name}.npz'), name)
+
+
 def test_fp32_class_engine_build(dev):
   """libdynibar_hip_x6.so (6-term bf16 split, fp32-class products): engine self-test at 2e-6 and static net parity, in a subprocess
   because a process binds one library."""

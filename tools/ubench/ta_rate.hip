@@ -41,22 +41,23 @@ __global__ void __launch_bounds__(256) k_load(const float4* __restrict__ buf, lo
   if (acc == 1.2345f) out[0] = acc;
 }
 
-// stores: mode 0 dwordx4 fully coalesced streaming (each wave its own 1 KiB per instruction), mode 1 the same non-temporal
+// stores: dwordx4, fully coalesced, streaming (each wave its own 1 KiB per instruction) over a buffer of `span4` float4:
+// mode 0 plain, 1 non-temporal builtin, 2 "sc1", 3 "sc0 sc1", 4 "nt sc1", 5 "nt sc0 sc1" (cache-policy bits of global_store on gfx942/950)
 template <int MODE>
-__global__ void __launch_bounds__(256) k_store(float4* __restrict__ buf, long n4, int iters) {
+__global__ void __launch_bounds__(256) k_store(float4* __restrict__ buf, long span4, int iters) {
   const long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (long)iters * 8 * 64 + (threadIdx.x & 63);
-  const float4 v = make_float4(1.f, 2.f, 3.f, (float)blockIdx.x);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 t = {1.f, 2.f, 3.f, (float)blockIdx.x};
   for (int it = 0; it < iters; ++it)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      float4* p = buf + (base + (long)(it * 8 + u) * 64) % n4;
-      if (MODE == 1) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 t = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
-      } else {
-        *p = v;
-      }
+      f4* p = reinterpret_cast<f4*>(buf + (base + (long)(it * 8 + u) * 64) % span4);
+      if (MODE == 0) *p = t;
+      else if (MODE == 1) __builtin_nontemporal_store(t, p);
+      else if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+      else if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+      else if (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(t) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1" ::"v"(p), "v"(t) : "memory");
     }
 }
 
@@ -91,18 +92,31 @@ int main() {
              ms * 1e-3 * ghz * 1e9 / instr_per_cu, ghz);
     }
   }
-  for (int wg_per_cu = 2; wg_per_cu <= 4; wg_per_cu *= 2)
-    for (int mode = 0; mode < 2; ++mode) {
-      const int grid = cus * wg_per_cu;
+  // streaming stores over a buffer far larger than every cache (1.34 GB) and over a cache-resident one (19 MB)
+  float4* big; const long big4 = 1340L * 1024 * 1024 / 16;
+  CHECK(hipMalloc(&big, big4 * 16));
+  const char* snames[6] = {"plain", "nt (builtin)", "sc1", "sc0 sc1", "nt sc1", "nt sc0 sc1"};
+  for (int which = 0; which < 2; ++which)
+    for (int mode = 0; mode < 6; ++mode) {
+      const int wg_per_cu = 4, grid = cus * wg_per_cu;
+      float4* dst = which ? buf : big; const long span = which ? n4 : big4;
+      const int it2 = which ? iters : 160;  // 1024 WGs x 4 waves x 160 x 8 KiB = 5.4 GB = four sweeps of the big buffer
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
         CHECK(hipEventRecord(e0));
-        if (mode == 0) k_store<0><<<grid, 256>>>(buf, n4, iters); else k_store<1><<<grid, 256>>>(buf, n4, iters);
+        switch (mode) {
+          case 0: k_store<0><<<grid, 256>>>(dst, span, it2); break;
+          case 1: k_store<1><<<grid, 256>>>(dst, span, it2); break;
+          case 2: k_store<2><<<grid, 256>>>(dst, span, it2); break;
+          case 3: k_store<3><<<grid, 256>>>(dst, span, it2); break;
+          case 4: k_store<4><<<grid, 256>>>(dst, span, it2); break;
+          default: k_store<5><<<grid, 256>>>(dst, span, it2); break;
+        }
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
       }
-      const double bytes = (double)grid * 4 * iters * 8 * 1024;
-      printf("store %-44s %d waves/CU: %7.1f us  %6.1f cycles per wave-instruction per CU, %.2f TB/s\n", mode ? "dwordx4 coalesced 1 KiB nt" : "dwordx4 coalesced 1 KiB", wg_per_cu * 4,
-             ms * 1e3, ms * 1e-3 * ghz * 1e9 / ((double)wg_per_cu * 4 * iters * 8), bytes / (ms * 1e-3) / 1e12);
+      const double bytes = (double)grid * 4 * it2 * 8 * 1024;
+      printf("store dwordx4 1 KiB %-14s %s: %8.1f us  %6.1f cycles per wave-instruction per CU, %.2f TB/s\n", snames[mode], which ? "19 MB buffer  " : "1.34 GB buffer",
+             ms * 1e3, ms * 1e-3 * ghz * 1e9 / ((double)wg_per_cu * 4 * it2 * 8), bytes / (ms * 1e-3) / 1e12);
     }
   return 0;
 }
