@@ -513,47 +513,75 @@ __device__ __forceinline__ float views_max(const DenseRows& d, float v) {
 }
 
 // base_fc.0's per-point statistics in the dense flavour: weighted mean and variance of the NX x 2 per-view slots over the views of
-// each point, into `pool` (the B operand of the per-point MFMA).  One-pass variance (sum w x^2 - mean^2 (2 - sum w)) of O(1) inputs;
-// four rounds of (NX + 1) / 2 slots x 2 halves through the table behind `pool`.
+// each point, into `pool` (the B operand of the per-point MFMA).  The rows deposit their slots ROW-major in 16-byte quads ([row][half]
+// [quad], row stride 36 floats: the 16 lanes of a quad access start 4 banks apart, conflict-free), a (point, half, quad) task then
+// walks the V rows of its point twice (mean, then sum w (x - mean)^2 -- the same two sweeps as the lane-segment flavour) with 16-byte
+// loads.  The table behind `pool` holds 4 quads per half, so the ceil(NX / 4) quads go in rounds.
 template <int NX>
-__device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float (&xin)[NX], float wgt, float wsum, float* pool, float* tab) {
-  constexpr int NH = (NX + 1) / 2;
-  constexpr int MAXT = 3;  // (point, slot) tasks per thread and round: PTW * 2 NH <= 28 * 38 = 1064 over 512 threads
+__device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float (&xin)[NX], float wgt, float* pool, float* tab) {
+  constexpr int QPH = 4, RS = 2 * 4 * QPH + 4;
+  constexpr int NQ = (NX + 3) / 4, ROUNDS = (NQ + QPH - 1) / QPH;
   const int tid = threadIdx.x, h = (tid >> 5) & 1;
-  float* wtab = d.scal;    // sum of the pooling weights per point (0 or ~1); published by the first barrier below
-  if (d.view == 0 && h == 0 && d.p_local < d.PTW) wtab[d.p_local] = wsum;
-  float means[2][MAXT];    // [half of the slot list][task]: the means of rounds 0 / 1, consumed by rounds 2 / 3
+  float* wrow = d.scal;  // the pooling weight of every row; published by the first barrier below
+  if (h == 0) wrow[d.rw] = wgt;
+  auto X = [&](int i) { return i < NX ? xin[i < NX ? i : 0] : 0.f; };
 #pragma unroll
-  for (int round = 0; round < 4; ++round) {
-    const int stat = round >> 1, half = round & 1, q0 = half * NH;
+  for (int round = 0; round < ROUNDS; ++round) {
+    const int nq = (NQ - round * QPH < QPH) ? NQ - round * QPH : QPH;
+    float4* mine = reinterpret_cast<float4*>(tab + d.rw * RS + h * (4 * QPH));
 #pragma unroll
-    for (int qq = 0; qq < NH; ++qq) {
-      const int q = q0 + qq;
-      if (q < NX) {
-        const float wx = wgt * xin[q];
-        tab[(qq * 2 + h) * DENSE_STRIDE + d.rw] = stat ? wx * xin[q] : wx;
-      }
+    for (int qq = 0; qq < QPH; ++qq) {
+      const int q = round * QPH + qq;
+      if (q < NQ) mine[qq] = make_float4(X(4 * q), X(4 * q + 1), X(4 * q + 2), X(4 * q + 3));
     }
     __syncthreads();
-    const int ns = (q0 + NH <= NX ? NH : NX - q0) * 2, total = d.PTW * ns;
+    const int total = d.PTW * 2 * nq;
+    for (int task = tid; task < total; task += DYN_VIEW_THREADS) {
+      const int pnt = task / (2 * nq), rem = task - pnt * (2 * nq), hh = rem / nq, qq = rem - hh * nq;
+      const float* src = tab + pnt * d.V * RS + hh * (4 * QPH) + qq * 4;
+      const float* w = wrow + pnt * d.V;
+      float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+      int k = 0;
+      for (; k + 2 <= d.V; k += 2) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
+        const float w0 = w[k], w1 = w[k + 1];
+        m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
+        m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
+      }
+      if (k < d.V) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
+        const float w0 = w[k];
+        m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
+      }
+      const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
+      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+      for (k = 0; k + 2 <= d.V; k += 2) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
+        const float w0 = w[k], w1 = w[k + 1];
+        const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-    for (int it = 0; it < MAXT; ++it) {
-      const int task = tid + it * DYN_VIEW_THREADS;
-      if (task < total) {
-        const int pnt = task / ns, slot = task - pnt * ns;
-        const float* src = tab + slot * DENSE_STRIDE + pnt * d.V;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= d.V; k += 4) { c0 += src[k]; c1 += src[k + 1]; c2 += src[k + 2]; c3 += src[k + 3]; }
-        for (; k < d.V; ++k) c0 += src[k];
-        const float acc = (c0 + c1) + (c2 + c3);
-        if (stat == 0) {
-          means[half][it] = acc;
-        } else {
-          const float m = means[half][it], W = wtab[pnt];
-          const int q = q0 + (slot >> 1), hh = slot & 1;
-          pool[(q * 2 + hh) * 32 + pnt] = m;
-          pool[((NX + q) * 2 + hh) * 32 + pnt] = acc - m * m * (2.0f - W);  // sum w (x - m)^2 with sum w = W
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = a0[e] - mean[e], d1 = a1[e] - mean[e];
+          v0[e] = fmaf(w0, d0 * d0, v0[e]);
+          v1[e] = fmaf(w1, d1 * d1, v1[e]);
+        }
+      }
+      if (k < d.V) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
+        const float w0 = w[k];
+        const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = a0[e] - mean[e];
+          v0[e] = fmaf(w0, d0 * d0, v0[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = 4 * (round * QPH + qq) + e;
+        if (q < NX) {
+          pool[(q * 2 + hh) * 32 + pnt] = mean[e];
+          pool[((NX + q) * 2 + hh) * 32 + pnt] = v0[e] + v1[e];
         }
       }
     }
@@ -573,7 +601,7 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     float* res = pool + POOL_FLOATS(NX);
     B6TileW<2 * NX> pw;
     b6_tile_prefetch<8, 2 * NX>(pooled_w, wave, pw);
-    dense_pool_stats<NX>(*dr, xin, wgt, wsum, pool, res);
+    dense_pool_stats<NX>(*dr, xin, wgt, pool, res);
     if (threadIdx.x < 2 * 2 * NX)
       for (int c = dr->PTW; c < 32; ++c) pool[threadIdx.x * 32 + c] = 0.f;
     __syncthreads();
@@ -722,53 +750,70 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     dense_all2(d, vis2, msk, vsum, nvalid);
     const float w2 = vis2 / (vsum + 1e-8f);
     const float wmean = (vsum / (vsum + 1e-8f)) / (float)V;  // mean over the views of w2 (its sum, over V)
-    constexpr int FS = 257;                 // row stride of a feature slot (odd: the reducers below walk consecutive features conflict-free)
-    float* tab = lds_base;                  // [128 features][FS]
-    float* mt = lds_base + 128 * FS + 3;    // means [PTW][128] in the lanes' own order: p * 128 + h * 64 + t * 16 + r   (16-byte aligned)
+    // x goes into LDS ROW-major in 16-byte quads (row stride 132 floats: 16 lanes of a quad access start 4 banks apart, conflict-free);
+    // a (point, quad) task walks the V rows of its point twice -- mean, then sum w (x - mean)^2, as the lane segments do -- and
+    // stores both quads of the point record with one 16-byte store each.  One table pass, one barrier.
+    constexpr int XS = 132;
+    float* tab = lds_base;             // [256 rows][XS]
+    float* wrow = lds_base + 256 * XS;  // [256] w2 of every row
     const long point0 = (long)blockIdx.x * d.PTW;
     // (the last dense_all2 barrier also retired every wave's reads of the constant tables and of the weight ring)
+    {
+      float4* mine = reinterpret_cast<float4*>(tab + d.rw * XS) + h;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 0) {
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tab[(32 * t + dyn_fi(r, h)) * FS + d.rw] = x[t][r] * w2;
-      } else {
-        const float4* mu = reinterpret_cast<const float4*>(mt + (d.p_local < d.PTW ? d.p_local : d.PTW - 1) * 128 + h * 64);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 m4 = mu[t * 4 + q];
-            const float ms[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float dd = x[t][q * 4 + e] - ms[e];
-              tab[(32 * t + dyn_fi(q * 4 + e, h)) * FS + d.rw] = w2 * (dd * dd);
-            }
-          }
+        for (int q = 0; q < 4; ++q) mine[8 * t + 2 * q] = make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]);
+      if (h == 0) wrow[d.rw] = w2;
+    }
+    __syncthreads();
+    for (int task = tid; task < d.PTW * 32; task += DYN_VIEW_THREADS) {
+      const int pnt = task >> 5, qd = task & 31;  // quad qd = 8 t + 2 q + half: features 32 t + 8 q + 4 half + (0..3)
+      const float* src = tab + pnt * V * XS + qd * 4;
+      const float* w = wrow + pnt * V;
+      float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+      int k = 0;
+      for (; k + 2 <= V; k += 2) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
+        const float w0 = w[k], w1 = w[k + 1];
+        m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
+        m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
       }
-      __syncthreads();
-      // tasks: (point, feature), the feature running fastest over the threads: consecutive threads read consecutive slots (stride FS, odd)
-      for (int task = tid; task < d.PTW * 128; task += DYN_VIEW_THREADS) {
-        const int pnt = task >> 7, f = task & 127;
-        const float* src = tab + f * FS + pnt * V;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= V; k += 4) { c0 += src[k]; c1 += src[k + 1]; c2 += src[k + 2]; c3 += src[k + 3]; }
-        for (; k < V; ++k) c0 += src[k];
-        const float acc = (c0 + c1) + (c2 + c3);
-        // feature f = 32 t + w sits in record g = 4 t + (w >> 3) of half hh = (w >> 2) & 1, component w & 3; register r = (w & 3) + 4 (w >> 3)
-        const int t = f >> 5, w = f & 31, hh = (w >> 2) & 1;
-        const long pt = point0 + pnt;
-        if (pt < p.n_pts) {
-          float* gin = p.ws + p.o.off_gin + (point_rec(p, pt, hh, SB_GIN_RECS) + (long)(pass * 16 + t * 4 + (w >> 3)) * 64) * 4 + (w & 3);
-          nt_store1<4>(gin, acc);
+      if (k < V) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
+        const float w0 = w[k];
+        m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
+      }
+      const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
+      float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+      for (k = 0; k + 2 <= V; k += 2) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
+        const float w0 = w[k], w1 = w[k + 1];
+        const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, b0[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = a0[e] - mean[e], d1 = b0[e] - mean[e];
+          v0[e] = fmaf(w0, d0 * d0, v0[e]);
+          v1[e] = fmaf(w1, d1 * d1, v1[e]);
         }
-        if (pass == 0) mt[pnt * 128 + hh * 64 + t * 16 + (w & 3) + 4 * (w >> 3)] = acc;
       }
-      __syncthreads();
+      if (k < V) {
+        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
+        const float w0 = w[k];
+        const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = a0[e] - mean[e];
+          v0[e] = fmaf(w0, d0 * d0, v0[e]);
+        }
+      }
+      const long pt = point0 + pnt;
+      if (pt < p.n_pts) {
+        const int g = 4 * (qd >> 3) + ((qd >> 1) & 3);  // record 4 t + q of half qd & 1
+        float4* gin = reinterpret_cast<float4*>(p.ws + p.o.off_gin) + point_rec(p, pt, qd & 1, SB_GIN_RECS);
+        nt_store4<4>(gin + g * 64, make_float4(mean[0], mean[1], mean[2], mean[3]));
+        nt_store4<4>(gin + (16 + g) * 64, make_float4(v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2], v0[3] + v1[3]));
+      }
     }
     if (valid && view == 0) {
       float4* gin = reinterpret_cast<float4*>(p.ws + p.o.off_gin) + point_rec(p, point, h, SB_GIN_RECS);
@@ -1794,7 +1839,9 @@ __device__ __forceinline__ void motion_embed(const float (&c4)[4], const float* 
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
       float sn, cs;
-      sincosf(freq[f] * c4[c], &sn, &cs);
+      const float arg = freq[f] * c4[c];
+      sincos_small(arg, sn, cs);
+      if (fabsf(arg) > 1.0e6f) sincosf(arg, &sn, &cs);  // beyond the two-constant reduction's reach: the library's full-range path
       pe[c * 16 + f] = h == 0 ? cs : sn;
     }
   pe[64] = h == 0 ? c4[0] : c4[1];
@@ -1822,18 +1869,11 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
   const float* freq = blob + MO_OFF_FREQ;
   const float one_h0 = h == 0 ? 1.0f : 0.0f;
   f32x16 a[8], b[8];
-  {
-    float pe[MO_PE_STEPS];
-    motion_embed(c4, freq, h, pe);
-    acc_zero(a);
-    net_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
-    acc_relu8(a);
-  }
-  acc_zero(b);
-  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
-  acc_relu8(b);
+  // the embedding feeds layer 0 and the skip layer: evaluated once and kept (one wave per SIMD: 512 registers per lane to spend)
+  float pe[MO_PE_STEPS];
+  motion_embed(c4, freq, h, pe);
   acc_zero(a);
-  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  net_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
   acc_relu8(a);
   acc_zero(b);
   net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
@@ -1841,16 +1881,18 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
   acc_zero(a);
   net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   acc_relu8(a);
-  {
-    float pe[MO_PE_STEPS];
-    motion_embed(c4, freq, h, pe);
-    acc_zero(b);
-    net_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
-      if (s < MO_PE_STEPS) return pe[s];
-      return s - MO_PE_STEPS < 128 ? a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16] : one_h0;
-    });
-    acc_relu8(b);
-  }
+  acc_zero(b);
+  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
+  acc_relu8(b);
+  acc_zero(a);
+  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  acc_relu8(a);
+  acc_zero(b);
+  net_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
+    if (s < MO_PE_STEPS) return pe[s];
+    return s - MO_PE_STEPS < 128 ? a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16] : one_h0;
+  });
+  acc_relu8(b);
   acc_zero(a);
   net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
   acc_relu8(a);
