@@ -14,9 +14,10 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'libdynibar_hip.so')
 OUT_X6 = os.path.join(CSRC, 'libdynibar_hip_x6.so')
 UNITS = [
-    ('dyn_geometry.hip', ['-ffp-contract=off']),
+    ('dyn_geometry.hip', ['-ffp-contract=off', '-munsafe-fp-atomics']),
     ('dyn_nets.hip', []),
     ('dyn_encoder.hip', []),
+    ('dyn_train.hip', ['-munsafe-fp-atomics']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

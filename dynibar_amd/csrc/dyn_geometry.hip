@@ -35,7 +35,8 @@ static const char* const g_prof_names[DYN_K_COUNT] = {
     "k_prepare_cameras", "k_nchw_to_nhwc", "k_sample_along_ray", "k_points_from_z", "k_project_gather", "k_sample_mask", "k_composite",
     "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest", "k_dynamic_time_feat",
     "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points", "k_render_flows", "k_expected_scene_flow", "k_image_rays",
-    "k_static_points_qkv", "k_dynamic_points_qkv", "k_enc_conv7", "k_enc_conv3", "k_enc_conv1", "k_enc_block_out"};
+    "k_static_points_qkv", "k_dynamic_points_qkv", "k_enc_conv7", "k_enc_conv3", "k_enc_conv1", "k_enc_block_out",
+    "k_train_gemm", "k_train_rows", "k_train_attn", "k_gather_bwd"};
 
 static void prof_flush(int slot) {
   for (int i = 0; i < g_prof.used[slot]; ++i) {
@@ -759,6 +760,67 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<32>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
                reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the feature gather (training; the autograd of F.grid_sample w.r.t. its input, projection.py:160-167):
+// d featmaps[v, y, x, :] += w_tap * d rgb_feat[row, 3:3+F] at the four taps of every (point, view) row.  The pixel location is
+// recomputed with the forward kernel's own arithmetic (same projection, same make_taps), so the taps and weights are the forward's.
+// One thread per (row, group of four channels); fp32 hardware atomics into the channels-last gradient map (zeroed by the caller).
+// Sample points are static (xyz = pts_st); no gradient flows to the locations in the static branch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __restrict__ pts_st, const float4* __restrict__ proj4,
+                                                    const float* __restrict__ drgb_feat, long ld_d, int col0, float* __restrict__ dfeat) {
+  const int G = q.F / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / G;
+  const int cg = (int)(idx - row * G);
+  if (row >= q.N) return;
+  const long rs = row / q.V;
+  const int v = (int)(row - rs * q.V);
+  const float x = pts_st[rs * 3 + 0], y = pts_st[rs * 3 + 1], z3 = pts_st[rs * 3 + 2];
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  const float izc = __builtin_amdgcn_rcpf(zc);
+  float px = hx * izc, py = hy * izc;
+  px = fminf(fmaxf(px, -1e6f), 1e6f);
+  py = fminf(fmaxf(py, -1e6f), 1e6f);
+  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
+  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const Taps t = make_taps(nx, ny, q.Wf, q.Hf);
+  const float* d = drgb_feat + row * ld_d + col0 + cg * 4;
+  const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+  float* base = dfeat + (long)v * q.Hf * q.Wf * q.F + cg * 4;
+  const float wts[4] = {t.w_nw, t.w_ne, t.w_sw, t.w_se};
+  const int offs[4] = {t.y0 * q.Wf + t.x0, t.y0 * q.Wf + t.x1, t.y1 * q.Wf + t.x0, t.y1 * q.Wf + t.x1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (wts[k] == 0.f) continue;
+    float* o = base + (long)offs[k] * q.F;
+    atomicAdd(o + 0, wts[k] * d0);
+    atomicAdd(o + 1, wts[k] * d1);
+    atomicAdd(o + 2, wts[k] * d2);
+    atomicAdd(o + 3, wts[k] * d3);
+  }
+}
+
+extern "C" int dyn_gather_bwd(const float* pts_st, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
+                              const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream) {
+  DYN_REQUIRE(pts_st && proj && drgb_feat && dfeat_cl, "dyn_gather_bwd: null pointer");
+  DYN_REQUIRE(R > 0 && S > 0 && V > 0 && Hf > 1 && Wf > 1 && F > 0 && (F % 4) == 0, "dyn_gather_bwd: bad shape");
+  PGShape q;
+  q.R = R; q.S = S; q.V = V; q.H = 0; q.W = 0; q.Hf = Hf; q.Wf = Wf; q.F = F;
+  q.img_h = img_h; q.img_w = img_w;
+  q.inv_wm1 = 1.0f / (img_w - 1.0f); q.inv_hm1 = 1.0f / (img_h - 1.0f);
+  q.N = (long)R * S * V;
+  q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
+  const long n = q.N * (F / 4);
+  DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, pts_st,
+             reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);
   return 0;
 }
 

@@ -1,0 +1,971 @@
+// Training kernels (first slice): forward-with-saved-activations and backward of the static branch, i.e. the
+// step the reference's static bootstrap stage trains on (train.py:116-199: loss on ret['outputs_coarse_st']['rgb'], gradients to
+// DynibarStatic's parameters and to the static feature maps).
+//
+// Design, as opposed to the inference kernels of dyn_nets.hip (register-resident chains, nothing saved): a training step needs every
+// layer's output again in the backward pass, so the step is a sequence of
+//   * ONE tiled GEMM kernel on the matrix pipe (k_train_gemm) used for forward (Y = act(X W^T + b + P[row / V])), data gradients
+//     (dX = dZ W) and weight gradients (dW += dZ^T X, split over the rows with fp32 atomics), and
+//   * small HBM-bound row / per-point kernels for everything between the Linear layers (Fourier features, pooling over views,
+//     sigmoids, softmaxes, ray attention, LayerNorm, compositing) with their hand-derived backward forms,
+// over row-major fp32 activation matrices that stay in HBM between kernels (a step of 2048 rays x 64 samples x 15 views keeps
+// about 12 GB: sized for the 288 GB of an MI355X, nothing is recomputed).
+//
+// Arithmetic of the GEMM: fp32 in, fp32 accumulate; every fp32 operand is split EXACTLY into three bf16 parts (8 + 8 + 8 mantissa
+// bits, truncation, so the parts keep fp32's full exponent range -- gradients of 1e-9 lose nothing, which the half-float split of
+// the inference engine cannot promise) and the six partial products down to 2^-18 run on v_mfma_f32_32x32x16_bf16: fp32-class
+// products at 2500/6 = 417 TFLOP/s peak against 157 TFLOP/s of the native fp32 MFMA.  The split happens once per element when a
+// tile is written to LDS, not per use.
+#include "dyn_device.h"
+#include "dyn_host.h"
+
+typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tr_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short tr_u16;
+typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
+
+#define TG_BM 128
+#define TG_BN 128
+#define TG_BK 32
+#define TG_ROW 40                        // bf16 elements per LDS row (32 used + 8 pad: 80-byte stride, conflict-free b128 reads)
+#define TG_PART (TG_BM * TG_ROW)         // elements of one part image
+#define TG_LDS_BYTES (2 * 3 * TG_PART * 2)
+
+__device__ __forceinline__ void tr_split3(float x, tr_u16& h, tr_u16& m, tr_u16& l) {
+  const unsigned b = __float_as_uint(x);
+  h = (tr_u16)(b >> 16);
+  const float r1 = x - __uint_as_float(b & 0xffff0000u);
+  const unsigned b1 = __float_as_uint(r1);
+  m = (tr_u16)(b1 >> 16);
+  const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+  l = (tr_u16)(__float_as_uint(r2) >> 16);
+}
+
+struct TrOperand {
+  const float* p;
+  long rs, ks;   // element (r, k) at p[r * rs + k * ks]; exactly one of rs, ks is 1 (or both for a vector)
+  int nrows;     // bound of r
+  int aligned;   // base pointer 16-byte aligned
+};
+
+// global -> registers: the thread's 16 elements of a [128 rows x 32 k] operand tile (zero beyond the bounds)
+template <bool KMINOR>
+__device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k0, int kend, float4 (&st)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KMINOR) {
+      const int r = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
+      if (r < o.nrows && k < kend) {
+        const float* g = o.p + (long)r * o.rs + k;
+        if (o.aligned && (o.rs & 3) == 0 && k + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(g);
+        } else {
+          v.x = g[0];
+          if (k + 1 < kend) v.y = g[1];
+          if (k + 2 < kend) v.z = g[2];
+          if (k + 3 < kend) v.w = g[3];
+        }
+      }
+    } else {
+      const int k = k0 + (tid >> 5) + 8 * i, r = row0 + (tid & 31) * 4;
+      if (k < kend && r < o.nrows) {
+        const float* g = o.p + (long)k * o.ks + r;
+        if (o.aligned && (o.ks & 3) == 0 && r + 3 < o.nrows) {
+          v = *reinterpret_cast<const float4*>(g);
+        } else {
+          v.x = g[0];
+          if (r + 1 < o.nrows) v.y = g[1];
+          if (r + 2 < o.nrows) v.z = g[2];
+          if (r + 3 < o.nrows) v.w = g[3];
+        }
+      }
+    }
+    st[i] = v;
+  }
+}
+
+// registers -> LDS part images [part][row][k] (k contiguous: what the MFMA operand reads want), splitting on the way
+template <bool KMINOR>
+__device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+    tr_u16 h[4], m[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tr_split3(v[q], h[q], m[q], l[q]);
+    if (KMINOR) {
+      const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
+      tr_u16* d = img + r * TG_ROW + k;
+      *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
+      *reinterpret_cast<tr_u32x2*>(d + TG_PART) = tr_u32x2{m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16)};
+      *reinterpret_cast<tr_u32x2*>(d + 2 * TG_PART) = tr_u32x2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
+    } else {
+      const int k = (tid >> 5) + 8 * i, r = (tid & 31) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        tr_u16* d = img + (r + q) * TG_ROW + k;
+        d[0] = h[q];
+        d[TG_PART] = m[q];
+        d[2 * TG_PART] = l[q];
+      }
+    }
+  }
+}
+
+struct TrGemmArgs {
+  TrOperand a, b;  // a: rows = m, b: rows = n
+  float* c;
+  long ldc;
+  int M, N, K;
+  int k_chunk;           // k range per blockIdx.z (multiple of TG_BK)
+  const float* bias;     // [N] or null
+  const float* addend;   // [(M / add_div), ld_add] or null
+  long ld_add;
+  int add_div;
+  int act;               // 0 none, 1 ELU
+  int accumulate;        // 0 store, 1 c += result, 2 atomicAdd
+};
+
+__device__ __forceinline__ f32x16 tr_mfma(tr_u32x4 a, tr_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tr_bf16x8, a), __builtin_bit_cast(tr_bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool A_KMINOR, bool B_KMINOR>
+__global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
+  tr_u16* As = reinterpret_cast<tr_u16*>(dyn_smem);
+  tr_u16* Bs = As + 3 * TG_PART;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = g.K < kbeg + g.k_chunk ? g.K : kbeg + g.k_chunk;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 sa[4], sb[4];
+  tr_load_tile<A_KMINOR>(g.a, m0, kbeg, kend, sa, tid);
+  tr_load_tile<B_KMINOR>(g.b, n0, kbeg, kend, sb, tid);
+  for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
+    tr_store_tile<A_KMINOR>(As, sa, tid);
+    tr_store_tile<B_KMINOR>(Bs, sb, tid);
+    __syncthreads();
+    if (k0 + TG_BK < kend) {  // next tile in flight while this one feeds the matrix pipe
+      tr_load_tile<A_KMINOR>(g.a, m0, k0 + TG_BK, kend, sa, tid);
+      tr_load_tile<B_KMINOR>(g.b, n0, k0 + TG_BK, kend, sb, tid);
+    }
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16) {
+      tr_u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          a[i][part] = *reinterpret_cast<const tr_u32x4*>(As + part * TG_PART + (wm * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
+          b[i][part] = *reinterpret_cast<const tr_u32x4*>(Bs + part * TG_PART + (wn * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // smallest partial products first
+          acc[i][j] = tr_mfma(a[i][2], b[j][0], acc[i][j]);
+          acc[i][j] = tr_mfma(a[i][0], b[j][2], acc[i][j]);
+          acc[i][j] = tr_mfma(a[i][1], b[j][1], acc[i][j]);
+          acc[i][j] = tr_mfma(a[i][1], b[j][0], acc[i][j]);
+          acc[i][j] = tr_mfma(a[i][0], b[j][1], acc[i][j]);
+          acc[i][j] = tr_mfma(a[i][0], b[j][0], acc[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+  // epilogue: D layout -- lane (j = lane & 31: column n, h = lane >> 5), register r: row (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.addend != nullptr) v += g.addend[(long)(m / g.add_div) * g.ld_add + n];
+        if (g.act == 1) v = v > 0.f ? v : expm1f(v);
+        float* c = g.c + (long)m * g.ldc + n;
+        if (g.accumulate == 0) *c = v;
+        else if (g.accumulate == 1) *c += v;
+        else atomicAdd(c, v);
+      }
+    }
+}
+
+extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
+  DYN_REQUIRE(p != nullptr && p->A && p->B && p->C, "dyn_train_gemm: null pointer");
+  DYN_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "dyn_train_gemm: empty problem (M %d N %d K %d)", p->M, p->N, p->K);
+  DYN_REQUIRE((p->a_rs == 1 || p->a_ks == 1) && (p->b_rs == 1 || p->b_ks == 1), "dyn_train_gemm: each operand needs one unit stride");
+  DYN_REQUIRE(p->k_split >= 1 && (p->k_split == 1 || (p->accumulate == 2 && p->act == 0 && p->addend == nullptr)),
+              "dyn_train_gemm: a split reduction needs accumulate = 2 (atomic) and a linear epilogue");
+  DYN_REQUIRE(p->addend == nullptr || p->add_div >= 1, "dyn_train_gemm: add_div must be >= 1");
+  TrGemmArgs g;
+  g.a.p = p->A; g.a.rs = p->a_rs; g.a.ks = p->a_ks; g.a.nrows = p->M; g.a.aligned = ((uintptr_t)p->A & 15) == 0;
+  g.b.p = p->B; g.b.rs = p->b_rs; g.b.ks = p->b_ks; g.b.nrows = p->N; g.b.aligned = ((uintptr_t)p->B & 15) == 0;
+  g.c = p->C; g.ldc = p->ldc; g.M = p->M; g.N = p->N; g.K = p->K;
+  int chunk = (p->K + p->k_split - 1) / p->k_split;
+  chunk = ((chunk + TG_BK - 1) / TG_BK) * TG_BK;
+  g.k_chunk = chunk;
+  const int nz = (p->K + chunk - 1) / chunk;
+  g.bias = p->bias; g.addend = p->addend; g.ld_add = p->ld_add; g.add_div = p->add_div > 0 ? p->add_div : 1;
+  g.act = p->act; g.accumulate = p->accumulate;
+  const dim3 grid(dyn_cdiv(p->N, TG_BN), dyn_cdiv(p->M, TG_BM), nz);
+  const bool ak = p->a_ks == 1, bk = p->b_ks == 1;
+  if (ak && bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<true, true>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
+  else if (ak && !bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<true, false>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
+  else if (!ak && bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<false, true>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
+  else DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<false, false>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
+  return 0;
+}
+
+// =====================================================================================================================
+// Row kernels.  N = P * V rows (row = point * V + view), P = R * S points.
+// =====================================================================================================================
+__device__ __forceinline__ float tr_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// dZ = dY * act'(Y) in place (ELU: y > 0 ? 1 : y + 1, from the saved OUTPUT), plus the bias gradient (column sums, atomics) and the
+// gradient of a per-point addend (sums over the seg rows of a point).  A thread owns one column of a run of rows.
+__global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, const float* __restrict__ y, long rows, int cols, long ld_dy, long ld_y,
+                                                       int act, float* __restrict__ dbias, int seg, float* __restrict__ dseg, long ld_seg, int ct,
+                                                       int run) {
+  const int cx = threadIdx.x % ct, cy = threadIdx.x / ct;
+  const long chunk = (long)blockIdx.x * (256 / ct) + cy;
+  const long r0 = chunk * run;
+  for (int c = cx; c < cols; c += ct) {
+    float colsum = 0.f, segsum = 0.f;
+    for (long r = r0; r < r0 + run && r < rows; ++r) {
+      float d = dy[r * ld_dy + c];
+      if (act == 1) {
+        const float yv = y[r * ld_y + c];
+        d = yv > 0.f ? d : d * (yv + 1.0f);
+        dy[r * ld_dy + c] = d;
+      }
+      colsum += d;
+      if (dseg != nullptr) {
+        segsum += d;
+        if ((r + 1) % seg == 0) {
+          dseg[(r / seg) * ld_seg + c] = segsum;
+          segsum = 0.f;
+        }
+      }
+    }
+    if (dbias != nullptr && r0 < rows) atomicAdd(dbias + c, colsum);
+  }
+}
+
+extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg,
+                                 float* dseg, long ld_seg, void* stream) {
+  DYN_REQUIRE(dY != nullptr && rows > 0 && cols > 0, "dyn_train_act_bwd: bad arguments");
+  DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_act_bwd: ELU backward needs the saved output");
+  DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
+  const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
+  int run = dseg != nullptr ? seg : 1;
+  while (run < 64) run += (dseg != nullptr ? seg : 1);
+  const long chunks = (rows + run - 1) / run;
+  const int per_block = 256 / ct;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), 0,
+             (hipStream_t)stream, dY, Y, rows, cols, ld_dy, ld_y, act, dbias, seg, dseg, ld_seg, ct, run);
+  return 0;
+}
+
+// ---- Fourier features of the static net's per-view input (mlp_network.py:423-441; render_ray.py:372-396) ---------------------------
+// a0[row] = [PE(pts) (33) | PE(src Pluecker) (66) | ray_diff (4) | 0]  (ld 104);  ref_pe[ray] = PE(ref Pluecker) (66, ld 68);
+// mask_eff = mask * (sum(rgb) > 1e-3) when mask_rgb (mlp_network.py:445-448).  No gradient flows into any of these.
+__device__ __forceinline__ void tr_embed(float x, float* out, int stride) {  // out[0] = x, out[(1 + f) stride] = cos(2^f x), out[(6 + f) stride] = sin
+  out[0] = x;
+#pragma unroll
+  for (int f = 0; f < 5; ++f) {
+    float s, c;
+    sincosf((float)(1 << f) * x, &s, &c);
+    out[(1 + f) * stride] = c;
+    out[(6 + f) * stride] = s;
+  }
+}
+__device__ __forceinline__ void tr_unit3(float x, float y, float z, float& ox, float& oy, float& oz) {
+  const float d = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  ox = x / d; oy = y / d; oz = z / d;
+}
+
+__global__ void __launch_bounds__(256) k_train_static_embed(const float* __restrict__ pts, const float* __restrict__ ray_o,
+                                                            const float* __restrict__ ray_d, const float* __restrict__ centers, int center_stride,
+                                                            const float* __restrict__ ray_diff, const float* __restrict__ rgb_feat,
+                                                            const float* __restrict__ mask, int R, int S, int V, int mask_rgb,
+                                                            float* __restrict__ a0, float* __restrict__ ref_pe, float* __restrict__ mask_eff) {
+  const long N = (long)R * S * V;
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < R) {  // the first R threads also make the per-ray reference features
+    const int r = (int)row;
+    float d[3], c[6];
+    tr_unit3(ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2], d[0], d[1], d[2]);
+    const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+    c[0] = d[0]; c[1] = d[1]; c[2] = d[2];
+    c[3] = oy * d[2] - oz * d[1];
+    c[4] = oz * d[0] - ox * d[2];
+    c[5] = ox * d[1] - oy * d[0];
+    float* o = ref_pe + (long)r * 68;
+    for (int k = 0; k < 6; ++k) tr_embed(c[k], o + k, 6);
+    o[66] = 0.f; o[67] = 0.f;
+  }
+  if (row >= N) return;
+  const long p = row / V;
+  const int v = (int)(row - p * V);
+  float* o = a0 + row * 104;
+  const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+  tr_embed(px, o + 0, 3);
+  tr_embed(py, o + 1, 3);
+  tr_embed(pz, o + 2, 3);
+  const float cx = centers[v * center_stride], cy = centers[v * center_stride + 1], cz = centers[v * center_stride + 2];
+  float c[6];
+  tr_unit3(px - cx, py - cy, pz - cz, c[0], c[1], c[2]);
+  c[3] = cy * c[2] - cz * c[1];
+  c[4] = cz * c[0] - cx * c[2];
+  c[5] = cx * c[1] - cy * c[0];
+  for (int k = 0; k < 6; ++k) tr_embed(c[k], o + 33 + k, 6);
+  const float4 rd = *reinterpret_cast<const float4*>(ray_diff + row * 4);
+  o[99] = rd.x; o[100] = rd.y; o[101] = rd.z; o[102] = rd.w; o[103] = 0.f;
+  float m = mask[row];
+  if (mask_rgb) {
+    const float* f = rgb_feat + row * 35;
+    m = m * (((f[0] + f[1]) + f[2]) > 1e-3f ? 1.0f : 0.0f);
+  }
+  mask_eff[row] = m;
+}
+
+extern "C" int dyn_train_static_embed(const float* pts, const float* ray_o, const float* ray_d, const float* centers, int center_stride,
+                                      const float* ray_diff, const float* rgb_feat, const float* mask, int R, int S, int V, int mask_rgb,
+                                      float* a0, float* ref_pe, float* mask_eff, void* stream) {
+  DYN_REQUIRE(pts && ray_o && ray_d && centers && ray_diff && rgb_feat && mask && a0 && ref_pe && mask_eff, "dyn_train_static_embed: null pointer");
+  DYN_REQUIRE(R > 0 && S > 0 && V > 0, "dyn_train_static_embed: empty shape");
+  const long N = (long)R * S * V;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_static_embed", k_train_static_embed, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             pts, ray_o, ray_d, centers, center_stride, ray_diff, rgb_feat, mask, R, S, V, mask_rgb, a0, ref_pe, mask_eff);
+  return 0;
+}
+
+// ---- f = [rgb_feat | src_feat * ref_feat] (mlp_network.py:450) and its backward ---------------------------------------------------------
+// forward: one thread per (row, c < 70), f ld 72.  backward: one workgroup per ray (its S V rows are contiguous):
+// d src_feat[row, c] = df[row, 35 + c] ref_feat[ray, c]; d ref_feat[ray, c] = sum_rows df[row, 35 + c] src_feat[row, c].
+__global__ void __launch_bounds__(256) k_train_build_f(const float* __restrict__ rgb_feat, const float* __restrict__ src_feat, long ld_src,
+                                                       const float* __restrict__ ref_feat, long ld_ref, long N, int rows_per_ray,
+                                                       float* __restrict__ f) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / 72;
+  const int c = (int)(idx - row * 72);
+  if (row >= N) return;
+  float v = 0.f;
+  if (c < 35) v = rgb_feat[row * 35 + c];
+  else if (c < 70) v = src_feat[row * ld_src + c - 35] * ref_feat[(row / rows_per_ray) * ld_ref + c - 35];
+  f[row * 72 + c] = v;
+}
+__global__ void __launch_bounds__(256) k_train_build_f_bwd(const float* __restrict__ df, long ld_df, const float* __restrict__ src_feat, long ld_src,
+                                                           const float* __restrict__ ref_feat, long ld_ref, int rows_per_ray,
+                                                           float* __restrict__ dsrc, long ld_dsrc, float* __restrict__ dref, long ld_dref) {
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [256]
+  const long ray = blockIdx.x;
+  const int c = threadIdx.x % 36, slot = threadIdx.x / 36;  // 7 row slots x 36 columns (35 used) = 252 threads
+  float acc = 0.f;
+  if (slot < 7 && c < 35) {
+    const float rf = ref_feat[ray * ld_ref + c];
+    for (int i = slot; i < rows_per_ray; i += 7) {
+      const long row = ray * rows_per_ray + i;
+      const float d = df[row * ld_df + 35 + c];
+      dsrc[row * ld_dsrc + c] = d * rf;
+      acc += d * src_feat[row * ld_src + c];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 35) {
+    float s = 0.f;
+    for (int k = 0; k < 7; ++k) s += red[k * 36 + threadIdx.x];
+    dref[ray * ld_dref + threadIdx.x] = s;
+  }
+}
+extern "C" int dyn_train_build_f(const float* rgb_feat, const float* src_feat, long ld_src, const float* ref_feat, long ld_ref, long N,
+                                 int rows_per_ray, float* f, void* stream) {
+  DYN_REQUIRE(rgb_feat && src_feat && ref_feat && f && N > 0 && rows_per_ray > 0, "dyn_train_build_f: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_build_f", k_train_build_f, dim3((unsigned)((N * 72 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             rgb_feat, src_feat, ld_src, ref_feat, ld_ref, N, rows_per_ray, f);
+  return 0;
+}
+extern "C" int dyn_train_build_f_bwd(const float* df, long ld_df, const float* src_feat, long ld_src, const float* ref_feat, long ld_ref, long R,
+                                     int rows_per_ray, float* dsrc, long ld_dsrc, float* dref, long ld_dref, void* stream) {
+  DYN_REQUIRE(df && src_feat && ref_feat && dsrc && dref && R > 0 && rows_per_ray > 0, "dyn_train_build_f_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_build_f_bwd", k_train_build_f_bwd, dim3((unsigned)R), dim3(256), 1024, (hipStream_t)stream, df, ld_df,
+             src_feat, ld_src, ref_feat, ld_ref, rows_per_ray, dsrc, ld_dsrc, dref, ld_dref);
+  return 0;
+}
+
+// ---- pooling weights over the views of a point ---------------------------------------------------------------------------------------
+// mode 0 (mlp_network.py:452-459): aa: u = (e - min_v e) mask, e = exp(|s| (dot - 1)); else u = mask.  w = u / (sum_v u + 1e-8).
+// mode 1 (:470-471, :476): vis = sigmoid(logit) mask; w = vis / (sum_v vis + 1e-8); also wmean = mean_v w and nvalid = sum_v mask.
+// One thread per point.  Backward: dw -> (mode 0) ds (one atomic per workgroup), (mode 1) dlogit, with the direct gradient of vis added.
+__global__ void __launch_bounds__(256) k_train_view_weights(int mode, const float* __restrict__ in, long in_stride, const float* __restrict__ mask,
+                                                            const float* __restrict__ s_param, long P, int V, float* __restrict__ w,
+                                                            float* __restrict__ vis_out, long vis_stride, float* __restrict__ wmean, long wmean_stride,
+                                                            float* __restrict__ nvalid) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long r0 = p * V;
+  if (mode == 0) {
+    if (s_param != nullptr) {
+      const float sa = fabsf(s_param[0]);
+      float mn = INFINITY;
+      for (int v = 0; v < V; ++v) mn = fminf(mn, expf(sa * (in[(r0 + v) * in_stride] - 1.0f)));
+      float sum = 0.f;
+      for (int v = 0; v < V; ++v) sum += (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
+      for (int v = 0; v < V; ++v) w[r0 + v] = (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v] / (sum + 1e-8f);
+    } else {
+      float sum = 0.f;
+      for (int v = 0; v < V; ++v) sum += mask[r0 + v];
+      for (int v = 0; v < V; ++v) w[r0 + v] = mask[r0 + v] / (sum + 1e-8f);
+    }
+  } else {
+    float sum = 0.f, nv = 0.f;
+    for (int v = 0; v < V; ++v) {
+      const float vi = tr_sigmoid(in[(r0 + v) * in_stride]) * mask[r0 + v];
+      vis_out[(r0 + v) * vis_stride] = vi;
+      sum += vi;
+      nv += mask[r0 + v];
+    }
+    float ws = 0.f;
+    for (int v = 0; v < V; ++v) {
+      const float wv = vis_out[(r0 + v) * vis_stride] / (sum + 1e-8f);
+      w[r0 + v] = wv;
+      ws += wv;
+    }
+    wmean[p * wmean_stride] = ws / (float)V;
+    nvalid[p] = nv;
+  }
+}
+__global__ void __launch_bounds__(256) k_train_view_weights_bwd(int mode, const float* __restrict__ in, long in_stride, const float* __restrict__ mask,
+                                                                const float* __restrict__ s_param, long P, int V, const float* __restrict__ w,
+                                                                const float* __restrict__ dw, const float* __restrict__ dvis_direct,
+                                                                long dvis_stride, const float* __restrict__ vis, long vis_stride,
+                                                                const float* __restrict__ dwmean, long dwmean_stride,
+                                                                float* __restrict__ dlogit, long dlogit_stride, float* __restrict__ ds) {
+  float* red = reinterpret_cast<float*>(dyn_smem);
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float ds_local = 0.f;
+  if (p < P) {
+    const long r0 = p * V;
+    if (mode == 0) {
+      // w_v = u_v / (U + eps), u_v = (e_v - e_min) m_v:  du_v = (dw_v - sum_k dw_k w_k) / (U + eps)
+      const float s0 = s_param[0], sa = fabsf(s0);
+      float mn = INFINITY, U = 0.f, dot = 0.f;
+      int amin = 0;
+      for (int v = 0; v < V; ++v) {
+        const float e = expf(sa * (in[(r0 + v) * in_stride] - 1.0f));
+        if (e < mn) { mn = e; amin = v; }
+      }
+      for (int v = 0; v < V; ++v) {
+        U += (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
+        dot += dw[r0 + v] * w[r0 + v];
+      }
+      // d/d|s| of u_v = (e_v - e_min) m_v is (e_v x_v - e_min x_min) m_v, x = dot - 1: formed per view as one difference of
+      // neighbours rather than as two large sums that cancel
+      const float xm = in[(r0 + amin) * in_stride] - 1.0f;
+      const float em = expf(sa * xm) * xm;
+      float dsa = 0.f;
+      for (int v = 0; v < V; ++v) {
+        const float du = (dw[r0 + v] - dot) / (U + 1e-8f);
+        const float x = in[(r0 + v) * in_stride] - 1.0f;
+        dsa += du * mask[r0 + v] * (expf(sa * x) * x - em);
+      }
+      ds_local = dsa * (s0 > 0.f ? 1.0f : (s0 < 0.f ? -1.0f : 0.0f));
+    } else {
+      float U = 0.f, dot = 0.f;
+      const float dwm = dwmean != nullptr ? dwmean[p * dwmean_stride] / (float)V : 0.f;
+      for (int v = 0; v < V; ++v) {
+        U += vis[(r0 + v) * vis_stride];
+        dot += (dw[r0 + v] + dwm) * w[r0 + v];
+      }
+      for (int v = 0; v < V; ++v) {
+        float dv = (dw[r0 + v] + dwm - dot) / (U + 1e-8f);
+        if (dvis_direct != nullptr) dv += dvis_direct[(r0 + v) * dvis_stride];
+        const float sg = tr_sigmoid(in[(r0 + v) * in_stride]);
+        dlogit[(r0 + v) * dlogit_stride] = dv * mask[r0 + v] * sg * (1.0f - sg);
+      }
+    }
+  }
+  if (mode == 0) {
+    red[threadIdx.x] = ds_local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(ds, red[0]);
+  }
+}
+extern "C" int dyn_train_view_weights(int mode, const float* in, long in_stride, const float* mask, const float* s_param, long P, int V, float* w,
+                                      float* vis_out, long vis_stride, float* wmean, long wmean_stride, float* nvalid, void* stream) {
+  DYN_REQUIRE(mask && w && P > 0 && V > 0, "dyn_train_view_weights: bad arguments");
+  DYN_REQUIRE(mode == 0 ? (s_param == nullptr || in != nullptr) : (in && vis_out && wmean && nvalid), "dyn_train_view_weights: missing arrays for mode %d", mode);
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_view_weights", k_train_view_weights, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             mode, in, in_stride, mask, s_param, P, V, w, vis_out, vis_stride, wmean, wmean_stride, nvalid);
+  return 0;
+}
+extern "C" int dyn_train_view_weights_bwd(int mode, const float* in, long in_stride, const float* mask, const float* s_param, long P, int V,
+                                          const float* w, const float* dw, const float* dvis_direct, long dvis_stride, const float* vis,
+                                          long vis_stride, const float* dwmean, long dwmean_stride, float* dlogit, long dlogit_stride, float* ds,
+                                          void* stream) {
+  DYN_REQUIRE(in && mask && w && dw && P > 0 && V > 0, "dyn_train_view_weights_bwd: bad arguments");
+  DYN_REQUIRE(mode == 0 ? (s_param && ds) : (vis && dlogit), "dyn_train_view_weights_bwd: missing arrays for mode %d", mode);
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_view_weights_bwd", k_train_view_weights_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 1024,
+             (hipStream_t)stream, mode, in, in_stride, mask, s_param, P, V, w, dw, dvis_direct, dvis_stride, vis, vis_stride, dwmean, dwmean_stride,
+             dlogit, dlogit_stride, ds);
+  return 0;
+}
+
+// ---- weighted mean / variance over the views of a point (mlp_network.py:115-119) ------------------------------------------------------
+// one thread per (point, column).  backward: dX (+)= w (dmean_t + 2 (x - mean) dvar), dmean_t = dmean - 2 dvar sum_v w (x - mean);
+// dw[row] = sum_c [x dmean_t + (x - mean)^2 dvar] via a shared-memory reduction over the columns (one workgroup per point).
+__global__ void __launch_bounds__(256) k_train_meanvar(const float* __restrict__ x, long ldx, const float* __restrict__ w, long P, int V, int C,
+                                                       float* __restrict__ mean, float* __restrict__ var, long ld_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long p = idx / C;
+  const int c = (int)(idx - p * C);
+  if (p >= P) return;
+  const long r0 = p * V;
+  float m = 0.f;
+  for (int v = 0; v < V; ++v) m += x[(r0 + v) * ldx + c] * w[r0 + v];
+  float s = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float d = x[(r0 + v) * ldx + c] - m;
+    s += w[r0 + v] * (d * d);
+  }
+  mean[p * ld_out + c] = m;
+  var[p * ld_out + c] = s;
+}
+__global__ void __launch_bounds__(256) k_train_meanvar_bwd(const float* __restrict__ x, long ldx, const float* __restrict__ w, int V, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ dmean,
+                                                           const float* __restrict__ dvar, long ld_stat, float* __restrict__ dx, long ld_dx,
+                                                           int accumulate, float* __restrict__ dw, int dw_accumulate) {
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [V][256]
+  const long p = blockIdx.x;
+  const long r0 = p * V;
+  const int t = threadIdx.x;
+  for (int v = 0; v < V; ++v) red[v * 256 + t] = 0.f;
+  for (int c = t; c < C; c += 256) {
+    const float m = mean[p * ld_stat + c], dm = dmean[p * ld_stat + c], dv = dvar[p * ld_stat + c];
+    float sw = 0.f;
+    for (int v = 0; v < V; ++v) sw += w[r0 + v] * (x[(r0 + v) * ldx + c] - m);
+    const float dmt = dm - 2.0f * dv * sw;
+    for (int v = 0; v < V; ++v) {
+      const float xv = x[(r0 + v) * ldx + c], d = xv - m;
+      const float g = w[r0 + v] * (dmt + 2.0f * d * dv);
+      float* o = dx + (r0 + v) * ld_dx + c;
+      if (accumulate) *o += g; else *o = g;
+      red[v * 256 + t] += xv * dmt + d * d * dv;
+    }
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o)
+      for (int v = 0; v < V; ++v) red[v * 256 + t] += red[v * 256 + t + o];
+    __syncthreads();
+  }
+  if (t < V) {
+    if (dw_accumulate) dw[r0 + t] += red[t * 256];
+    else dw[r0 + t] = red[t * 256];
+  }
+}
+extern "C" int dyn_train_meanvar(const float* x, long ldx, const float* w, long P, int V, int C, float* mean, float* var, long ld_out, void* stream) {
+  DYN_REQUIRE(x && w && mean && var && P > 0 && V > 0 && C > 0, "dyn_train_meanvar: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar", k_train_meanvar, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+             P, V, C, mean, var, ld_out);
+  return 0;
+}
+extern "C" int dyn_train_meanvar_bwd(const float* x, long ldx, const float* w, long P, int V, int C, const float* mean, const float* dmean,
+                                     const float* dvar, long ld_stat, float* dx, long ld_dx, int accumulate, float* dw, int dw_accumulate,
+                                     void* stream) {
+  DYN_REQUIRE(x && w && mean && dmean && dvar && dx && dw && P > 0 && V > 0 && V <= 32 && C > 0, "dyn_train_meanvar_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar_bwd", k_train_meanvar_bwd, dim3((unsigned)P), dim3(256), (size_t)V * 1024, (hipStream_t)stream, x, ldx,
+             w, V, C, mean, dmean, dvar, ld_stat, dx, ld_dx, accumulate, dw, dw_accumulate);
+  return 0;
+}
+
+// ---- y[row, :] = x[row, :] * s[row]; backward dx (+)= dy s, ds[row] (+)= sum_c dy x: one wavefront per row ---------------------------
+__global__ void __launch_bounds__(256) k_train_rowscale(const float* __restrict__ x, long ldx, const float* __restrict__ s, long s_stride, long N, int C,
+                                                        float* __restrict__ y, long ldy) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / C;
+  const int c = (int)(idx - row * C);
+  if (row >= N) return;
+  y[row * ldy + c] = x[row * ldx + c] * s[row * s_stride];
+}
+__global__ void __launch_bounds__(256) k_train_rowscale_bwd(const float* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ s, long s_stride, long N, int C, float* __restrict__ dx,
+                                                            long ld_dx, int accumulate, float* __restrict__ ds, long ds_stride, int ds_accumulate) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const float sv = s[row * s_stride];
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = dy[row * ld_dy + c];
+    acc += d * x[row * ldx + c];
+    float* o = dx + row * ld_dx + c;
+    if (accumulate) *o += d * sv; else *o = d * sv;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (ds_accumulate) ds[row * ds_stride] += acc; else ds[row * ds_stride] = acc;
+  }
+}
+extern "C" int dyn_train_rowscale(const float* x, long ldx, const float* s, long s_stride, long N, int C, float* y, long ldy, void* stream) {
+  DYN_REQUIRE(x && s && y && N > 0 && C > 0, "dyn_train_rowscale: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale", k_train_rowscale, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, s,
+             s_stride, N, C, y, ldy);
+  return 0;
+}
+extern "C" int dyn_train_rowscale_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, int C, float* dx,
+                                      long ld_dx, int accumulate, float* ds, long ds_stride, int ds_accumulate, void* stream) {
+  DYN_REQUIRE(dy && x && s && dx && ds && N > 0 && C > 0, "dyn_train_rowscale_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale_bwd", k_train_rowscale_bwd, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy,
+             x, ldx, s, s_stride, N, C, dx, ld_dx, accumulate, ds, ds_stride, ds_accumulate);
+  return 0;
+}
+
+// ---- vis_fc output split (mlp_network.py:466-469): x2 = x1 + xv[:, :128]; vis0 = sigmoid(xv[:, 128]) mask -----------------------------
+// backward: dxv[:, :128] = dx2; dxv[:, 128] = dvis0 mask sig (1 - sig)   (dx1 += dx2 is the caller's accumulate of the same array)
+__global__ void __launch_bounds__(256) k_train_vis_split(const float* __restrict__ x1, long ld1, const float* __restrict__ xv, long ldv,
+                                                         const float* __restrict__ mask, const float* __restrict__ ray_diff, long N,
+                                                         float* __restrict__ x2, long ld2, float* __restrict__ vis0) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> 7;
+  const int c = (int)(idx & 127);
+  if (row >= N) return;
+  x2[row * ld2 + c] = x1[row * ld1 + c] + xv[row * ldv + c];
+  if (c == 0) vis0[row] = tr_sigmoid(xv[row * ldv + 128]) * mask[row];
+  if (ray_diff != nullptr && c >= 4 && c < 11) x2[row * ld2 + 125 + c] = c < 8 ? ray_diff[row * 4 + c - 4] : 0.f;  // columns 129..132 | 133..135
+}
+__global__ void __launch_bounds__(256) k_train_vis_split_bwd(const float* __restrict__ dx2, long ld_dx2, const float* __restrict__ dvis0,
+                                                             const float* __restrict__ xv, long ldv, const float* __restrict__ mask, long N,
+                                                             float* __restrict__ dxv, long ld_dxv) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> 7;
+  const int c = (int)(idx & 127);
+  if (row >= N) return;
+  dxv[row * ld_dxv + c] = dx2[row * ld_dx2 + c];
+  if (c == 0) {
+    const float sg = tr_sigmoid(xv[row * ldv + 128]);
+    dxv[row * ld_dxv + 128] = dvis0[row] * mask[row] * sg * (1.0f - sg);
+  }
+}
+extern "C" int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, const float* mask, const float* ray_diff, long N, float* x2,
+                                   long ld2, float* vis0, void* stream) {
+  DYN_REQUIRE(x1 && xv && mask && x2 && vis0 && N > 0, "dyn_train_vis_split: bad arguments");
+  DYN_REQUIRE(ray_diff == nullptr || ld2 >= 136, "dyn_train_vis_split: the [x2 | vis | ray_diff | 0 0 0] layout needs ld2 >= 136");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split", k_train_vis_split, dim3((unsigned)((N * 128 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1,
+             ld1, xv, ldv, mask, ray_diff, N, x2, ld2, vis0);
+  return 0;
+}
+extern "C" int dyn_train_vis_split_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
+                                       float* dxv, long ld_dxv, void* stream) {
+  DYN_REQUIRE(dx2 && dvis0 && xv && mask && dxv && N > 0, "dyn_train_vis_split_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split_bwd", k_train_vis_split_bwd, dim3((unsigned)((N * 128 + 255) / 256)), dim3(256), 0,
+             (hipStream_t)stream, dx2, ld_dx2, dvis0, xv, ldv, mask, N, dxv, ld_dxv);
+  return 0;
+}
+
+// ---- ray attention core (mlp_network.py:13-31, :83-97): per (ray, head) softmax(q k^T / sqrt(d_k), query rows masked) v ----------------
+// qkv [P, 3 * 128] (q | k | v, head h in columns 32 h .. 32 h + 31 of each), one workgroup of S threads per (ray, head): thread = query
+// row, K and V of the head in LDS.  The probabilities are saved for the backward pass.  A query row whose point is seen by fewer than two views
+// (mask = num_valid_obs > 1, mlp_network.py:486-488) has every score replaced by
+// -1e9 (uniform probabilities, no gradient into its scores).
+__global__ void k_train_attn(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, float* __restrict__ out,
+                             float* __restrict__ prob) {
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]
+  float* vs = ks + S * 33;
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x;
+  const long p = (long)ray * S + i;
+  float q[32];
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
+    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
+    q[d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;
+  }
+  __syncthreads();
+  float* pr = prob + ((long)blockIdx.x * S + i) * S;
+  const bool live = nvalid[p] > 1.0f;
+  float mx = -INFINITY;
+  for (int j = 0; j < S; ++j) {
+    float s = 0.f;
+    for (int d = 0; d < 32; ++d) s += q[d] * ks[j * 33 + d];
+    if (!live) s = -1e9f;
+    pr[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float e = expf(pr[j] - mx);
+    pr[j] = e;
+    den += e;
+  }
+  float o[32];
+  for (int d = 0; d < 32; ++d) o[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float a = pr[j] / den;
+    pr[j] = a;
+    for (int d = 0; d < 32; ++d) o[d] += a * vs[j * 33 + d];
+  }
+  for (int d = 0; d < 32; ++d) out[p * 128 + head * 32 + d] = o[d];
+}
+// backward: thread i first as query row (dP_ij = dO_i . V_j, dS = P (dP - sum_j P dP), dQ_i = sum_j dS_ij K_j / sqrt(d)), dS kept in the
+// prob buffer; then as key row (dK_i = sum_q dS_qi Q_q / sqrt(d), dV_i = sum_q P_qi dO_q) -- P is needed again, so dS goes to LDS-free
+// scratch: the second half of the prob buffer row is not available, hence dS overwrites a separate array.
+__global__ void k_train_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, const float* __restrict__ prob,
+                                 const float* __restrict__ dout, float* __restrict__ dscore, float* __restrict__ dqkv) {
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]: K, later Q
+  float* vs = ks + S * 33;                         // [S][33]: V, later dO
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x;
+  const long p = (long)ray * S + i;
+  float dO[32];
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
+    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
+    dO[d] = dout[p * 128 + head * 32 + d];
+  }
+  __syncthreads();
+  const float* pr = prob + ((long)blockIdx.x * S + i) * S;
+  float* dsr = dscore + ((long)blockIdx.x * S + i) * S;
+  const bool live = nvalid[p] > 1.0f;
+  float dot = 0.f;
+  for (int j = 0; j < S; ++j) {
+    float dp = 0.f;
+    for (int d = 0; d < 32; ++d) dp += dO[d] * vs[j * 33 + d];
+    dsr[j] = dp;
+    dot += dp * pr[j];
+  }
+  float dq[32];
+  for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float ds = live ? pr[j] * (dsr[j] - dot) : 0.f;
+    dsr[j] = ds;
+    for (int d = 0; d < 32; ++d) dq[d] += ds * ks[j * 33 + d];
+  }
+  for (int d = 0; d < 32; ++d) dqkv[p * 384 + head * 32 + d] = dq[d] / 5.656854249492381f;
+  __syncthreads();  // every thread is done with K and V
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;  // Q / sqrt(d)
+    vs[i * 33 + d] = dO[d];
+  }
+  __threadfence_block();
+  __syncthreads();
+  float dk[32], dv[32];
+  for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  const float* pcol = prob + (long)blockIdx.x * S * S + i;
+  const float* dcol = dscore + (long)blockIdx.x * S * S + i;
+  for (int qi = 0; qi < S; ++qi) {
+    const float a = pcol[(long)qi * S], ds = dcol[(long)qi * S];
+    for (int d = 0; d < 32; ++d) {
+      dk[d] += ds * ks[qi * 33 + d];
+      dv[d] += a * vs[qi * 33 + d];
+    }
+  }
+  for (int d = 0; d < 32; ++d) {
+    dqkv[p * 384 + 128 + head * 32 + d] = dk[d];
+    dqkv[p * 384 + 256 + head * 32 + d] = dv[d];
+  }
+}
+extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int S, float* out, float* prob, void* stream) {
+  DYN_REQUIRE(qkv && nvalid && out && prob && R > 0 && S > 0 && S <= 256, "dyn_train_attn: bad arguments (S <= 256)");
+  DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn, dim3((unsigned)R * 4), dim3(S), (size_t)S * 33 * 8, (hipStream_t)stream, qkv, nvalid, S,
+             out, prob);
+  return 0;
+}
+extern "C" int dyn_train_attn_bwd(const float* qkv, const float* nvalid, int R, int S, const float* prob, const float* dout, float* dscore,
+                                  float* dqkv, void* stream) {
+  DYN_REQUIRE(qkv && nvalid && prob && dout && dscore && dqkv && R > 0 && S > 0 && S <= 256, "dyn_train_attn_bwd: bad arguments (S <= 256)");
+  DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd, dim3((unsigned)R * 4), dim3(S), (size_t)S * 33 * 8, (hipStream_t)stream, qkv,
+             nvalid, S, prob, dout, dscore, dqkv);
+  return 0;
+}
+
+// ---- residual + LayerNorm(eps 1e-6) over 128 columns (mlp_network.py:99-102): one wavefront per row ------------------------------------
+// forward saves xhat and rstd; backward: dy_in = rstd (g - mean(g) - xhat mean(g xhat)), g = dout gamma; dgamma, dbeta by atomics.
+__global__ void __launch_bounds__(256) k_train_layernorm(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, long P, float* __restrict__ out, float* __restrict__ xhat,
+                                                         float* __restrict__ rstd) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= P) return;
+  const float y0 = a[row * 128 + lane] + b[row * 128 + lane], y1 = a[row * 128 + 64 + lane] + b[row * 128 + 64 + lane];
+  const float mean = wave_sum(y0 + y1) * (1.0f / 128.0f);
+  const float d0 = y0 - mean, d1 = y1 - mean;
+  const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f);
+  const float rs = 1.0f / sqrtf(var + 1e-6f);
+  xhat[row * 128 + lane] = d0 * rs;
+  xhat[row * 128 + 64 + lane] = d1 * rs;
+  out[row * 128 + lane] = d0 * rs * gamma[lane] + beta[lane];
+  out[row * 128 + 64 + lane] = d1 * rs * gamma[64 + lane] + beta[64 + lane];
+  if (lane == 0) rstd[row] = rs;
+}
+__global__ void __launch_bounds__(256) k_train_layernorm_bwd(const float* __restrict__ dout, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, long P, int rows_per_wave, float* __restrict__ din,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
+  for (long row = w * rows_per_wave; row < (w + 1) * rows_per_wave && row < P; ++row) {
+    const float o0 = dout[row * 128 + lane], o1 = dout[row * 128 + 64 + lane];
+    const float x0 = xhat[row * 128 + lane], x1 = xhat[row * 128 + 64 + lane];
+    const float g0 = o0 * gamma[lane], g1 = o1 * gamma[64 + lane];
+    const float mg = wave_sum(g0 + g1) * (1.0f / 128.0f);
+    const float mgx = wave_sum(g0 * x0 + g1 * x1) * (1.0f / 128.0f);
+    const float rs = rstd[row];
+    din[row * 128 + lane] = rs * (g0 - mg - x0 * mgx);
+    din[row * 128 + 64 + lane] = rs * (g1 - mg - x1 * mgx);
+    dg0 += o0 * x0; dg1 += o1 * x1; db0 += o0; db1 += o1;
+  }
+  if (w * rows_per_wave < P) {
+    atomicAdd(dgamma + lane, dg0); atomicAdd(dgamma + 64 + lane, dg1);
+    atomicAdd(dbeta + lane, db0); atomicAdd(dbeta + 64 + lane, db1);
+  }
+}
+extern "C" int dyn_train_layernorm(const float* a, const float* b, const float* gamma, const float* beta, long P, float* out, float* xhat, float* rstd,
+                                   void* stream) {
+  DYN_REQUIRE(a && b && gamma && beta && out && xhat && rstd && P > 0, "dyn_train_layernorm: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_layernorm", k_train_layernorm, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta,
+             P, out, xhat, rstd);
+  return 0;
+}
+extern "C" int dyn_train_layernorm_bwd(const float* dout, const float* xhat, const float* rstd, const float* gamma, long P, float* din, float* dgamma,
+                                       float* dbeta, void* stream) {
+  DYN_REQUIRE(dout && xhat && rstd && gamma && din && dgamma && dbeta && P > 0, "dyn_train_layernorm_bwd: bad arguments");
+  const int rpw = 16;
+  const long waves = (P + rpw - 1) / rpw;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_layernorm_bwd", k_train_layernorm_bwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+             xhat, rstd, gamma, P, rpw, din, dgamma, dbeta);
+  return 0;
+}
+
+// ---- colour blending over views + density fill (mlp_network.py:503-527): one thread per point ------------------------------------------
+// logit masked to -1e9 where mask == 0, softmax over views, rgb = sum_v rgb_in blend; raw = [rgb, nvalid < 1 ? -1e9 : sigma].
+__global__ void __launch_bounds__(256) k_train_blend(const float* __restrict__ logit, long logit_stride, const float* __restrict__ mask,
+                                                     const float* __restrict__ rgb_feat, const float* __restrict__ sigma, long sigma_stride,
+                                                     const float* __restrict__ nvalid, long P, int V, float* __restrict__ blend,
+                                                     float* __restrict__ raw) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long r0 = p * V;
+  float mx = -INFINITY;
+  for (int v = 0; v < V; ++v) {
+    const float l = mask[r0 + v] == 0.f ? -1e9f : logit[(r0 + v) * logit_stride];
+    mx = fmaxf(mx, l);
+  }
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float l = mask[r0 + v] == 0.f ? -1e9f : logit[(r0 + v) * logit_stride];
+    den += expf(l - mx);
+  }
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float l = mask[r0 + v] == 0.f ? -1e9f : logit[(r0 + v) * logit_stride];
+    const float bw = expf(l - mx) / den;
+    blend[r0 + v] = bw;
+    const float* f = rgb_feat + (r0 + v) * 35;
+    c0 += f[0] * bw; c1 += f[1] * bw; c2 += f[2] * bw;
+  }
+  raw[p * 4] = c0; raw[p * 4 + 1] = c1; raw[p * 4 + 2] = c2;
+  raw[p * 4 + 3] = nvalid[p] < 1.0f ? -1e9f : sigma[p * sigma_stride];
+}
+__global__ void __launch_bounds__(256) k_train_blend_bwd(const float* __restrict__ draw, const float* __restrict__ blend, const float* __restrict__ mask,
+                                                         const float* __restrict__ rgb_feat, const float* __restrict__ nvalid, long P, int V,
+                                                         float* __restrict__ dlogit, long dlogit_stride, float* __restrict__ dsigma,
+                                                         long dsigma_stride) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const long r0 = p * V;
+  const float d0 = draw[p * 4], d1 = draw[p * 4 + 1], d2 = draw[p * 4 + 2];
+  float dot = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float* f = rgb_feat + (r0 + v) * 35;
+    dot += (d0 * f[0] + d1 * f[1] + d2 * f[2]) * blend[r0 + v];
+  }
+  for (int v = 0; v < V; ++v) {
+    const float* f = rgb_feat + (r0 + v) * 35;
+    const float db = d0 * f[0] + d1 * f[1] + d2 * f[2];
+    dlogit[(r0 + v) * dlogit_stride] = mask[r0 + v] == 0.f ? 0.f : blend[r0 + v] * (db - dot);
+  }
+  dsigma[p * dsigma_stride] = nvalid[p] < 1.0f ? 0.f : draw[p * 4 + 3];
+}
+extern "C" int dyn_train_blend(const float* logit, long logit_stride, const float* mask, const float* rgb_feat, const float* sigma, long sigma_stride,
+                               const float* nvalid, long P, int V, float* blend, float* raw, void* stream) {
+  DYN_REQUIRE(logit && mask && rgb_feat && sigma && nvalid && blend && raw && P > 0 && V > 0, "dyn_train_blend: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_blend", k_train_blend, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logit, logit_stride,
+             mask, rgb_feat, sigma, sigma_stride, nvalid, P, V, blend, raw);
+  return 0;
+}
+extern "C" int dyn_train_blend_bwd(const float* draw, const float* blend, const float* mask, const float* rgb_feat, const float* nvalid, long P, int V,
+                                   float* dlogit, long dlogit_stride, float* dsigma, long dsigma_stride, void* stream) {
+  DYN_REQUIRE(draw && blend && mask && rgb_feat && nvalid && dlogit && dsigma && P > 0 && V > 0, "dyn_train_blend_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_blend_bwd", k_train_blend_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, draw, blend,
+             mask, rgb_feat, nvalid, P, V, dlogit, dlogit_stride, dsigma, dsigma_stride);
+  return 0;
+}
+
+// ---- backward of raw2outputs_vanilla (render_ray.py:134-201): one thread per ray ---------------------------------------------------------
+// weights_i = alpha_i T_i, T_i = prod_{j<i} (1 - alpha_j + 1e-10); rgb = sum w_i c_i; depth = sum w_i z_i.
+// dw_i = drgb . c_i + ddepth z_i + dweights_i;  dalpha_i = dw_i T_i - (sum_{j>i} dw_j w_j) / (1 - alpha_i + 1e-10);
+// alpha = 1 - exp(-softplus(sigma) dist), dist = 1 (last sample 1e10): dsigma = dalpha exp(-sp dist) dist sigmoid(sigma).
+__global__ void __launch_bounds__(64) k_train_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                            const float* __restrict__ alpha, const float* __restrict__ weights,
+                                                            const float* __restrict__ drgb, const float* __restrict__ ddepth,
+                                                            const float* __restrict__ dweights, int R, int S, float* __restrict__ draw) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float g0 = drgb ? drgb[r * 3] : 0.f, g1 = drgb ? drgb[r * 3 + 1] : 0.f, g2 = drgb ? drgb[r * 3 + 2] : 0.f;
+  const float gd = ddepth ? ddepth[r] : 0.f;
+  // pass 1: colour gradients, dw_i stashed in the density slot, total = sum_j dw_j w_j
+  float total = 0.f;
+  for (int i = 0; i < S; ++i) {
+    const long o = (long)r * S + i;
+    const float w = weights[o];
+    const float* c = raw + o * 4;
+    const float dw = g0 * c[0] + g1 * c[1] + g2 * c[2] + gd * z_vals[o] + (dweights ? dweights[o] : 0.f);
+    draw[o * 4] = g0 * w; draw[o * 4 + 1] = g1 * w; draw[o * 4 + 2] = g2 * w;
+    draw[o * 4 + 3] = dw;
+    total += dw * w;
+  }
+  // pass 2: running transmittance, suffix sums as total - prefix
+  float T = 1.0f;
+  float prefix = 0.f;
+  for (int i = 0; i < S; ++i) {
+    const long o = (long)r * S + i;
+    const float a = alpha[o], dw = draw[o * 4 + 3];
+    prefix += dw * weights[o];
+    const float suf = total - prefix;
+    const float one_m = 1.0f - a + 1e-10f;
+    const float dalpha = dw * T - suf / one_m;
+    const float sg = raw[o * 4 + 3];
+    const float sp = sg > 20.0f ? sg : log1pf(expf(sg));
+    const float dist = (i == S - 1) ? 1e10f : 1.0f;
+    const float ex = expf(-sp * dist);
+    const float dsp = dalpha * ex * dist;
+    draw[o * 4 + 3] = sg > 20.0f ? dsp : dsp * tr_sigmoid(sg);
+    T *= one_m;
+  }
+}
+extern "C" int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
+                                       const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream) {
+  DYN_REQUIRE(raw && z_vals && alpha && weights && draw && R > 0 && S > 0, "dyn_train_composite_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite_bwd", k_train_composite_bwd, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw,
+             z_vals, alpha, weights, drgb, ddepth, dweights, R, S, draw);
+  return 0;
+}

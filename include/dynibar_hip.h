@@ -260,6 +260,113 @@ int dyn_profile_count(void);
 const char* dyn_profile_name(int slot);
 int dyn_profile_read(float* total_ms, int* launches);
 
+/* ==== f3 (first slice): training of the static branch -- the reference's static bootstrap stage (train.py:116-199: loss on
+ * ret['outputs_coarse_st']['rgb'], loss.backward() through raw2outputs_vanilla (render_ray.py:134-201), DynibarStatic.forward
+ * (mlp_network.py:423-527) and Projector.compute's F.grid_sample (projection.py:160-167) into the module's parameters and the static
+ * feature maps).  Replaces torch autograd for that graph.  The step is a sequence of the primitives below over row-major fp32
+ * activation matrices kept in HBM (dynibar_amd/train_static.py holds the sequence); N = R S V rows (row = point * V + view),
+ * P = R S points.  `ld*` are leading dimensions in floats, `*_stride` element strides of per-row scalars. =============================== */
+
+/* C[M,N] (ldc) = epilogue(A . B): element (m,k) of A at A[m a_rs + k a_ks], element (k,n) of B at B[n b_rs + k b_ks] (one unit stride
+ * each).  Forward of nn.Linear: A = X (a_ks = 1), B = W[N,K] (b_rs = ldw, b_ks = 1).  Data gradient dX = dZ W: A = dZ, B rows = input
+ * features (b_rs = 1, b_ks = ldw).  Weight gradient dW = dZ^T X: A rows = output features (a_rs = 1, a_ks = ld_dz), B rows = input
+ * features (b_rs = 1, b_ks = ldx), K = number of rows, k_split > 1 with accumulate = 2.
+ * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip), act (0 none, 1 ELU); accumulate 0 store, 1 +=, 2 atomic +=.
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x16_bf16 with exact three-way bf16 splits (6 partial products). */
+typedef struct {
+  const float* A;
+  long a_rs, a_ks;
+  const float* B;
+  long b_rs, b_ks;
+  float* C;
+  long ldc;
+  int M, N, K;
+  const float* bias;
+  const float* addend;
+  long ld_add;
+  int add_div;
+  int act;
+  int accumulate;
+  int k_split;
+} DynTrainGemmParams;
+int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
+
+/* dZ = dY * act'(Y) in place (act 1: ELU from the saved output Y; act 0: unchanged); dbias[c] += column sums (NULL to skip);
+ * dseg[(row / seg), c] = sums over the seg rows of a point (gradient of a per-point addend; NULL to skip). */
+int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg, float* dseg,
+                      long ld_seg, void* stream);
+
+/* mlp_network.py:423-448 + render_ray.py:372-396: a0 [N,104] = [PE(pts) 33 | PE(src Pluecker) 66 | ray_diff 4 | 0], ref_pe [R,68] =
+ * [PE(ref Pluecker) 66 | 0 0], mask_eff [N] = mask (* (sum rgb > 1e-3) when mask_rgb).  centers: source camera centres, centers[v *
+ * center_stride + 0..2] (proj + 12 with stride 16 from dyn_prepare_cameras). */
+int dyn_train_static_embed(const float* pts, const float* ray_o, const float* ray_d, const float* centers, int center_stride,
+                           const float* ray_diff, const float* rgb_feat, const float* mask, int R, int S, int V, int mask_rgb, float* a0,
+                           float* ref_pe, float* mask_eff, void* stream);
+
+/* mlp_network.py:450: f [N,72] = [rgb_feat 35 | src_feat * ref_feat[ray] 35 | 0 0]; backward: dsrc [N,.], dref [R,.] */
+int dyn_train_build_f(const float* rgb_feat, const float* src_feat, long ld_src, const float* ref_feat, long ld_ref, long N, int rows_per_ray,
+                      float* f, void* stream);
+int dyn_train_build_f_bwd(const float* df, long ld_df, const float* src_feat, long ld_src, const float* ref_feat, long ld_ref, long R,
+                          int rows_per_ray, float* dsrc, long ld_dsrc, float* dref, long ld_dref, void* stream);
+
+/* pooling weights over the views of a point.  mode 0 (mlp_network.py:452-459): in = dot products (ray_diff + 3, stride 4), s_param =
+ * the pooling temperature `s` (NULL: anti_alias_pooling = 0); mode 1 (:470-471,:476,:481): in = vis_fc2 logits; also writes vis, the mean
+ * weight per point and the number of valid views.  backward: dw -> ds (mode 0, += one scalar) or dlogit (mode 1; dvis_direct and dwmean
+ * are the other uses of vis and of the mean weight). */
+int dyn_train_view_weights(int mode, const float* in, long in_stride, const float* mask, const float* s_param, long P, int V, float* w,
+                           float* vis_out, long vis_stride, float* wmean, long wmean_stride, float* nvalid, void* stream);
+int dyn_train_view_weights_bwd(int mode, const float* in, long in_stride, const float* mask, const float* s_param, long P, int V,
+                               const float* w, const float* dw, const float* dvis_direct, long dvis_stride, const float* vis, long vis_stride,
+                               const float* dwmean, long dwmean_stride, float* dlogit, long dlogit_stride, float* ds, void* stream);
+
+/* fused_mean_variance (mlp_network.py:115-119) over the V rows of each point, C columns; backward into dx (accumulate 0/1) and dw. */
+int dyn_train_meanvar(const float* x, long ldx, const float* w, long P, int V, int C, float* mean, float* var, long ld_out, void* stream);
+int dyn_train_meanvar_bwd(const float* x, long ldx, const float* w, long P, int V, int C, const float* mean, const float* dmean,
+                          const float* dvar, long ld_stat, float* dx, long ld_dx, int accumulate, float* dw, int dw_accumulate, void* stream);
+
+/* y = x * s[row] (mlp_network.py:465,:469) and its backward */
+int dyn_train_rowscale(const float* x, long ldx, const float* s, long s_stride, long N, int C, float* y, long ldy, void* stream);
+int dyn_train_rowscale_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, int C, float* dx,
+                           long ld_dx, int accumulate, float* ds, long ds_stride, int ds_accumulate, void* stream);
+
+/* mlp_network.py:466-468: x2 = x1 + xv[:, :128], vis0 = sigmoid(xv[:, 128]) mask; with ray_diff [N,4] != NULL the row of x2 is laid out as
+ * rgb_fc.0's per-view input [x2 128 | vis (written later) | ray_diff 4 | 0 0 0] (ld2 >= 136, :495-503); backward fills dxv [N, 129] */
+int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, const float* mask, const float* ray_diff, long N, float* x2,
+                        long ld2, float* vis0, void* stream);
+int dyn_train_vis_split_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N, float* dxv,
+                            long ld_dxv, void* stream);
+
+/* ScaledDotProductAttention (mlp_network.py:13-31) for 4 heads of 32: qkv [P,384] = q | k | v, nvalid [P] = views that see the point
+ * (query rows with nvalid <= 1 are masked, :24 and :486-488), out [P,128], prob [R,4,S,S] saved for the backward;
+ * backward: dscore [R,4,S,S] scratch, dqkv [P,384]. */
+int dyn_train_attn(const float* qkv, const float* nvalid, int R, int S, float* out, float* prob, void* stream);
+int dyn_train_attn_bwd(const float* qkv, const float* nvalid, int R, int S, const float* prob, const float* dout, float* dscore, float* dqkv,
+                       void* stream);
+
+/* out = LayerNorm_128(a + b; eps 1e-6) gamma + beta (mlp_network.py:99-102); saves xhat [P,128], rstd [P]; backward: din (the gradient
+ * of both a and b), dgamma / dbeta += */
+int dyn_train_layernorm(const float* a, const float* b, const float* gamma, const float* beta, long P, float* out, float* xhat, float* rstd,
+                        void* stream);
+int dyn_train_layernorm_bwd(const float* dout, const float* xhat, const float* rstd, const float* gamma, long P, float* din, float* dgamma,
+                            float* dbeta, void* stream);
+
+/* mlp_network.py:503-527: masked softmax of the rgb_fc logits over views, rgb = sum_v rgb_in blend, sigma filled with -1e9 where no
+ * view sees the point -> raw [P,4]; blend [N] saved.  backward: draw [P,4] -> dlogit [N], dsigma [P]. */
+int dyn_train_blend(const float* logit, long logit_stride, const float* mask, const float* rgb_feat, const float* sigma, long sigma_stride,
+                    const float* nvalid, long P, int V, float* blend, float* raw, void* stream);
+int dyn_train_blend_bwd(const float* draw, const float* blend, const float* mask, const float* rgb_feat, const float* nvalid, long P, int V,
+                        float* dlogit, long dlogit_stride, float* dsigma, long dsigma_stride, void* stream);
+
+/* backward of raw2outputs_vanilla (render_ray.py:134-201): alpha, weights as saved by dyn_composite; drgb [R,3], ddepth [R],
+ * dweights [R,S] (each may be NULL) -> draw [R,S,4] */
+int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
+                            const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream);
+
+/* backward of the bilinear feature gather (projection.py:160-167, F.grid_sample w.r.t. the maps): drgb_feat[row, col0 .. col0 + F)
+ * scattered with the forward's taps into dfeat_cl [V,Hf,Wf,F] (channels-last, zeroed by the caller; atomic +=).  pts_st [R,S,3]. */
+int dyn_gather_bwd(const float* pts_st, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
+                   const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -900,3 +900,116 @@ def check_render_rays_mono_train(device, golden, tag, shift, mode, name='small',
     n += check_group_vs_golden(f'{tag}/{grp}/', ret[grp], golden, name)
   return n
 
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training of the static branch (first slice): values and gradients vs autograd through the oracle
+# ----------------------------------------------------------------------------------------------------------------------
+def train_static_reference(name, S, R, aa, mask_rgb, weights, seed=0, dtype=torch.float32):
+  """Oracle side: the static bootstrap graph (train.py:116-199) on torch-CPU autograd.  -> inputs, outputs, cotangents, gradients.
+  dtype=float64 evaluates the same graph in double (how far the reference's own fp32 round-off moves a gradient)."""
+  scene, o, d, uv, _ = cases.scene_case(name)
+  if R is not None:
+    o, d = o[:R], d[:R]
+  sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in O.tdict(_weights(weights)['net_coarse_st']).items() if (aa or k != 's')}
+  sc = {k: (v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in scene.items()}
+  fm = scene['static_featmaps'].clone().to(dtype).requires_grad_(True)
+  sc['static_featmaps'] = fm
+  o, d = o.to(dtype), d.to(dtype)
+  prev = torch.get_default_dtype()
+  torch.set_default_dtype(dtype)  # the oracle's linspace / ones / tensor constructors follow the default dtype
+  try:
+    out, st = O.static_branch_pass(sd, sc, o, d, S, True, True, aa, mask_rgb, return_stages=True)
+  finally:
+    torch.set_default_dtype(prev)
+  # rays with a sample on a frustum boundary may flip a mask bit between implementations (see check_static_pass): no cotangent for them
+  Vs = scene['static_src_rgbs'].shape[1]
+  keep = ~boundary_margin(st['pts'].detach()[None].repeat(Vs, 1, 1, 1).float(), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
+  g = torch.Generator().manual_seed(100 + seed)
+  n = o.shape[0]
+  cot = dict(rgb=torch.randn(n, 3, generator=g) * keep[:, None], depth=0.1 * torch.randn(n, generator=g) * keep,
+             weights=0.3 * torch.randn(n, S, generator=g) * keep[:, None])
+  loss = sum((out[k] * cot[k].to(dtype)).sum() for k in cot)
+  loss.backward()
+  grads = {k: v.grad.detach() for k, v in sd.items()}
+  grads['featmaps'] = fm.grad.detach()
+  return scene, o, d, sd, out, st, cot, grads, keep
+
+
+def run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot):
+  """HIP side: gather -> StaticNetFunction -> CompositeVanillaFunction, loss.backward() through the dyn_train_* kernels."""
+  from dynibar_amd import train_static as TS
+  sc = to_dev(scene, device)
+  fm = scene['static_featmaps'].to(device).requires_grad_(True)
+  views = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm.detach())
+  od, dd = o.to(device), d.to(device)
+  R = o.shape[0]
+  pts, z, _ = ops.sample_along_ray(od, dd, sc['depth_range'], S, True)
+  rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+  prm = {k: v.detach().to(device).requires_grad_(True) for k, v in sd.items()}
+  raw = TS.static_raw(prm, (aa, mask_rgb), views, fm, od, dd, pts, rgb_feat, ray_diff, mask)
+  out = TS.composite_vanilla(raw, z, pm)
+  loss = sum((out[k] * cot[k].to(device)).sum() for k in cot)
+  loss.backward()
+  grads = {k: v.grad for k, v in prm.items()}
+  grads['featmaps'] = fm.grad
+  return out, raw, grads
+
+
+def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=False, weights='init', seed=0):
+  scene, o, d, sd, out_ref, st, cot, g_ref, keep = train_static_reference(name, S, R, aa, mask_rgb, weights, seed)
+  g_ref64 = train_static_reference(name, S, R, aa, mask_rgb, weights, seed, dtype=torch.float64)[7]
+  assert int(keep.sum()) > 0
+  out, raw, g = run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot)
+  tag = f'train {name} aa={int(aa)} mask_rgb={int(mask_rgb)}'
+  assert_close(cpu(raw)[keep][..., :3], st['raw'].detach()[keep][..., :3], 1e-4, 0.0, f'{tag} raw rgb')
+  assert_close(cpu(raw)[keep][..., 3], st['raw'].detach()[keep][..., 3], 1e-4, 1e-4, f'{tag} raw sigma')
+  assert_close(cpu(out['rgb'])[keep], out_ref['rgb'].detach()[keep], 1e-4, 0.0, f'{tag} rgb')
+  assert_close(cpu(out['weights'])[keep], out_ref['weights'].detach()[keep], 1e-4, 0.0, f'{tag} weights')
+  # gradients: fp32-class products, fp32 sums in another order (atomics, split reductions): 2e-4 of the tensor's largest gradient
+  # plus 1e-3 relative, plus -- per element -- 3x the distance between the reference's own fp32 and fp64 gradients (conditioning of
+  # the reference's arithmetic: the pooling temperature `s` acts through (e - min_v e), a difference of nearly equal numbers, and
+  # its fp32 autograd gradient is itself a few percent off the fp64 one).  A gradient that is a sum of cancelling terms (rgb_fc.4.bias: the blending softmax is shift invariant, so its
+  # gradient is analytically zero and both sides hold round-off only) gets an absolute floor of 2e-6 of the largest parameter gradient.
+  worst = 0.0
+  gmax = max(float(v.abs().max()) for k, v in g_ref.items() if k != 'featmaps')
+  for k, ref in g_ref.items():
+    assert g[k] is not None, f'{tag}: no gradient for {k}'
+    got = cpu(g[k]).reshape(ref.shape)
+    scale = float(ref.abs().max())
+    assert_close(got, ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=3.0 * (ref.double() - g_ref64[k]).abs())
+    worst = max(worst, float((got - ref).abs().max()) / (scale + 1e-30))
+  return worst
+
+
+def check_train_gemm(device):
+  """dyn_train_gemm in its three roles (forward with bias / per-point addend / ELU, data gradient, split weight gradient) vs fp64 matmul,
+  on shapes that are not multiples of the tile, at gradient-like magnitudes as well (the bf16 split keeps fp32's exponent range)."""
+  import ctypes
+  from dynibar_amd import train_static as TS
+  g = torch.Generator().manual_seed(5)
+  M, N, K, V = 150, 37, 103, 3
+  for scale in (1.0, 1e-7):
+    X = (torch.randn(M, 104, generator=g) * scale).to(device)
+    W = torch.randn(N, K, generator=g).to(device) * 0.3
+    b = torch.randn(N, generator=g).to(device) * scale
+    Pp = (torch.randn(M // V, 40, generator=g) * scale).to(device)
+    Y = torch.full((M, 40), float('nan'), device=device)
+    lin = TS._Lin(W, b)
+    lin.fwd(TS.stream_of(X), X, 0, 104, Y, 0, 40, M, TS.ELU, addend=Pp, ld_add=40, add_div=V)
+    ref = torch.nn.functional.elu(X[:, :K].double().cpu() @ W.double().cpu().T + b.double().cpu() + Pp.double().cpu()[:, :N].repeat_interleave(V, 0))
+    assert_close(Y[:, :N], ref, 1e-5 * scale, 4e-6, f'train gemm forward (scale {scale:g})')
+    dZ = (torch.randn(M, 40, generator=g) * scale).to(device)
+    dW = torch.zeros_like(W)
+    dX = torch.full((M, 104), float('nan'), device=device)
+    lin.bwd(TS.stream_of(X), dZ, 0, 40, X, 0, 104, dW, M, dX, 0, 104)
+    assert_close(dX[:, :K], dZ[:, :N].double().cpu() @ W.double().cpu(), 1e-5 * scale, 4e-6, f'train gemm data gradient (scale {scale:g})')
+    assert_close(dW, dZ[:, :N].double().cpu().T @ X[:, :K].double().cpu(), 3e-5 * scale * scale, 4e-6, f'train gemm weight gradient (scale {scale:g})')
+  # split reduction over many rows
+  M = 5000
+  X = torch.randn(M, 64, generator=g).to(device)
+  dZ = torch.randn(M, 1, generator=g).to(device)
+  W = torch.randn(1, 64, generator=g).to(device)
+  dW = torch.zeros_like(W)
+  TS._Lin(W).bwd(TS.stream_of(X), dZ, 0, 1, X, 0, 64, dW, M)
+  assert_close(dW, dZ.double().cpu().T @ X.double().cpu(), 2e-4, 2e-6, 'train gemm split weight gradient')

@@ -174,3 +174,16 @@ def test_fp32_class_engine_build(dev):
           "parity.check_mlp_selftest('cuda:0', 500); e = parity.check_static_net('cuda:0', 'small', S=64); print('ok', e)") % (root, os.path.join(root, 'tests'))
   r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DYNIBAR_HIP_LIB=lib), capture_output=True, text=True, timeout=600)
   assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
+
+
+# ---- SURVEY section 8(f)3, first slice: the static bootstrap training step (train.py:116-199) -------------------------------------------
+def test_train_gemm(dev):
+  parity.check_train_gemm(dev)
+
+
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=64, aa=False, mask_rgb=True),
+                                dict(name='small', S=48, R=5, weights='trained'), dict(name='many', S=16, R=3)])
+def test_train_static_step(dev, kw):
+  """values of raw / rgb / weights and EVERY gradient (39 or 38 parameters + the static feature maps) of the static bootstrap graph against
+  torch autograd through the CPU oracle"""
+  parity.check_train_static(dev, **kw)
