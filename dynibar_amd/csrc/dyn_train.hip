@@ -68,17 +68,23 @@ __device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k
         }
       }
     } else {
-      const int k = k0 + (tid >> 5) + 8 * i, r = row0 + (tid & 31) * 4;
-      if (k < kend && r < o.nrows) {
-        const float* g = o.p + (long)k * o.ks + r;
-        if (o.aligned && (o.ks & 3) == 0 && r + 3 < o.nrows) {
-          v = *reinterpret_cast<const float4*>(g);
-        } else {
-          v.x = g[0];
-          if (r + 1 < o.nrows) v.y = g[1];
-          if (r + 2 < o.nrows) v.z = g[2];
-          if (r + 3 < o.nrows) v.w = g[3];
+      // k-major source (rows contiguous): the thread takes rows 2 rp, 2 rp + 1 of the eight k of its k-group; st[i] = (k = 2 i: r0, r1 | k = 2 i + 1: r0, r1)
+      const int r = row0 + (tid & 63) * 2, kb = k0 + (tid >> 6) * 8 + 2 * i;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = kb + e;
+        float x0 = 0.f, x1 = 0.f;
+        if (k < kend && r < o.nrows) {
+          const float* g = o.p + (long)k * o.ks + r;
+          if (o.aligned && (o.ks & 1) == 0 && r + 1 < o.nrows) {
+            const float2 t = *reinterpret_cast<const float2*>(g);
+            x0 = t.x; x1 = t.y;
+          } else {
+            x0 = g[0];
+            if (r + 1 < o.nrows) x1 = g[1];
+          }
         }
+        if (e == 0) { v.x = x0; v.y = x1; } else { v.z = x0; v.w = x1; }
       }
     }
     st[i] = v;
@@ -90,25 +96,38 @@ template <bool KMINOR>
 __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4], int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
-    tr_u16 h[4], m[4], l[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) tr_split3(v[q], h[q], m[q], l[q]);
     if (KMINOR) {
+      const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+      tr_u16 h[4], m[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tr_split3(v[q], h[q], m[q], l[q]);
       const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
       tr_u16* d = img + r * TG_ROW + k;
       *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
       *reinterpret_cast<tr_u32x2*>(d + TG_PART) = tr_u32x2{m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16)};
       *reinterpret_cast<tr_u32x2*>(d + 2 * TG_PART) = tr_u32x2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
-    } else {
-      const int k = (tid >> 5) + 8 * i, r = (tid & 31) * 4;
+    }
+  }
+  if (!KMINOR) {
+    // two rows x eight consecutive k per thread: one 16-byte write per (part, row)
+    const int r = (tid & 63) * 2, k = (tid >> 6) * 8;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        tr_u16* d = img + (r + q) * TG_ROW + k;
-        d[0] = h[q];
-        d[TG_PART] = m[q];
-        d[2 * TG_PART] = l[q];
+    for (int q = 0; q < 2; ++q) {
+      tr_u32x4 ph, pm, pl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = q == 0 ? st[i].x : st[i].y, b = q == 0 ? st[i].z : st[i].w;
+        tr_u16 h0, m0, l0, h1, m1, l1;
+        tr_split3(a, h0, m0, l0);
+        tr_split3(b, h1, m1, l1);
+        ph[i] = h0 | ((unsigned)h1 << 16);
+        pm[i] = m0 | ((unsigned)m1 << 16);
+        pl[i] = l0 | ((unsigned)l1 << 16);
       }
+      tr_u16* d = img + (r + q) * TG_ROW + k;
+      *reinterpret_cast<tr_u32x4*>(d) = ph;
+      *reinterpret_cast<tr_u32x4*>(d + TG_PART) = pm;
+      *reinterpret_cast<tr_u32x4*>(d + 2 * TG_PART) = pl;
     }
   }
 }
@@ -273,7 +292,7 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
   DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
   const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
   int run = dseg != nullptr ? seg : 1;
-  while (run < 64) run += (dseg != nullptr ? seg : 1);
+  while (run < 256) run += (dseg != nullptr ? seg : 1);  // rows per thread: 256 keeps the bias atomics at one per 256 rows and column
   const long chunks = (rows + run - 1) / run;
   const int per_block = 256 / ct;
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), 0,

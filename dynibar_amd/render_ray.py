@@ -6,8 +6,11 @@ executed by the HIP kernels of libdynibar_hip.so.
 may be ``nn.Module``s (optionally ``DataParallel``-wrapped) or plain state dicts.  Their weights are packed into MFMA operand
 tiles once and re-packed only when a parameter's version counter changes.
 
-Scope: forward rendering.  The kernels have no backward pass yet, so the tensors returned here carry no
-autograd graph (``render_rays_mono(is_train=True)`` returns the cross-time supervision outputs as forward values).
+Scope: forward rendering, plus the first slice of the backward pass: under grad mode, when the static net's
+parameters or the static feature maps require grad, ``render_rays_mono`` builds ``outputs_coarse_st`` (rgb / depth / weights) through
+``dynibar_amd.train_static`` so that the reference's static bootstrap stage (train.py:116-199: ``loss.backward()`` on
+``ret['outputs_coarse_st']['rgb']``) runs on the HIP training kernels.  Every other returned tensor is a forward value without graph
+(``render_rays_mono(is_train=True)`` returns the cross-time supervision outputs as forward values).
 """
 from __future__ import annotations
 
@@ -16,7 +19,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, train_static
 
 USE_DISTANCE = False   # reference render_ray.py:14-16 (module constants; the kernels implement exactly this setting)
 USE_SOFTPLUS = True
@@ -223,7 +226,13 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
   rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
   rgb_feat_st, ray_diff_st, mask_st, pm_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals, pix_mask_thresh=1.0)
   raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
-  raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
+  net_st = getattr(model, names['st'])
+  if train_static.wants_grad(net_st, featmaps_st):
+    # training: the same network on the kernels that keep their activations, with an autograd graph to the parameters and the maps
+    flags = (_flag(net_st, args, 'anti_alias_pooling', True), _flag(net_st, args, 'mask_rgb', False))
+    raw_st = train_static.static_raw(net_st, flags, views_st, featmaps_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
+  else:
+    raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
   return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis)
 
 
@@ -334,7 +343,10 @@ def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, f
   stage = _dual_branch(model, names, args, projector, ray_batch, featmaps[0], featmaps[2], pts, z_vals, ref_frame_idx, ref_time_embedding,
                        ref_time_offset, num_vv=num_vv)
   out = _finish(stage, z_vals, _KEYS2, _KEYS1)
-  out_st = _vanilla(stage['raw_st'], z_vals, stage['pm_st'])
+  if stage['raw_st'].requires_grad:
+    out_st = train_static.composite_vanilla(stage['raw_st'], z_vals, stage['pm_st'])  # the graph the static bootstrap stage differentiates
+  else:
+    out_st = _vanilla(stage['raw_st'], z_vals, stage['pm_st'])
   out_dy = _vanilla(stage['raw_dy'], z_vals, stage['pm_dy'])
   exp_sf = _motion_outputs(out, stage, ray_batch, ref_frame_idx, 1, flow_views=6)
   out['s_vals'] = s_vals

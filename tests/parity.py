@@ -905,9 +905,24 @@ def check_render_rays_mono_train(device, golden, tag, shift, mode, name='small',
 # ----------------------------------------------------------------------------------------------------------------------
 # training of the static branch (first slice): values and gradients vs autograd through the oracle
 # ----------------------------------------------------------------------------------------------------------------------
-def train_static_reference(name, S, R, aa, mask_rgb, weights, seed=0, dtype=torch.float32):
+def _oracle_static_graph(sd, sc, o, d, S, aa, mask_rgb, exp_jitter=None):
+  """static_branch_pass (the composition behind ret['outputs_coarse_st']) with the oracle's exp-jitter hook exposed"""
+  pts, z, _ = O.sample_along_camera_ray(o, d, sc['depth_range'], S, True, True)
+  Vs = sc['static_src_rgbs'].shape[1]
+  rgb_feat, ray_diff, mask = O.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), sc['camera'], sc['static_src_rgbs'],
+                                                    sc['static_src_cameras'], sc['static_featmaps'])
+  pm = mask[..., 0].sum(dim=2) > 1
+  raw = O.static_net(sd, pts, O.ref_plucker(o, d), O.src_plucker(pts, sc['static_src_cameras']), rgb_feat, F.normalize(d, dim=-1), ray_diff, mask,
+                     aa, mask_rgb, exp_jitter=exp_jitter)
+  out = O.raw2outputs_vanilla(raw, z, pm)
+  out['raw'] = raw
+  return out, pts, mask
+
+
+def train_static_reference(name, S, R, aa, mask_rgb, weights, seed=0, dtype=torch.float32, jitter_seed=None):
   """Oracle side: the static bootstrap graph (train.py:116-199) on torch-CPU autograd.  -> inputs, outputs, cotangents, gradients.
-  dtype=float64 evaluates the same graph in double (how far the reference's own fp32 round-off moves a gradient)."""
+  dtype=float64 evaluates the same graph in double (how far the reference's own fp32 round-off moves a value or a gradient);
+  jitter_seed perturbs exp() of the anti-alias pooling by +-1 ulp (see check_static_net)."""
   scene, o, d, uv, _ = cases.scene_case(name)
   if R is not None:
     o, d = o[:R], d[:R]
@@ -916,15 +931,18 @@ def train_static_reference(name, S, R, aa, mask_rgb, weights, seed=0, dtype=torc
   fm = scene['static_featmaps'].clone().to(dtype).requires_grad_(True)
   sc['static_featmaps'] = fm
   o, d = o.to(dtype), d.to(dtype)
+  Vs = scene['static_src_rgbs'].shape[1]
+  jit = None
+  if jitter_seed is not None:
+    jit = ((torch.randint(0, 3, (o.shape[0], S, Vs, 1), generator=torch.Generator().manual_seed(50 + jitter_seed)).float() - 1.0) * 6e-8).to(dtype)
   prev = torch.get_default_dtype()
   torch.set_default_dtype(dtype)  # the oracle's linspace / ones / tensor constructors follow the default dtype
   try:
-    out, st = O.static_branch_pass(sd, sc, o, d, S, True, True, aa, mask_rgb, return_stages=True)
+    out, pts, _ = _oracle_static_graph(sd, sc, o, d, S, aa, mask_rgb, jit)
   finally:
     torch.set_default_dtype(prev)
   # rays with a sample on a frustum boundary may flip a mask bit between implementations (see check_static_pass): no cotangent for them
-  Vs = scene['static_src_rgbs'].shape[1]
-  keep = ~boundary_margin(st['pts'].detach()[None].repeat(Vs, 1, 1, 1).float(), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
+  keep = ~boundary_margin(pts.detach()[None].repeat(Vs, 1, 1, 1).float(), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
   g = torch.Generator().manual_seed(100 + seed)
   n = o.shape[0]
   cot = dict(rgb=torch.randn(n, 3, generator=g) * keep[:, None], depth=0.1 * torch.randn(n, generator=g) * keep,
@@ -933,7 +951,8 @@ def train_static_reference(name, S, R, aa, mask_rgb, weights, seed=0, dtype=torc
   loss.backward()
   grads = {k: v.grad.detach() for k, v in sd.items()}
   grads['featmaps'] = fm.grad.detach()
-  return scene, o, d, sd, out, st, cot, grads, keep
+  vals = {k: out[k].detach() for k in ('raw', 'rgb', 'depth', 'weights')}
+  return scene, o, d, sd, vals, cot, grads, keep
 
 
 def run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot):
@@ -957,27 +976,39 @@ def run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot):
 
 
 def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=False, weights='init', seed=0):
-  scene, o, d, sd, out_ref, st, cot, g_ref, keep = train_static_reference(name, S, R, aa, mask_rgb, weights, seed)
-  g_ref64 = train_static_reference(name, S, R, aa, mask_rgb, weights, seed, dtype=torch.float64)[7]
+  args = (name, S, R, aa, mask_rgb, weights, seed)
+  scene, o, d, sd, v_ref, cot, g_ref, keep = train_static_reference(*args)
   assert int(keep.sum()) > 0
+  # Conditioning of the reference's own arithmetic, per element: (i) its fp32 values / gradients against the same graph in fp64,
+  # (ii) with anti-alias pooling, +-1 ulp jitter of exp() in the weights (e - min_v e), a difference of nearly equal numbers that a
+  # different libm already triggers (check_static_net).  Allowance = 3 x (i) + 4 x (ii) on top of the plain limits.
+  _, _, _, _, v64, _, g64, _ = train_static_reference(*args, dtype=torch.float64)
+  sens_v = {k: 3.0 * (v_ref[k].double() - v64[k]).abs() for k in v_ref}
+  sens_g = {k: 3.0 * (g_ref[k].double() - g64[k]).abs() for k in g_ref}
+  if aa:
+    for js in range(3):
+      _, _, _, _, vj, _, gj, _ = train_static_reference(*args, jitter_seed=js)
+      for k in v_ref:
+        sens_v[k] = torch.maximum(sens_v[k], 4.0 * (vj[k] - v_ref[k]).abs().double())
+      for k in g_ref:
+        sens_g[k] = torch.maximum(sens_g[k], 4.0 * (gj[k] - g_ref[k]).abs().double())
   out, raw, g = run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot)
   tag = f'train {name} aa={int(aa)} mask_rgb={int(mask_rgb)}'
-  assert_close(cpu(raw)[keep][..., :3], st['raw'].detach()[keep][..., :3], 1e-4, 0.0, f'{tag} raw rgb')
-  assert_close(cpu(raw)[keep][..., 3], st['raw'].detach()[keep][..., 3], 1e-4, 1e-4, f'{tag} raw sigma')
-  assert_close(cpu(out['rgb'])[keep], out_ref['rgb'].detach()[keep], 1e-4, 0.0, f'{tag} rgb')
-  assert_close(cpu(out['weights'])[keep], out_ref['weights'].detach()[keep], 1e-4, 0.0, f'{tag} weights')
+  assert_close(cpu(raw)[keep][..., :3], v_ref['raw'][keep][..., :3], 1e-4, 0.0, f'{tag} raw rgb', extra=sens_v['raw'][keep][..., :3])
+  assert_close(cpu(raw)[keep][..., 3], v_ref['raw'][keep][..., 3], 1e-4, 1e-4, f'{tag} raw sigma', extra=sens_v['raw'][keep][..., 3])
+  assert_close(cpu(out['rgb'])[keep], v_ref['rgb'][keep], 1e-4, 0.0, f'{tag} rgb', extra=sens_v['rgb'][keep])
+  assert_close(cpu(out['weights'])[keep], v_ref['weights'][keep], 1e-4, 0.0, f'{tag} weights', extra=sens_v['weights'][keep])
   # gradients: fp32-class products, fp32 sums in another order (atomics, split reductions): 2e-4 of the tensor's largest gradient
-  # plus 1e-3 relative, plus -- per element -- 3x the distance between the reference's own fp32 and fp64 gradients (conditioning of
-  # the reference's arithmetic: the pooling temperature `s` acts through (e - min_v e), a difference of nearly equal numbers, and
-  # its fp32 autograd gradient is itself a few percent off the fp64 one).  A gradient that is a sum of cancelling terms (rgb_fc.4.bias: the blending softmax is shift invariant, so its
-  # gradient is analytically zero and both sides hold round-off only) gets an absolute floor of 2e-6 of the largest parameter gradient.
+  # plus 1e-3 relative (+ the conditioning allowance).  A gradient that is a sum of cancelling terms (rgb_fc.4.bias: the blending
+  # softmax is shift invariant, so its gradient is analytically zero and both sides hold round-off only) gets an absolute floor of
+  # 2e-6 of the largest parameter gradient.
   worst = 0.0
   gmax = max(float(v.abs().max()) for k, v in g_ref.items() if k != 'featmaps')
   for k, ref in g_ref.items():
     assert g[k] is not None, f'{tag}: no gradient for {k}'
     got = cpu(g[k]).reshape(ref.shape)
     scale = float(ref.abs().max())
-    assert_close(got, ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=3.0 * (ref.double() - g_ref64[k]).abs())
+    assert_close(got, ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens_g[k])
     worst = max(worst, float((got - ref).abs().max()) / (scale + 1e-30))
   return worst
 
@@ -1013,3 +1044,75 @@ def check_train_gemm(device):
   dW = torch.zeros_like(W)
   TS._Lin(W).bwd(TS.stream_of(X), dZ, 0, 1, X, 0, 64, dW, M)
   assert_close(dW, dZ.double().cpu().T @ X.double().cpu(), 2e-4, 2e-6, 'train gemm split weight gradient')
+
+
+def check_static_bootstrap_step(device, kid=True, S=32):
+  """One iteration of the reference's static bootstrap loop (train.py:116-199) exactly as the script drives it: render_rays_mono(...,
+  is_train=False) under grad mode on DataParallel-wrapped nn.Modules, Charbonnier loss (criterion.py:58-62, utils.py:32-39) on
+  ret['outputs_coarse_st']['rgb'] with the script's static mask, loss.backward(): the gradients that land in the modules' .grad and in
+  the static feature maps against torch autograd through the oracle."""
+  import types
+  from dynibar_amd import projection, render_ray
+  name = 'kid' if kid else 'small'
+  scene, o, d, uv, _ = cases.scene_case(name)
+  Vd = scene['src_rgbs'].shape[1]
+  num_vv = 3 if kid else 0
+  fidx, temb, toff = cases.time_args(Vd - num_vv)
+  args = types.SimpleNamespace(anti_alias_pooling=0 if kid else 1, mask_rgb=1 if kid else 0, input_dir=True, input_xyz=False, occ_weights_mode=0)
+  aa, mr = bool(args.anti_alias_pooling), bool(args.mask_rgb)
+  model = make_module_model(device, args, shift=5.0)
+  batch = make_ray_batch(scene, o, d, uv, device)
+  g = torch.Generator().manual_seed(77)
+  n = o.shape[0]
+  gt = torch.rand(n, 3, generator=g)
+  static_mask = (torch.rand(n, generator=g) < 0.3).float()
+  batch['rgb'], batch['static_mask'] = gt.to(device), static_mask.to(device)
+  fm_st = scene['static_featmaps'].to(device).requires_grad_(True)
+  feat = (scene['featmaps'].to(device), None, fm_st)
+  ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, projection.Projector(device), S, args,
+                                    inv_uniform=True, det=True, is_train=False, num_vv=num_vv)
+
+  def charbonnier(x, y, mask, eps=0.001):
+    return torch.sum(torch.sqrt((x - y) ** 2 + eps ** 2) * mask.unsqueeze(-1)) / (torch.sum(mask) * x.shape[-1] + 1e-6)
+
+  pred = ret['outputs_coarse_st']['rgb']
+  assert pred.requires_grad, "outputs_coarse_st['rgb'] must carry the autograd graph in grad mode"
+  w = (1.0 - batch['static_mask']) * ret['outputs_coarse_ref']['mask'].float()
+  loss = charbonnier(pred, batch['rgb'], w)
+  loss.backward()
+  # oracle: the same graph on CPU autograd, same mask (a forward value of the dual composite)
+  sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in render_ray._state_dict(model.net_coarse_st).items()}
+  sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+  sc = dict(scene)
+  fm = scene['static_featmaps'].clone().requires_grad_(True)
+  sc['static_featmaps'] = fm
+  out, pts, _ = _oracle_static_graph(sd, sc, o, d, S, aa, mr)
+  loss_ref = charbonnier(out['rgb'], gt, cpu(w))
+  loss_ref.backward()
+  # with anti-alias pooling: how far the reference's own gradients move under +-1 ulp jitter of exp() (see check_train_static)
+  sens = {k: torch.zeros_like(v) for k, v in sd.items()}
+  sens['featmaps'] = torch.zeros_like(fm)
+  if aa:
+    Vs = scene['static_src_rgbs'].shape[1]
+    for js in range(3):
+      sdj = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+      fmj = scene['static_featmaps'].clone().requires_grad_(True)
+      jit = (torch.randint(0, 3, (n, S, Vs, 1), generator=torch.Generator().manual_seed(50 + js)).float() - 1.0) * 6e-8
+      oj, _, _ = _oracle_static_graph(sdj, dict(sc, static_featmaps=fmj), o, d, S, aa, mr, jit)
+      charbonnier(oj['rgb'], gt, cpu(w)).backward()
+      for k in sd:
+        sens[k] = torch.maximum(sens[k], 4.0 * (sdj[k].grad - sd[k].grad).abs())
+      sens['featmaps'] = torch.maximum(sens['featmaps'], 4.0 * (fmj.grad - fm.grad).abs())
+  assert_close(loss, loss_ref.detach(), 1e-5, 1e-4, f'bootstrap step ({name}) loss')
+  params = dict(render_ray._unwrap(model.net_coarse_st).named_parameters())
+  gmax = max(float(v.grad.abs().max()) for v in sd.values())
+  for k, ref in sd.items():
+    got = params[k].grad
+    assert got is not None, f'no .grad on net_coarse_st.{k}'
+    scale = float(ref.grad.abs().max())
+    assert_close(got, ref.grad, 3e-4 * scale + 3e-6 * gmax, 1e-3, f'bootstrap step ({name}) grad {k} (max |g| {scale:.2e})', extra=sens[k])
+  scale = float(fm.grad.abs().max())
+  assert_close(fm_st.grad, fm.grad, 3e-4 * scale, 1e-3, f'bootstrap step ({name}) grad static featmaps (max |g| {scale:.2e})', extra=sens['featmaps'])
+  # parameters outside the static branch receive nothing from this loss, like in the reference
+  assert all(p.grad is None for p in model.net_coarse_dy.parameters())
+  return float(loss)

@@ -187,3 +187,9 @@ def test_train_static_step(dev, kw):
   """values of raw / rgb / weights and EVERY gradient (39 or 38 parameters + the static feature maps) of the static bootstrap graph against
   torch autograd through the CPU oracle"""
   parity.check_train_static(dev, **kw)
+
+
+@pytest.mark.parametrize('kid', [True, False])
+def test_static_bootstrap_step_drop_in(dev, kid):
+  """train.py:116-199 through render_rays_mono on DataParallel-wrapped modules: loss.backward() fills the modules' .grad"""
+  parity.check_static_bootstrap_step(dev, kid=kid)
