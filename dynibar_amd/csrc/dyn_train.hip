@@ -48,44 +48,47 @@ struct TrOperand {
   int aligned;   // base pointer 16-byte aligned
 };
 
-// global -> registers: the thread's 16 elements of a [128 rows x 32 k] operand tile (zero beyond the bounds)
-template <bool KMINOR>
+// global -> registers: the thread's 16 elements of a [128 rows x 32 k] operand tile (zero beyond the bounds).  Branch-free: every
+// address is clamped into the operand and the out-of-range elements are zeroed by selects, so that all loads of a tile issue back
+// to back (a loader with bounds branches waits for each load in turn: measured 10x slower on the 3 M-row layers).
+// MODE 0: k-minor, rows 16-byte aligned and padded to a multiple of four floats (one dwordx4 per four k);
+// MODE 1: k-minor, any alignment (four dword loads); MODE 2: k-major (rows contiguous; two dword loads per k for a row pair).
+template <int MODE>
 __device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k0, int kend, float4 (&st)[4], int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KMINOR) {
+    float4 v;
+    if (MODE == 0 || MODE == 1) {
       const int r = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
-      if (r < o.nrows && k < kend) {
-        const float* g = o.p + (long)r * o.rs + k;
-        if (o.aligned && (o.rs & 3) == 0 && k + 3 < kend) {
-          v = *reinterpret_cast<const float4*>(g);
-        } else {
-          v.x = g[0];
-          if (k + 1 < kend) v.y = g[1];
-          if (k + 2 < kend) v.z = g[2];
-          if (k + 3 < kend) v.w = g[3];
-        }
+      const int rc = r < o.nrows ? r : o.nrows - 1;
+      const bool rok = r < o.nrows;
+      if (MODE == 0) {
+        const int kc = k < kend ? k : 0;  // a row holds at least round_up4(kend) floats (checked by the host wrapper)
+        v = *reinterpret_cast<const float4*>(o.p + (long)rc * o.rs + kc);
+      } else {
+        const float* g = o.p + (long)rc * o.rs;
+        const int km = kend - 1;
+        v.x = g[k < km ? k : km];
+        v.y = g[k + 1 < km ? k + 1 : km];
+        v.z = g[k + 2 < km ? k + 2 : km];
+        v.w = g[k + 3 < km ? k + 3 : km];
       }
+      v.x = (rok && k < kend) ? v.x : 0.f;
+      v.y = (rok && k + 1 < kend) ? v.y : 0.f;
+      v.z = (rok && k + 2 < kend) ? v.z : 0.f;
+      v.w = (rok && k + 3 < kend) ? v.w : 0.f;
     } else {
-      // k-major source (rows contiguous): the thread takes rows 2 rp, 2 rp + 1 of the eight k of its k-group; st[i] = (k = 2 i: r0, r1 | k = 2 i + 1: r0, r1)
+      // the thread takes rows 2 rp, 2 rp + 1 of the eight k of its k-group; st[i] = (k = 2 i: r0, r1 | k = 2 i + 1: r0, r1)
       const int r = row0 + (tid & 63) * 2, kb = k0 + (tid >> 6) * 8 + 2 * i;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int k = kb + e;
-        float x0 = 0.f, x1 = 0.f;
-        if (k < kend && r < o.nrows) {
-          const float* g = o.p + (long)k * o.ks + r;
-          if (o.aligned && (o.ks & 1) == 0 && r + 1 < o.nrows) {
-            const float2 t = *reinterpret_cast<const float2*>(g);
-            x0 = t.x; x1 = t.y;
-          } else {
-            x0 = g[0];
-            if (r + 1 < o.nrows) x1 = g[1];
-          }
-        }
-        if (e == 0) { v.x = x0; v.y = x1; } else { v.z = x0; v.w = x1; }
-      }
+      const int rm = o.nrows - 1, km = kend - 1;
+      const int r0 = r < rm ? r : rm, r1 = r + 1 < rm ? r + 1 : rm;
+      const float* g0 = o.p + (long)(kb < km ? kb : km) * o.ks;
+      const float* g1 = o.p + (long)(kb + 1 < km ? kb + 1 : km) * o.ks;
+      v.x = g0[r0]; v.y = g0[r1]; v.z = g1[r0]; v.w = g1[r1];
+      v.x = (kb < kend && r < o.nrows) ? v.x : 0.f;
+      v.y = (kb < kend && r + 1 < o.nrows) ? v.y : 0.f;
+      v.z = (kb + 1 < kend && r < o.nrows) ? v.z : 0.f;
+      v.w = (kb + 1 < kend && r + 1 < o.nrows) ? v.w : 0.f;
     }
     st[i] = v;
   }
@@ -150,8 +153,9 @@ __device__ __forceinline__ f32x16 tr_mfma(tr_u32x4 a, tr_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tr_bf16x8, a), __builtin_bit_cast(tr_bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool A_KMINOR, bool B_KMINOR>
+template <int A_MODE, int B_MODE>
 __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
+  constexpr bool A_KMINOR = A_MODE != 2, B_KMINOR = B_MODE != 2;
   tr_u16* As = reinterpret_cast<tr_u16*>(dyn_smem);
   tr_u16* Bs = As + 3 * TG_PART;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,15 +171,15 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 sa[4], sb[4];
-  tr_load_tile<A_KMINOR>(g.a, m0, kbeg, kend, sa, tid);
-  tr_load_tile<B_KMINOR>(g.b, n0, kbeg, kend, sb, tid);
+  tr_load_tile<A_MODE>(g.a, m0, kbeg, kend, sa, tid);
+  tr_load_tile<B_MODE>(g.b, n0, kbeg, kend, sb, tid);
   for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
     tr_store_tile<A_KMINOR>(As, sa, tid);
     tr_store_tile<B_KMINOR>(Bs, sb, tid);
     __syncthreads();
     if (k0 + TG_BK < kend) {  // next tile in flight while this one feeds the matrix pipe
-      tr_load_tile<A_KMINOR>(g.a, m0, k0 + TG_BK, kend, sa, tid);
-      tr_load_tile<B_KMINOR>(g.b, n0, k0 + TG_BK, kend, sb, tid);
+      tr_load_tile<A_MODE>(g.a, m0, k0 + TG_BK, kend, sa, tid);
+      tr_load_tile<B_MODE>(g.b, n0, k0 + TG_BK, kend, sb, tid);
     }
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
@@ -201,25 +205,59 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     }
     __syncthreads();
   }
-  // epilogue: D layout -- lane (j = lane & 31: column n, h = lane >> 5), register r: row (r & 3) + 8 (r >> 2) + 4 h
+  // epilogue: D layout -- lane (j = lane & 31: column n, h = lane >> 5), register r: row (r & 3) + 8 (r >> 2) + 4 h.
+  // Loads first (bias, per-point addend: clamped addresses, no branches, so they issue back to back), then arithmetic, then stores.
+  const int nA = n0 + wn * 64 + (lane & 31), nB = nA + 32;
+  const int nAc = nA < g.N ? nA : g.N - 1, nBc = nB < g.N ? nB : g.N - 1;
+  const int mbase = m0 + wm * 64 + 4 * (lane >> 5);
+  if (g.addend != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const float* add = g.addend + (long)((m < g.M ? m : g.M - 1) / g.add_div) * g.ld_add;
+        acc[i][0][r] += add[nAc];
+        acc[i][1][r] += add[nBc];
+      }
+  }
+  if (g.bias != nullptr && blockIdx.z == 0) {
+    const float bA = g.bias[nAc], bB = g.bias[nBc];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][0][r] += bA;
+        acc[i][1][r] += bB;
+      }
+  }
+  if (g.act == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // ELU: exp(v) - 1 (6e-8 absolute error) away from zero, the cubic Taylor polynomial (4e-8 relative) for -0.01 < v <= 0
+          const float v = acc[i][j][r];
+          const float e = __expf(v) - 1.0f, q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
+          acc[i][j][r] = v > 0.f ? v : (v > -0.01f ? q : e);
+        }
+  }
+  const bool okA = nA < g.N, okB = nB < g.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (n >= g.N) continue;
-      const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.addend != nullptr) v += g.addend[(long)(m / g.add_div) * g.ld_add + n];
-        if (g.act == 1) v = v > 0.f ? v : expm1f(v);
-        float* c = g.c + (long)m * g.ldc + n;
-        if (g.accumulate == 0) *c = v;
-        else if (g.accumulate == 1) *c += v;
-        else atomicAdd(c, v);
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+      if (m >= g.M) continue;
+      float* crow = g.c + (long)m * g.ldc;
+      if (g.accumulate == 0) {
+        if (okA) crow[nA] = acc[i][0][r];
+        if (okB) crow[nB] = acc[i][1][r];
+      } else {  // += : fire-and-forget fp32 atomics (no read latency in the epilogue)
+        if (okA) atomicAdd(crow + nA, acc[i][0][r]);
+        if (okB) atomicAdd(crow + nB, acc[i][1][r]);
       }
     }
 }
@@ -242,11 +280,18 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   g.bias = p->bias; g.addend = p->addend; g.ld_add = p->ld_add; g.add_div = p->add_div > 0 ? p->add_div : 1;
   g.act = p->act; g.accumulate = p->accumulate;
   const dim3 grid(dyn_cdiv(p->N, TG_BN), dyn_cdiv(p->M, TG_BM), nz);
-  const bool ak = p->a_ks == 1, bk = p->b_ks == 1;
-  if (ak && bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<true, true>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
-  else if (ak && !bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<true, false>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
-  else if (!ak && bk) DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<false, true>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
-  else DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<false, false>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);
+  // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
+  // dword, 2 = k-major
+  const int k4 = (p->K + 3) & ~3;
+  const int am = p->a_ks == 1 ? ((g.a.aligned && (p->a_rs & 3) == 0 && p->a_rs >= k4 && p->k_split == 1) ? 0 : 1) : 2;
+  const int bm = p->b_ks == 1 ? ((g.b.aligned && (p->b_rs & 3) == 0 && p->b_rs >= k4 && p->k_split == 1) ? 0 : 1) : 2;
+#define TG_CASE(A, B)                                                                                                                      \
+  if (am == A && bm == B) {                                                                                                                \
+    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm<A, B>), grid, dim3(256), TG_LDS_BYTES, (hipStream_t)stream, g);            \
+    return 0;                                                                                                                              \
+  }
+  TG_CASE(0, 0) TG_CASE(0, 1) TG_CASE(0, 2) TG_CASE(1, 0) TG_CASE(1, 1) TG_CASE(1, 2) TG_CASE(2, 0) TG_CASE(2, 1) TG_CASE(2, 2)
+#undef TG_CASE
   return 0;
 }
 
@@ -265,7 +310,10 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
   const long r0 = chunk * run;
   for (int c = cx; c < cols; c += ct) {
     float colsum = 0.f, segsum = 0.f;
-    for (long r = r0; r < r0 + run && r < rows; ++r) {
+    int in_seg = 0;  // r0 is a multiple of seg (run is)
+    long sidx = dseg != nullptr ? r0 / seg : 0;
+    const long rend = r0 + run < rows ? r0 + run : rows;
+    for (long r = r0; r < rend; ++r) {
       float d = dy[r * ld_dy + c];
       if (act == 1) {
         const float yv = y[r * ld_y + c];
@@ -275,9 +323,10 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
       colsum += d;
       if (dseg != nullptr) {
         segsum += d;
-        if ((r + 1) % seg == 0) {
-          dseg[(r / seg) * ld_seg + c] = segsum;
+        if (++in_seg == seg) {
+          dseg[sidx++ * ld_seg + c] = segsum;
           segsum = 0.f;
+          in_seg = 0;
         }
       }
     }
@@ -552,7 +601,7 @@ extern "C" int dyn_train_view_weights_bwd(int mode, const float* in, long in_str
 
 // ---- weighted mean / variance over the views of a point (mlp_network.py:115-119) ------------------------------------------------------
 // one thread per (point, column).  backward: dX (+)= w (dmean_t + 2 (x - mean) dvar), dmean_t = dmean - 2 dvar sum_v w (x - mean);
-// dw[row] = sum_c [x dmean_t + (x - mean)^2 dvar] via a shared-memory reduction over the columns (one workgroup per point).
+// dw[row] = sum_c [x dmean_t + (x - mean)^2 dvar] by a wave reduction over the columns (one wavefront per point).
 __global__ void __launch_bounds__(256) k_train_meanvar(const float* __restrict__ x, long ldx, const float* __restrict__ w, long P, int V, int C,
                                                        float* __restrict__ mean, float* __restrict__ var, long ld_out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,37 +619,46 @@ __global__ void __launch_bounds__(256) k_train_meanvar(const float* __restrict__
   mean[p * ld_out + c] = m;
   var[p * ld_out + c] = s;
 }
-__global__ void __launch_bounds__(256) k_train_meanvar_bwd(const float* __restrict__ x, long ldx, const float* __restrict__ w, int V, int C,
+__global__ void __launch_bounds__(256) k_train_meanvar_bwd(const float* __restrict__ x, long ldx, const float* __restrict__ w, long P, int V, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ dmean,
                                                            const float* __restrict__ dvar, long ld_stat, float* __restrict__ dx, long ld_dx,
                                                            int accumulate, float* __restrict__ dw, int dw_accumulate) {
-  float* red = reinterpret_cast<float*>(dyn_smem);  // [V][256]
-  const long p = blockIdx.x;
+  // one wavefront per point, lane = column (+ 64, + 128, + 192: C <= 256); the per-view sums over the columns are wave reductions
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= P) return;
   const long r0 = p * V;
-  const int t = threadIdx.x;
-  for (int v = 0; v < V; ++v) red[v * 256 + t] = 0.f;
-  for (int c = t; c < C; c += 256) {
-    const float m = mean[p * ld_stat + c], dm = dmean[p * ld_stat + c], dv = dvar[p * ld_stat + c];
-    float sw = 0.f;
-    for (int v = 0; v < V; ++v) sw += w[r0 + v] * (x[(r0 + v) * ldx + c] - m);
-    const float dmt = dm - 2.0f * dv * sw;
-    for (int v = 0; v < V; ++v) {
-      const float xv = x[(r0 + v) * ldx + c], d = xv - m;
-      const float g = w[r0 + v] * (dmt + 2.0f * d * dv);
-      float* o = dx + (r0 + v) * ld_dx + c;
-      if (accumulate) *o += g; else *o = g;
-      red[v * 256 + t] += xv * dmt + d * d * dv;
+  float m[4], dmt[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = lane + 64 * q;
+    m[q] = 0.f; dmt[q] = 0.f; dv[q] = 0.f;
+    if (c < C) {
+      m[q] = mean[p * ld_stat + c];
+      dv[q] = dvar[p * ld_stat + c];
+      float sw = 0.f;
+      for (int v = 0; v < V; ++v) sw += w[r0 + v] * (x[(r0 + v) * ldx + c] - m[q]);
+      dmt[q] = dmean[p * ld_stat + c] - 2.0f * dv[q] * sw;
     }
   }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o)
-      for (int v = 0; v < V; ++v) red[v * 256 + t] += red[v * 256 + t + o];
-    __syncthreads();
-  }
-  if (t < V) {
-    if (dw_accumulate) dw[r0 + t] += red[t * 256];
-    else dw[r0 + t] = red[t * 256];
+  for (int v = 0; v < V; ++v) {
+    const float wv = w[r0 + v];
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + 64 * q;
+      if (c < C) {
+        const float xv = x[(r0 + v) * ldx + c], d = xv - m[q];
+        const float g = wv * (dmt[q] + 2.0f * d * dv[q]);
+        float* o = dx + (r0 + v) * ld_dx + c;
+        if (accumulate) *o += g; else *o = g;
+        part += xv * dmt[q] + d * d * dv[q];
+      }
+    }
+    part = wave_sum(part);
+    if (lane == 0) {
+      if (dw_accumulate) dw[r0 + v] += part; else dw[r0 + v] = part;
+    }
   }
 }
 extern "C" int dyn_train_meanvar(const float* x, long ldx, const float* w, long P, int V, int C, float* mean, float* var, long ld_out, void* stream) {
@@ -612,9 +670,9 @@ extern "C" int dyn_train_meanvar(const float* x, long ldx, const float* w, long 
 extern "C" int dyn_train_meanvar_bwd(const float* x, long ldx, const float* w, long P, int V, int C, const float* mean, const float* dmean,
                                      const float* dvar, long ld_stat, float* dx, long ld_dx, int accumulate, float* dw, int dw_accumulate,
                                      void* stream) {
-  DYN_REQUIRE(x && w && mean && dmean && dvar && dx && dw && P > 0 && V > 0 && V <= 32 && C > 0, "dyn_train_meanvar_bwd: bad arguments");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar_bwd", k_train_meanvar_bwd, dim3((unsigned)P), dim3(256), (size_t)V * 1024, (hipStream_t)stream, x, ldx,
-             w, V, C, mean, dmean, dvar, ld_stat, dx, ld_dx, accumulate, dw, dw_accumulate);
+  DYN_REQUIRE(x && w && mean && dmean && dvar && dx && dw && P > 0 && V > 0 && C > 0 && C <= 256, "dyn_train_meanvar_bwd: bad arguments (C <= 256)");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar_bwd", k_train_meanvar_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+             w, P, V, C, mean, dmean, dvar, ld_stat, dx, ld_dx, accumulate, dw, dw_accumulate);
   return 0;
 }
 

@@ -107,3 +107,21 @@ def time_args(n_views):
   """(frame_idx, time_embedding[1], time_offset list) like eval_nvidia.py:323-329."""
   offs = [-3, -2, -1, 0, 1, 2, 3][:n_views] if n_views <= 7 else [((i * 5) % 7) - 3 for i in range(n_views)]
   return REF_FRAME, torch.tensor([REF_FRAME / float(NUM_FRAMES)], dtype=torch.float32), offs
+
+
+def bootstrap_case(kid):
+  """The static bootstrap iteration of tests/parity.check_static_bootstrap_step and its golden (tests/golden/train_static.npz):
+  scene name, samples, num_vv, (anti_alias_pooling, mask_rgb), seeded ground-truth colours [R,3] and static-region mask [R] (ray_batch['rgb'],
+  ray_batch['static_mask'] of train.py:180-186)."""
+  name = 'kid' if kid else 'small'
+  scene, o, d, uv, _ = scene_case(name)
+  g = torch.Generator().manual_seed(77)
+  n = o.shape[0]
+  gt = torch.rand(n, 3, generator=g)
+  static_mask = (torch.rand(n, generator=g) < 0.3).float()
+  return dict(name=name, S=32, num_vv=3 if kid else 0, aa=0 if kid else 1, mask_rgb=1 if kid else 0, gt=gt, static_mask=static_mask)
+
+
+def charbonnier(x, y, mask, eps=0.001):
+  """utils.img2charbonier (utils.py:32-39) with TINY_NUMBER = 1e-6"""
+  return torch.sum(torch.sqrt((x - y) ** 2 + eps ** 2) * mask.unsqueeze(-1)) / (torch.sum(mask) * x.shape[-1] + 1e-6)

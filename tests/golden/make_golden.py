@@ -356,8 +356,44 @@ def mono_kid_goldens():
   print('mono_kid', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def train_static_goldens():
+  """One iteration of the reference's static bootstrap loop (train.py:116-199) on the REAL modules with the REAL autograd:
+  render_rays_mono(is_train=False) under grad mode, the script's Charbonnier loss on ret['outputs_coarse_st']['rgb'] with its static mask,
+  loss.backward(); stores the loss, the mask and the gradient of every DynibarStatic parameter and of the static feature maps, for the
+  kid-running argument set (anti_alias_pooling=0, mask_rgb=1, num_vv=3) and the Nvidia one (anti_alias_pooling=1, mask_rgb=0)."""
+  out = {}
+  for kid in (True, False):
+    c = cases.bootstrap_case(kid)
+    scene, o, d, uv, pix = cases.scene_case(c['name'])
+    args = ref_args(anti_alias_pooling=c['aa'], mask_rgb=c['mask_rgb'])
+    model = build_ref_model(cases.model_weights(0), c['S'], 2 * c['S'], args, shift=5.0)
+    model.net_coarse_st.train()
+    Vd = scene['src_rgbs'].shape[1]
+    fidx, temb, toff = cases.time_args(Vd - c['num_vv'])
+    fm = scene['static_featmaps'].clone().requires_grad_(True)
+    ret = RR.render_rays_mono((fidx, None), (temb, None), (toff, None), ray_batch_of(scene, o, d, uv), model,
+                              (scene['featmaps'], None, fm), PJ.Projector('cpu'), c['S'], args, inv_uniform=True,
+                              N_importance=0, det=True, is_train=False, num_vv=c['num_vv'])
+    w = (1.0 - c['static_mask']) * ret['outputs_coarse_ref']['mask'].float()
+    loss = cases.charbonnier(ret['outputs_coarse_st']['rgb'], c['gt'], w)
+    loss.backward()
+    tag = c['name'] + '/'
+    out[tag + 'loss'] = npy(loss)
+    out[tag + 'w'] = npy(w)
+    out[tag + 'rgb'] = npy(ret['outputs_coarse_st']['rgb'])
+    out[tag + 'grad/featmaps'] = npy(fm.grad)
+    for k, p in model.net_coarse_st.named_parameters():
+      out[tag + 'grad/' + k] = npy(p.grad)
+    assert all(p.grad is None for p in model.net_coarse_dy.parameters())
+  np.savez_compressed(os.path.join(HERE, 'train_static.npz'), **out)
+  print('train_static', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
   import sys
+  if 'train_static' in sys.argv[1:]:
+    train_static_goldens()
+    sys.exit(0)
   if 'encoder' in sys.argv[1:]:
     encoder_goldens()
     sys.exit(0)

@@ -1046,73 +1046,80 @@ def check_train_gemm(device):
   assert_close(dW, dZ.double().cpu().T @ X.double().cpu(), 2e-4, 2e-6, 'train gemm split weight gradient')
 
 
-def check_static_bootstrap_step(device, kid=True, S=32):
+def oracle_bootstrap_step(kid, w, jitter_seed=None):
+  """The static bootstrap iteration on torch-CPU autograd through the oracle -> (loss, {param: grad} + 'featmaps', rgb).
+  w [R]: the loss weights (1 - static_mask) * outputs_coarse_ref['mask'] (a forward value of the dual composite)."""
+  c = cases.bootstrap_case(kid)
+  scene, o, d, uv, _ = cases.scene_case(c['name'])
+  S, aa, mr = c['S'], bool(c['aa']), bool(c['mask_rgb'])
+  sd = {k: v.clone().requires_grad_(True) for k, v in O.tdict(cases.model_weights(0)['net_coarse_st']).items() if (aa or k != 's')}
+  sc = dict(scene)
+  fm = scene['static_featmaps'].clone().requires_grad_(True)
+  sc['static_featmaps'] = fm
+  jit = None
+  if jitter_seed is not None:
+    Vs = scene['static_src_rgbs'].shape[1]
+    jit = (torch.randint(0, 3, (o.shape[0], S, Vs, 1), generator=torch.Generator().manual_seed(50 + jitter_seed)).float() - 1.0) * 6e-8
+  out, pts, _ = _oracle_static_graph(sd, sc, o, d, S, aa, mr, jit)
+  loss = cases.charbonnier(out['rgb'], c['gt'], w)
+  loss.backward()
+  grads = {k: v.grad.detach() for k, v in sd.items()}
+  grads['featmaps'] = fm.grad.detach()
+  return loss.detach(), grads, out['rgb'].detach()
+
+
+def bootstrap_sensitivity(kid, w, g_ref):
+  """4 x how far the oracle's own gradients move under +-1 ulp jitter of exp() in the anti-alias pooling weights (see check_train_static)"""
+  sens = {k: torch.zeros_like(v) for k, v in g_ref.items()}
+  if cases.bootstrap_case(kid)['aa']:
+    for js in range(3):
+      gj = oracle_bootstrap_step(kid, w, jitter_seed=js)[1]
+      for k in g_ref:
+        sens[k] = torch.maximum(sens[k], 4.0 * (gj[k] - g_ref[k]).abs())
+  return sens
+
+
+def check_static_bootstrap_step(device, golden, kid=True):
   """One iteration of the reference's static bootstrap loop (train.py:116-199) exactly as the script drives it: render_rays_mono(...,
   is_train=False) under grad mode on DataParallel-wrapped nn.Modules, Charbonnier loss (criterion.py:58-62, utils.py:32-39) on
   ret['outputs_coarse_st']['rgb'] with the script's static mask, loss.backward(): the gradients that land in the modules' .grad and in
-  the static feature maps against torch autograd through the oracle."""
+  the static feature maps against the REAL reference's autograd (tests/golden/train_static.npz) and against autograd through the oracle."""
   import types
   from dynibar_amd import projection, render_ray
-  name = 'kid' if kid else 'small'
+  c = cases.bootstrap_case(kid)
+  name, S, num_vv = c['name'], c['S'], c['num_vv']
   scene, o, d, uv, _ = cases.scene_case(name)
   Vd = scene['src_rgbs'].shape[1]
-  num_vv = 3 if kid else 0
   fidx, temb, toff = cases.time_args(Vd - num_vv)
-  args = types.SimpleNamespace(anti_alias_pooling=0 if kid else 1, mask_rgb=1 if kid else 0, input_dir=True, input_xyz=False, occ_weights_mode=0)
-  aa, mr = bool(args.anti_alias_pooling), bool(args.mask_rgb)
+  args = types.SimpleNamespace(anti_alias_pooling=c['aa'], mask_rgb=c['mask_rgb'], input_dir=True, input_xyz=False, occ_weights_mode=0)
   model = make_module_model(device, args, shift=5.0)
   batch = make_ray_batch(scene, o, d, uv, device)
-  g = torch.Generator().manual_seed(77)
-  n = o.shape[0]
-  gt = torch.rand(n, 3, generator=g)
-  static_mask = (torch.rand(n, generator=g) < 0.3).float()
-  batch['rgb'], batch['static_mask'] = gt.to(device), static_mask.to(device)
+  batch['rgb'], batch['static_mask'] = c['gt'].to(device), c['static_mask'].to(device)
   fm_st = scene['static_featmaps'].to(device).requires_grad_(True)
   feat = (scene['featmaps'].to(device), None, fm_st)
   ret = render_ray.render_rays_mono((fidx, None), (temb.to(device), None), (toff, None), batch, model, feat, projection.Projector(device), S, args,
                                     inv_uniform=True, det=True, is_train=False, num_vv=num_vv)
-
-  def charbonnier(x, y, mask, eps=0.001):
-    return torch.sum(torch.sqrt((x - y) ** 2 + eps ** 2) * mask.unsqueeze(-1)) / (torch.sum(mask) * x.shape[-1] + 1e-6)
-
   pred = ret['outputs_coarse_st']['rgb']
   assert pred.requires_grad, "outputs_coarse_st['rgb'] must carry the autograd graph in grad mode"
   w = (1.0 - batch['static_mask']) * ret['outputs_coarse_ref']['mask'].float()
-  loss = charbonnier(pred, batch['rgb'], w)
+  loss = cases.charbonnier(pred, batch['rgb'], w)
   loss.backward()
-  # oracle: the same graph on CPU autograd, same mask (a forward value of the dual composite)
-  sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in render_ray._state_dict(model.net_coarse_st).items()}
-  sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
-  sc = dict(scene)
-  fm = scene['static_featmaps'].clone().requires_grad_(True)
-  sc['static_featmaps'] = fm
-  out, pts, _ = _oracle_static_graph(sd, sc, o, d, S, aa, mr)
-  loss_ref = charbonnier(out['rgb'], gt, cpu(w))
-  loss_ref.backward()
-  # with anti-alias pooling: how far the reference's own gradients move under +-1 ulp jitter of exp() (see check_train_static)
-  sens = {k: torch.zeros_like(v) for k, v in sd.items()}
-  sens['featmaps'] = torch.zeros_like(fm)
-  if aa:
-    Vs = scene['static_src_rgbs'].shape[1]
-    for js in range(3):
-      sdj = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-      fmj = scene['static_featmaps'].clone().requires_grad_(True)
-      jit = (torch.randint(0, 3, (n, S, Vs, 1), generator=torch.Generator().manual_seed(50 + js)).float() - 1.0) * 6e-8
-      oj, _, _ = _oracle_static_graph(sdj, dict(sc, static_featmaps=fmj), o, d, S, aa, mr, jit)
-      charbonnier(oj['rgb'], gt, cpu(w)).backward()
-      for k in sd:
-        sens[k] = torch.maximum(sens[k], 4.0 * (sdj[k].grad - sd[k].grad).abs())
-      sens['featmaps'] = torch.maximum(sens['featmaps'], 4.0 * (fmj.grad - fm.grad).abs())
-  assert_close(loss, loss_ref.detach(), 1e-5, 1e-4, f'bootstrap step ({name}) loss')
+  w_ref = torch.from_numpy(golden[f'{name}/w'])
+  assert_bitexact(cpu(w), w_ref, f'bootstrap step ({name}) loss weights (static mask x ray mask)')
+  loss_o, g_o, _ = oracle_bootstrap_step(kid, w_ref)
+  sens = bootstrap_sensitivity(kid, w_ref, g_o)
   params = dict(render_ray._unwrap(model.net_coarse_st).named_parameters())
-  gmax = max(float(v.grad.abs().max()) for v in sd.values())
-  for k, ref in sd.items():
-    got = params[k].grad
-    assert got is not None, f'no .grad on net_coarse_st.{k}'
-    scale = float(ref.grad.abs().max())
-    assert_close(got, ref.grad, 3e-4 * scale + 3e-6 * gmax, 1e-3, f'bootstrap step ({name}) grad {k} (max |g| {scale:.2e})', extra=sens[k])
-  scale = float(fm.grad.abs().max())
-  assert_close(fm_st.grad, fm.grad, 3e-4 * scale, 1e-3, f'bootstrap step ({name}) grad static featmaps (max |g| {scale:.2e})', extra=sens['featmaps'])
+  got = {k: p.grad for k, p in params.items()}
+  got['featmaps'] = fm_st.grad
+  for label, loss_ref, g_ref in (('real reference', torch.from_numpy(golden[f'{name}/loss']), {k: torch.from_numpy(golden[f'{name}/grad/{k}']) for k in g_o}),
+                                 ('oracle', loss_o, g_o)):
+    assert_close(loss, loss_ref, 1e-5, 1e-4, f'bootstrap step ({name}) loss vs {label}')
+    gmax = max(float(v.abs().max()) for k, v in g_ref.items() if k != 'featmaps')
+    for k, ref in g_ref.items():
+      assert got[k] is not None, f'no gradient on {k}'
+      scale = float(ref.abs().max())
+      assert_close(got[k].reshape(ref.shape), ref, 3e-4 * scale + 3e-6 * gmax, 1e-3, f'bootstrap step ({name}) grad {k} vs {label} (max |g| {scale:.2e})',
+                   extra=sens[k].reshape(ref.shape))
   # parameters outside the static branch receive nothing from this loss, like in the reference
   assert all(p.grad is None for p in model.net_coarse_dy.parameters())
   return float(loss)

@@ -190,6 +190,7 @@ def test_train_static_step(dev, kw):
 
 
 @pytest.mark.parametrize('kid', [True, False])
-def test_static_bootstrap_step_drop_in(dev, kid):
-  """train.py:116-199 through render_rays_mono on DataParallel-wrapped modules: loss.backward() fills the modules' .grad"""
-  parity.check_static_bootstrap_step(dev, kid=kid)
+def test_static_bootstrap_step_drop_in(dev, golden_dir, kid):
+  """train.py:116-199 through render_rays_mono on DataParallel-wrapped modules: loss.backward() fills the modules' .grad; against the
+  real reference's autograd gradients (golden) and the oracle's"""
+  parity.check_static_bootstrap_step(dev, dict(np.load(os.path.join(golden_dir, 'train_static.npz'))), kid=kid)

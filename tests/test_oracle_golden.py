@@ -166,3 +166,25 @@ def test_image_rays(golden_dir):
   close(o, g['rays_o']); close(d, g['rays_d']); close(uv, g['uv_grid'])
   _, d2, _ = O.image_rays(scene['camera'], render_stride=2)
   close(d2, g['stride2/rays_d'])
+
+
+@pytest.mark.parametrize('kid', [True, False])
+def test_static_bootstrap_gradients(golden_dir, kid):
+  """Section 8(f)3: torch autograd through the oracle's restatement of the static bootstrap graph (train.py:116-199) against the REAL
+  reference's autograd on its own modules: loss, rendered colours and the gradient of every DynibarStatic parameter and of the static
+  feature maps.  Pins the gradients the GPU tests compare the HIP backward kernels with."""
+  import parity
+  g = load(golden_dir, 'train_static.npz')
+  c = cases.bootstrap_case(kid)
+  name = c['name']
+  loss, grads, rgb = parity.oracle_bootstrap_step(kid, torch.from_numpy(g[f'{name}/w']))
+  close(rgb, g[f'{name}/rgb'], rtol=1e-5, atol=2e-6)
+  close(loss, g[f'{name}/loss'], rtol=1e-5, atol=1e-7)
+  assert set(grads) == {k[len(name) + 6:] for k in g if k.startswith(f'{name}/grad/')}, 'gradient key set differs from the reference'
+  gmax = max(float(np.abs(g[f'{name}/grad/{k}']).max()) for k in grads if k != 'featmaps')
+  for k, v in grads.items():
+    ref = g[f'{name}/grad/{k}']
+    scale = float(np.abs(ref).max())
+    # same ATen operators in the same order: fp32 round-off of a different graph shape only (the pooling temperature `s` is the
+    # ill-conditioned one, see parity.check_train_static)
+    close(v.reshape(ref.shape), ref, rtol=1e-3 if k != 's' else 5e-2, atol=2e-5 * scale + 1e-7 * gmax)

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from dynibar_amd import _lib, ops, synthetic as syn, train_static as TS  # noqa: E402
 
 
