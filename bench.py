@@ -278,6 +278,70 @@ def main():
       except Exception as e:
         extra['feature_encoder'] = {'error': str(e)[:300]}
 
+      try:
+        # section 8(f)3, first slice: one static bootstrap training step (train.py:116-199) at the reference's training shape
+        # (configs/train_kid-running.txt: N_rand 3072, 64 samples, 15 static views, anti_alias_pooling 0, mask_rgb 1): forward with saved
+        # activations + backward through the dyn_train_* kernels into DynibarStatic's parameters and the static feature maps
+        from dynibar_amd import ops as _ops, synthetic as syn, train_static as TS
+        Rt, St, Vt = 3072, 64, 15
+        sc = syn.make_scene(seed=21, H=H, W=W, V=7, n_static=Vt, smooth=False)
+        td = lambda x: torch.from_numpy(x).to(dev)
+        fm = td(sc['static_featmaps']).requires_grad_(True)
+        tviews = _ops.SourceViews(td(sc['camera']), td(sc['static_src_rgbs']), td(sc['static_src_cameras']), fm.detach())
+        to_, td_, _ = syn.pixel_rays(sc['camera'], syn.sample_pixels(21, H, W, Rt))
+        to_, td_ = td(to_), td(td_)
+        prm = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in syn.make_weights('static', 0).items() if k != 's'}
+        tdr = td(sc['depth_range'])
+        cot = torch.randn(Rt, 3, device=dev)
+
+        def train_step():
+          pts_, z_, _s = _ops.sample_along_ray(to_, td_, tdr, St, True)
+          rf_, rd_, mk_, pm_ = _ops.project_gather(tviews, Rt, St, ray_o=to_, ray_d=td_, z_vals=z_, pix_mask_thresh=1.0)
+          raw_ = TS.static_raw(prm, (False, True), tviews, fm, to_, td_, pts_, rf_, rd_, mk_)
+          (TS.composite_vanilla(raw_, z_, pm_)['rgb'] * cot).sum().backward()
+
+        train_step(); train_step(); fence()
+        lib.dyn_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+          train_step()
+        fence()
+        tdt = (time.perf_counter() - t0) / 3
+        lib.dyn_profile_enable(0)
+        tk = read_kernels(lib)
+        tflop = 3.0 * (0.361e6 + 0.033e6 * (St / 64) + 0.4305e6 * Vt) * Rt * St  # forward + data gradient + weight gradient
+        extra['train_static_step'] = {
+            'what': 'ONE static bootstrap training step (train.py:116-199): gather -> DynibarStatic -> raw2outputs_vanilla, loss.backward() into the 38 '
+                    'parameters and the static feature maps; 3072 rays x 64 samples x 15 views (configs/train_kid-running.txt)',
+            'ms_per_step': tdt * 1e3, 'rays_per_s': Rt / tdt, 'algorithmic_tflop_per_step': tflop / 1e12, 'algorithmic_tflops': tflop / tdt / 1e12,
+            'frac_of_split6_mfma_peak': tflop / tdt / 1e12 / (2500.0 / 6), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30,
+            'kernel_ms': {k: round(v['avg_ms'] * v['launches'] / 3, 3) for k, v in tk.items()}}
+        try:  # the reference's own route on this GPU: the same graph as PyTorch eager ops + autograd (the oracle's restatement on the device)
+          from oracle import ibr_oracle as O
+          sdv = {k: v.detach().clone().requires_grad_(True) for k, v in prm.items()}
+          osc = {k: td(sc[k]) for k in ('camera', 'static_src_rgbs', 'static_src_cameras', 'depth_range')}
+          ofm = fm.detach().clone().requires_grad_(True)
+          osc['static_featmaps'] = ofm
+
+          def eager_step():
+            out = O.static_branch_pass(sdv, osc, to_, td_, St, True, True, False, True)
+            (out['rgb'] * cot).sum().backward()
+
+          eager_step(); fence()
+          t0 = time.perf_counter()
+          for _ in range(2):
+            eager_step()
+          fence()
+          extra['train_static_step']['pytorch_eager_same_gpu_ms'] = (time.perf_counter() - t0) / 2 * 1e3
+          gk = 'base_fc.2.weight'
+          extra['train_static_step']['grad_rel_diff_vs_pytorch_eager'] = float((prm[gk].grad / 5 - sdv[gk].grad / 3).abs().max() / (sdv[gk].grad / 3).abs().max())
+        except Exception as e:
+          extra['train_static_step']['pytorch_eager_same_gpu_ms'] = 'failed: ' + str(e)[:160]
+        del prm, fm, tviews
+        torch.cuda.empty_cache()
+      except Exception as e:
+        extra['train_static_step'] = {'error': str(e)[:300]}
+
   if rank != 0:
     if world > 1:
       dist.destroy_process_group()

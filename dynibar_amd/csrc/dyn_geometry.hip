@@ -768,9 +768,10 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
 // d featmaps[v, y, x, :] += w_tap * d rgb_feat[row, 3:3+F] at the four taps of every (point, view) row.  The pixel location is
 // recomputed with the forward kernel's own arithmetic (same projection, same make_taps), so the taps and weights are the forward's.
 // One thread per (row, group of four channels); fp32 hardware atomics into the channels-last gradient map (zeroed by the caller).
-// Sample points are static (xyz = pts_st); no gradient flows to the locations in the static branch.
+// xyz [V,R,S,3] (the dynamic branch's motion-displaced points) or NULL (static branch: every view sees pts_st).  The gradient w.r.t.
+// the locations themselves (the motion path) is not part of this slice.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __restrict__ pts_st, const float4* __restrict__ proj4,
+__global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
                                                     const float* __restrict__ drgb_feat, long ld_d, int col0, float* __restrict__ dfeat) {
   const int G = q.F / 4;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -779,7 +780,8 @@ __global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __re
   if (row >= q.N) return;
   const long rs = row / q.V;
   const int v = (int)(row - rs * q.V);
-  const float x = pts_st[rs * 3 + 0], y = pts_st[rs * 3 + 1], z3 = pts_st[rs * 3 + 2];
+  const float* pt = xyz != nullptr ? xyz + ((long)v * q.R * q.S + rs) * 3 : pts_st + rs * 3;  // per-view (motion displaced) point
+  const float x = pt[0], y = pt[1], z3 = pt[2];
   const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
   const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
@@ -808,9 +810,9 @@ __global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __re
   }
 }
 
-extern "C" int dyn_gather_bwd(const float* pts_st, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
+extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
                               const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream) {
-  DYN_REQUIRE(pts_st && proj && drgb_feat && dfeat_cl, "dyn_gather_bwd: null pointer");
+  DYN_REQUIRE((pts_st || xyz) && proj && drgb_feat && dfeat_cl, "dyn_gather_bwd: null pointer");
   DYN_REQUIRE(R > 0 && S > 0 && V > 0 && Hf > 1 && Wf > 1 && F > 0 && (F % 4) == 0, "dyn_gather_bwd: bad shape");
   PGShape q;
   q.R = R; q.S = S; q.V = V; q.H = 0; q.W = 0; q.Hf = Hf; q.Wf = Wf; q.F = F;
@@ -819,7 +821,7 @@ extern "C" int dyn_gather_bwd(const float* pts_st, const float* proj, int R, int
   q.N = (long)R * S * V;
   q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
   const long n = q.N * (F / 4);
-  DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, pts_st,
+  DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, pts_st, xyz,
              reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);
   return 0;
 }

@@ -1046,3 +1046,175 @@ extern "C" int dyn_train_composite_bwd(const float* raw, const float* z_vals, co
              z_vals, alpha, weights, drgb, ddepth, dweights, R, S, draw);
   return 0;
 }
+
+// =====================================================================================================================
+// Second slice: the dynamic branch's network (DynibarDynamic.forward, mlp_network.py:236-316) and the two-branch compositing
+// (raw2outputs, render_ray.py:214-330).  The dynamic net reuses the GEMM and the pooling / visibility / attention / LayerNorm kernels
+// above; what it adds: a broadcast add (time feature onto every row, positional table onto every ray), its Fourier features, its
+// colour head (sigmoid, masked to 0 where no view sees the point) and the backward of the two-branch compositing.
+// =====================================================================================================================
+
+// y[row, c] = x[row, c] + tab[(row % period), c]   (period 1: one vector for every row; period S: the positional table of a ray)
+__global__ void __launch_bounds__(256) k_train_add_table(const float* __restrict__ x, long ldx, const float* __restrict__ tab, long ld_tab, int period,
+                                                         long rows, int C, float* __restrict__ y, long ldy) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / C;
+  const int c = (int)(idx - row * C);
+  if (row >= rows) return;
+  y[row * ldy + c] = x[row * ldx + c] + tab[(row % period) * ld_tab + c];
+}
+extern "C" int dyn_train_add_table(const float* x, long ldx, const float* tab, long ld_tab, int period, long rows, int C, float* y, long ldy,
+                                   void* stream) {
+  DYN_REQUIRE(x && tab && y && rows > 0 && C > 0 && period >= 1, "dyn_train_add_table: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_add_table", k_train_add_table, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+             ldx, tab, ld_tab, period, rows, C, y, ldy);
+  return 0;
+}
+
+// Fourier features of the dynamic net (mlp_network.py:147-160, :290, :303): pts_pe [P,36] = [PE_5(pts) 33 | 0 0 0], dir_pe [R,28] =
+// [PE_4(glb_ray_dir) 27 | 0]
+__global__ void __launch_bounds__(256) k_train_dynamic_embed(const float* __restrict__ pts, const float* __restrict__ ray_d, long P, int R,
+                                                             float* __restrict__ pts_pe, float* __restrict__ dir_pe) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P) {
+    float* o = pts_pe + i * 36;
+    tr_embed(pts[i * 3], o + 0, 3);
+    tr_embed(pts[i * 3 + 1], o + 1, 3);
+    tr_embed(pts[i * 3 + 2], o + 2, 3);
+    o[33] = 0.f; o[34] = 0.f; o[35] = 0.f;
+  }
+  if (i < R) {
+    float* o = dir_pe + i * 28;
+    float dn[3];
+    tr_unit3(ray_d[i * 3], ray_d[i * 3 + 1], ray_d[i * 3 + 2], dn[0], dn[1], dn[2]);  // input_ray_dir = F.normalize(ray_d) (render_ray.py:915)
+    for (int k = 0; k < 3; ++k) {
+      const float x = dn[k];
+      o[k] = x;
+      for (int f = 0; f < 4; ++f) {
+        float s, c;
+        sincosf((float)(1 << f) * x, &s, &c);
+        o[3 + f * 3 + k] = c;
+        o[15 + f * 3 + k] = s;
+      }
+    }
+    o[27] = 0.f;
+  }
+}
+extern "C" int dyn_train_dynamic_embed(const float* pts, const float* ray_d, long P, int R, float* pts_pe, float* dir_pe, void* stream) {
+  DYN_REQUIRE(pts && ray_d && pts_pe && dir_pe && P > 0 && R > 0 && R <= P, "dyn_train_dynamic_embed: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_dynamic_embed", k_train_dynamic_embed, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+             ray_d, P, R, pts_pe, dir_pe);
+  return 0;
+}
+
+// colour / density head (mlp_network.py:295-315): raw = [sigmoid(logit) masked to 0 where no view sees the point | sigma - shift, -1e9
+// where no view sees the point]; backward into dlogit [P,3(ld)] and dsigma [P]
+__global__ void __launch_bounds__(256) k_train_dynamic_head(const float* __restrict__ logit, long ld_logit, const float* __restrict__ sigma,
+                                                            const float* __restrict__ nvalid, float shift, long P, float* __restrict__ raw) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const bool seen = nvalid[p] != 0.f;
+  for (int c = 0; c < 3; ++c) raw[p * 4 + c] = seen ? tr_sigmoid(logit[p * ld_logit + c]) : 0.f;
+  raw[p * 4 + 3] = nvalid[p] < 1.0f ? -1e9f : sigma[p] - shift;
+}
+__global__ void __launch_bounds__(256) k_train_dynamic_head_bwd(const float* __restrict__ draw, const float* __restrict__ raw,
+                                                                const float* __restrict__ nvalid, long P, float* __restrict__ dlogit, long ld_dlogit,
+                                                                float* __restrict__ dsigma) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const bool seen = nvalid[p] != 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float s = raw[p * 4 + c];
+    dlogit[p * ld_dlogit + c] = seen ? draw[p * 4 + c] * s * (1.0f - s) : 0.f;
+  }
+  dsigma[p] = nvalid[p] < 1.0f ? 0.f : draw[p * 4 + 3];
+}
+extern "C" int dyn_train_dynamic_head(const float* logit, long ld_logit, const float* sigma, const float* nvalid, float shift, long P, float* raw,
+                                      void* stream) {
+  DYN_REQUIRE(logit && sigma && nvalid && raw && P > 0, "dyn_train_dynamic_head: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_dynamic_head", k_train_dynamic_head, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logit,
+             ld_logit, sigma, nvalid, shift, P, raw);
+  return 0;
+}
+extern "C" int dyn_train_dynamic_head_bwd(const float* draw, const float* raw, const float* nvalid, long P, float* dlogit, long ld_dlogit, float* dsigma,
+                                          void* stream) {
+  DYN_REQUIRE(draw && raw && nvalid && dlogit && dsigma && P > 0, "dyn_train_dynamic_head_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_dynamic_head_bwd", k_train_dynamic_head_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             draw, raw, nvalid, P, dlogit, ld_dlogit, dsigma);
+  return 0;
+}
+
+// backward of the two-branch compositing (render_ray.py:246-330): one thread per ray.
+//   a_d, a_s = 1 - exp(-softplus(sigma) dist);  A = 1 - (1 - a_s)(1 - a_d);  T_i = prod_{j<i} (1 - A_j + 1e-10)
+//   w_d = a_d T, w_s = a_s T, w = A T;  rgb_dy = sum w_d c_d, rgb_static = sum w_s c_s, rgb = rgb_dy + rgb_static, depth = sum w z
+// upstream: g_rgb, g_rgb_static, g_rgb_dy [R,3], g_depth [R], g_wd, g_ws, g_w [R,S] (each may be NULL)
+//   Wd_i = (g_rgb + g_rgb_dy) . c_d,i + g_wd,i;  Ws_i likewise;  Ww_i = g_depth z_i + g_w,i;  Q_i = Wd_i a_d,i + Ws_i a_s,i + Ww_i A_i
+//   dA_j = Ww_j T_j - (sum_{i>j} Q_i T_i) / (1 - A_j + 1e-10);  da_d,j = Wd_j T_j + dA_j (1 - a_s,j);  da_s,j = Ws_j T_j + dA_j (1 - a_d,j)
+__device__ __forceinline__ float tr_alpha(float sg, bool last, float& dalpha_dsigma) {
+  const float sp = sg > 20.0f ? sg : log1pf(expf(sg));
+  const float dist = last ? 1e10f : 1.0f;
+  const float ex = expf(-sp * dist);
+  dalpha_dsigma = ex * dist * (sg > 20.0f ? 1.0f : tr_sigmoid(sg));
+  return 1.0f - ex;
+}
+__global__ void __launch_bounds__(64) k_train_composite2_bwd(const float* __restrict__ raw_dy, const float* __restrict__ raw_st,
+                                                             const float* __restrict__ z_vals, const float* __restrict__ g_rgb,
+                                                             const float* __restrict__ g_rgb_st, const float* __restrict__ g_rgb_dy,
+                                                             const float* __restrict__ g_depth, const float* __restrict__ g_wd,
+                                                             const float* __restrict__ g_ws, const float* __restrict__ g_w, int R, int S,
+                                                             float* __restrict__ draw_dy, float* __restrict__ draw_st) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float gd[3], gs[3];
+  for (int c = 0; c < 3; ++c) {
+    const float g = g_rgb ? g_rgb[r * 3 + c] : 0.f;
+    gd[c] = g + (g_rgb_dy ? g_rgb_dy[r * 3 + c] : 0.f);
+    gs[c] = g + (g_rgb_st ? g_rgb_st[r * 3 + c] : 0.f);
+  }
+  const float gz = g_depth ? g_depth[r] : 0.f;
+  // pass 1: total = sum_i Q_i T_i
+  float T = 1.0f, total = 0.f;
+  for (int i = 0; i < S; ++i) {
+    const long o = (long)r * S + i;
+    float dd, ds;
+    const float ad = tr_alpha(raw_dy[o * 4 + 3], i == S - 1, dd), as = tr_alpha(raw_st[o * 4 + 3], i == S - 1, ds);
+    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
+    const float Wd = gd[0] * raw_dy[o * 4] + gd[1] * raw_dy[o * 4 + 1] + gd[2] * raw_dy[o * 4 + 2] + (g_wd ? g_wd[o] : 0.f);
+    const float Ws = gs[0] * raw_st[o * 4] + gs[1] * raw_st[o * 4 + 1] + gs[2] * raw_st[o * 4 + 2] + (g_ws ? g_ws[o] : 0.f);
+    const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
+    total += (Wd * ad + Ws * as + Ww * A) * T;
+    T *= 1.0f - A + 1e-10f;
+  }
+  // pass 2
+  T = 1.0f;
+  float prefix = 0.f;
+  for (int i = 0; i < S; ++i) {
+    const long o = (long)r * S + i;
+    float dd, ds;
+    const float ad = tr_alpha(raw_dy[o * 4 + 3], i == S - 1, dd), as = tr_alpha(raw_st[o * 4 + 3], i == S - 1, ds);
+    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
+    const float Wd = gd[0] * raw_dy[o * 4] + gd[1] * raw_dy[o * 4 + 1] + gd[2] * raw_dy[o * 4 + 2] + (g_wd ? g_wd[o] : 0.f);
+    const float Ws = gs[0] * raw_st[o * 4] + gs[1] * raw_st[o * 4 + 1] + gs[2] * raw_st[o * 4 + 2] + (g_ws ? g_ws[o] : 0.f);
+    const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
+    prefix += (Wd * ad + Ws * as + Ww * A) * T;
+    const float one_m = 1.0f - A + 1e-10f;
+    const float dA = Ww * T - (total - prefix) / one_m;
+    const float dad = Wd * T + dA * (1.0f - as), das = Ws * T + dA * (1.0f - ad);
+    const float wd = ad * T, ws = as * T;
+    for (int c = 0; c < 3; ++c) {
+      draw_dy[o * 4 + c] = gd[c] * wd;
+      draw_st[o * 4 + c] = gs[c] * ws;
+    }
+    draw_dy[o * 4 + 3] = dad * dd;
+    draw_st[o * 4 + 3] = das * ds;
+    T *= one_m;
+  }
+}
+extern "C" int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
+                                        const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R,
+                                        int S, float* draw_dy, float* draw_st, void* stream) {
+  DYN_REQUIRE(raw_dy && raw_st && z_vals && draw_dy && draw_st && R > 0 && S > 0, "dyn_train_composite2_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw_dy,
+             raw_st, z_vals, g_rgb, g_rgb_st, g_rgb_dy, g_depth, g_wd, g_ws, g_w, R, S, draw_dy, draw_st);
+  return 0;
+}

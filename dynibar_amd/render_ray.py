@@ -6,11 +6,13 @@ executed by the HIP kernels of libdynibar_hip.so.
 may be ``nn.Module``s (optionally ``DataParallel``-wrapped) or plain state dicts.  Their weights are packed into MFMA operand
 tiles once and re-packed only when a parameter's version counter changes.
 
-Scope: forward rendering, plus the first slice of the backward pass: under grad mode, when the static net's
-parameters or the static feature maps require grad, ``render_rays_mono`` builds ``outputs_coarse_st`` (rgb / depth / weights) through
-``dynibar_amd.train_static`` so that the reference's static bootstrap stage (train.py:116-199: ``loss.backward()`` on
-``ret['outputs_coarse_st']['rgb']``) runs on the HIP training kernels.  Every other returned tensor is a forward value without graph
-(``render_rays_mono(is_train=True)`` returns the cross-time supervision outputs as forward values).
+Scope: forward rendering, plus two slices of the backward pass.  Under grad mode, when a net's parameters or its
+feature maps require grad, ``render_rays_mono`` evaluates DynibarStatic / DynibarDynamic and both compositing functions through
+``dynibar_amd.train_static`` / ``train_dynamic`` (HIP training kernels with hand-written backward): the colour / depth / weight
+outputs of ``outputs_coarse_st``, ``outputs_coarse_ref``, ``outputs_coarse_ref_dy`` (and of the anchor pass) then carry a graph to both
+nets' parameters and to the feature maps -- the reference's static bootstrap stage (train.py:116-199) runs unchanged.  NOT yet
+differentiable: anything w.r.t. the sample *locations* (the motion path: MotionMLP, trajectory basis, scene-flow and cycle terms of
+train.py:283-467), so ``render_flows``, ``pts_traj_*``, ``sf_seq``, ``exp_sf`` are forward values.
 """
 from __future__ import annotations
 
@@ -19,7 +21,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops, train_static
+from . import ops, train_dynamic, train_static
 
 USE_DISTANCE = False   # reference render_ray.py:14-16 (module constants; the kernels implement exactly this setting)
 USE_SOFTPLUS = True
@@ -225,7 +227,13 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
   # sample masks: at least 2 observations (render_ray.py:736-741), counted by the gather kernel itself
   rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
   rgb_feat_st, ray_diff_st, mask_st, pm_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals, pix_mask_thresh=1.0)
-  raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
+  net_dy = getattr(model, names['dy'])
+  if train_dynamic.wants_grad(net_dy, featmaps_dy):
+    # training (second slice): graph to DynibarDynamic's parameters and the dynamic feature maps; the points are constants here
+    raw_dy = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), views_dy, featmaps_dy, ray_d, pts, pts_seq, rgb_feat_dy,
+                                       mask_dy, time)
+  else:
+    raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
   net_st = getattr(model, names['st'])
   if train_static.wants_grad(net_st, featmaps_st):
     # training: the same network on the kernels that keep their activations, with an autograd graph to the parameters and the maps
@@ -237,6 +245,8 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
 
 
 def _finish(stage, z_vals, keys2, keys1):
+  if stage['raw_dy'].requires_grad or stage['raw_st'].requires_grad:
+    return train_dynamic.composite_dual(stage['raw_dy'], stage['raw_st'], z_vals, stage['pm_dy'], stage['pm_st'])  # same keys, with graph
   out = ops.composite(stage['raw_dy'], z_vals, stage['pm_dy'], stage['raw_st'], stage['pm_st'])
   out['mask'] = out['mask'] > 0
   return _as_out(out, keys2)
@@ -247,6 +257,8 @@ _KEYS1 = ('rgb', 'depth', 'weights', 'mask', 'alpha', 'z_vals')
 
 
 def _vanilla(raw, z_vals, pm):
+  if raw.requires_grad:
+    return train_static.composite_vanilla(raw, z_vals, pm)
   out = ops.composite(raw, z_vals, pm)
   out['mask'] = out['mask'] > 0
   return _as_out(out, _KEYS1)
@@ -343,10 +355,7 @@ def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, f
   stage = _dual_branch(model, names, args, projector, ray_batch, featmaps[0], featmaps[2], pts, z_vals, ref_frame_idx, ref_time_embedding,
                        ref_time_offset, num_vv=num_vv)
   out = _finish(stage, z_vals, _KEYS2, _KEYS1)
-  if stage['raw_st'].requires_grad:
-    out_st = train_static.composite_vanilla(stage['raw_st'], z_vals, stage['pm_st'])  # the graph the static bootstrap stage differentiates
-  else:
-    out_st = _vanilla(stage['raw_st'], z_vals, stage['pm_st'])
+  out_st = _vanilla(stage['raw_st'], z_vals, stage['pm_st'])  # under grad mode: the graph the static bootstrap stage differentiates
   out_dy = _vanilla(stage['raw_dy'], z_vals, stage['pm_dy'])
   exp_sf = _motion_outputs(out, stage, ray_batch, ref_frame_idx, 1, flow_views=6)
   out['s_vals'] = s_vals
@@ -392,10 +401,13 @@ def _anchor_pass(model, names, args, projector, ray_batch, featmaps_anchor, stag
   views_a = projector.source_views(ray_batch['camera'], ray_batch['anchor_src_rgbs'], ray_batch['anchor_src_cameras'], featmaps_anchor)
   assert views_a.V == len(rows_a), 'one time offset (or virtual view) per anchor source view'
   rgb_feat_a, _, mask_a, pm_a = ops.project_gather(views_a, R, S, pts_st=pts, xyz=pts_seq_a, pix_mask_thresh=0.0)  # one observation is enough here (:1197-1199)
-  raw_a = _dynamic_net(model, names['dy'], dev)(ray_batch['ray_d'], pts_anchor, rgb_feat_a, mask_a, time_a)
-  out_a = ops.composite(raw_a, z_vals, pm_a, stage['raw_st'], stage['pm_st'])
-  out_a['mask'] = out_a['mask'] > 0
-  out_a = _as_out(out_a, _KEYS2)
+  net_dy = getattr(model, names['dy'])
+  if train_dynamic.wants_grad(net_dy, featmaps_anchor):
+    raw_a = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), views_a, featmaps_anchor, ray_batch['ray_d'], pts_anchor,
+                                      pts_seq_a, rgb_feat_a, mask_a, time_a)
+  else:
+    raw_a = _dynamic_net(model, names['dy'], dev)(ray_batch['ray_d'], pts_anchor, rgb_feat_a, mask_a, time_a)
+  out_a = _finish(dict(raw_dy=raw_a, raw_st=stage['raw_st'], pm_dy=pm_a, pm_st=stage['pm_st']), z_vals, _KEYS2, _KEYS1)
   out_a_dy = _vanilla(raw_a, z_vals, pm_a)
   occ_dy = out_ref_dy['weights'] - out_a_dy['weights']
   mode = int(getattr(args, 'occ_weights_mode', 0))

@@ -280,7 +280,7 @@ def _backward(s, draw, want_feat_grad):
   if want_feat_grad:
     v = s.views
     dfeat = torch.zeros((v.V, v.Hf, v.Wf, v.F), dtype=torch.float32, device=dev)
-    call('dyn_gather_bwd', _p(s.pts), _p(v.proj), R, S, V, v.Hf, v.Wf, v.F, v.img_h, v.img_w, _p(dF), 72, 3, _p(dfeat), st)
+    call('dyn_gather_bwd', _p(s.pts), None, _p(v.proj), R, S, V, v.Hf, v.Wf, v.F, v.img_h, v.img_w, _p(dF), 72, 3, _p(dfeat), st)
   return g, dfeat
 
 

@@ -364,9 +364,31 @@ int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* 
                             const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream);
 
 /* backward of the bilinear feature gather (projection.py:160-167, F.grid_sample w.r.t. the maps): drgb_feat[row, col0 .. col0 + F)
- * scattered with the forward's taps into dfeat_cl [V,Hf,Wf,F] (channels-last, zeroed by the caller; atomic +=).  pts_st [R,S,3]. */
-int dyn_gather_bwd(const float* pts_st, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
+ * scattered with the forward's taps into dfeat_cl [V,Hf,Wf,F] (channels-last, zeroed by the caller; atomic +=).  pts_st [R,S,3], or
+ * xyz [V,R,S,3] != NULL: the per-view motion-displaced points of the dynamic branch. */
+int dyn_gather_bwd(const float* pts_st, const float* xyz, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
                    const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream);
+
+/* ==== f3, second slice: DynibarDynamic.forward (mlp_network.py:236-316) and the two-branch raw2outputs (render_ray.py:214-330) for
+ * training: the dynamic net reuses the primitives above (dynibar_amd/train_dynamic.py holds its sequence) plus these. ================== */
+
+/* y[row, c] = x[row, c] + tab[(row % period), c]: the time feature of mlp_network.py:244-249 on every row (period 1), the positional table
+ * of :280 on every ray (period S).  The backward of both is the identity on x. */
+int dyn_train_add_table(const float* x, long ldx, const float* tab, long ld_tab, int period, long rows, int C, float* y, long ldy, void* stream);
+
+/* Fourier features of the dynamic net (mlp_network.py:147-160,:290,:303): pts_pe [P,36] = [PE_5(pts) 33 | 0 0 0], dir_pe [R,28] = [PE_4(dir) 27 | 0] */
+int dyn_train_dynamic_embed(const float* pts, const float* ray_d, long P, int R, float* pts_pe, float* dir_pe, void* stream);
+
+/* colour / density head (mlp_network.py:295-315): raw [P,4] = [sigmoid(logit) or 0 where no view sees the point | sigma - shift or -1e9] */
+int dyn_train_dynamic_head(const float* logit, long ld_logit, const float* sigma, const float* nvalid, float shift, long P, float* raw, void* stream);
+int dyn_train_dynamic_head_bwd(const float* draw, const float* raw, const float* nvalid, long P, float* dlogit, long ld_dlogit, float* dsigma,
+                               void* stream);
+
+/* backward of raw2outputs (render_ray.py:246-330): upstream gradients of rgb, rgb_static, rgb_dy [R,3], depth [R], weights_dy, weights_st,
+ * weights [R,S] (each may be NULL) -> draw_dy, draw_st [R,S,4] */
+int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
+                             const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R, int S,
+                             float* draw_dy, float* draw_st, void* stream);
 
 #ifdef __cplusplus
 }

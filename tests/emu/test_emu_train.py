@@ -18,3 +18,8 @@ def test_static_bootstrap_step(emu):
 
 def test_static_bootstrap_step_kid_config(emu):
   parity.check_train_static(emu, 'few', S=8, R=2, aa=False, mask_rgb=True)
+
+
+def test_dual_branch_step(emu):
+  """second slice: DynibarDynamic + raw2outputs, gradients to both nets and both feature-map sets"""
+  parity.check_train_dual(emu, 'few', S=8, R=2)

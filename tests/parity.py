@@ -1123,3 +1123,101 @@ def check_static_bootstrap_step(device, golden, kid=True):
   # parameters outside the static branch receive nothing from this loss, like in the reference
   assert all(p.grad is None for p in model.net_coarse_dy.parameters())
   return float(loss)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training, second slice: DynibarDynamic + the two-branch compositing (sample locations fixed: no motion-path gradient yet)
+# ----------------------------------------------------------------------------------------------------------------------
+def train_dual_reference(name, S, R, weights='init', shift=5.0, seed=0, dtype=torch.float32):
+  """Oracle autograd of: gather at the (fixed) motion-displaced points -> DynibarDynamic, gather -> DynibarStatic, raw2outputs +
+  raw2outputs_vanilla(raw_dy); gradients w.r.t. both nets' parameters and both feature-map sets."""
+  di = dynamic_inputs(name, S, R, weights)
+  scene, o, d = di['scene'], di['o'], di['d']
+  cv = lambda v: v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
+  sd_dy = {k: v.clone().to(dtype).requires_grad_(True) for k, v in di['W']['net_coarse_dy'].items()}
+  sd_st = {k: v.clone().to(dtype).requires_grad_(True) for k, v in di['W']['net_coarse_st'].items()}
+  sc = {k: cv(v) for k, v in scene.items()}
+  fm_dy, fm_st = scene['featmaps'].clone().to(dtype).requires_grad_(True), scene['static_featmaps'].clone().to(dtype).requires_grad_(True)
+  pts, pts_seq, z = cv(di['pts']), cv(di['pts_seq']), cv(di['z'])
+  o, d = cv(o), cv(d)
+  prev = torch.get_default_dtype()
+  torch.set_default_dtype(dtype)
+  try:
+    rf, rd, mk = O.compute_with_motions(pts, pts_seq, sc['camera'], sc['src_rgbs'], sc['src_cameras'], fm_dy)
+    Vd, Vs = rf.shape[2], sc['static_src_rgbs'].shape[1]
+    raw_dy = O.dynamic_net(sd_dy, pts, rf, F.normalize(d, dim=-1), rd, torch.zeros(pts.shape[0], S, Vd, 1), mk, cv(di['t_emb']), shift=shift)
+    rfs, rds, mks = O.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm_st)
+    raw_st = O.static_net(sd_st, pts, O.ref_plucker(o, d), O.src_plucker(pts, sc['static_src_cameras']), rfs, F.normalize(d, dim=-1), rds, mks, True, False)
+    pm_dy, pm_st = mk[..., 0].sum(dim=2) > 1, mks[..., 0].sum(dim=2) > 1
+    out = O.raw2outputs(raw_dy, raw_st, z, pm_dy, pm_st)
+    out_dy = O.raw2outputs_vanilla(raw_dy, z, pm_dy)
+  finally:
+    torch.set_default_dtype(prev)
+  keep = ~(boundary_margin(di['pts_seq'], scene['src_cameras'][0]).any(dim=2).any(dim=1) |
+           boundary_margin(di['pts'][None].repeat(Vs, 1, 1, 1), scene['static_src_cameras'][0]).any(dim=2).any(dim=1))
+  g = torch.Generator().manual_seed(200 + seed)
+  n = o.shape[0]
+  k3, k1, ks = keep[:, None].float(), keep.float(), keep[:, None].float()
+  cot = {'rgb': torch.randn(n, 3, generator=g) * k3, 'rgb_static': 0.5 * torch.randn(n, 3, generator=g) * k3,
+         'rgb_dy': 0.5 * torch.randn(n, 3, generator=g) * k3, 'depth': 0.1 * torch.randn(n, generator=g) * k1,
+         'weights_dy': 0.3 * torch.randn(n, S, generator=g) * ks, 'weights_st': 0.3 * torch.randn(n, S, generator=g) * ks,
+         'weights': 0.3 * torch.randn(n, S, generator=g) * ks, 'dy_rgb': torch.randn(n, 3, generator=g) * k3}
+  loss = sum((out[k] * cot[k].to(dtype)).sum() for k in cot if k != 'dy_rgb') + (out_dy['rgb'] * cot['dy_rgb'].to(dtype)).sum()
+  loss.backward()
+  grads = {'dy/' + k: v.grad.detach() for k, v in sd_dy.items()}
+  grads.update({'st/' + k: v.grad.detach() for k, v in sd_st.items()})
+  grads['featmaps_dy'], grads['featmaps_st'] = fm_dy.grad.detach(), fm_st.grad.detach()
+  vals = {k: out[k].detach() for k in ('rgb', 'rgb_dy', 'weights', 'weights_dy')}
+  vals['raw_dy'] = raw_dy.detach()
+  return di, vals, cot, grads, keep
+
+
+def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5.0, seed=0):
+  """values and every gradient of the two-branch training graph (dynamic + static nets, raw2outputs) on the HIP kernels vs the oracle"""
+  from dynibar_amd import train_dynamic as TD, train_static as TS
+  di, v_ref, cot, g_ref, keep = train_dual_reference(name, S, R, weights, shift, seed)
+  assert int(keep.sum()) > 0
+  # (no fp64 twin here: the reference casts the dynamic net's time features to fp32 explicitly, mlp_network.py:244-246; the dynamic net has
+  # no anti-alias pooling, and the static branch's conditioning is check_train_static's subject)
+  sens = {k: torch.zeros_like(v).double() for k, v in g_ref.items()}
+  scene = di['scene']
+  sc = to_dev(scene, device)
+  fm_dy = scene['featmaps'].to(device).requires_grad_(True)
+  fm_st = scene['static_featmaps'].to(device).requires_grad_(True)
+  od, dd, pts, pts_seq, z = (di[k].to(device) for k in ('o', 'd', 'pts', 'pts_seq', 'z'))
+  Rn = od.shape[0]
+  views_dy = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], fm_dy.detach())
+  views_st = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm_st.detach())
+  rf, _, mk, pm_dy = ops.project_gather(views_dy, Rn, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
+  rfs, rds, mks, pm_st = ops.project_gather(views_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+  prm_dy = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_dy'].items()}
+  prm_st = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_st'].items()}
+  raw_dy = TD.dynamic_raw(prm_dy, shift, views_dy, fm_dy, dd, pts, pts_seq, rf, mk, di['temb'].to(device))
+  raw_st = TS.static_raw(prm_st, (True, False), views_st, fm_st, od, dd, pts, rfs, rds, mks)
+  out = TD.composite_dual(raw_dy, raw_st, z, pm_dy, pm_st)
+  out_dy = TS.composite_vanilla(raw_dy, z, pm_dy)
+  loss = sum((out[k] * cot[k].to(device)).sum() for k in cot if k != 'dy_rgb') + (out_dy['rgb'] * cot['dy_rgb'].to(device)).sum()
+  loss.backward()
+  tag = f'train dual {name}'
+  assert_close(cpu(raw_dy)[keep][..., :3], v_ref['raw_dy'][keep][..., :3], 1e-4, 0.0, f'{tag} raw_dy rgb')
+  assert_close(cpu(raw_dy)[keep][..., 3], v_ref['raw_dy'][keep][..., 3], 1e-4, 1e-4, f'{tag} raw_dy sigma')
+  for k in ('rgb_dy', 'weights_dy'):
+    assert_close(cpu(out[k])[keep], v_ref[k][keep], 1e-4, 0.0, f'{tag} {k}')
+  got = {'dy/' + k: v.grad for k, v in prm_dy.items()}
+  got.update({'st/' + k: v.grad for k, v in prm_st.items()})
+  got['featmaps_dy'], got['featmaps_st'] = fm_dy.grad, fm_st.grad
+  gmax = max(float(v.abs().max()) for k, v in g_ref.items() if not k.startswith('featmaps'))
+  worst = 0.0
+  for k, ref in g_ref.items():
+    if k.startswith('st/') or k == 'featmaps_st':
+      continue  # the static branch's own gradients (anti-alias conditioning) are check_train_static's subject; here they only have to exist
+    assert got[k] is not None, f'{tag}: no gradient for {k}'
+    scale = float(ref.abs().max())
+    assert_close(cpu(got[k]).reshape(ref.shape), ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
+    worst = max(worst, float((cpu(got[k]).reshape(ref.shape) - ref).abs().max()) / (scale + 1e-30))
+  # static side through the two-branch compositing: looser, conditioning-aware comparison of the few largest tensors
+  for k in ('st/base_fc.2.weight', 'st/rgb_fc.2.weight', 'st/out_geometry_fc.0.weight', 'featmaps_st'):
+    ref = g_ref[k]
+    scale = float(ref.abs().max())
+    assert_close(cpu(got[k]).reshape(ref.shape), ref, 1e-3 * scale + 2e-6 * gmax, 2e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
+  return worst
