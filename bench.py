@@ -282,7 +282,7 @@ def main():
         # section 8(f)3, first slice: one static bootstrap training step (train.py:116-199) at the reference's training shape
         # (configs/train_kid-running.txt: N_rand 3072, 64 samples, 15 static views, anti_alias_pooling 0, mask_rgb 1): forward with saved
         # activations + backward through the dyn_train_* kernels into DynibarStatic's parameters and the static feature maps
-        from dynibar_amd import ops as _ops, synthetic as syn, train_static as TS
+        from dynibar_amd import ops as _ops, synthetic as syn, train_motion as TM, train_static as TS
         Rt, St, Vt = 3072, 64, 15
         sc = syn.make_scene(seed=21, H=H, W=W, V=7, n_static=Vt, smooth=False)
         td = lambda x: torch.from_numpy(x).to(dev)
@@ -296,8 +296,8 @@ def main():
 
         def train_step():
           pts_, z_, _s = _ops.sample_along_ray(to_, td_, tdr, St, True)
-          rf_, rd_, mk_, pm_ = _ops.project_gather(tviews, Rt, St, ray_o=to_, ray_d=td_, z_vals=z_, pix_mask_thresh=1.0)
-          raw_ = TS.static_raw(prm, (False, True), tviews, fm, to_, td_, pts_, rf_, rd_, mk_)
+          rf_, rd_, mk_, pm_ = TM.gather(tviews, fm, Rt, St, ray_o=to_, ray_d=td_, z_vals=z_, pix_mask_thresh=1.0)
+          raw_ = TS.static_raw(prm, (False, True), tviews, rf_, to_, td_, pts_, rd_, mk_)
           (TS.composite_vanilla(raw_, z_, pm_)['rgb'] * cot).sum().backward()
 
         train_step(); train_step(); fence()

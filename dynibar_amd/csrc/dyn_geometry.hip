@@ -827,6 +827,87 @@ extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward of the gather w.r.t. the sample LOCATIONS (training, third slice: the motion path; the autograd of F.grid_sample w.r.t. its
+// grid, of normalize() and of compute_projections, projection.py:32-59,:134-167): d rgb_feat[row, 0:3+F] -> d xyz[v, point, 0:3].
+// For one map, val_c = (1-fy)[(1-fx) NW_c + fx NE_c] + fy [(1-fx) SW_c + fx SE_c] with zero-valued corners outside the map, so
+//   d val_c / d ix = (1-fy)(NE_c - NW_c) + fy (SE_c - SW_c),   d val_c / d iy = (1-fx)(SW_c - NW_c) + fx (SE_c - NE_c);
+// ix = (nx + 1)(W_m - 1)/2, nx = 2 px / (w - 1) - 1, px = clamp(hx / max(hz, 1e-8)), h = P [x y z 1]^T.  One thread per (point, view).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tap_grad(const float* __restrict__ map, int Wm, int Hm, int C, float nx, float ny, const float* __restrict__ d,
+                                         float& gnx, float& gny) {
+  const float ix = safe_floor_coord((nx + 1.0f) * ((float)(Wm - 1) / 2.0f), (float)Wm);
+  const float iy = safe_floor_coord((ny + 1.0f) * ((float)(Hm - 1) / 2.0f), (float)Hm);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float fx = ix - fx0, fy = iy - fy0;
+  const bool x0ok = (x0 >= 0) && (x0 < Wm), x1ok = (x0 + 1 >= 0) && (x0 + 1 < Wm);
+  const bool y0ok = (y0 >= 0) && (y0 < Hm), y1ok = (y0 + 1 >= 0) && (y0 + 1 < Hm);
+  const float* nw = map + ((long)iclamp(y0, Hm - 1) * Wm + iclamp(x0, Wm - 1)) * C;
+  const float* ne = map + ((long)iclamp(y0, Hm - 1) * Wm + iclamp(x0 + 1, Wm - 1)) * C;
+  const float* sw = map + ((long)iclamp(y0 + 1, Hm - 1) * Wm + iclamp(x0, Wm - 1)) * C;
+  const float* se = map + ((long)iclamp(y0 + 1, Hm - 1) * Wm + iclamp(x0 + 1, Wm - 1)) * C;
+  const float m_nw = (x0ok && y0ok) ? 1.f : 0.f, m_ne = (x1ok && y0ok) ? 1.f : 0.f, m_sw = (x0ok && y1ok) ? 1.f : 0.f, m_se = (x1ok && y1ok) ? 1.f : 0.f;
+  float gix = 0.f, giy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float a = nw[c] * m_nw, b = ne[c] * m_ne, e = sw[c] * m_sw, f = se[c] * m_se;
+    gix += d[c] * ((1.0f - fy) * (b - a) + fy * (f - e));
+    giy += d[c] * ((1.0f - fx) * (e - a) + fx * (f - b));
+  }
+  gnx += gix * ((float)(Wm - 1) / 2.0f);
+  gny += giy * ((float)(Hm - 1) / 2.0f);
+}
+
+__global__ void __launch_bounds__(256) k_gather_bwd_pts(PGShape q, const float* __restrict__ pts_st, const float* __restrict__ xyz,
+                                                        const float4* __restrict__ proj4, const float* __restrict__ src_rgb,
+                                                        const float* __restrict__ feat_cl, const float* __restrict__ drgb_feat, long ld_d,
+                                                        float* __restrict__ dxyz) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= q.N) return;
+  const long rs = row / q.V;
+  const int v = (int)(row - rs * q.V);
+  const float* pt = xyz != nullptr ? xyz + ((long)v * q.R * q.S + rs) * 3 : pts_st + rs * 3;
+  const float x = pt[0], y = pt[1], z3 = pt[2];
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  const float izc = 1.0f / zc;
+  const float pxu = hx * izc, pyu = hy * izc;
+  const float px = fminf(fmaxf(pxu, -1e6f), 1e6f), py = fminf(fmaxf(pyu, -1e6f), 1e6f);
+  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
+  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float* d = drgb_feat + row * ld_d;
+  float gnx = 0.f, gny = 0.f;
+  tap_grad(src_rgb + (long)v * q.H * q.W * 3, q.W, q.H, 3, nx, ny, d, gnx, gny);
+  tap_grad(feat_cl + (long)v * q.Hf * q.Wf * q.F, q.Wf, q.Hf, q.F, nx, ny, d + 3, gnx, gny);
+  const float gpx = (pxu >= -1e6f && pxu <= 1e6f) ? gnx * 2.0f * q.inv_wm1 : 0.f;
+  const float gpy = (pyu >= -1e6f && pyu <= 1e6f) ? gny * 2.0f * q.inv_hm1 : 0.f;
+  const float ghx = gpx * izc, ghy = gpy * izc;
+  const float ghz = hz > 1e-8f ? -(gpx * hx + gpy * hy) * izc * izc : 0.f;
+  float* o = dxyz + ((long)v * q.R * q.S + rs) * 3;
+  o[0] = P0.x * ghx + P1.x * ghy + P2.x * ghz;
+  o[1] = P0.y * ghx + P1.y * ghy + P2.y * ghz;
+  o[2] = P0.z * ghx + P1.z * ghy + P2.z * ghz;
+}
+
+extern "C" int dyn_gather_bwd_pts(const float* pts_st, const float* xyz, const float* proj, const float* src_rgb, const float* feat_cl, int R, int S,
+                                  int V, int H, int W, int Hf, int Wf, int F, float img_h, float img_w, const float* drgb_feat, long ld_d,
+                                  float* dxyz, void* stream) {
+  DYN_REQUIRE((pts_st || xyz) && proj && src_rgb && feat_cl && drgb_feat && dxyz, "dyn_gather_bwd_pts: null pointer");
+  DYN_REQUIRE(R > 0 && S > 0 && V > 0 && H > 1 && W > 1 && Hf > 1 && Wf > 1 && F > 0, "dyn_gather_bwd_pts: bad shape");
+  PGShape q;
+  q.R = R; q.S = S; q.V = V; q.H = H; q.W = W; q.Hf = Hf; q.Wf = Wf; q.F = F;
+  q.img_h = img_h; q.img_w = img_w;
+  q.inv_wm1 = 1.0f / (img_w - 1.0f); q.inv_hm1 = 1.0f / (img_h - 1.0f);
+  q.N = (long)R * S * V;
+  q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
+  DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd_pts", k_gather_bwd_pts, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q,
+             pts_st, xyz, reinterpret_cast<const float4*>(proj), src_rgb, feat_cl, drgb_feat, ld_d, dxyz);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K5: DCT-basis trajectory points  (render_ray.py:361-369, :686-709)
 // ---------------------------------------------------------------------------------------------------------------
 struct TrajRows {
@@ -923,6 +1004,99 @@ extern "C" int dyn_render_flows(const float* weights, const float* pts_seq, cons
   DYN_REQUIRE(weights && pts_seq && proj && uv && flows && R > 0 && S > 0 && V > 0, "dyn_render_flows: bad argument");
   DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_render_flows", k_render_flows, dim3(dyn_cdiv((long)V * R, 4)), dim3(256), 0, (hipStream_t)stream, weights,
              pts_seq, proj, uv, R, S, V, flows);
+  return 0;
+}
+
+// Backward of the trajectory points (training, third slice): pts_seq[v, p, a] = pts[p, a] + sum_b coeff[p, a B + b] (basis[row_v, b] -
+// basis[ref, b]) for row_v >= 0, = pts[p, a] otherwise.  d coeff and d pts are per point; d basis is reduced per workgroup in LDS and added
+// to the global table (zeroed by the caller) with atomics.
+__global__ void __launch_bounds__(256) k_trajectory_bwd(const float* __restrict__ dseq, const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                        long n_pts, int B, TrajRows tr, float* __restrict__ dcoeff, float* __restrict__ dbasis,
+                                                        float* __restrict__ dpts) {
+  float* acc = reinterpret_cast<float*>(dyn_smem);  // [(n + 1)][B]: per trajectory row, last = the reference row
+  const int tid = threadIdx.x;
+  for (int e = tid; e < (tr.n + 1) * B; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  const long p = (long)blockIdx.x * 256 + tid;
+  if (p < n_pts) {
+    float dp[3] = {0.f, 0.f, 0.f};
+    for (int e = 0; e < 3 * B; ++e) dcoeff[p * 3 * B + e] = 0.f;
+    for (int v = 0; v < tr.n; ++v) {
+      const float* d = dseq + ((long)v * n_pts + p) * 3;
+      const int row = tr.rows[v];
+      for (int a = 0; a < 3; ++a) {
+        dp[a] += d[a];
+        if (row >= 0) {
+          for (int b = 0; b < B; ++b) {
+            dcoeff[p * 3 * B + a * B + b] += d[a] * (basis[(long)row * B + b] - basis[(long)tr.ref * B + b]);
+            const float t = d[a] * coeff[p * 3 * B + a * B + b];
+            atomicAdd(acc + v * B + b, t);
+            atomicAdd(acc + tr.n * B + b, -t);
+          }
+        }
+      }
+    }
+    if (dpts != nullptr)
+      for (int a = 0; a < 3; ++a) dpts[p * 3 + a] = dp[a];
+  }
+  __syncthreads();
+  for (int e = tid; e < (tr.n + 1) * B; e += 256) {
+    const int v = e / B, b = e % B;
+    const int row = v < tr.n ? tr.rows[v] : tr.ref;
+    if (row >= 0 && acc[e] != 0.f) atomicAdd(dbasis + (long)row * B + b, acc[e]);
+  }
+}
+extern "C" int dyn_trajectory_bwd(const float* dseq, const float* coeff, const float* basis, long n_pts, int B, const int* rows, int n_rows,
+                                  int row_ref, float* dcoeff, float* dbasis, float* dpts, void* stream) {
+  DYN_REQUIRE(dseq && coeff && basis && rows && dcoeff && dbasis, "dyn_trajectory_bwd: null pointer");
+  DYN_REQUIRE(n_pts > 0 && B > 0 && n_rows > 0 && n_rows <= 32 && row_ref >= 0, "dyn_trajectory_bwd: bad argument");
+  TrajRows tr;
+  tr.n = n_rows; tr.ref = row_ref;
+  for (int i = 0; i < 32; ++i) tr.rows[i] = i < n_rows ? rows[i] : -1;
+  DYN_LAUNCH(DYN_K_TRAJECTORY, "dyn_trajectory_bwd", k_trajectory_bwd, dim3(dyn_cdiv(n_pts, 256)), dim3(256), (size_t)(n_rows + 1) * B * sizeof(float),
+             (hipStream_t)stream, dseq, coeff, basis, n_pts, B, tr, dcoeff, dbasis, dpts);
+  return 0;
+}
+
+// Backward of the expected optical flow (render_ray.py:333-358): flows[v, r] = pi(P_v E) - uv, E = sum_s w[r, s] q[v, r, s].
+// dE = J^T dflow; dw[r, s] = sum_v dE_v . q[v, r, s]; dq[v, r, s] = w[r, s] dE_v.  One wavefront per ray, lanes over samples.
+__global__ void __launch_bounds__(256) k_render_flows_bwd(const float* __restrict__ dflows, const float* __restrict__ weights,
+                                                          const float* __restrict__ pts_seq, const float* __restrict__ proj, int R, int S, int V,
+                                                          float* __restrict__ dweights, float* __restrict__ dseq) {
+  const int lane = dyn_lane();
+  const int r = blockIdx.x * 4 + dyn_wave();
+  if (r >= R) return;
+  for (int s = lane; s < S; s += 64) dweights[(long)r * S + s] = 0.f;
+  for (int v = 0; v < V; ++v) {
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float wt = weights[(long)r * S + s];
+      const float* q = pts_seq + (((long)v * R + r) * S + s) * 3;
+      ex += wt * q[0]; ey += wt * q[1]; ez += wt * q[2];
+    }
+    ex = wave_sum(ex); ey = wave_sum(ey); ez = wave_sum(ez);
+    const float* P = proj + v * 16;
+    const float hx = P[0] * ex + P[1] * ey + P[2] * ez + P[3];
+    const float hy = P[4] * ex + P[5] * ey + P[6] * ez + P[7];
+    const float hz = P[8] * ex + P[9] * ey + P[10] * ez + P[11];
+    const float gx = dflows[((long)v * R + r) * 2], gy = dflows[((long)v * R + r) * 2 + 1];
+    const float ghx = gx / hz, ghy = gy / hz, ghz = -(gx * hx + gy * hy) / (hz * hz);
+    const float dEx = P[0] * ghx + P[4] * ghy + P[8] * ghz;
+    const float dEy = P[1] * ghx + P[5] * ghy + P[9] * ghz;
+    const float dEz = P[2] * ghx + P[6] * ghy + P[10] * ghz;
+    for (int s = lane; s < S; s += 64) {
+      const long o = (((long)v * R + r) * S + s) * 3;
+      const float wt = weights[(long)r * S + s];
+      dweights[(long)r * S + s] += dEx * pts_seq[o] + dEy * pts_seq[o + 1] + dEz * pts_seq[o + 2];
+      dseq[o] = wt * dEx; dseq[o + 1] = wt * dEy; dseq[o + 2] = wt * dEz;
+    }
+  }
+}
+extern "C" int dyn_render_flows_bwd(const float* dflows, const float* weights, const float* pts_seq, const float* proj, int R, int S, int V,
+                                    float* dweights, float* dseq, void* stream) {
+  DYN_REQUIRE(dflows && weights && pts_seq && proj && dweights && dseq && R > 0 && S > 0 && V > 0, "dyn_render_flows_bwd: bad argument");
+  DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_render_flows_bwd", k_render_flows_bwd, dim3(dyn_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, dflows, weights,
+             pts_seq, proj, R, S, V, dweights, dseq);
   return 0;
 }
 

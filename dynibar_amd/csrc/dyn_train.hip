@@ -244,6 +244,14 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
           acc[i][j][r] = v > 0.f ? v : (v > -0.01f ? q : e);
         }
   }
+  if (g.act == 2) {  // ReLU (MotionMLP)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+  }
   const bool okA = nA < g.N, okB = nB < g.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -319,6 +327,9 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
         const float yv = y[r * ld_y + c];
         d = yv > 0.f ? d : d * (yv + 1.0f);
         dy[r * ld_dy + c] = d;
+      } else if (act == 2) {  // ReLU
+        d = y[r * ld_y + c] > 0.f ? d : 0.f;
+        dy[r * ld_dy + c] = d;
       }
       colsum += d;
       if (dseg != nullptr) {
@@ -337,7 +348,7 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
 extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg,
                                  float* dseg, long ld_seg, void* stream) {
   DYN_REQUIRE(dY != nullptr && rows > 0 && cols > 0, "dyn_train_act_bwd: bad arguments");
-  DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_act_bwd: ELU backward needs the saved output");
+  DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_act_bwd: ELU / ReLU backward needs the saved output");
   DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
   const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
   int run = dseg != nullptr ? seg : 1;
@@ -1216,5 +1227,82 @@ extern "C" int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st
   DYN_REQUIRE(raw_dy && raw_st && z_vals && draw_dy && draw_st && R > 0 && S > 0, "dyn_train_composite2_bwd: bad arguments");
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw_dy,
              raw_st, z_vals, g_rgb, g_rgb_st, g_rgb_dy, g_depth, g_wd, g_ws, g_w, R, S, draw_dy, draw_st);
+  return 0;
+}
+
+
+// =====================================================================================================================
+// Third slice: the motion path.  Generic Fourier features with their backward w.r.t. the input (PeriodicEmbed, mlp_network.py:530-555:
+// out = [x | cos(f_0 x) .. cos(f_{NF-1} x) | sin(f_0 x) .. ], x of D columns), and the zeroing of the last samples of every ray
+// (render_ray.py:961, :1129).  MotionMLP itself is the GEMM with ReLU (act 2) over these.
+// =====================================================================================================================
+struct TrFreqs {
+  int n;
+  float f[16];
+};
+__global__ void __launch_bounds__(256) k_train_embed(const float* __restrict__ x, long ldx, long rows, int D, TrFreqs fr, float* __restrict__ out, long ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / D;
+  const int d = (int)(idx - row * D);
+  if (row >= rows) return;
+  const float v = x[row * ldx + d];
+  float* o = out + row * ld;
+  o[d] = v;
+  for (int k = 0; k < fr.n; ++k) {
+    float sn, cs;
+    sincosf(fr.f[k] * v, &sn, &cs);
+    o[D + k * D + d] = cs;
+    o[D + fr.n * D + k * D + d] = sn;
+  }
+}
+__global__ void __launch_bounds__(256) k_train_embed_bwd(const float* __restrict__ x, long ldx, long rows, int D, TrFreqs fr, const float* __restrict__ dout,
+                                                         long ld, float* __restrict__ dx, long ld_dx, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx / D;
+  const int d = (int)(idx - row * D);
+  if (row >= rows) return;
+  const float v = x[row * ldx + d];
+  const float* g = dout + row * ld;
+  float acc = g[d];
+  for (int k = 0; k < fr.n; ++k) {
+    float sn, cs;
+    sincosf(fr.f[k] * v, &sn, &cs);
+    acc += fr.f[k] * (cs * g[D + fr.n * D + k * D + d] - sn * g[D + k * D + d]);
+  }
+  if (accumulate) dx[row * ld_dx + d] += acc; else dx[row * ld_dx + d] = acc;
+}
+static int tr_freqs(const float* freqs, int n, TrFreqs& fr) {
+  if (freqs == nullptr || n < 0 || n > 16) return 1;
+  fr.n = n;
+  for (int i = 0; i < 16; ++i) fr.f[i] = i < n ? freqs[i] : 0.f;
+  return 0;
+}
+extern "C" int dyn_train_embed(const float* x, long ldx, long rows, int D, const float* freqs, int n_freqs, float* out, long ld, void* stream) {
+  TrFreqs fr;
+  DYN_REQUIRE(x && out && rows > 0 && D > 0 && tr_freqs(freqs, n_freqs, fr) == 0 && ld >= (long)D * (1 + 2 * n_freqs), "dyn_train_embed: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_embed", k_train_embed, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, D,
+             fr, out, ld);
+  return 0;
+}
+extern "C" int dyn_train_embed_bwd(const float* x, long ldx, long rows, int D, const float* freqs, int n_freqs, const float* dout, long ld, float* dx,
+                                   long ld_dx, int accumulate, void* stream) {
+  TrFreqs fr;
+  DYN_REQUIRE(x && dout && dx && rows > 0 && D > 0 && tr_freqs(freqs, n_freqs, fr) == 0, "dyn_train_embed_bwd: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_embed_bwd", k_train_embed_bwd, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+             rows, D, fr, dout, ld, dx, ld_dx, accumulate);
+  return 0;
+}
+
+// x[r, s, :] = 0 for the last n_last samples of every ray (forward of raw_coeff[:, -n:, :] *= 0 and its backward), then the rest scaled
+__global__ void __launch_bounds__(256) k_train_zero_tail(float* __restrict__ x, long R, int S, int C, int n_last, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * S * C) return;
+  const int s = (int)((idx / C) % S);
+  x[idx] = s >= S - n_last ? 0.f : x[idx] * scale;
+}
+extern "C" int dyn_train_zero_tail(float* x, long R, int S, int C, int n_last, float scale, void* stream) {
+  DYN_REQUIRE(x && R > 0 && S > 0 && C > 0 && n_last >= 0 && n_last <= S, "dyn_train_zero_tail: bad arguments");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_zero_tail", k_train_zero_tail, dim3((unsigned)((R * S * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, R, S,
+             C, n_last, scale);
   return 0;
 }

@@ -10,9 +10,11 @@ Scope: forward rendering, plus two slices of the backward
 feature maps require grad, ``render_rays_mono`` evaluates DynibarStatic / DynibarDynamic and both compositing functions through
 ``dynibar_amd.train_static`` / ``train_dynamic`` (HIP training kernels with hand-written backward): the colour / depth / weight
 outputs of ``outputs_coarse_st``, ``outputs_coarse_ref``, ``outputs_coarse_ref_dy`` (and of the anchor pass) then carry a graph to both
-nets' parameters and to the feature maps -- the reference's static bootstrap stage (train.py:116-199) runs unchanged.  NOT yet
-differentiable: anything w.r.t. the sample *locations* (the motion path: MotionMLP, trajectory basis, scene-flow and cycle terms of
-train.py:283-467), so ``render_flows``, ``pts_traj_*``, ``sf_seq``, ``exp_sf`` are forward values.
+nets' parameters and to the feature maps, and -- third slice, ``train_motion`` -- the motion path does too: MotionMLP, the trajectory
+points (``pts_traj_*``, ``sf_seq``), the gather w.r.t. the displaced points and ``render_flows`` are autograd Functions over HIP kernels,
+so ``motion_mlp`` and ``trajectory_basis`` receive their gradients.  The reference's static bootstrap stage (train.py:116-199) and its
+main loop's ``loss.backward()`` (train.py:283-467) run on this path; ``exp_sf`` and the disocclusion weights are detached exactly where
+the reference detaches them.
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops, train_dynamic, train_static
+from . import ops, train_dynamic, train_motion, train_static
 
 USE_DISTANCE = False   # reference render_ray.py:14-16 (module constants; the kernels implement exactly this setting)
 USE_SOFTPLUS = True
@@ -207,38 +209,64 @@ def raw2outputs(raw_dy, raw_static, z_vals, mask_dy, mask_static, raw_noise_std=
 # ----------------------------------------------------------------------------------------------------------------------
 # one dynamic + static evaluation at given sample points (the body shared by render_ray.py:672-784, :461-597, :948-1098)
 # ----------------------------------------------------------------------------------------------------------------------
+def _needs_graph(*tensors):
+  return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _traj(coeff, basis, pts, rows, row_ref):
+  """k_trajectory_points; with a graph (train_motion.TrajectoryFunction) when the coefficients, the basis or the points carry one"""
+  if _needs_graph(coeff, basis, pts):
+    return train_motion.trajectory_points(coeff, basis, pts, rows, row_ref)
+  return ops.trajectory_points(coeff, basis, pts, rows, row_ref)
+
+
+def _coeff(model, name, dev, num_basis, pts, time, n_zero):
+  """MotionMLP coefficients; through the training kernels when MotionMLP's parameters (or the points) take part in a graph"""
+  net = getattr(model, name)
+  if train_motion.wants_grad(net) or _needs_graph(pts):
+    return train_motion.motion_coeff(net, pts, time, n_zero, float(getattr(_unwrap(net), 'sf_mag_div', 1.0)))
+  return _motion_mlp(model, name, dev, num_basis)(pts, time, n_zero)
+
+
+def _gather(views, featmaps, R, S, thresh, xyz=None, **kw):
+  if _needs_graph(featmaps, xyz):
+    return train_motion.gather(views, featmaps, R, S, xyz=xyz, pix_mask_thresh=thresh, **kw)
+  return ops.project_gather(views, R, S, xyz=xyz, pix_mask_thresh=thresh, **kw)
+
+
 def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps_st, pts, z_vals, ref_frame_idx, ref_time_embedding,
                  ref_time_offset, num_vv=0):
   dev = pts.device
   ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
   R, S = z_vals.shape
-  basis = getattr(model, names['basis']).detach()
+  basis = getattr(model, names['basis'])
+  if not _needs_graph(basis):
+    basis = basis.detach()
   num_basis = basis.shape[1]
   n_last = int(round(S * 0.1))
   time = ref_time_embedding.reshape(-1)[:1].to(dev).float()
   # raw_coeff[:, -n_last:, :] *= 0 : with n_last == 0 the reference's slice [-0:] is the whole array (render_ray.py:684)
-  coeff = _motion_mlp(model, names['motion'], dev, num_basis)(pts, time, n_last if n_last > 0 else S)
+  coeff = _coeff(model, names['motion'], dev, num_basis, pts, time, n_last if n_last > 0 else S)
   nf = basis.shape[0]
   rows = [(int(ref_frame_idx) + int(o)) % nf for o in ref_time_offset] + [-1] * num_vv  # negative rows wrap like basis[idx] does
-  pts_seq = ops.trajectory_points(coeff, basis, pts, rows, int(ref_frame_idx) % nf)
+  pts_seq = _traj(coeff, basis, pts, rows, int(ref_frame_idx) % nf)
   views_dy = projector.source_views(ray_batch['camera'], ray_batch['src_rgbs'], ray_batch['src_cameras'], featmaps_dy)
   views_st = projector.source_views(ray_batch['camera'], ray_batch['static_src_rgbs'], ray_batch['static_src_cameras'], featmaps_st)
   assert views_dy.V == len(rows), 'one time offset (or virtual view) per dynamic source view'
   # sample masks: at least 2 observations (render_ray.py:736-741), counted by the gather kernel itself
-  rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
-  rgb_feat_st, ray_diff_st, mask_st, pm_st = ops.project_gather(views_st, R, S, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals, pix_mask_thresh=1.0)
+  rgb_feat_dy, _, mask_dy, pm_dy = _gather(views_dy, featmaps_dy, R, S, 1.0, xyz=pts_seq, pts_st=pts)
+  rgb_feat_st, ray_diff_st, mask_st, pm_st = _gather(views_st, featmaps_st, R, S, 1.0, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals)
   net_dy = getattr(model, names['dy'])
-  if train_dynamic.wants_grad(net_dy, featmaps_dy):
-    # training (second slice): graph to DynibarDynamic's parameters and the dynamic feature maps; the points are constants here
-    raw_dy = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), views_dy, featmaps_dy, ray_d, pts, pts_seq, rgb_feat_dy,
-                                       mask_dy, time)
+  if train_dynamic.wants_grad(net_dy, rgb_feat_dy):
+    # training: graph to DynibarDynamic's parameters, the gathered features (maps, displaced points) and the points
+    raw_dy = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), rgb_feat_dy, ray_d, pts, mask_dy, time)
   else:
     raw_dy = _dynamic_net(model, names['dy'], dev)(ray_d, pts, rgb_feat_dy, mask_dy, time)
   net_st = getattr(model, names['st'])
-  if train_static.wants_grad(net_st, featmaps_st):
+  if train_static.wants_grad(net_st, rgb_feat_st):
     # training: the same network on the kernels that keep their activations, with an autograd graph to the parameters and the maps
     flags = (_flag(net_st, args, 'anti_alias_pooling', True), _flag(net_st, args, 'mask_rgb', False))
-    raw_st = train_static.static_raw(net_st, flags, views_st, featmaps_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
+    raw_st = train_static.static_raw(net_st, flags, views_st, rgb_feat_st, ray_o, ray_d, pts, ray_diff_st, mask_st)
   else:
     raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
   return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis)
@@ -269,14 +297,17 @@ def _motion_outputs(out, stage, ray_batch, ref_frame_idx, sf_off, flow_views=Non
   R, S = out['weights'].shape
   views = stage['views_dy']
   fv = stage['pts_seq'].shape[0] if flow_views is None else min(flow_views, stage['pts_seq'].shape[0])
-  flows = torch.empty((fv, R, 2), dtype=torch.float32, device=out['weights'].device)
   uv = ray_batch['uv_grid'].float().contiguous()
-  ops.call('dyn_render_flows', ops.ptr(out['weights']), ops.ptr(stage['pts_seq']), ops.ptr(views.proj), ops.ptr(uv), R, S, fv, ops.ptr(flows),
-           ops.stream_of(flows))
+  if _needs_graph(out['weights'], stage['pts_seq']):
+    flows = train_motion.render_flows(out['weights'], stage['pts_seq'][:fv], views.proj, uv)  # (a slice of leading views is contiguous)
+  else:
+    flows = torch.empty((fv, R, 2), dtype=torch.float32, device=out['weights'].device)
+    ops.call('dyn_render_flows', ops.ptr(out['weights']), ops.ptr(stage['pts_seq']), ops.ptr(views.proj), ops.ptr(uv), R, S, fv, ops.ptr(flows),
+             ops.stream_of(flows))
   out['render_flows'] = flows
   exp_sf = torch.empty((R, 3), dtype=torch.float32, device=flows.device)
-  basis = stage['basis'].float().contiguous()
-  ops.call('dyn_expected_scene_flow', ops.ptr(out['weights']), ops.ptr(stage['coeff']), ops.ptr(basis), R, S, basis.shape[1],
+  basis = stage['basis'].detach().float().contiguous()  # exp_sf is detached in the reference (:1096)
+  ops.call('dyn_expected_scene_flow', ops.ptr(out['weights'].detach()), ops.ptr(stage['coeff'].detach()), ops.ptr(basis), R, S, basis.shape[1],
            (int(ref_frame_idx) + sf_off) % basis.shape[0], (int(ref_frame_idx) - sf_off) % basis.shape[0], int(ref_frame_idx) % basis.shape[0],
            ops.ptr(exp_sf), ops.stream_of(exp_sf))
   return exp_sf
@@ -387,29 +418,28 @@ def _anchor_pass(model, names, args, projector, ray_batch, featmaps_anchor, stag
   n_last = int(round(S * 0.1))
   coeff = stage['coeff']
   # scene flow between consecutive frames around the reference time (:1101-1105): differences of (traj[o] - traj[0]), o = -3..3
-  rel = ops.trajectory_points(coeff, basis, torch.zeros_like(pts), [(r + o) % nf for o in range(-3, 4)], r % nf)
+  rel = _traj(coeff, basis, torch.zeros_like(pts), [(r + o) % nf for o in range(-3, 4)], r % nf)
   sf_seq = rel[1:7] - rel[0:6]
-  pts_anchor = ops.trajectory_points(coeff, basis, pts, [a % nf], r % nf)[0]
+  pts_anchor = _traj(coeff, basis, pts, [a % nf], r % nf)[0]
   time_a = anchor_time_embedding.reshape(-1)[:1].to(dev).float()
-  coeff_a = _motion_mlp(model, names['motion'], dev, num_basis)(pts_anchor, time_a, n_last if n_last > 0 else S)
+  coeff_a = _coeff(model, names['motion'], dev, num_basis, pts_anchor, time_a, n_last if n_last > 0 else S)
   rows_a = [(a + int(o)) % nf for o in anchor_time_offset] + [-1] * num_vv
-  pts_seq_a = ops.trajectory_points(coeff_a, basis, pts_anchor, rows_a, a % nf)
+  pts_seq_a = _traj(coeff_a, basis, pts_anchor, rows_a, a % nf)
   # the trajectory of the reference-time point and of its anchor-time correspondence at the frames both passes look at (:1147-1168)
   both = [(i, a + int(o) - r) for i, o in enumerate(anchor_time_offset) if -3 <= a + int(o) - r <= 3]
   pts_traj_anchor = torch.stack([pts_seq_a[i] for i, _ in both], 0)
-  pts_traj_ref = ops.trajectory_points(coeff, basis, pts, [(r + ro) % nf for _, ro in both], r % nf)
+  pts_traj_ref = _traj(coeff, basis, pts, [(r + ro) % nf for _, ro in both], r % nf)
   views_a = projector.source_views(ray_batch['camera'], ray_batch['anchor_src_rgbs'], ray_batch['anchor_src_cameras'], featmaps_anchor)
   assert views_a.V == len(rows_a), 'one time offset (or virtual view) per anchor source view'
-  rgb_feat_a, _, mask_a, pm_a = ops.project_gather(views_a, R, S, pts_st=pts, xyz=pts_seq_a, pix_mask_thresh=0.0)  # one observation is enough here (:1197-1199)
+  rgb_feat_a, _, mask_a, pm_a = _gather(views_a, featmaps_anchor, R, S, 0.0, xyz=pts_seq_a, pts_st=pts)  # one observation is enough here (:1197-1199)
   net_dy = getattr(model, names['dy'])
-  if train_dynamic.wants_grad(net_dy, featmaps_anchor):
-    raw_a = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), views_a, featmaps_anchor, ray_batch['ray_d'], pts_anchor,
-                                      pts_seq_a, rgb_feat_a, mask_a, time_a)
+  if train_dynamic.wants_grad(net_dy, rgb_feat_a) or _needs_graph(pts_anchor):
+    raw_a = train_dynamic.dynamic_raw(net_dy, float(getattr(_unwrap(net_dy), 'shift', 0.0)), rgb_feat_a, ray_batch['ray_d'], pts_anchor, mask_a, time_a)
   else:
     raw_a = _dynamic_net(model, names['dy'], dev)(ray_batch['ray_d'], pts_anchor, rgb_feat_a, mask_a, time_a)
   out_a = _finish(dict(raw_dy=raw_a, raw_st=stage['raw_st'], pm_dy=pm_a, pm_st=stage['pm_st']), z_vals, _KEYS2, _KEYS1)
   out_a_dy = _vanilla(raw_a, z_vals, pm_a)
-  occ_dy = out_ref_dy['weights'] - out_a_dy['weights']
+  occ_dy = (out_ref_dy['weights'] - out_a_dy['weights']).detach()  # disocclusion scores are detached in the reference (:1216, :1243)
   mode = int(getattr(args, 'occ_weights_mode', 0))
   if mode == 0:    # mix-mode: composite-dy weights when the anchor is more than one frame away, full weights otherwise
     key = 'weights_dy' if abs(r - a) > 1 else 'weights'
@@ -419,7 +449,7 @@ def _anchor_pass(model, names, args, projector, ray_batch, featmaps_anchor, stag
     key = 'weights'
   else:
     raise NotImplementedError
-  occ = out_ref[key] - out_a[key]
+  occ = (out_ref[key] - out_a[key]).detach()
   out_a['occ_weights'] = 1.0 - occ.abs()
   out_a['occ_weight_map'] = 1.0 - occ.sum(dim=1).abs()
   out_a['pts_traj_ref'] = pts_traj_ref

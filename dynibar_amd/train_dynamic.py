@@ -2,10 +2,9 @@
 slice): ``DynibarDynamic.forward`` (mlp_network.py:236-316) and ``raw2outputs`` (render_ray.py:214-330) as ``torch.autograd.Function``s
 whose forward and backward are sequences of the ``dyn_train_*`` kernels, like ``train_static``.
 
-What carries a graph after this slice: ``raw_dy`` w.r.t. DynibarDynamic's parameters and the dynamic feature maps (gathered at the
-motion-displaced points), and every colour / depth / weight output of the two-branch compositing w.r.t. ``raw_dy`` and ``raw_static``.
-What does not yet: the gradient w.r.t. the sample *locations* (bilinear taps, projection, trajectory, MotionMLP) -- the motion path of
-train.py:283-467 is the next slice, so ``motion_mlp`` / ``trajectory_basis`` receive no gradient from this package yet.
+``raw_dy`` carries a graph to DynibarDynamic's parameters, to the gathered features (and through train_motion.GatherFunction to the
+dynamic feature maps and the motion-displaced points) and to the points handed to the net; every colour / depth / weight output of
+the two-branch compositing carries one to ``raw_dy`` and ``raw_static``.
 """
 from __future__ import annotations
 
@@ -168,7 +167,8 @@ def _backward(s, draw):
   L['p2'].bwd(st, dG4, 0, 128, s.Q1, 0, 256, g['ref_pts_fc.2.weight'], P, dQ1, 0, 256)
   _act_bwd(st, dQ1, 0, 256, s.Q1, 0, 256, P, 256, ELU, g['ref_pts_fc.0.bias'])
   L['p0g'].bwd(st, dQ1, 0, 256, s.G3, 0, 128, g['ref_pts_fc.0.weight'], P, dG3, 0, 128)
-  L['p0p'].bwd(st, dQ1, 0, 256, s.PPE, 0, 36, g['ref_pts_fc.0.weight'], P)
+  s.dPPE = new(P, 36)
+  L['p0p'].bwd(st, dQ1, 0, 256, s.PPE, 0, 36, g['ref_pts_fc.0.weight'], P, s.dPPE, 0, 36)  # d PE(pts): on into the points (anchor pass)
   # LayerNorm(fc(attention) + (g2 + pos)), attention, qkv
   dY = new(P, 128)
   call('dyn_train_layernorm_bwd', _p(dG3), _p(s.XHAT), _p(s.RSTD), _p(w['ray_attention.layer_norm.weight']), P, _p(dY),
@@ -237,32 +237,34 @@ _posenc.cache = {}
 
 
 class DynamicNetFunction(torch.autograd.Function):
-  """raw_dy [R,S,4] = DynibarDynamic(features gathered at the motion-displaced points) with gradients to the dynamic feature maps and the
-  parameters (not to the points: module docstring)."""
+  """raw_dy [R,S,4] = DynibarDynamic(features gathered at the motion-displaced points) with gradients to rgb_feat (through the gather:
+  feature maps and displaced points), to pts_xyz (the Fourier features of ref_pts_fc; the anchor pass's points depend on the motion
+  coefficients) and to the parameters."""
 
   @staticmethod
-  def forward(ctx, featmaps, meta, *param_tensors):
-    names, shift, views, ray_d, pts, pts_seq, rgb_feat, mask, time = meta
+  def forward(ctx, rgb_feat, pts, meta, *param_tensors):
+    names, shift, ray_d, mask, time = meta
     w = {n: (t.detach() if t.dtype == torch.float32 and t.is_contiguous() else t.detach().float().contiguous()) for n, t in zip(names, param_tensors)}
     S = rgb_feat.shape[1]
-    raw, step = _forward(w, shift, _posenc(S, rgb_feat.device), ray_d, pts, rgb_feat, mask, time)
-    ctx.step, ctx.names, ctx.views, ctx.pts_seq = step, names, views, pts_seq
+    raw, step = _forward(w, shift, _posenc(S, rgb_feat.device), ray_d, pts.detach(), rgb_feat.detach(), mask, time)
+    step.pts = pts.detach() if (pts.dtype == torch.float32 and pts.is_contiguous()) else pts.detach().float().contiguous()
+    ctx.step, ctx.names, ctx.fshape, ctx.pshape = step, names, tuple(rgb_feat.shape), tuple(pts.shape)
     return raw
 
   @staticmethod
   def backward(ctx, draw):
     s = ctx.step
     g, dF = _backward(s, draw.float())
-    gf = None
-    if ctx.needs_input_grad[0]:
-      v = ctx.views
-      dfeat = torch.zeros((v.V, v.Hf, v.Wf, v.F), dtype=torch.float32, device=draw.device)
-      xyz = ctx.pts_seq if (ctx.pts_seq.dtype == torch.float32 and ctx.pts_seq.is_contiguous()) else ctx.pts_seq.float().contiguous()
-      call('dyn_gather_bwd', None, _p(xyz), _p(v.proj), s.R, s.S, s.V, v.Hf, v.Wf, v.F, v.img_h, v.img_w, _p(dF), 36, 3, _p(dfeat), stream_of(draw))
-      gf = dfeat.permute(0, 3, 1, 2)
+    gr = dF[:, :35].reshape(ctx.fshape) if ctx.needs_input_grad[0] else None
+    gpts = None
+    if ctx.needs_input_grad[1]:
+      from .train_motion import OCTAVES5, _freqs
+      fa, fp = _freqs(OCTAVES5)
+      gpts = torch.empty(ctx.pshape, dtype=torch.float32, device=draw.device)
+      call('dyn_train_embed_bwd', _p(s.pts), 3, s.P, 3, fp, 5, _p(s.dPPE), 36, _p(gpts), 3, 0, stream_of(draw))
     ctx.step = None
-    gp = tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(ctx.names))
-    return (gf, None) + gp
+    gp = tuple(g[n] if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(ctx.names))
+    return (gr, gpts, None) + gp
 
 
 def wants_grad(net, featmaps):
@@ -270,12 +272,13 @@ def wants_grad(net, featmaps):
   return wg(net, featmaps)
 
 
-def dynamic_raw(net, shift, views, featmaps, ray_d, pts, pts_seq, rgb_feat, mask, time):
+def dynamic_raw(net, shift, rgb_feat, ray_d, pts, mask, time):
   """raw_dy with an autograd graph.  net: the reference's DynibarDynamic (nn.Module, DataParallel-wrapped or not) or a dict of parameter
-  tensors; views: ops.SourceViews of the dynamic source views; pts_seq [V,R,S,3]: the per-view motion-displaced points the gather read."""
+  tensors; rgb_feat: the features gathered at the motion-displaced points (train_motion.gather); pts: the points handed to the net
+  (pts_ref, or pts_anchor in the cross-time pass)."""
   names, tensors = _param_list(net)
-  meta = (names, float(shift), views, ray_d, pts, pts_seq, rgb_feat, mask, time)
-  return DynamicNetFunction.apply(featmaps, meta, *tensors)
+  meta = (names, float(shift), ray_d, mask, time)
+  return DynamicNetFunction.apply(rgb_feat, pts, meta, *tensors)
 
 
 class CompositeDualFunction(torch.autograd.Function):

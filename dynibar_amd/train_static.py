@@ -189,8 +189,8 @@ def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask
   return raw, s
 
 
-def _backward(s, draw, want_feat_grad):
-  """draw [R,S,4] -> ({param name: grad}, dfeat_cl [V,Hf,Wf,F] | None)"""
+def _backward(s, draw):
+  """draw [R,S,4] -> ({param name: grad}, dF [N,72] whose columns 0..34 are d rgb_feat)"""
   R, S, V, P, N, w, L = s.R, s.S, s.V, s.P, s.N, s.w, s.L
   dev = draw.device
   st = stream_of(draw)
@@ -275,36 +275,30 @@ def _backward(s, draw, want_feat_grad):
   L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256)
   _act_bwd(st, dH1, 0, 256, s.H1, 0, 256, N, 256, ELU, g['ray_dir_fc.0.bias'])
   L['rd0'].bwd(st, dH1, 0, 256, s.A0, 0, 104, g['ray_dir_fc.0.weight'], N)
-  # feature maps: scatter d rgb_feat[..., 3:3+F] = dF[:, 3:35] through the forward's bilinear taps
-  dfeat = None
-  if want_feat_grad:
-    v = s.views
-    dfeat = torch.zeros((v.V, v.Hf, v.Wf, v.F), dtype=torch.float32, device=dev)
-    call('dyn_gather_bwd', _p(s.pts), None, _p(v.proj), R, S, V, v.Hf, v.Wf, v.F, v.img_h, v.img_w, _p(dF), 72, 3, _p(dfeat), st)
-  return g, dfeat
+  return g, dF  # dF[:, 0:35] = d rgb_feat (the gather's backward, train_motion.GatherFunction, carries it on into the maps)
 
 
 class StaticNetFunction(torch.autograd.Function):
-  """raw_static [R,S,4] = DynibarStatic(gathered static features) with gradients to the feature maps and the parameters."""
+  """raw_static [R,S,4] = DynibarStatic(gathered static features) with gradients to rgb_feat (and through the gather to the feature
+  maps) and to the parameters."""
 
   @staticmethod
-  def forward(ctx, featmaps, meta, *param_tensors):
-    names, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask = meta
+  def forward(ctx, rgb_feat, meta, *param_tensors):
+    names, aa, mask_rgb, views, ray_o, ray_d, pts, ray_diff, mask = meta
     w = {n: (t.detach() if t.dtype == torch.float32 and t.is_contiguous() else t.detach().float().contiguous()) for n, t in zip(names, param_tensors)}
     w = {n: (t.reshape(1) if t.dim() == 0 else t) for n, t in w.items()}
-    raw, step = _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts.contiguous(), rgb_feat, ray_diff, mask)
+    raw, step = _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts.contiguous(), rgb_feat.detach(), ray_diff, mask)
     ctx.step, ctx.names, ctx.shapes = step, names, [tuple(t.shape) for t in param_tensors]
-    ctx.feat_shape = tuple(featmaps.shape)
+    ctx.fshape = tuple(rgb_feat.shape)
     return raw
 
   @staticmethod
   def backward(ctx, draw):
-    want_feat = ctx.needs_input_grad[0]
-    g, dfeat = _backward(ctx.step, draw.float(), want_feat)
+    g, dF = _backward(ctx.step, draw.float())
     ctx.step = None  # the saved activations are released with the step
-    gf = dfeat.permute(0, 3, 1, 2) if dfeat is not None else None  # [V,F,Hf,Wf] view of the channels-last gradient
+    gr = dF[:, :35].reshape(ctx.fshape) if ctx.needs_input_grad[0] else None  # a column-slice view: the gather's backward reads it in place
     gp = tuple(g[n].reshape(shp) if ctx.needs_input_grad[2 + i] else None for i, (n, shp) in enumerate(zip(ctx.names, ctx.shapes)))
-    return (gf, None) + gp
+    return (gr, None) + gp
 
 
 class CompositeVanillaFunction(torch.autograd.Function):
@@ -329,10 +323,10 @@ class CompositeVanillaFunction(torch.autograd.Function):
     return draw, None, None
 
 
-def static_raw(net, args_flags, views, featmaps, ray_o, ray_d, pts, rgb_feat, ray_diff, mask):
+def static_raw(net, args_flags, views, rgb_feat, ray_o, ray_d, pts, ray_diff, mask):
   """raw_static with an autograd graph.  net: the reference's DynibarStatic (nn.Module, DataParallel-wrapped or not) or a dict of
-  parameter tensors; args_flags = (anti_alias_pooling, mask_rgb); views: ops.SourceViews of the static source views (built from
-  `featmaps`, whose values the gather already read)."""
+  parameter tensors; args_flags = (anti_alias_pooling, mask_rgb); rgb_feat: the gathered static features -- from
+  train_motion.gather(...) when the feature maps take part in the graph."""
   aa, mask_rgb = args_flags
   names, tensors = _param_list(net)
   if aa and 's' not in names:
@@ -340,8 +334,8 @@ def static_raw(net, args_flags, views, featmaps, ray_o, ray_d, pts, rgb_feat, ra
   if not aa and 's' in names:
     i = names.index('s')
     names, tensors = names[:i] + names[i + 1:], tensors[:i] + tensors[i + 1:]
-  meta = (names, bool(aa), bool(mask_rgb), views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
-  return StaticNetFunction.apply(featmaps, meta, *tensors)
+  meta = (names, bool(aa), bool(mask_rgb), views, ray_o, ray_d, pts, ray_diff, mask)
+  return StaticNetFunction.apply(rgb_feat, meta, *tensors)
 
 
 def composite_vanilla(raw, z_vals, pix_mask):

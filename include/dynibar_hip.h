@@ -271,7 +271,7 @@ int dyn_profile_read(float* total_ms, int* launches);
  * each).  Forward of nn.Linear: A = X (a_ks = 1), B = W[N,K] (b_rs = ldw, b_ks = 1).  Data gradient dX = dZ W: A = dZ, B rows = input
  * features (b_rs = 1, b_ks = ldw).  Weight gradient dW = dZ^T X: A rows = output features (a_rs = 1, a_ks = ld_dz), B rows = input
  * features (b_rs = 1, b_ks = ldx), K = number of rows, k_split > 1 with accumulate = 2.
- * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip), act (0 none, 1 ELU); accumulate 0 store, 1 or 2: += by fp32 atomics
+ * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip), act (0 none, 1 ELU, 2 ReLU); accumulate 0 store, 1 or 2: += by fp32 atomics
  * (2 is required with k_split > 1).
  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x16_bf16 with exact three-way bf16 splits (6 partial products). */
 typedef struct {
@@ -292,7 +292,7 @@ typedef struct {
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
 
-/* dZ = dY * act'(Y) in place (act 1: ELU from the saved output Y; act 0: unchanged); dbias[c] += column sums (NULL to skip);
+/* dZ = dY * act'(Y) in place (act 1: ELU, act 2: ReLU, both from the saved output Y; act 0: unchanged); dbias[c] += column sums (NULL to skip);
  * dseg[(row / seg), c] = sums over the seg rows of a point (gradient of a per-point addend; NULL to skip). */
 int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg, float* dseg,
                       long ld_seg, void* stream);
@@ -389,6 +389,33 @@ int dyn_train_dynamic_head_bwd(const float* draw, const float* raw, const float*
 int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
                              const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R, int S,
                              float* draw_dy, float* draw_st, void* stream);
+
+/* ==== f3, third slice: the motion path of train.py:283-467 -- gradients w.r.t. the sample locations and through them into MotionMLP
+ * (mlp_network.py:558-618; its Linear layers are dyn_train_gemm with act 2 = ReLU, dyn_train_act_bwd act 2) and the trajectory basis. ====== */
+
+/* PeriodicEmbed (mlp_network.py:530-555) of x [rows, D] (ldx): out [rows, ld] = [x | cos(f_k x) k < n | sin(f_k x)]; freqs: HOST array of
+ * n_freqs <= 16 frequencies.  backward w.r.t. x (accumulate 0/1). */
+int dyn_train_embed(const float* x, long ldx, long rows, int D, const float* freqs, int n_freqs, float* out, long ld, void* stream);
+int dyn_train_embed_bwd(const float* x, long ldx, long rows, int D, const float* freqs, int n_freqs, const float* dout, long ld, float* dx, long ld_dx,
+                        int accumulate, void* stream);
+
+/* x [R,S,C]: the last n_last samples of every ray zeroed, the rest multiplied by scale (render_ray.py:961,:1129 `raw_coeff[:, -n:, :] *= 0`,
+ * mlp_network.py:618 `/ sf_mag_div`); applied to the gradient it is the backward of the same. */
+int dyn_train_zero_tail(float* x, long R, int S, int C, int n_last, float scale, void* stream);
+
+/* backward of dyn_trajectory_points (render_ray.py:361-369,:965-985): dseq [n_rows, n_pts, 3] -> dcoeff [n_pts, 3B] (=), dbasis [frames, B]
+ * (atomic +=, zeroed by the caller), dpts [n_pts, 3] (= ; may be NULL) */
+int dyn_trajectory_bwd(const float* dseq, const float* coeff, const float* basis, long n_pts, int B, const int* rows, int n_rows, int row_ref,
+                       float* dcoeff, float* dbasis, float* dpts, void* stream);
+
+/* backward of dyn_render_flows (render_ray.py:333-358): dflows [V,R,2] -> dweights [R,S] (=), dseq [V,R,S,3] (=) */
+int dyn_render_flows_bwd(const float* dflows, const float* weights, const float* pts_seq, const float* proj, int R, int S, int V, float* dweights,
+                         float* dseq, void* stream);
+
+/* backward of the gather w.r.t. the sample locations (F.grid_sample w.r.t. its grid, normalize(), compute_projections: projection.py:32-59,
+ * :134-167): drgb_feat [N, ld_d] (columns 0..2 colours, 3..3+F features) -> dxyz [V,R,S,3] (=).  pts_st / xyz as in dyn_gather_bwd. */
+int dyn_gather_bwd_pts(const float* pts_st, const float* xyz, const float* proj, const float* src_rgb, const float* feat_cl, int R, int S, int V,
+                       int H, int W, int Hf, int Wf, int F, float img_h, float img_w, const float* drgb_feat, long ld_d, float* dxyz, void* stream);
 
 #ifdef __cplusplus
 }

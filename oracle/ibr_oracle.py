@@ -659,7 +659,7 @@ def dual_branch_stage(models, scene, featmaps_dy, featmaps_st, ray_o, ray_d, uv_
   out['s_vals'] = s_vals
   sf_p = torch.sum(out['weights'][..., None] * (traj[sf_offsets[0]] - traj[0]), dim=-2)
   sf_m = torch.sum(out['weights'][..., None] * (traj[sf_offsets[1]] - traj[0]), dim=-2)
-  out['exp_sf'] = torch.max(sf_p, sf_m)
+  out['exp_sf'] = torch.max(sf_p, sf_m).detach()  # detached in the monocular path (render_ray.py:1096); nothing differentiates the other callers' copy
   return out, out_dy, out_st, dict(raw_dy=raw_dy, raw_st=raw_st, coeff=coeff, pts_seq=pts_seq, pm_dy=pm_dy, pm_st=pm_st)
 
 
@@ -701,7 +701,7 @@ def render_rays_mono_eval(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_
 
 def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time_embedding, time_offset, N_samples,
                            inv_uniform=True, det=True, anti_alias_pooling=True, mask_rgb=False, num_vv=2, occ_weights_mode=0,
-                           t_rand=None):
+                           t_rand=None, dy_shift=0.0):
   """Monocular path with is_train=True, forward values (render_ray.py:870-1277): the reference-time pass plus the cross-time
   rendering at the anchor time (:1099-1270).  frame_idx / time_embedding / time_offset are (ref, anchor) pairs; the anchor
   sources are scene['anchor_src_rgbs'], scene['anchor_src_cameras'], scene['featmaps_anchor']."""
@@ -712,7 +712,7 @@ def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time
   pts, z_vals, s_vals = sample_along_camera_ray(ray_o, ray_d, scene['depth_range'], N_samples, inv_uniform, det, t_rand)
   out, out_dy, out_st, st = dual_branch_stage(models, scene, scene['featmaps'], scene['static_featmaps'], ray_o, ray_d, uv_grid, pts,
                                               z_vals, s_vals, ref_idx, ref_temb, ref_off, 'coarse', num_frames, anti_alias_pooling,
-                                              mask_rgb, num_vv=num_vv, time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1))
+                                              mask_rgb, num_vv=num_vv, time_diff_scaled=False, flow_views=6, sf_offsets=(1, -1), dy_shift=dy_shift)
   basis = models['trajectory_basis']
   R, S = pts.shape[:2]
   n_last = int(round(S * 0.1))
@@ -742,10 +742,10 @@ def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time
   tdiff = torch.from_numpy(np.array(anc_off))[None, None, :, None].expand(R, S, -1, -1)
   pm_a = mk_a[..., 0].sum(dim=2) > 0                                           # :1197-1199 (one observation is enough here)
   ray_dir = F.normalize(ray_d, dim=-1)
-  raw_a = dynamic_net(models['net_coarse_dy'], pts_anchor, rf_a, ray_dir, rd_a, tdiff, mk_a, t_anc)
+  raw_a = dynamic_net(models['net_coarse_dy'], pts_anchor, rf_a, ray_dir, rd_a, tdiff, mk_a, t_anc, shift=dy_shift)
   out_a = raw2outputs(raw_a, st['raw_st'], z_vals, pm_a, st['pm_st'])
   out_a_dy = raw2outputs_vanilla(raw_a, z_vals, pm_a)
-  occ_dy = out_dy['weights'] - out_a_dy['weights']
+  occ_dy = (out_dy['weights'] - out_a_dy['weights']).detach()  # disocclusion scores carry no gradient (render_ray.py:1216, :1243)
   if occ_weights_mode == 0:
     key = 'weights_dy' if abs(ref_idx - anc_idx) > 1 else 'weights'
   elif occ_weights_mode == 1:
@@ -754,7 +754,7 @@ def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time
     key = 'weights'
   else:
     raise NotImplementedError
-  occ = out[key] - out_a[key]
+  occ = (out[key] - out_a[key]).detach()
   out_a['occ_weights'] = 1.0 - occ.abs()
   out_a['occ_weight_map'] = 1.0 - occ.sum(dim=1).abs()
   out_a['pts_traj_ref'] = torch.stack(tr_ref, 0)

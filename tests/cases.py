@@ -125,3 +125,86 @@ def bootstrap_case(kid):
 def charbonnier(x, y, mask, eps=0.001):
   """utils.img2charbonier (utils.py:32-39) with TINY_NUMBER = 1e-6"""
   return torch.sum(torch.sqrt((x - y) ** 2 + eps ** 2) * mask.unsqueeze(-1)) / (torch.sum(mask) * x.shape[-1] + 1e-6)
+
+
+# ---- the reference's main-loop loss (train.py:302-446) restated for the gradient goldens / tests (test infrastructure) ------------------
+def train_batch_targets(n_rays, n_flow_views=6, seed=91):
+  """Seeded stand-ins for the data loader's supervision in ray_batch (train.py:302-446): rgb, disp, flows, masks, motion_mask, static_mask."""
+  g = torch.Generator().manual_seed(seed)
+  return dict(rgb=torch.rand(n_rays, 3, generator=g), disp=0.05 + 0.5 * torch.rand(n_rays, generator=g),
+              flows=4.0 * torch.randn(n_flow_views, n_rays, 2, generator=g), masks=(torch.rand(n_flow_views, n_rays, 1, generator=g) < 0.8).float(),
+              motion_mask=(torch.rand(n_rays, generator=g) < 0.5).float(), static_mask=(torch.rand(n_rays, generator=g) < 0.3).float())
+
+
+def _distloss(w, m, interval):
+  """eff_distloss_native of the third-party package torch_efficient_distloss (environment_dynibar.yml:17, un-pinned; absent here):
+  its published O(N) form of the mip-NeRF-360 distortion loss."""
+  loss_uni = (1.0 / 3.0) * (interval * w.pow(2)).sum(dim=-1).mean()
+  wm = w * m
+  w_cs, wm_cs = w.cumsum(dim=-1), wm.cumsum(dim=-1)
+  loss_bi = 2.0 * (wm[..., 1:] * w_cs[..., :-1] - w[..., 1:] * wm_cs[..., :-1]).sum(dim=-1).mean()
+  return loss_bi + loss_uni
+
+
+def mono_train_loss(ret, tgt, terms=('rgb', 'disp', 'flow', 'cycle', 'reg', 'entropy', 'distortion', 'static'), epoch=0):
+  """train.py:302-446 with configs/train_kid-running.txt's weights (w_disp 0.1, w_flow 0.01, w_cycle 0.1, w_reg 0.05, w_skew_entropy 5e-4,
+  w_distortion 1e-3, decay_rate 10, init_decay_epoch 400).  `terms` selects a subset (each with its train.py weight)."""
+  ref, anc = ret['outputs_coarse_ref'], ret['outputs_coarse_anchor']
+  ref_dy, anc_dy = ret['outputs_coarse_ref_dy'], ret['outputs_coarse_anchor_dy']
+  divisor = epoch // 400
+  dev = ref['rgb'].device
+  t = {k: v.to(dev) for k, v in tgt.items()}
+  crit = lambda out, mm=None: charbonnier(out['rgb'], t['rgb'], out['mask'].float() * (mm if mm is not None else 1.0))
+
+  def temporal(out, mm=None):
+    pm = out['mask'].float() * (mm if mm is not None else 1.0)
+    fw = (pm * out['occ_weight_map']).unsqueeze(-1).repeat(1, 3)
+    return torch.sum(fw * torch.sqrt((out['rgb'] - t['rgb']) ** 2 + 0.001 ** 2)) / (torch.sum(fw) + 1e-8)
+
+  loss = 0.0
+  if 'rgb' in terms:
+    l = crit(ref) + temporal(anc)
+    if epoch < 400:
+      l = l + charbonnier(ref['rgb_dy'], t['rgb'], ref['mask'].float() * t['motion_mask'])
+    l = l + crit(ref_dy, t['motion_mask']) / (10.0 ** divisor) + temporal(anc_dy, t['motion_mask']) / (10.0 ** divisor)
+    loss = loss + l
+  pred_mask = ref['mask'].float()
+  if 'disp' in terms:
+    pred_disp = 1.0 / torch.clamp(ref['depth'], min=1e-2)
+    loss = loss + 0.1 / (10.0 ** divisor) * torch.sum(torch.abs(pred_disp - t['disp']) * pred_mask) / (torch.sum(pred_mask) + 1e-8)
+  if 'flow' in terms:
+    nv = ref['render_flows'].shape[0]  # min(6, dynamic views) (render_ray.py:1077-1082)
+    fm = (pred_mask[None, :, None] * t['masks'][:nv]).repeat(1, 1, 2)
+    loss = loss + 0.01 / (10.0 ** divisor) * torch.sum(torch.abs(ref['render_flows'] - t['flows'][:nv]) * fm) / (torch.sum(fm) + 1e-8)
+  if 'cycle' in terms:
+    pa, pr = anc['pts_traj_anchor'], anc['pts_traj_ref']
+    ow = anc['occ_weights'][None, ..., None].repeat(pa.shape[0], 1, 1, pa.shape[-1])
+    loss = loss + 0.1 * torch.sum(torch.abs(pr - pa) * ow) / (torch.sum(ow) + 1e-8)
+  if 'reg' in terms:
+    sf = anc['sf_seq']
+    loss = loss + 0.05 * torch.mean(torch.abs(sf)) + 0.05 * 0.5 * torch.mean(torch.pow(sf[:-1] - sf[1:], 2)) + \
+        0.05 * torch.mean(torch.abs(sf[:, :, 1:, :] - sf[:, :, :-1, :]))
+  wdy, wst = torch.sum(ref['weights_dy'], dim=-1), torch.sum(ref['weights_st'], dim=-1)
+  ratio = wdy / torch.clamp(wdy + wst, min=1e-9)
+  if 'entropy' in terms:
+    loss = loss + 5e-4 * torch.mean(-(ratio * torch.log(ratio + 1e-9) + (1.0 - ratio) * torch.log(1.0 - ratio + 1e-9)))
+  if 'distortion' in terms:
+    sv = ref['s_vals']
+    loss = loss + 1e-3 * _distloss(ref['weights'][:, :-1], (sv[:, 1:] + sv[:, :-1]) * 0.5, sv[:, 1:] - sv[:, :-1])
+  if 'static' in terms:
+    ssm = (1.0 - t['static_mask']) * pred_mask * (1.0 - ratio).float().detach()
+    loss = loss + charbonnier(ref['rgb_static'], t['rgb'], ssm)
+  return loss
+
+
+def grad_digest(g, seed=5):
+  """A gradient tensor -> small fingerprint: four seeded random projections, the largest magnitude and the first 32 values (keeps the
+  golden file small while any wrong element moves a projection)."""
+  g = g.detach().double().reshape(-1).cpu()
+  gen = torch.Generator().manual_seed(seed)
+  pr = torch.stack([(g * torch.randn(g.numel(), generator=gen, dtype=torch.float64)).sum() for _ in range(4)])
+  return dict(proj=pr, absmax=g.abs().max().reshape(1), head=g[:32].clone(), l1=g.abs().sum().reshape(1))
+
+
+MONO_TRAIN_LOSSES = {'full': ('rgb', 'disp', 'flow', 'cycle', 'reg', 'entropy', 'distortion', 'static'), 'flow': ('flow',), 'cycle': ('cycle',),
+                     'reg': ('reg',), 'rgb': ('rgb',)}

@@ -1,5 +1,7 @@
 """The training kernels (csrc/dyn_train.hip, the gather backward) under the wave-level emulator: a tiny static bootstrap step, values and
 every gradient against autograd through the oracle.  Debugging aid in a container without a GPU; -m gpu is authoritative."""
+import os
+
 import pytest
 import torch
 
@@ -23,3 +25,12 @@ def test_static_bootstrap_step_kid_config(emu):
 def test_dual_branch_step(emu):
   """second slice: DynibarDynamic + raw2outputs, gradients to both nets and both feature-map sets"""
   parity.check_train_dual(emu, 'few', S=8, R=2)
+
+
+@pytest.mark.skipif(not os.environ.get('DYN_EMU_FULL'), reason='17 minutes under the emulator: set DYN_EMU_FULL=1 (the -m gpu suite runs the same check on hardware)')
+def test_full_training_iteration(emu, golden_dir):
+  """third slice: render_rays_mono(is_train=True) under grad mode, the reference's main-loop loss, every gradient incl. MotionMLP and the
+  trajectory basis against the real reference's autograd digests"""
+  import os
+  import numpy as np
+  parity.check_train_mono(emu, dict(np.load(os.path.join(golden_dir, 'mono_train_grad.npz'))), losses=('full', 'flow', 'cycle'))

@@ -389,8 +389,48 @@ def train_static_goldens():
   print('train_static', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def mono_train_grad_goldens(name='few', S=16, R=4):
+  """The reference's main training iteration (train.py:203-467) on the REAL modules with the REAL autograd: render_rays_mono(is_train=True)
+  under grad mode, the script's loss (tests/cases.mono_train_loss: the full sum, and the flow / cycle / regularisation / colour terms on
+  their own so that every gradient route is visible), loss.backward().  Stores a digest (cases.grad_digest) of the gradient of every
+  parameter of net_coarse_st, net_coarse_dy, motion_mlp, of the trajectory basis and of the three feature-map sets."""
+  out = {}
+  scene, o, d, uv, pix = cases.scene_case(name)
+  o, d, uv = o[:R], d[:R], uv[:R]
+  sc, fidx, temb, toff = cases.anchor_case(scene, num_vv=1)
+  tgt = cases.train_batch_targets(R)
+  args = ref_args(anti_alias_pooling=0, mask_rgb=1)
+  for lname, terms in cases.MONO_TRAIN_LOSSES.items():
+    model = build_ref_model(cases.model_weights_trained(), S, 2 * S, args, shift=5.0)
+    for m in (model.net_coarse_st, model.net_coarse_dy, model.motion_mlp):
+      m.train()
+    model.trajectory_basis = model.trajectory_basis.clone().requires_grad_(True)
+    fms = [sc['featmaps'].clone().requires_grad_(True), sc['featmaps_anchor'].clone().requires_grad_(True), sc['static_featmaps'].clone().requires_grad_(True)]
+    batch = ray_batch_of(sc, o, d, uv)
+    batch['anchor_src_rgbs'], batch['anchor_src_cameras'] = sc['anchor_src_rgbs'], sc['anchor_src_cameras']
+    ret = RR.render_rays_mono(fidx, temb, toff, batch, model, tuple(fms), PJ.Projector('cpu'), S, args, inv_uniform=True, N_importance=0, det=True,
+                              is_train=True, num_vv=1)
+    loss = cases.mono_train_loss(ret, tgt, terms)
+    loss.backward()
+    out[f'{lname}/loss'] = npy(loss)
+    grads = {'basis': model.trajectory_basis.grad, 'featmaps_ref': fms[0].grad, 'featmaps_anchor': fms[1].grad, 'featmaps_static': fms[2].grad}
+    for net in ('net_coarse_st', 'net_coarse_dy', 'motion_mlp'):
+      for k, p in getattr(model, net).named_parameters():
+        grads[f'{net}.{k}'] = p.grad
+    for k, g in grads.items():
+      if g is None:
+        continue
+      for dk, dv in cases.grad_digest(g).items():
+        out[f'{lname}/{k}/{dk}'] = npy(dv)
+  np.savez_compressed(os.path.join(HERE, 'mono_train_grad.npz'), **out)
+  print('mono_train_grad', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
   import sys
+  if 'mono_train_grad' in sys.argv[1:]:
+    mono_train_grad_goldens()
+    sys.exit(0)
   if 'train_static' in sys.argv[1:]:
     train_static_goldens()
     sys.exit(0)

@@ -523,12 +523,12 @@ def check_render_rays_mono(device, golden, name='small', S=64):
   return n
 
 
-def make_module_model(device, args, shift=5.0, wrap=True):
+def make_module_model(device, args, shift=5.0, wrap=True, weights=None):
   """A DynibarMono-shaped model whose nets are real nn.Modules on `device`, DataParallel-wrapped like model.py:382-397, with the
   conditional parameter set of the reference's constructors for `args` (no `s` when anti_alias_pooling = 0)."""
   import types
   import refmodules
-  W = cases.model_weights(0)
+  W = cases.model_weights(0) if weights is None else weights
   dp = (lambda m: torch.nn.DataParallel(m.to(device))) if wrap else (lambda m: m.to(device))
   m = types.SimpleNamespace()
   m.net_coarse_st = dp(refmodules.load_numpy_state(refmodules.like_reference('static', args), W['net_coarse_st']))
@@ -964,9 +964,10 @@ def run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot):
   od, dd = o.to(device), d.to(device)
   R = o.shape[0]
   pts, z, _ = ops.sample_along_ray(od, dd, sc['depth_range'], S, True)
-  rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+  from dynibar_amd import train_motion as TM
+  rgb_feat, ray_diff, mask, pm = TM.gather(views, fm, R, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
   prm = {k: v.detach().to(device).requires_grad_(True) for k, v in sd.items()}
-  raw = TS.static_raw(prm, (aa, mask_rgb), views, fm, od, dd, pts, rgb_feat, ray_diff, mask)
+  raw = TS.static_raw(prm, (aa, mask_rgb), views, rgb_feat, od, dd, pts, ray_diff, mask)
   out = TS.composite_vanilla(raw, z, pm)
   loss = sum((out[k] * cot[k].to(device)).sum() for k in cot)
   loss.backward()
@@ -1188,12 +1189,13 @@ def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5
   Rn = od.shape[0]
   views_dy = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], fm_dy.detach())
   views_st = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm_st.detach())
-  rf, _, mk, pm_dy = ops.project_gather(views_dy, Rn, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
-  rfs, rds, mks, pm_st = ops.project_gather(views_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+  from dynibar_amd import train_motion as TM
+  rf, _, mk, pm_dy = TM.gather(views_dy, fm_dy, Rn, S, xyz=pts_seq, pts_st=pts, pix_mask_thresh=1.0)
+  rfs, rds, mks, pm_st = TM.gather(views_st, fm_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
   prm_dy = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_dy'].items()}
   prm_st = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_st'].items()}
-  raw_dy = TD.dynamic_raw(prm_dy, shift, views_dy, fm_dy, dd, pts, pts_seq, rf, mk, di['temb'].to(device))
-  raw_st = TS.static_raw(prm_st, (True, False), views_st, fm_st, od, dd, pts, rfs, rds, mks)
+  raw_dy = TD.dynamic_raw(prm_dy, shift, rf, dd, pts, mk, di['temb'].to(device))
+  raw_st = TS.static_raw(prm_st, (True, False), views_st, rfs, od, dd, pts, rds, mks)
   out = TD.composite_dual(raw_dy, raw_st, z, pm_dy, pm_st)
   out_dy = TS.composite_vanilla(raw_dy, z, pm_dy)
   loss = sum((out[k] * cot[k].to(device)).sum() for k in cot if k != 'dy_rgb') + (out_dy['rgb'] * cot['dy_rgb'].to(device)).sum()
@@ -1221,3 +1223,92 @@ def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5
     scale = float(ref.abs().max())
     assert_close(cpu(got[k]).reshape(ref.shape), ref, 1e-3 * scale + 2e-6 * gmax, 2e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
   return worst
+
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training, third slice: the whole main-loop iteration (train.py:203-467) incl. the motion path
+# ----------------------------------------------------------------------------------------------------------------------
+MONO_TRAIN_CASE = dict(name='few', S=16, R=4, num_vv=1)
+
+
+def _digest_close(got, ref_d, what, n, gmax):
+  """gradient tensor vs its golden digest (cases.grad_digest): projections within (3e-4 absmax + 3e-6 gmax) sqrt(n) + 2e-3 relative, first
+  values likewise (gmax: the largest gradient of any network parameter -- the round-off floor of tensors whose own gradient is tiny)"""
+  d = cases.grad_digest(got)
+  am = float(ref_d['absmax'][0])
+  assert_close(d['proj'], torch.from_numpy(ref_d['proj']), (3e-4 * am + 3e-6 * gmax) * (n ** 0.5) + 1e-12, 2e-3, f'{what} projections (max |g| {am:.2e})')
+  assert_close(d['head'], torch.from_numpy(ref_d['head']), 3e-4 * am + 3e-6 * gmax + 1e-12, 2e-3, f'{what} first values')
+
+
+def oracle_mono_train_step(terms, dtype=torch.float32):
+  """torch-CPU autograd through the oracle's render_rays_mono_train + the restated train.py loss -> (loss, {name: grad})"""
+  c = MONO_TRAIN_CASE
+  scene, o, d, uv, _ = cases.scene_case(c['name'])
+  o, d, uv = o[:c['R']], d[:c['R']], uv[:c['R']]
+  sc, fidx, temb, toff = cases.anchor_case(scene, num_vv=c['num_vv'])
+  W = {k: {n: v.clone().requires_grad_(True) for n, v in O.tdict(sd).items()} for k, sd in cases.model_weights_trained().items()}
+  W['net_coarse_st'].pop('s', None)
+  basis = O.init_dct_basis(cases.NUM_BASIS, cases.NUM_FRAMES).clone().requires_grad_(True)
+  W['trajectory_basis'] = basis
+  sc = dict(sc)
+  fms = {k: sc[k].clone().requires_grad_(True) for k in ('featmaps', 'featmaps_anchor', 'static_featmaps')}
+  sc.update(fms)
+  ret = O.render_rays_mono_train(W, sc, o, d, uv, fidx, temb, toff, c['S'], True, True, anti_alias_pooling=False, mask_rgb=True, num_vv=c['num_vv'],
+                                 dy_shift=5.0)
+  loss = cases.mono_train_loss(ret, cases.train_batch_targets(c['R']), terms)
+  loss.backward()
+  grads = {'basis': basis.grad, 'featmaps_ref': fms['featmaps'].grad, 'featmaps_anchor': fms['featmaps_anchor'].grad,
+           'featmaps_static': fms['static_featmaps'].grad}
+  for net in ('net_coarse_st', 'net_coarse_dy', 'motion_mlp'):
+    for k, v in W[net].items():
+      grads[f'{net}.{k}'] = v.grad
+  return loss.detach(), grads
+
+
+def run_mono_train_step(device, terms):
+  """the HIP path: render_ray.render_rays_mono(is_train=True) on DataParallel-wrapped modules under grad mode, the restated loss, backward"""
+  import types
+  from dynibar_amd import projection, render_ray
+  c = MONO_TRAIN_CASE
+  scene, o, d, uv, _ = cases.scene_case(c['name'])
+  o, d, uv = o[:c['R']], d[:c['R']], uv[:c['R']]
+  sc, fidx, temb, toff = cases.anchor_case(scene, num_vv=c['num_vv'])
+  args = types.SimpleNamespace(anti_alias_pooling=0, mask_rgb=1, input_dir=True, input_xyz=False, occ_weights_mode=0)
+  model = make_module_model(device, args, shift=5.0, weights=cases.model_weights_trained())
+  batch = make_ray_batch(sc, o, d, uv, device)
+  batch['anchor_src_rgbs'], batch['anchor_src_cameras'] = sc['anchor_src_rgbs'].to(device), sc['anchor_src_cameras'].to(device)
+  fms = [sc[k].to(device).requires_grad_(True) for k in ('featmaps', 'featmaps_anchor', 'static_featmaps')]
+  ret = render_ray.render_rays_mono(fidx, tuple(t.to(device) for t in temb), toff, batch, model, tuple(fms), projection.Projector(device), c['S'], args,
+                                    inv_uniform=True, det=True, is_train=True, num_vv=c['num_vv'])
+  loss = cases.mono_train_loss(ret, cases.train_batch_targets(c['R']), terms)
+  loss.backward()
+  grads = {'basis': model.trajectory_basis.grad, 'featmaps_ref': fms[0].grad, 'featmaps_anchor': fms[1].grad, 'featmaps_static': fms[2].grad}
+  for net in ('net_coarse_st', 'net_coarse_dy', 'motion_mlp'):
+    for k, p in render_ray._unwrap(getattr(model, net)).named_parameters():
+      grads[f'{net}.{k}'] = p.grad
+  return loss.detach(), grads
+
+
+def check_train_mono(device, golden, losses=('full', 'flow', 'cycle', 'reg', 'rgb')):
+  """One iteration of the reference's main loop (train.py:203-467) through dynibar_amd.render_ray.render_rays_mono: the loss value and the
+  gradient of EVERY parameter (DynibarStatic, DynibarDynamic, MotionMLP, trajectory basis) and of the three feature-map sets against the
+  REAL reference's autograd (digests in tests/golden/mono_train_grad.npz), for the full loss and for single terms (so that the flow,
+  cycle and regularisation routes into MotionMLP / the basis are each visible on their own)."""
+  n_checked = 0
+  for lname in losses:
+    loss, grads = run_mono_train_step(device, cases.MONO_TRAIN_LOSSES[lname])
+    assert_close(loss, torch.from_numpy(golden[f'{lname}/loss']), 1e-5, 2e-4, f'mono train [{lname}] loss')
+    keys = sorted({k.split('/')[1] for k in golden if k.startswith(lname + '/') and k.count('/') == 2})
+    gmax = max(float(golden[f'{lname}/{k}/absmax'][0]) for k in keys if not k.startswith('featmaps'))
+    for k in keys:
+      ref_d = {dk: golden[f'{lname}/{k}/{dk}'] for dk in ('proj', 'absmax', 'head', 'l1')}
+      g = grads.get(k)
+      if g is None:
+        assert float(ref_d['absmax'][0]) == 0.0, f'mono train [{lname}]: no gradient for {k} but the reference has one (max {float(ref_d["absmax"][0]):.2e})'
+        continue
+      _digest_close(g, ref_d, f'mono train [{lname}] grad {k}', g.numel(), gmax)
+      n_checked += 1
+    missing = [k for k, g in grads.items() if g is not None and f'{lname}/{k}/proj' not in golden and float(g.abs().max()) > 0]
+    assert not missing, f'mono train [{lname}]: gradients the reference does not produce: {missing[:5]}'
+  return n_checked

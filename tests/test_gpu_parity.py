@@ -201,3 +201,11 @@ def test_train_dual_branch_step(dev, kw):
   """section 8(f)3, second slice: DynibarDynamic (features gathered at the motion-displaced points) + DynibarStatic + raw2outputs +
   raw2outputs_vanilla: values and the gradients of both nets' parameters and both feature-map sets vs autograd through the oracle"""
   parity.check_train_dual(dev, **kw)
+
+
+def test_full_training_iteration(dev, golden_dir):
+  """section 8(f)3 complete: one iteration of the reference's main loop (train.py:203-467) through render_rays_mono(is_train=True) under grad
+  mode with the script's loss -- the gradient of every parameter of DynibarStatic, DynibarDynamic, MotionMLP, of the trajectory basis and of
+  the three feature-map sets against the REAL reference's autograd, for the full loss and for its flow / cycle / regularisation / colour terms"""
+  n = parity.check_train_mono(dev, dict(np.load(os.path.join(golden_dir, 'mono_train_grad.npz'))))
+  assert n > 300

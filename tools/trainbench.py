@@ -7,7 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from dynibar_amd import _lib, ops, synthetic as syn, train_static as TS  # noqa: E402
+from dynibar_amd import _lib, ops, synthetic as syn, train_motion as TM, train_static as TS  # noqa: E402
 
 
 def main():
@@ -27,8 +27,8 @@ def main():
 
   def step():
     pts, z, _ = ops.sample_along_ray(o, d, dr, S, True)
-    rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=o, ray_d=d, z_vals=z, pix_mask_thresh=1.0)
-    raw = TS.static_raw(prm, (False, True), views, fm, o, d, pts, rgb_feat, ray_diff, mask)
+    rgb_feat, ray_diff, mask, pm = TM.gather(views, fm, R, S, ray_o=o, ray_d=d, z_vals=z, pix_mask_thresh=1.0)
+    raw = TS.static_raw(prm, (False, True), views, rgb_feat, o, d, pts, ray_diff, mask)
     out = TS.composite_vanilla(raw, z, pm)
     loss = (out['rgb'] * cot).sum()
     loss.backward()
