@@ -342,6 +342,57 @@ def main():
       except Exception as e:
         extra['train_static_step'] = {'error': str(e)[:300]}
 
+      try:
+        # section 8(f)3 complete: the reference's whole main-loop iteration (train.py:203-467) at the kid-running training shape:
+        # render_rays_mono(is_train=True) under grad mode + backward into the 3 nets, the trajectory basis and the 3 feature-map sets
+        from train_case import TrainCase
+        leg = {}
+        for Rt in (3072, 1024):
+          tc = TrainCase(dev, R=Rt)
+          tc.step(); tc.step(); fence()
+          lib.dyn_profile_enable(1)
+          t0 = time.perf_counter()
+          for _ in range(3):
+            tc.step()
+          fence()
+          tdt = (time.perf_counter() - t0) / 3
+          lib.dyn_profile_enable(0)
+          tk = read_kernels(lib)
+          fl = tc.algorithmic_flops()
+          leg[f'rays_{Rt}'] = {'ms_per_step': tdt * 1e3, 'rays_per_s': Rt / tdt, 'algorithmic_tflop_per_step': fl / 1e12, 'algorithmic_tflops': fl / tdt / 1e12,
+                               'frac_of_split6_mfma_peak': fl / tdt / 1e12 / (2500.0 / 6),
+                               'kernel_ms': {k: round(v['avg_ms'] * v['launches'] / 3, 3) for k, v in tk.items()}}
+          if Rt == 1024:
+            try:  # the reference's own route on this GPU: the same iteration as PyTorch eager ops + autograd (the oracle's restatement on the device)
+              from oracle import ibr_oracle as O
+              Wd = {k: {n: v.detach().clone().requires_grad_(True) for n, v in getattr(tc.model, k).items()} for k in ('net_coarse_st', 'net_coarse_dy', 'motion_mlp')}
+              Wd['trajectory_basis'] = tc.model.trajectory_basis.detach().clone().requires_grad_(True)
+              osc = {k: tc.batch[k] for k in ('camera', 'depth_range', 'src_rgbs', 'src_cameras', 'static_src_rgbs', 'static_src_cameras', 'anchor_src_rgbs',
+                                             'anchor_src_cameras')}
+              osc['featmaps'], osc['featmaps_anchor'], osc['static_featmaps'] = (f.detach().clone().requires_grad_(True) for f in tc.feat)
+
+              def eager_step():
+                ret = O.render_rays_mono_train(Wd, osc, tc.batch['ray_o'], tc.batch['ray_d'], tc.batch['uv_grid'], tc.fidx, tc.temb, tc.toff, tc.S, True, True,
+                                               anti_alias_pooling=False, mask_rgb=True, num_vv=tc.num_vv)
+                (ret['outputs_coarse_ref']['rgb'] * tc.c_rgb).sum().backward()
+
+              eager_step(); fence()
+              t0 = time.perf_counter()
+              for _ in range(2):
+                eager_step()
+              fence()
+              leg['rays_1024']['pytorch_eager_same_gpu_ms'] = (time.perf_counter() - t0) / 2 * 1e3
+            except Exception as e:
+              leg['rays_1024']['pytorch_eager_same_gpu_ms'] = 'failed: ' + str(e)[:160]
+          del tc
+          torch.cuda.empty_cache()
+        leg['what'] = ('ONE iteration of the reference main loop (train.py:203-467): render_rays_mono(is_train=True) + loss.backward() through the HIP training '
+                       'kernels; 64 samples, 10 + 10 dynamic (reference + anchor frame) and 15 static views (configs/train_kid-running.txt)')
+        leg['peak_mem_gb'] = torch.cuda.max_memory_allocated() / 2**30
+        extra['train_full_iteration'] = leg
+      except Exception as e:
+        extra['train_full_iteration'] = {'error': str(e)[:300]}
+
   if rank != 0:
     if world > 1:
       dist.destroy_process_group()

@@ -441,7 +441,7 @@ def dynamic_net(sd, pts_xyz, rgb_feat, glb_ray_dir, ray_diff, time_diff, mask, t
   g = torch.cat([mean.squeeze(2), var.squeeze(2), weight.mean(dim=2)], dim=-1)
   g = _mlp2(sd, 'geometry_fc', g)
   n_valid = torch.sum(mask, dim=2)
-  g = g + posenc_table(128, g.shape[1])
+  g = g + posenc_table(128, g.shape[1]).to(g.device)
   g = ray_attention(sd, g, (n_valid > 1).float())
   g = _mlp2(sd, 'ref_pts_fc', torch.cat([g, periodic_embed(pts_xyz, 5, 5, False)], dim=-1))
   sigma = _lin(sd, 'out_geometry_fc.2', F.elu(_lin(sd, 'out_geometry_fc.0', g))) - shift

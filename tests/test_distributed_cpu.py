@@ -183,3 +183,51 @@ def test_frame_outputs_mapping_semantics():
   k = FrameOutputs()
   k._defer('a', lambda: torch.ones(1))
   assert float(k.pop('a')) == 1.0 and 'a' not in k
+
+
+# ---- data-parallel training: the gradient all-reduce (section 8e / 8(f)3) on two gloo ranks ------------------------------------------------
+def _grad_worker(rank, world, port, q):
+  import torch.distributed as dist
+  import torch
+  from dynibar_amd import train_dist
+  dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+  try:
+    torch.manual_seed(0)
+    model = types.SimpleNamespace(net_coarse_st=torch.nn.Linear(7, 5), net_coarse_dy=torch.nn.DataParallel(torch.nn.Linear(3, 4)),
+                                  motion_mlp=torch.nn.Linear(2, 2), trajectory_basis=torch.nn.Parameter(torch.zeros(6, 3)))
+    params = train_dist.trainable_parameters(model)
+    g = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+      if not (rank == 1 and i == 2):   # rank 1 has no gradient for one parameter: it must still join the collective with zeros
+        p.grad = torch.randn(p.shape, generator=g)
+    n = train_dist.allreduce_gradients(params, bucket_bytes=64)   # tiny buckets: several collectives
+    q.put((rank, n, [p.grad.numpy().copy() for p in params]))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks():
+  import torch
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29731
+  procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  # expected: the mean over ranks of the per-rank seeded gradients (zeros where a rank had none)
+  shapes = [(5, 7), (5,), (4, 3), (4,), (2, 2), (2,), (6, 3)]
+  per_rank = []
+  for rank in range(2):
+    g = torch.Generator().manual_seed(100 + rank)
+    gs = []
+    for i, shp in enumerate(shapes):
+      gs.append(torch.zeros(shp) if (rank == 1 and i == 2) else torch.randn(shp, generator=g))
+    per_rank.append(gs)
+  for (rank, n, grads) in res:
+    assert n > 1
+    for i, got in enumerate(grads):
+      np.testing.assert_allclose(got, ((per_rank[0][i] + per_rank[1][i]) / 2).numpy(), rtol=1e-6, atol=1e-7)

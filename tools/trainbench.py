@@ -10,7 +10,36 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 from dynibar_amd import _lib, ops, synthetic as syn, train_motion as TM, train_static as TS  # noqa: E402
 
 
+def full_iteration(R):
+  """the reference's whole main-loop iteration (train.py:203-467) at the kid-running shape"""
+  import ctypes
+  from train_case import TrainCase
+  tc = TrainCase('cuda:0', R=R)
+  for _ in range(2):
+    tc.step()
+  torch.cuda.synchronize()
+  _lib.lib().dyn_profile_enable(1)
+  n = 3
+  t0 = time.perf_counter()
+  for _ in range(n):
+    tc.step()
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / n * 1e3
+  cnt = _lib.lib().dyn_profile_count()
+  tot = (ctypes.c_float * cnt)()
+  lau = (ctypes.c_int * cnt)()
+  _lib.lib().dyn_profile_read(tot, lau)
+  _lib.lib().dyn_profile_name.restype = ctypes.c_char_p
+  kern = {_lib.lib().dyn_profile_name(i).decode(): (round(tot[i] / n, 3), lau[i] // n) for i in range(cnt) if lau[i]}
+  fl = tc.algorithmic_flops()
+  print(json.dumps(dict(what='full training iteration (render_rays_mono is_train=True + backward)', R=R, S=tc.S, ms_per_step=round(ms, 2),
+                        rays_per_s=round(R / ms * 1e3), algorithmic_tflop_per_step=round(fl / 1e12, 3), tflops=round(fl / ms / 1e9, 1),
+                        peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), kernels_ms_launches=kern)))
+
+
 def main():
+  if len(sys.argv) > 2 and sys.argv[2] == 'full':
+    return full_iteration(int(sys.argv[1]))
   R = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
   S, V = 64, 15
   dev = 'cuda:0'
