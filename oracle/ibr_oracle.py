@@ -259,7 +259,7 @@ def compute_with_motions(xyz_st, xyz, query_camera, train_imgs, train_cameras, f
   qcam = query_camera.squeeze(0)
   h, w = cams[0][:2]
   pix, in_front = compute_projections(xyz, cams)
-  resize = torch.tensor([w - 1.0, h - 1.0])[None, None, :]
+  resize = torch.tensor([w - 1.0, h - 1.0]).to(pix.device)[None, None, :]  # (.to(device): projection.py:25)
   norm = 2 * pix / resize - 1.0
   rgb = F.grid_sample(imgs, norm, align_corners=True).permute(2, 3, 0, 1)
   feat = F.grid_sample(featmaps, norm, align_corners=True).permute(2, 3, 0, 1)
