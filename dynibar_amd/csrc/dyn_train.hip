@@ -31,6 +31,17 @@ typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
 #define TG_PART (TG_BM * TG_ROW)         // elements of one part image
 #define TG_LDS_BYTES (2 * 3 * TG_PART * 2)
 
+// two fp32 values -> their three bf16 parts, packed as (second << 16 | first) words: 2 x (and, sub, and, sub) + 3 byte permutes = 11
+// VALU operations per pair (the conversions are this kernel's VALU load: measured 38 % VALU-busy beside 33 % MFMA-busy before)
+__device__ __forceinline__ void tr_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+  const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);  // upper halves of (b1, b0)
+  m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
 __device__ __forceinline__ void tr_split3(float x, tr_u16& h, tr_u16& m, tr_u16& l) {
   const unsigned b = __float_as_uint(x);
   h = (tr_u16)(b >> 16);
@@ -55,13 +66,14 @@ struct TrOperand {
 // MODE 1: k-minor, any alignment (four dword loads); MODE 2: k-major (rows contiguous; two dword loads per k for a row pair).
 template <int MODE>
 __device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k0, int kend, float4 (&st)[4], int tid) {
+  // RAW values only: the bounds masks are applied when the tile is converted (tr_mask_tile, a k-step or two later) -- a select right
+  // here makes the compiler wait for every load where it is issued (measured: the loads of this kernel were effectively synchronous)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float4 v;
     if (MODE == 0 || MODE == 1) {
       const int r = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
       const int rc = r < o.nrows ? r : o.nrows - 1;
-      const bool rok = r < o.nrows;
       if (MODE == 0) {
         const int kc = k < kend ? k : 0;  // a row holds at least round_up4(kend) floats (checked by the host wrapper)
         v = *reinterpret_cast<const float4*>(o.p + (long)rc * o.rs + kc);
@@ -73,10 +85,6 @@ __device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k
         v.z = g[k + 2 < km ? k + 2 : km];
         v.w = g[k + 3 < km ? k + 3 : km];
       }
-      v.x = (rok && k < kend) ? v.x : 0.f;
-      v.y = (rok && k + 1 < kend) ? v.y : 0.f;
-      v.z = (rok && k + 2 < kend) ? v.z : 0.f;
-      v.w = (rok && k + 3 < kend) ? v.w : 0.f;
     } else {
       // the thread takes rows 2 rp, 2 rp + 1 of the eight k of its k-group; st[i] = (k = 2 i: r0, r1 | k = 2 i + 1: r0, r1)
       const int r = row0 + (tid & 63) * 2, kb = k0 + (tid >> 6) * 8 + 2 * i;
@@ -85,6 +93,25 @@ __device__ __forceinline__ void tr_load_tile(const TrOperand& o, int row0, int k
       const float* g0 = o.p + (long)(kb < km ? kb : km) * o.ks;
       const float* g1 = o.p + (long)(kb + 1 < km ? kb + 1 : km) * o.ks;
       v.x = g0[r0]; v.y = g0[r1]; v.z = g1[r0]; v.w = g1[r1];
+    }
+    st[i] = v;
+  }
+}
+// zero the elements of a raw tile that lie beyond the operand's bounds (same index maps as tr_load_tile)
+template <int MODE>
+__device__ __forceinline__ void tr_mask_tile(const TrOperand& o, int row0, int k0, int kend, float4 (&st)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 v = st[i];
+    if (MODE == 0 || MODE == 1) {
+      const int r = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
+      const bool rok = r < o.nrows;
+      v.x = (rok && k < kend) ? v.x : 0.f;
+      v.y = (rok && k + 1 < kend) ? v.y : 0.f;
+      v.z = (rok && k + 2 < kend) ? v.z : 0.f;
+      v.w = (rok && k + 3 < kend) ? v.w : 0.f;
+    } else {
+      const int r = row0 + (tid & 63) * 2, kb = k0 + (tid >> 6) * 8 + 2 * i;
       v.x = (kb < kend && r < o.nrows) ? v.x : 0.f;
       v.y = (kb < kend && r + 1 < o.nrows) ? v.y : 0.f;
       v.z = (kb + 1 < kend && r < o.nrows) ? v.z : 0.f;
@@ -100,15 +127,14 @@ __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4]
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (KMINOR) {
-      const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
-      tr_u16 h[4], m[4], l[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) tr_split3(v[q], h[q], m[q], l[q]);
+      unsigned h0, m0, l0, h1, m1, l1;
+      tr_split3_pair(st[i].x, st[i].y, h0, m0, l0);
+      tr_split3_pair(st[i].z, st[i].w, h1, m1, l1);
       const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
       tr_u16* d = img + r * TG_ROW + k;
-      *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
-      *reinterpret_cast<tr_u32x2*>(d + TG_PART) = tr_u32x2{m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16)};
-      *reinterpret_cast<tr_u32x2*>(d + 2 * TG_PART) = tr_u32x2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
+      *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h0, h1};
+      *reinterpret_cast<tr_u32x2*>(d + TG_PART) = tr_u32x2{m0, m1};
+      *reinterpret_cast<tr_u32x2*>(d + 2 * TG_PART) = tr_u32x2{l0, l1};
     }
   }
   if (!KMINOR) {
@@ -120,12 +146,9 @@ __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float a = q == 0 ? st[i].x : st[i].y, b = q == 0 ? st[i].z : st[i].w;
-        tr_u16 h0, m0, l0, h1, m1, l1;
-        tr_split3(a, h0, m0, l0);
-        tr_split3(b, h1, m1, l1);
-        ph[i] = h0 | ((unsigned)h1 << 16);
-        pm[i] = m0 | ((unsigned)m1 << 16);
-        pl[i] = l0 | ((unsigned)l1 << 16);
+        unsigned th, tm, tl;
+        tr_split3_pair(a, b, th, tm, tl);
+        ph[i] = th; pm[i] = tm; pl[i] = tl;
       }
       tr_u16* d = img + (r + q) * TG_ROW + k;
       *reinterpret_cast<tr_u32x4*>(d) = ph;
@@ -149,6 +172,16 @@ struct TrGemmArgs {
   int accumulate;        // 0 store, 1 c += result, 2 atomicAdd
 };
 
+// Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
+// workgroup-scope fence, i.e. s_waitcnt vmcnt(0), which would drain the prefetched tiles at every k-step.  The empty asm statements keep
+// the compiler from moving LDS accesses across.
+__device__ __forceinline__ void tr_barrier_lds() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ f32x16 tr_mfma(tr_u32x4 a, tr_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tr_bf16x8, a), __builtin_bit_cast(tr_bf16x8, b), c, 0, 0, 0);
 }
@@ -170,16 +203,24 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float4 sa[4], sb[4];
-  tr_load_tile<A_MODE>(g.a, m0, kbeg, kend, sa, tid);
-  tr_load_tile<B_MODE>(g.b, n0, kbeg, kend, sb, tid);
-  for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
+  // Two register stages of raw global loads: the tile of k-step t + 2 is requested while step t feeds the matrix pipe; the barrier of
+  // a step publishes LDS writes only (tr_barrier_lds), so those loads stay in flight across it.
+  float4 sa0[4], sb0[4], sa1[4], sb1[4];
+  tr_load_tile<A_MODE>(g.a, m0, kbeg, kend, sa0, tid);
+  tr_load_tile<B_MODE>(g.b, n0, kbeg, kend, sb0, tid);
+  if (kbeg + TG_BK < kend) {
+    tr_load_tile<A_MODE>(g.a, m0, kbeg + TG_BK, kend, sa1, tid);
+    tr_load_tile<B_MODE>(g.b, n0, kbeg + TG_BK, kend, sb1, tid);
+  }
+  auto body = [&](float4 (&sa)[4], float4 (&sb)[4], int k0) {
+    tr_mask_tile<A_MODE>(g.a, m0, k0, kend, sa, tid);
+    tr_mask_tile<B_MODE>(g.b, n0, k0, kend, sb, tid);
     tr_store_tile<A_KMINOR>(As, sa, tid);
     tr_store_tile<B_KMINOR>(Bs, sb, tid);
-    __syncthreads();
-    if (k0 + TG_BK < kend) {  // next tile in flight while this one feeds the matrix pipe
-      tr_load_tile<A_MODE>(g.a, m0, k0 + TG_BK, kend, sa, tid);
-      tr_load_tile<B_MODE>(g.b, n0, k0 + TG_BK, kend, sb, tid);
+    tr_barrier_lds();
+    if (k0 + 2 * TG_BK < kend) {
+      tr_load_tile<A_MODE>(g.a, m0, k0 + 2 * TG_BK, kend, sa, tid);
+      tr_load_tile<B_MODE>(g.b, n0, k0 + 2 * TG_BK, kend, sb, tid);
     }
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
@@ -191,19 +232,23 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
           a[i][part] = *reinterpret_cast<const tr_u32x4*>(As + part * TG_PART + (wm * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
           b[i][part] = *reinterpret_cast<const tr_u32x4*>(Bs + part * TG_PART + (wn * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
         }
+      // the six partial products of a tile form a dependent chain through its accumulator: issue them term by term ACROSS the four
+      // tiles so that consecutive MFMAs are independent (smallest partial products first)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int term = 0; term < 6; ++term) {
+        const int pa = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
+        const int pb = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {  // smallest partial products first
-          acc[i][j] = tr_mfma(a[i][2], b[j][0], acc[i][j]);
-          acc[i][j] = tr_mfma(a[i][0], b[j][2], acc[i][j]);
-          acc[i][j] = tr_mfma(a[i][1], b[j][1], acc[i][j]);
-          acc[i][j] = tr_mfma(a[i][1], b[j][0], acc[i][j]);
-          acc[i][j] = tr_mfma(a[i][0], b[j][1], acc[i][j]);
-          acc[i][j] = tr_mfma(a[i][0], b[j][0], acc[i][j]);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = tr_mfma(a[i][pa], b[j][pb], acc[i][j]);
+      }
     }
-    __syncthreads();
+    tr_barrier_lds();
+  };
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * TG_BK) {
+    body(sa0, sb0, k0);
+    if (k0 + TG_BK < kend) body(sa1, sb1, k0 + TG_BK);
   }
   // epilogue: D layout -- lane (j = lane & 31: column n, h = lane >> 5), register r: row (r & 3) + 8 (r >> 2) + 4 h.
   // Loads first (bias, per-point addend: clamped addresses, no branches, so they issue back to back), then arithmetic, then stores.

@@ -164,6 +164,13 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) {
   return emu::unbits<T>(s[0][0]);
 }
 static inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {a (bytes 7..4), b (bytes 3..0)} (selectors 0..7 only)
+static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
+  const unsigned long long v = ((unsigned long long)a << 32) | b;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffu) << (8 * i);
+  return r;
+}
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
