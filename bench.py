@@ -279,6 +279,14 @@ def main():
         extra['feature_encoder'] = {'error': str(e)[:300]}
 
       try:
+        # section 8(f)2: the per-view body of the reference's evaluation loop (sampler, four encoder passes, full-frame render, pixels to the
+        # host, PSNR) -- what the README's "hours per scene" is made of
+        import eval_loop
+        extra['eval_loop'] = eval_loop.run(dev, views=2)
+        torch.cuda.empty_cache()
+      except Exception as e:
+        extra['eval_loop'] = {'error': str(e)[:300]}
+      try:
         # section 8(f)3, first slice: one static bootstrap training step (train.py:116-199) at the reference's training shape
         # (configs/train_kid-running.txt: N_rand 3072, 64 samples, 15 static views, anti_alias_pooling 0, mask_rgb 1): forward with saved
         # activations + backward through the dyn_train_* kernels into DynibarStatic's parameters and the static feature maps
