@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   tr_u16* Bs = As + 3 * TG_PART;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
+  const int m0 = blockIdx.x * TG_BM, n0 = blockIdx.y * TG_BN;  // the row tiles on grid.x: more than 65535 of them beyond 8 M rows
   const int kbeg = blockIdx.z * g.k_chunk;
   const int kend = g.K < kbeg + g.k_chunk ? g.K : kbeg + g.k_chunk;
   f32x16 acc[2][2];
@@ -332,7 +332,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   const int nz = (p->K + chunk - 1) / chunk;
   g.bias = p->bias; g.addend = p->addend; g.ld_add = p->ld_add; g.add_div = p->add_div > 0 ? p->add_div : 1;
   g.act = p->act; g.accumulate = p->accumulate;
-  const dim3 grid(dyn_cdiv(p->N, TG_BN), dyn_cdiv(p->M, TG_BM), nz);
+  const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major
   const int k4 = (p->K + 3) & ~3;
