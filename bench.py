@@ -342,7 +342,9 @@ def main():
           fence()
           extra['train_static_step']['pytorch_eager_same_gpu_ms'] = (time.perf_counter() - t0) / 2 * 1e3
           gk = 'base_fc.2.weight'
-          extra['train_static_step']['grad_rel_diff_vs_pytorch_eager'] = float((prm[gk].grad / 5 - sdv[gk].grad / 3).abs().max() / (sdv[gk].grad / 3).abs().max())
+          g_ours, g_eager = (prm[gk].grad / 5).double(), (sdv[gk].grad / 3).double()
+          extra['train_static_step']['grad_check_vs_pytorch_eager'] = {'tensor': gk, 'max_abs_ours': float(g_ours.abs().max()), 'max_abs_eager': float(g_eager.abs().max()),
+                                                                       'max_abs_diff': float((g_ours - g_eager).abs().max())}
         except Exception as e:
           extra['train_static_step']['pytorch_eager_same_gpu_ms'] = 'failed: ' + str(e)[:160]
         del prm, fm, tviews

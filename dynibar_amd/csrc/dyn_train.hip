@@ -11,11 +11,13 @@
 // over row-major fp32 activation matrices that stay in HBM between kernels (a step of 2048 rays x 64 samples x 15 views keeps
 // about 12 GB: sized for the 288 GB of an MI355X, nothing is recomputed).
 //
-// Arithmetic of the GEMM: fp32 in, fp32 accumulate; every fp32 operand is split EXACTLY into three bf16 parts (8 + 8 + 8 mantissa
-// bits, truncation, so the parts keep fp32's full exponent range -- gradients of 1e-9 lose nothing, which the half-float split of
-// the inference engine cannot promise) and the six partial products down to 2^-18 run on v_mfma_f32_32x32x16_bf16: fp32-class
-// products at 2500/6 = 417 TFLOP/s peak against 157 TFLOP/s of the native fp32 MFMA.  The split happens once per element when a
-// tile is written to LDS, not per use.
+// Arithmetic of the GEMM: fp32 in, fp32 accumulate; every fp32 operand is split into two IEEE half parts x = hi + mid (22 mantissa
+// bits, like the inference engine) and the three partial products hi.hi + hi.mid + mid.hi run on v_mfma_f32_32x32x16_f16: fp32-class
+// products at 2500/3 = 833 TFLOP/s peak.  Halves have 5 exponent bits, and gradients live at 1e-3 .. 1e-9: the gradient operand of the
+// backward GEMMs is therefore multiplied, on its way into the split, by a power of two that brings the tensor's largest magnitude to
+// 2^14 (the magnitude is a by-product of the kernel that produced the tensor; the result is scaled back in the epilogue; exact).
+// The kernel is issue-bound on MFMAs + conversions, so two parts / three products instead of three bf16 parts / six
+// products halve both.  The split happens once per element when a tile is written to LDS, not per use.
 #include "dyn_device.h"
 #include "dyn_host.h"
 
@@ -29,27 +31,17 @@ typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
 #define TG_BK 32
 #define TG_ROW 40                        // bf16 elements per LDS row (32 used + 8 pad: 80-byte stride, conflict-free b128 reads)
 #define TG_PART (TG_BM * TG_ROW)         // elements of one part image
-#define TG_LDS_BYTES (2 * 3 * TG_PART * 2)
+#define TG_LDS_BYTES (2 * 2 * TG_PART * 2)  // (A | B) x two parts x 2 bytes = 40 KiB
 
-// two fp32 values -> their three bf16 parts, packed as (second << 16 | first) words: 2 x (and, sub, and, sub) + 3 byte permutes = 11
-// VALU operations per pair (the conversions are this kernel's VALU load: measured 38 % VALU-busy beside 33 % MFMA-busy before)
-__device__ __forceinline__ void tr_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-  const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
-  const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-  const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);  // upper halves of (b1, b0)
-  m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-}
-__device__ __forceinline__ void tr_split3(float x, tr_u16& h, tr_u16& m, tr_u16& l) {
-  const unsigned b = __float_as_uint(x);
-  h = (tr_u16)(b >> 16);
-  const float r1 = x - __uint_as_float(b & 0xffff0000u);
-  const unsigned b1 = __float_as_uint(r1);
-  m = (tr_u16)(b1 >> 16);
-  const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
-  l = (tr_u16)(__float_as_uint(r2) >> 16);
+typedef _Float16 tr_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 tr_f16x8 __attribute__((ext_vector_type(8)));
+// two fp32 values (times a power of two) -> packed half pairs hi and mid: truncating convert, exact residual, convert again
+__device__ __forceinline__ void tr_split2_pair(float x0, float x1, float scale, unsigned& h, unsigned& m) {
+  x0 *= scale; x1 *= scale;
+  const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const auto mm = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]);
+  h = __builtin_bit_cast(unsigned, hh);
+  m = __builtin_bit_cast(unsigned, mm);
 }
 
 struct TrOperand {
@@ -123,18 +115,17 @@ __device__ __forceinline__ void tr_mask_tile(const TrOperand& o, int row0, int k
 
 // registers -> LDS part images [part][row][k] (k contiguous: what the MFMA operand reads want), splitting on the way
 template <bool KMINOR>
-__device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4], int tid) {
+__device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4], float scale, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (KMINOR) {
-      unsigned h0, m0, l0, h1, m1, l1;
-      tr_split3_pair(st[i].x, st[i].y, h0, m0, l0);
-      tr_split3_pair(st[i].z, st[i].w, h1, m1, l1);
+      unsigned h0, m0, h1, m1;
+      tr_split2_pair(st[i].x, st[i].y, scale, h0, m0);
+      tr_split2_pair(st[i].z, st[i].w, scale, h1, m1);
       const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
       tr_u16* d = img + r * TG_ROW + k;
       *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h0, h1};
       *reinterpret_cast<tr_u32x2*>(d + TG_PART) = tr_u32x2{m0, m1};
-      *reinterpret_cast<tr_u32x2*>(d + 2 * TG_PART) = tr_u32x2{l0, l1};
     }
   }
   if (!KMINOR) {
@@ -142,18 +133,17 @@ __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4]
     const int r = (tid & 63) * 2, k = (tid >> 6) * 8;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      tr_u32x4 ph, pm, pl;
+      tr_u32x4 ph, pm;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float a = q == 0 ? st[i].x : st[i].y, b = q == 0 ? st[i].z : st[i].w;
-        unsigned th, tm, tl;
-        tr_split3_pair(a, b, th, tm, tl);
-        ph[i] = th; pm[i] = tm; pl[i] = tl;
+        unsigned th, tm;
+        tr_split2_pair(a, b, scale, th, tm);
+        ph[i] = th; pm[i] = tm;
       }
       tr_u16* d = img + (r + q) * TG_ROW + k;
       *reinterpret_cast<tr_u32x4*>(d) = ph;
       *reinterpret_cast<tr_u32x4*>(d + TG_PART) = pm;
-      *reinterpret_cast<tr_u32x4*>(d + 2 * TG_PART) = pl;
     }
   }
 }
@@ -170,6 +160,7 @@ struct TrGemmArgs {
   int add_div;
   int act;               // 0 none, 1 ELU
   int accumulate;        // 0 store, 1 c += result, 2 atomicAdd
+  const float* a_absmax; // device: largest |a| (a gradient tensor: scaled into the half range), or null (operands of order one)
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -183,14 +174,14 @@ __device__ __forceinline__ void tr_barrier_lds() {
 }
 
 __device__ __forceinline__ f32x16 tr_mfma(tr_u32x4 a, tr_u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tr_bf16x8, a), __builtin_bit_cast(tr_bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tr_f16x8, a), __builtin_bit_cast(tr_f16x8, b), c, 0, 0, 0);
 }
 
 template <int A_MODE, int B_MODE>
 __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   constexpr bool A_KMINOR = A_MODE != 2, B_KMINOR = B_MODE != 2;
   tr_u16* As = reinterpret_cast<tr_u16*>(dyn_smem);
-  tr_u16* Bs = As + 3 * TG_PART;
+  tr_u16* Bs = As + 2 * TG_PART;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * TG_BM, n0 = blockIdx.y * TG_BN;  // the row tiles on grid.x: more than 65535 of them beyond 8 M rows
@@ -203,6 +194,18 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // power-of-two scale of the gradient operand: its largest magnitude goes to [2^14, 2^15) (exact; undone in the epilogue)
+  float a_scale = 1.0f, a_unscale = 1.0f;
+  if (g.a_absmax != nullptr) {
+    const unsigned mx = __float_as_uint(g.a_absmax[0]);
+    const int e = (int)((mx >> 23) & 0xff);              // biased exponent of the largest magnitude (0: zero / subnormal tensor)
+    if (e > 0 && e < 255) {
+      const int sh = (127 + 14) - e;                       // multiply by 2^sh
+      const int shc = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+      a_scale = __uint_as_float((unsigned)(127 + shc) << 23);
+      a_unscale = __uint_as_float((unsigned)(127 - shc) << 23);
+    }
+  }
   // Two register stages of raw global loads: the tile of k-step t + 2 is requested while step t feeds the matrix pipe; the barrier of
   // a step publishes LDS writes only (tr_barrier_lds), so those loads stay in flight across it.
   float4 sa0[4], sb0[4], sa1[4], sb1[4];
@@ -215,8 +218,8 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   auto body = [&](float4 (&sa)[4], float4 (&sb)[4], int k0) {
     tr_mask_tile<A_MODE>(g.a, m0, k0, kend, sa, tid);
     tr_mask_tile<B_MODE>(g.b, n0, k0, kend, sb, tid);
-    tr_store_tile<A_KMINOR>(As, sa, tid);
-    tr_store_tile<B_KMINOR>(Bs, sb, tid);
+    tr_store_tile<A_KMINOR>(As, sa, a_scale, tid);
+    tr_store_tile<B_KMINOR>(Bs, sb, 1.0f, tid);
     tr_barrier_lds();
     if (k0 + 2 * TG_BK < kend) {
       tr_load_tile<A_MODE>(g.a, m0, k0 + 2 * TG_BK, kend, sa, tid);
@@ -224,20 +227,19 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     }
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
-      tr_u32x4 a[2][3], b[2][3];
+      tr_u32x4 a[2][2], b[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int part = 0; part < 3; ++part) {
+        for (int part = 0; part < 2; ++part) {
           a[i][part] = *reinterpret_cast<const tr_u32x4*>(As + part * TG_PART + (wm * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
           b[i][part] = *reinterpret_cast<const tr_u32x4*>(Bs + part * TG_PART + (wn * 64 + i * 32 + (lane & 31)) * TG_ROW + k16 * 16 + (lane >> 5) * 8);
         }
-      // the six partial products of a tile form a dependent chain through its accumulator: issue them term by term ACROSS the four
-      // tiles so that consecutive MFMAs are independent (smallest partial products first)
+      // the three partial products of a tile form a dependent chain through its accumulator: issue them term by term ACROSS the four
+      // tiles so that consecutive MFMAs are independent (smallest partial products first: mid.hi, hi.mid, hi.hi)
 #pragma unroll
-      for (int term = 0; term < 6; ++term) {
-        const int pa = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
-        const int pb = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
+      for (int term = 0; term < 3; ++term) {
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -255,6 +257,14 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   const int nA = n0 + wn * 64 + (lane & 31), nB = nA + 32;
   const int nAc = nA < g.N ? nA : g.N - 1, nBc = nB < g.N ? nB : g.N - 1;
   const int mbase = m0 + wm * 64 + 4 * (lane >> 5);
+  if (g.a_absmax != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= a_unscale;
+  }
   if (g.addend != nullptr) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -331,7 +341,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   g.k_chunk = chunk;
   const int nz = (p->K + chunk - 1) / chunk;
   g.bias = p->bias; g.addend = p->addend; g.ld_add = p->ld_add; g.add_div = p->add_div > 0 ? p->add_div : 1;
-  g.act = p->act; g.accumulate = p->accumulate;
+  g.act = p->act; g.accumulate = p->accumulate; g.a_absmax = p->a_absmax;
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major
@@ -357,10 +367,11 @@ __device__ __forceinline__ float tr_sigmoid(float v) { return 1.0f / (1.0f + exp
 // gradient of a per-point addend (sums over the seg rows of a point).  A thread owns one column of a run of rows.
 __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, const float* __restrict__ y, long rows, int cols, long ld_dy, long ld_y,
                                                        int act, float* __restrict__ dbias, int seg, float* __restrict__ dseg, long ld_seg, int ct,
-                                                       int run) {
+                                                       int run, float* __restrict__ absmax) {
   const int cx = threadIdx.x % ct, cy = threadIdx.x / ct;
   const long chunk = (long)blockIdx.x * (256 / ct) + cy;
   const long r0 = chunk * run;
+  float amax = 0.f;
   for (int c = cx; c < cols; c += ct) {
     float colsum = 0.f, segsum = 0.f;
     int in_seg = 0;  // r0 is a multiple of seg (run is)
@@ -377,6 +388,7 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
         dy[r * ld_dy + c] = d;
       }
       colsum += d;
+      amax = fmaxf(amax, fabsf(d));
       if (dseg != nullptr) {
         segsum += d;
         if (++in_seg == seg) {
@@ -388,10 +400,14 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
     }
     if (dbias != nullptr && r0 < rows) atomicAdd(dbias + c, colsum);
   }
+  if (absmax != nullptr) {  // largest |dZ| of the tensor (non-negative floats order like their bit patterns): scales the backward GEMMs
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+  }
 }
 
 extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg,
-                                 float* dseg, long ld_seg, void* stream) {
+                                 float* dseg, long ld_seg, float* absmax, void* stream) {
   DYN_REQUIRE(dY != nullptr && rows > 0 && cols > 0, "dyn_train_act_bwd: bad arguments");
   DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_act_bwd: ELU / ReLU backward needs the saved output");
   DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
@@ -401,7 +417,27 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
   const long chunks = (rows + run - 1) / run;
   const int per_block = 256 / ct;
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), 0,
-             (hipStream_t)stream, dY, Y, rows, cols, ld_dy, ld_y, act, dbias, seg, dseg, ld_seg, ct, run);
+             (hipStream_t)stream, dY, Y, rows, cols, ld_dy, ld_y, act, dbias, seg, dseg, ld_seg, ct, run, absmax);
+  return 0;
+}
+
+// largest |x| of a [rows, cols] matrix (leading dimension ld): the scale of a gradient tensor that no activation-derivative pass produced
+__global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ x, long rows, int cols, long ld, float* __restrict__ absmax) {
+  const long n = rows * cols;
+  float amax = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    amax = fmaxf(amax, fabsf(x[r * ld + (i - r * cols)]));
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+}
+extern "C" int dyn_train_absmax(const float* x, long rows, int cols, long ld, float* absmax, void* stream) {
+  DYN_REQUIRE(x && absmax && rows > 0 && cols > 0, "dyn_train_absmax: bad arguments");
+  const long n = rows * cols;
+  const long blocks = (n + 255) / 256;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_absmax", k_train_absmax, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, x,
+             rows, cols, ld, absmax);
   return 0;
 }
 

@@ -33,9 +33,10 @@ def _p(t, off=0):
   return ctypes.c_void_p(t.data_ptr() + 4 * int(off))
 
 
-def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1):
+def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
+          a_absmax=None):
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
-             ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split)
+             ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax)
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
@@ -53,16 +54,28 @@ class _Lin:
           ld_add=ld_add, add_div=add_div, act=act)
 
   def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0):
-    """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K]"""
+    """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K].  dZ is the GEMMs' scaled operand:
+    its largest magnitude comes from the activation-derivative pass that made it (_act_bwd leaves it on the tensor) or is measured here."""
+    tag = getattr(dZ, '_dyn_absmax', None)
+    if tag is not None and tag[0] == (dz_off, ld_dz, M, self.n_out):
+      am = tag[1]
+    else:
+      am = torch.zeros(1, dtype=torch.float32, device=dZ.device)
+      call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
+      dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
     ks = max(1, min(512, M // 1024))
-    _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks)
+    _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
+          a_absmax=_p(am))
     if dX is not None:
-      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx)
+      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
+            a_absmax=_p(am))
 
 
 def _act_bwd(st, dY, dy_off, ld_dy, Y, y_off, ld_y, rows, cols, act, dbias=None, seg=1, dseg=None, ld_seg=0):
+  am = torch.zeros(1, dtype=torch.float32, device=dY.device)
   call('dyn_train_act_bwd', _p(dY, dy_off), _p(Y, y_off) if Y is not None else None, rows, cols, ld_dy, ld_y, act,
-       _p(dbias) if dbias is not None else None, seg, _p(dseg) if dseg is not None else None, ld_seg, st)
+       _p(dbias) if dbias is not None else None, seg, _p(dseg) if dseg is not None else None, ld_seg, _p(am), st)
+  dY._dyn_absmax = ((dy_off, ld_dy, rows, cols), am)  # largest |dZ|: the scale of the backward GEMMs that consume this tensor
 
 
 PARAM_NAMES = tuple(n for n in ops.STATIC_TENSORS)  # state-dict order; 's' (last) only exists with anti_alias_pooling

@@ -273,7 +273,8 @@ int dyn_profile_read(float* total_ms, int* launches);
  * features (b_rs = 1, b_ks = ldx), K = number of rows, k_split > 1 with accumulate = 2.
  * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip), act (0 none, 1 ELU, 2 ReLU); accumulate 0 store, 1 or 2: += by fp32 atomics
  * (2 is required with k_split > 1).
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x16_bf16 with exact three-way bf16 splits (6 partial products). */
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x16_f16: every operand split into two half parts (22 mantissa bits), 3 partial products; the
+ * gradient operand A is first multiplied by the power of two that brings a_absmax to 2^14 (undone in the epilogue). */
 typedef struct {
   const float* A;
   long a_rs, a_ks;
@@ -289,13 +290,17 @@ typedef struct {
   int act;
   int accumulate;
   int k_split;
+  const float* a_absmax; /* DEVICE scalar: largest |A| when A is a gradient tensor (scaled into the half range), NULL for operands of order one */
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
 
 /* dZ = dY * act'(Y) in place (act 1: ELU, act 2: ReLU, both from the saved output Y; act 0: unchanged); dbias[c] += column sums (NULL to skip);
- * dseg[(row / seg), c] = sums over the seg rows of a point (gradient of a per-point addend; NULL to skip). */
+ * dseg[(row / seg), c] = sums over the seg rows of a point (gradient of a per-point addend; NULL to skip); absmax: see dyn_train_absmax. */
 int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg, float* dseg,
-                      long ld_seg, void* stream);
+                      long ld_seg, float* absmax, void* stream);
+/* absmax[0] = max(absmax[0], largest |x|) over a [rows, cols] matrix: the scale of a gradient tensor for dyn_train_gemm's a_absmax (the
+ * same by-product of dyn_train_act_bwd when `absmax` != NULL there); absmax is zeroed by the caller. */
+int dyn_train_absmax(const float* x, long rows, int cols, long ld, float* absmax, void* stream);
 
 /* mlp_network.py:423-448 + render_ray.py:372-396: a0 [N,104] = [PE(pts) 33 | PE(src Pluecker) 66 | ray_diff 4 | 0], ref_pe [R,68] =
  * [PE(ref Pluecker) 66 | 0 0], mask_eff [N] = mask (* (sum rgb > 1e-3) when mask_rgb).  centers: source camera centres, centers[v *

@@ -304,6 +304,11 @@ static inline double atomicAdd(double* p, double v) {
   return old;
 }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
 
 namespace emu {
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);

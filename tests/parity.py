@@ -1010,7 +1010,8 @@ def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=Fal
     got = cpu(g[k]).reshape(ref.shape)
     scale = float(ref.abs().max())
     assert_close(got, ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens_g[k])
-    worst = max(worst, float((got - ref).abs().max()) / (scale + 1e-30))
+    if scale > 1e-3 * gmax:  # (tensors whose whole gradient is round-off are held to the absolute floor above, not to a ratio)
+      worst = max(worst, float((got - ref).abs().max()) / scale)
   return worst
 
 
@@ -1021,22 +1022,24 @@ def check_train_gemm(device):
   from dynibar_amd import train_static as TS
   g = torch.Generator().manual_seed(5)
   M, N, K, V = 150, 37, 103, 3
-  for scale in (1.0, 1e-7):
-    X = (torch.randn(M, 104, generator=g) * scale).to(device)
+  for scale in (1.0, 1e-7):  # gradient-like magnitudes too: the gradient operand is rescaled into the half range inside the kernel
+    X = torch.randn(M, 104, generator=g).to(device)
     W = torch.randn(N, K, generator=g).to(device) * 0.3
-    b = torch.randn(N, generator=g).to(device) * scale
-    Pp = (torch.randn(M // V, 40, generator=g) * scale).to(device)
+    b = torch.randn(N, generator=g).to(device)
+    Pp = torch.randn(M // V, 40, generator=g).to(device)
     Y = torch.full((M, 40), float('nan'), device=device)
     lin = TS._Lin(W, b)
-    lin.fwd(TS.stream_of(X), X, 0, 104, Y, 0, 40, M, TS.ELU, addend=Pp, ld_add=40, add_div=V)
-    ref = torch.nn.functional.elu(X[:, :K].double().cpu() @ W.double().cpu().T + b.double().cpu() + Pp.double().cpu()[:, :N].repeat_interleave(V, 0))
-    assert_close(Y[:, :N], ref, 1e-5 * scale, 4e-6, f'train gemm forward (scale {scale:g})')
-    dZ = (torch.randn(M, 40, generator=g) * scale).to(device)
+    if scale == 1.0:
+      lin.fwd(TS.stream_of(X), X, 0, 104, Y, 0, 40, M, TS.ELU, addend=Pp, ld_add=40, add_div=V)
+      ref = torch.nn.functional.elu(X[:, :K].double().cpu() @ W.double().cpu().T + b.double().cpu() + Pp.double().cpu()[:, :N].repeat_interleave(V, 0))
+      assert_close(Y[:, :N], ref, 1e-5, 4e-6, 'train gemm forward')
+    dZ = (torch.randn(M, 40, generator=g) * scale * torch.exp(3.0 * torch.randn(M, 1, generator=g))).to(device)  # rows of very different size
     dW = torch.zeros_like(W)
     dX = torch.full((M, 104), float('nan'), device=device)
     lin.bwd(TS.stream_of(X), dZ, 0, 40, X, 0, 104, dW, M, dX, 0, 104)
-    assert_close(dX[:, :K], dZ[:, :N].double().cpu() @ W.double().cpu(), 1e-5 * scale, 4e-6, f'train gemm data gradient (scale {scale:g})')
-    assert_close(dW, dZ[:, :N].double().cpu().T @ X[:, :K].double().cpu(), 3e-5 * scale * scale, 4e-6, f'train gemm weight gradient (scale {scale:g})')
+    big = float(dZ.abs().max())
+    assert_close(dX[:, :K], dZ[:, :N].double().cpu() @ W.double().cpu(), 3e-6 * big, 4e-6, f'train gemm data gradient (scale {scale:g})')
+    assert_close(dW, dZ[:, :N].double().cpu().T @ X[:, :K].double().cpu(), 1e-5 * big, 4e-6, f'train gemm weight gradient (scale {scale:g})')
   # split reduction over many rows
   M = 5000
   X = torch.randn(M, 64, generator=g).to(device)
@@ -1216,7 +1219,8 @@ def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5
     assert got[k] is not None, f'{tag}: no gradient for {k}'
     scale = float(ref.abs().max())
     assert_close(cpu(got[k]).reshape(ref.shape), ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
-    worst = max(worst, float((cpu(got[k]).reshape(ref.shape) - ref).abs().max()) / (scale + 1e-30))
+    if scale > 1e-3 * gmax:
+      worst = max(worst, float((cpu(got[k]).reshape(ref.shape) - ref).abs().max()) / scale)
   # static side through the two-branch compositing: looser, conditioning-aware comparison of the few largest tensors
   for k in ('st/base_fc.2.weight', 'st/rgb_fc.2.weight', 'st/out_geometry_fc.0.weight', 'featmaps_st'):
     ref = g_ref[k]
