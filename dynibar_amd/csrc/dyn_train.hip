@@ -35,13 +35,21 @@ typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
 
 typedef _Float16 tr_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 tr_f16x8 __attribute__((ext_vector_type(8)));
-// two fp32 values (times a power of two) -> packed half pairs hi and mid: truncating convert, exact residual, convert again
+// two fp32 values (times a power of two when SCALED) -> packed half pairs hi and mid: truncating pack-convert, then the exact residual
+// written as a half by the mixed-precision fma (three instructions per pair, the inference engine's form; dyn_mlp.h)
+template <bool SCALED>
 __device__ __forceinline__ void tr_split2_pair(float x0, float x1, float scale, unsigned& h, unsigned& m) {
-  x0 *= scale; x1 *= scale;
+  if (SCALED) { x0 *= scale; x1 *= scale; }
   const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const auto mm = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]);
   h = __builtin_bit_cast(unsigned, hh);
-  m = __builtin_bit_cast(unsigned, mm);
+#if defined(__AMDGCN__)
+  unsigned mm;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(mm) : "v"(h), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mm) : "v"(h), "v"(x1));
+  m = mm;
+#else  /* the wave-level emulator of tests/emu: the same two residuals, converted like the first part */
+  m = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]));
+#endif
 }
 
 struct TrOperand {
@@ -114,14 +122,14 @@ __device__ __forceinline__ void tr_mask_tile(const TrOperand& o, int row0, int k
 }
 
 // registers -> LDS part images [part][row][k] (k contiguous: what the MFMA operand reads want), splitting on the way
-template <bool KMINOR>
+template <bool KMINOR, bool SCALED>
 __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4], float scale, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (KMINOR) {
       unsigned h0, m0, h1, m1;
-      tr_split2_pair(st[i].x, st[i].y, scale, h0, m0);
-      tr_split2_pair(st[i].z, st[i].w, scale, h1, m1);
+      tr_split2_pair<SCALED>(st[i].x, st[i].y, scale, h0, m0);
+      tr_split2_pair<SCALED>(st[i].z, st[i].w, scale, h1, m1);
       const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
       tr_u16* d = img + r * TG_ROW + k;
       *reinterpret_cast<tr_u32x2*>(d) = tr_u32x2{h0, h1};
@@ -138,7 +146,7 @@ __device__ __forceinline__ void tr_store_tile(tr_u16* img, const float4 (&st)[4]
       for (int i = 0; i < 4; ++i) {
         const float a = q == 0 ? st[i].x : st[i].y, b = q == 0 ? st[i].z : st[i].w;
         unsigned th, tm;
-        tr_split2_pair(a, b, scale, th, tm);
+        tr_split2_pair<SCALED>(a, b, scale, th, tm);
         ph[i] = th; pm[i] = tm;
       }
       tr_u16* d = img + (r + q) * TG_ROW + k;
@@ -218,8 +226,8 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   auto body = [&](float4 (&sa)[4], float4 (&sb)[4], int k0) {
     tr_mask_tile<A_MODE>(g.a, m0, k0, kend, sa, tid);
     tr_mask_tile<B_MODE>(g.b, n0, k0, kend, sb, tid);
-    tr_store_tile<A_KMINOR>(As, sa, a_scale, tid);
-    tr_store_tile<B_KMINOR>(Bs, sb, 1.0f, tid);
+    tr_store_tile<A_KMINOR, true>(As, sa, a_scale, tid);
+    tr_store_tile<B_KMINOR, false>(Bs, sb, 1.0f, tid);
     tr_barrier_lds();
     if (k0 + 2 * TG_BK < kend) {
       tr_load_tile<A_MODE>(g.a, m0, k0 + 2 * TG_BK, kend, sa, tid);
@@ -377,7 +385,28 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
     int in_seg = 0;  // r0 is a multiple of seg (run is)
     long sidx = dseg != nullptr ? r0 / seg : 0;
     const long rend = r0 + run < rows ? r0 + run : rows;
-    for (long r = r0; r < rend; ++r) {
+    long r = r0;
+    if (dseg == nullptr) {
+      // four independent rows per trip: the loop carries only the sums, so the loads of a trip are in flight together
+      float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+      for (; r + 3 < rend; r += 4) {
+        float d0 = dy[r * ld_dy + c], d1 = dy[(r + 1) * ld_dy + c], d2 = dy[(r + 2) * ld_dy + c], d3 = dy[(r + 3) * ld_dy + c];
+        if (act != 0) {
+          const float y0 = y[r * ld_y + c], y1 = y[(r + 1) * ld_y + c], y2 = y[(r + 2) * ld_y + c], y3 = y[(r + 3) * ld_y + c];
+          if (act == 1) {
+            d0 = y0 > 0.f ? d0 : d0 * (y0 + 1.0f); d1 = y1 > 0.f ? d1 : d1 * (y1 + 1.0f);
+            d2 = y2 > 0.f ? d2 : d2 * (y2 + 1.0f); d3 = y3 > 0.f ? d3 : d3 * (y3 + 1.0f);
+          } else {
+            d0 = y0 > 0.f ? d0 : 0.f; d1 = y1 > 0.f ? d1 : 0.f; d2 = y2 > 0.f ? d2 : 0.f; d3 = y3 > 0.f ? d3 : 0.f;
+          }
+          dy[r * ld_dy + c] = d0; dy[(r + 1) * ld_dy + c] = d1; dy[(r + 2) * ld_dy + c] = d2; dy[(r + 3) * ld_dy + c] = d3;
+        }
+        colsum += d0; cs1 += d1; cs2 += d2; cs3 += d3;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+      }
+      colsum += (cs1 + cs2) + cs3;
+    }
+    for (; r < rend; ++r) {
       float d = dy[r * ld_dy + c];
       if (act == 1) {
         const float yv = y[r * ld_y + c];
@@ -413,7 +442,10 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
   DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
   const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
   int run = dseg != nullptr ? seg : 1;
-  while (run < 256) run += (dseg != nullptr ? seg : 1);  // rows per thread: 256 keeps the bias atomics at one per 256 rows and column
+  // rows per thread: the bias gradient costs one fp32 atomic per column and run, and same-address atomics are what this kernel waits for
+  // (measured: 64-row runs 2x slower than 256-row runs): 1024 rows for the 3 M-row matrices, fewer where that would leave CUs idle
+  const int target = rows >= (1L << 20) ? 1024 : 256;
+  while (run < target) run += (dseg != nullptr ? seg : 1);
   const long chunks = (rows + run - 1) / run;
   const int per_block = 256 / ct;
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), 0,
