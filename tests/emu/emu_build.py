@@ -22,17 +22,20 @@ def build(opt='-O2', sanitize=False):
   common = [CXX, '-std=c++20', opt, '-g', '-pthread', '-fPIC', '-I', HERE, '-Wno-unused-function']
   if sanitize:
     common += ['-fsanitize=address', '-fno-omit-frame-pointer']
-  objs = []
-  for src, flags in UNITS:
+  objs, procs = [], []
+  for src, flags in UNITS:  # the translation units compile side by side (dyn_nets.hip alone takes minutes at -O2)
     path = os.path.join(CSRC, src)
     if not os.path.exists(path):
       continue
     obj = os.path.join(OUT_DIR, src.replace('.hip', '_asan.o' if sanitize else '.o'))
-    subprocess.check_call(common + flags + ['-x', 'c++', '-c', path, '-o', obj])
+    procs.append((src, subprocess.Popen(common + flags + ['-x', 'c++', '-c', path, '-o', obj])))
     objs.append(obj)
   obj = os.path.join(OUT_DIR, 'emu_runtime_asan.o' if sanitize else 'emu_runtime.o')
-  subprocess.check_call(common + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', obj])
+  procs.append(('emu_runtime.cpp', subprocess.Popen(common + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', obj])))
   objs.append(obj)
+  for src, pr in procs:
+    if pr.wait() != 0:
+      raise RuntimeError(f'emulator build: compiling {src} failed')
   subprocess.check_call(common + ['-shared'] + objs + ['-o', out])
   return out
 
