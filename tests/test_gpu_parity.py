@@ -209,3 +209,14 @@ def test_full_training_iteration(dev, golden_dir):
   the three feature-map sets against the REAL reference's autograd, for the full loss and for its flow / cycle / regularisation / colour terms"""
   n = parity.check_train_mono(dev, dict(np.load(os.path.join(golden_dir, 'mono_train_grad.npz'))))
   assert n > 300
+
+
+def test_training_loop_reduces_the_loss(dev):
+  """both training stages of the reference end to end on this package (tools/train_loop.py: Adam over the three MLPs + the trajectory basis,
+  render_rays_mono under grad mode, the script's loss, backward through the HIP kernels): the loss must go down in each stage"""
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  import train_loop
+  h = train_loop.run(dev, iters=25, R=256, S=32, log_every=24, quiet=True)
+  assert h['bootstrap'][-1] < 0.97 * h['bootstrap'][0], h
+  assert h['main'][-1] < 0.97 * h['main'][0], h
