@@ -279,6 +279,34 @@ def main():
         extra['feature_encoder'] = {'error': str(e)[:300]}
 
       try:
+        # BASELINE configs[3] (kid-running monocular full frame, dual branch, scene-flow-warped views) and configs[4] (stress: 16 + 16 views,
+        # 128 + 128 samples, one 8192-ray chunk) as timed legs; their parity is tests/test_gpu_parity.py (mono_kid / stress goldens)
+        import config_cases
+        with torch.no_grad():
+          mf = config_cases.MonoFrame(dev)
+          mf.render(); fence()
+          t0 = time.perf_counter()
+          mf.render()
+          fence()
+          mdt = time.perf_counter() - t0
+          extra['mono_frame_kid'] = {'what': 'ONE render_single_image_mono call (BASELINE configs[3]): 147456 rays, 64 samples, 7 + 3 dynamic and 15 static views, '
+                                             'anti_alias_pooling 0 / mask_rgb 1, chunk 8192; one GPU', 'ms_per_frame': mdt * 1e3, 'rays_per_s': mf.rays / mdt}
+          del mf
+          torch.cuda.empty_cache()
+          stc = config_cases.StressChunk(dev)
+          stc.render(); fence()
+          t0 = time.perf_counter()
+          for _ in range(3):
+            stc.render()
+          fence()
+          sdt = (time.perf_counter() - t0) / 3
+          extra['stress_chunk'] = {'what': 'ONE render_rays_mv chunk (BASELINE configs[4]): 8192 rays, 128 coarse + 128 fine samples, 16 dynamic + 16 static views; one GPU',
+                                   'ms_per_chunk': sdt * 1e3, 'rays_per_s': stc.R / sdt}
+          del stc
+          torch.cuda.empty_cache()
+      except Exception as e:
+        extra['config_legs'] = {'error': str(e)[:300]}
+      try:
         # section 8(f)2: the per-view body of the reference's evaluation loop (sampler, four encoder passes, full-frame render, pixels to the
         # host, PSNR) -- what the README's "hours per scene" is made of
         import eval_loop
@@ -322,7 +350,7 @@ def main():
             'what': 'ONE static bootstrap training step (train.py:116-199): gather -> DynibarStatic -> raw2outputs_vanilla, loss.backward() into the 38 '
                     'parameters and the static feature maps; 3072 rays x 64 samples x 15 views (configs/train_kid-running.txt)',
             'ms_per_step': tdt * 1e3, 'rays_per_s': Rt / tdt, 'algorithmic_tflop_per_step': tflop / 1e12, 'algorithmic_tflops': tflop / tdt / 1e12,
-            'frac_of_split6_mfma_peak': tflop / tdt / 1e12 / (2500.0 / 6), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30,
+            'frac_of_split3_mfma_peak': tflop / tdt / 1e12 / (2500.0 / 3), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30,
             'kernel_ms': {k: round(v['avg_ms'] * v['launches'] / 3, 3) for k, v in tk.items()}}
         try:  # the reference's own route on this GPU: the same graph as PyTorch eager ops + autograd (the oracle's restatement on the device)
           from oracle import ibr_oracle as O
@@ -361,17 +389,28 @@ def main():
           tc = TrainCase(dev, R=Rt)
           tc.step(); tc.step(); fence()
           lib.dyn_profile_enable(1)
+          from dynibar_amd import train_static as _ts
+          _ts.GEMM_STATS = {'bytes': 0, 'flops': 0, 'calls': 0}
           t0 = time.perf_counter()
           for _ in range(3):
             tc.step()
           fence()
           tdt = (time.perf_counter() - t0) / 3
           lib.dyn_profile_enable(0)
+          gst, _ts.GEMM_STATS = _ts.GEMM_STATS, None
           tk = read_kernels(lib)
           fl = tc.algorithmic_flops()
           leg[f'rays_{Rt}'] = {'ms_per_step': tdt * 1e3, 'rays_per_s': Rt / tdt, 'algorithmic_tflop_per_step': fl / 1e12, 'algorithmic_tflops': fl / tdt / 1e12,
-                               'frac_of_split6_mfma_peak': fl / tdt / 1e12 / (2500.0 / 6),
+                               'frac_of_split3_mfma_peak': fl / tdt / 1e12 / (2500.0 / 3),
                                'kernel_ms': {k: round(v['avg_ms'] * v['launches'] / 3, 3) for k, v in tk.items()}}
+          if 'k_train_gemm' in tk:
+            gms = tk['k_train_gemm']['avg_ms'] * tk['k_train_gemm']['launches'] / 3
+            leg[f'rays_{Rt}']['roofline_train_gemm'] = {
+                'kernel': 'k_train_gemm (all %d launches of an iteration: forward, data gradient, weight gradient)' % (gst['calls'] // 3), 'bound': 'hbm',
+                'achieved': gst['bytes'] / 3 / gms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gst['bytes'] / 3 / gms / 1e6 / 8000.0,
+                'algorithmic_bytes_per_iteration': gst['bytes'] / 3, 'ms_per_iteration': gms, 'algorithmic_tflops': gst['flops'] / 3 / gms / 1e9,
+                'frac_of_split3_mfma_peak': gst['flops'] / 3 / gms / 1e9 / (2500.0 / 3),
+                'note': 'activations round-trip through HBM between layers (about 40 FLOP per byte): HBM-bound by design; launch time from HIP events on the launch stream'}
           if Rt == 1024:
             try:  # the reference's own route on this GPU: the same iteration as PyTorch eager ops + autograd (the oracle's restatement on the device)
               from oracle import ibr_oracle as O

@@ -33,8 +33,15 @@ def _p(t, off=0):
   return ctypes.c_void_p(t.data_ptr() + 4 * int(off))
 
 
+GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} to total the algorithmic traffic / work of the GEMM launches
+
+
 def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
           a_absmax=None):
+  if GEMM_STATS is not None:  # algorithmic: every operand element read once, every result element written once
+    GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N)
+    GEMM_STATS['flops'] += 2 * M * N * K
+    GEMM_STATS['calls'] += 1
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
              ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax)
   call('dyn_train_gemm', ctypes.byref(p), st)
