@@ -21,7 +21,6 @@
 #include "dyn_device.h"
 #include "dyn_host.h"
 
-typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned tr_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short tr_u16;
 typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
@@ -29,7 +28,7 @@ typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
 #define TG_BM 128
 #define TG_BN 128
 #define TG_BK 32
-#define TG_ROW 40                        // bf16 elements per LDS row (32 used + 8 pad: 80-byte stride, conflict-free b128 reads)
+#define TG_ROW 40                        // half elements per LDS row (32 used + 8 pad: 80-byte stride, conflict-free b128 reads)
 #define TG_PART (TG_BM * TG_ROW)         // elements of one part image
 #define TG_LDS_BYTES (2 * 2 * TG_PART * 2)  // (A | B) x two parts x 2 bytes = 40 KiB
 

@@ -7,7 +7,7 @@ bootstrap stage differentiates (train.py:116-199) --
                                            ->  DynibarStatic's parameters and the static feature maps (feature_net_st's output)
 
 as two ``torch.autograd.Function``s whose forward AND backward are sequences of the ``dyn_train_*`` kernels
-(csrc/dyn_train.hip): a tiled split-bf16 MFMA GEMM for every Linear (forward, data gradient, weight gradient) and small
+(csrc/dyn_train.hip): a tiled split-half-float MFMA GEMM for every Linear (forward, data gradient, weight gradient) and small
 row / per-point kernels for what sits between them.  PyTorch's role is the one it has in the rest of the package: device memory,
 the stream, and the autograd *graph* that carries the gradients on into whichever encoder produced the feature maps and into the
 optimizer; no ATen kernel computes any of the values or gradients of this graph.
