@@ -196,7 +196,8 @@ def test_static_bootstrap_step_drop_in(dev, golden_dir, kid):
   parity.check_static_bootstrap_step(dev, dict(np.load(os.path.join(golden_dir, 'train_static.npz'))), kid=kid)
 
 
-@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=48, R=4), dict(name='many', S=16, R=3)])
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=48, R=4), dict(name='many', S=16, R=3),
+                                dict(name='stress', S=128, R=3), dict(name='few', S=200, R=2)])
 def test_train_dual_branch_step(dev, kw):
   """section 8(f)3, second slice: DynibarDynamic (features gathered at the motion-displaced points) + DynibarStatic + raw2outputs +
   raw2outputs_vanilla: values and the gradients of both nets' parameters and both feature-map sets vs autograd through the oracle"""
