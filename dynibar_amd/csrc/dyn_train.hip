@@ -808,6 +808,17 @@ __global__ void __launch_bounds__(256) k_train_rowscale(const float* __restrict_
   if (row >= N) return;
   y[row * ldy + c] = x[row * ldx + c] * s[row * s_stride];
 }
+// the same for rows of 4 * 2^k floats at 16-byte alignment: one 16-byte access per thread, no 64-bit division
+__global__ void __launch_bounds__(256) k_train_rowscale4(const float4* __restrict__ x, int ldx4, const float* __restrict__ s, long s_stride, long N,
+                                                         int c4_shift, float4* __restrict__ y, int ldy4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> c4_shift;
+  const int c = (int)(idx & ((1 << c4_shift) - 1));
+  if (row >= N) return;
+  const float4 v = x[row * ldx4 + c];
+  const float f = s[row * s_stride];
+  y[row * ldy4 + c] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+}
 __global__ void __launch_bounds__(256) k_train_rowscale_bwd(const float* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ s, long s_stride, long N, int C, float* __restrict__ dx,
                                                             long ld_dx, int accumulate, float* __restrict__ ds, long ds_stride, int ds_accumulate) {
@@ -829,6 +840,14 @@ __global__ void __launch_bounds__(256) k_train_rowscale_bwd(const float* __restr
 }
 extern "C" int dyn_train_rowscale(const float* x, long ldx, const float* s, long s_stride, long N, int C, float* y, long ldy, void* stream) {
   DYN_REQUIRE(x && s && y && N > 0 && C > 0, "dyn_train_rowscale: bad arguments");
+  const int c4 = C / 4;
+  if ((C & 3) == 0 && (c4 & (c4 - 1)) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+    int sh = 0;
+    while ((1 << sh) < c4) ++sh;
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale", k_train_rowscale4, dim3((unsigned)((N * c4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const float4*>(x), (int)(ldx / 4), s, s_stride, N, sh, reinterpret_cast<float4*>(y), (int)(ldy / 4));
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale", k_train_rowscale, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, s,
              s_stride, N, C, y, ldy);
   return 0;
@@ -846,22 +865,28 @@ extern "C" int dyn_train_rowscale_bwd(const float* dy, long ld_dy, const float* 
 __global__ void __launch_bounds__(256) k_train_vis_split(const float* __restrict__ x1, long ld1, const float* __restrict__ xv, long ldv,
                                                          const float* __restrict__ mask, const float* __restrict__ ray_diff, long N,
                                                          float* __restrict__ x2, long ld2, float* __restrict__ vis0) {
+  // one thread per four columns (all leading dimensions are multiples of four floats: checked by the host wrapper)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long row = idx >> 7;
-  const int c = (int)(idx & 127);
+  const long row = idx >> 5;
+  const int c = (int)(idx & 31) * 4;
   if (row >= N) return;
-  x2[row * ld2 + c] = x1[row * ld1 + c] + xv[row * ldv + c];
+  const float4 a = *reinterpret_cast<const float4*>(x1 + row * ld1 + c), b = *reinterpret_cast<const float4*>(xv + row * ldv + c);
+  *reinterpret_cast<float4*>(x2 + row * ld2 + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
   if (c == 0) vis0[row] = tr_sigmoid(xv[row * ldv + 128]) * mask[row];
-  if (ray_diff != nullptr && c >= 4 && c < 11) x2[row * ld2 + 125 + c] = c < 8 ? ray_diff[row * 4 + c - 4] : 0.f;  // columns 129..132 | 133..135
+  if (ray_diff != nullptr && c == 4) {  // columns 129..132 = ray_diff, 133..135 = 0 (column 128, vis, is written later)
+    const float4 rd = *reinterpret_cast<const float4*>(ray_diff + row * 4);
+    float* o = x2 + row * ld2 + 129;
+    o[0] = rd.x; o[1] = rd.y; o[2] = rd.z; o[3] = rd.w; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f;
+  }
 }
 __global__ void __launch_bounds__(256) k_train_vis_split_bwd(const float* __restrict__ dx2, long ld_dx2, const float* __restrict__ dvis0,
                                                              const float* __restrict__ xv, long ldv, const float* __restrict__ mask, long N,
                                                              float* __restrict__ dxv, long ld_dxv) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long row = idx >> 7;
-  const int c = (int)(idx & 127);
+  const long row = idx >> 5;
+  const int c = (int)(idx & 31) * 4;
   if (row >= N) return;
-  dxv[row * ld_dxv + c] = dx2[row * ld_dx2 + c];
+  *reinterpret_cast<float4*>(dxv + row * ld_dxv + c) = *reinterpret_cast<const float4*>(dx2 + row * ld_dx2 + c);
   if (c == 0) {
     const float sg = tr_sigmoid(xv[row * ldv + 128]);
     dxv[row * ld_dxv + 128] = dvis0[row] * mask[row] * sg * (1.0f - sg);
@@ -870,15 +895,19 @@ __global__ void __launch_bounds__(256) k_train_vis_split_bwd(const float* __rest
 extern "C" int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, const float* mask, const float* ray_diff, long N, float* x2,
                                    long ld2, float* vis0, void* stream) {
   DYN_REQUIRE(x1 && xv && mask && x2 && vis0 && N > 0, "dyn_train_vis_split: bad arguments");
+  DYN_REQUIRE(((ld1 | ldv | ld2) & 3) == 0 && (((uintptr_t)x1 | (uintptr_t)xv | (uintptr_t)x2) & 15) == 0,
+              "dyn_train_vis_split: rows must be 16-byte aligned (leading dimensions multiples of 4 floats)");
   DYN_REQUIRE(ray_diff == nullptr || ld2 >= 136, "dyn_train_vis_split: the [x2 | vis | ray_diff | 0 0 0] layout needs ld2 >= 136");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split", k_train_vis_split, dim3((unsigned)((N * 128 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split", k_train_vis_split, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1,
              ld1, xv, ldv, mask, ray_diff, N, x2, ld2, vis0);
   return 0;
 }
 extern "C" int dyn_train_vis_split_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
                                        float* dxv, long ld_dxv, void* stream) {
   DYN_REQUIRE(dx2 && dvis0 && xv && mask && dxv && N > 0, "dyn_train_vis_split_bwd: bad arguments");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split_bwd", k_train_vis_split_bwd, dim3((unsigned)((N * 128 + 255) / 256)), dim3(256), 0,
+  DYN_REQUIRE(((ld_dx2 | ldv | ld_dxv) & 3) == 0 && (((uintptr_t)dx2 | (uintptr_t)dxv) & 15) == 0,
+              "dyn_train_vis_split_bwd: rows must be 16-byte aligned (leading dimensions multiples of 4 floats)");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split_bwd", k_train_vis_split_bwd, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0,
              (hipStream_t)stream, dx2, ld_dx2, dvis0, xv, ldv, mask, N, dxv, ld_dxv);
   return 0;
 }
