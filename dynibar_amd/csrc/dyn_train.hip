@@ -510,10 +510,16 @@ __global__ void __launch_bounds__(256) k_train_static_embed(const float* __restr
     for (int k = 0; k < 6; ++k) tr_embed(c[k], o + k, 6);
     o[66] = 0.f; o[67] = 0.f;
   }
-  if (row >= N) return;
-  const long p = row / V;
-  const int v = (int)(row - p * V);
-  float* o = a0 + row * 104;
+  // the 104-float row of a thread is assembled in LDS ([64 rows][105]: odd stride) and the wave's 64 rows leave as ONE contiguous run of
+  // 26 KiB: per-thread scalar stores into 416-byte rows measured 8.8 GB of HBM traffic per launch for 1.7 GB of algorithmic bytes
+  float* tile = reinterpret_cast<float*>(dyn_smem) + (threadIdx.x >> 6) * (64 * 105);
+  const int lane = threadIdx.x & 63;
+  const long wrow0 = row - lane;                       // first row of this wave
+  const bool has = row < N;
+  const long rowc = has ? row : N - 1;                 // idle lanes shadow the last row (their LDS row is never copied out)
+  const long p = rowc / V;
+  const int v = (int)(rowc - p * V);
+  float* o = tile + lane * 105;
   const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
   tr_embed(px, o + 0, 3);
   tr_embed(py, o + 1, 3);
@@ -525,14 +531,30 @@ __global__ void __launch_bounds__(256) k_train_static_embed(const float* __restr
   c[4] = cz * c[0] - cx * c[2];
   c[5] = cx * c[1] - cy * c[0];
   for (int k = 0; k < 6; ++k) tr_embed(c[k], o + 33 + k, 6);
-  const float4 rd = *reinterpret_cast<const float4*>(ray_diff + row * 4);
+  const float4 rd = *reinterpret_cast<const float4*>(ray_diff + rowc * 4);
   o[99] = rd.x; o[100] = rd.y; o[101] = rd.z; o[102] = rd.w; o[103] = 0.f;
-  float m = mask[row];
-  if (mask_rgb) {
-    const float* f = rgb_feat + row * 35;
-    m = m * (((f[0] + f[1]) + f[2]) > 1e-3f ? 1.0f : 0.0f);
+  if (has) {
+    float m = mask[row];
+    if (mask_rgb) {
+      const float* f = rgb_feat + row * 35;
+      m = m * (((f[0] + f[1]) + f[2]) > 1e-3f ? 1.0f : 0.0f);
+    }
+    mask_eff[row] = m;
   }
-  mask_eff[row] = m;
+  // (the wave's own LDS rows: no workgroup barrier needed, a wave executes in lock step; the fence orders the LDS writes before the reads)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  const long nrows = N - wrow0 < 64 ? N - wrow0 : 64;
+  if (nrows > 0) {
+    float* dst = a0 + wrow0 * 104;
+    const int total = (int)nrows * 104;
+    for (int t = lane; t < total; t += 64) {
+      const int rr = t / 104;
+      dst[t] = tile[rr * 105 + (t - rr * 104)];
+    }
+  }
 }
 
 extern "C" int dyn_train_static_embed(const float* pts, const float* ray_o, const float* ray_d, const float* centers, int center_stride,
@@ -541,7 +563,7 @@ extern "C" int dyn_train_static_embed(const float* pts, const float* ray_o, cons
   DYN_REQUIRE(pts && ray_o && ray_d && centers && ray_diff && rgb_feat && mask && a0 && ref_pe && mask_eff, "dyn_train_static_embed: null pointer");
   DYN_REQUIRE(R > 0 && S > 0 && V > 0, "dyn_train_static_embed: empty shape");
   const long N = (long)R * S * V;
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_static_embed", k_train_static_embed, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_static_embed", k_train_static_embed, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)4 * 64 * 105 * 4, (hipStream_t)stream,
              pts, ray_o, ray_d, centers, center_stride, ray_diff, rgb_feat, mask, R, S, V, mask_rgb, a0, ref_pe, mask_eff);
   return 0;
 }
@@ -1012,8 +1034,114 @@ __global__ void k_train_attn_bwd(const float* __restrict__ qkv, const float* __r
     dqkv[p * 384 + 256 + head * 32 + d] = dv[d];
   }
 }
+// The same two kernels with the S x S score / probability tiles of a (ray, head) kept in LDS (rays of up to 112 samples): the kernels
+// above use the global `prob` / `dscore` arrays as per-thread scratch rows -- 4-byte accesses at a stride of S floats, measured at 6-8 GB of
+// HBM traffic per launch for 0.6 GB of algorithmic bytes.  Here the probabilities leave once, as coalesced rows, and come back once.
+__global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, float* __restrict__ out,
+                                 float* __restrict__ prob) {
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]
+  float* vs = ks + S * 33;                         // [S][33]
+  float* ps = vs + S * 33;                         // [S][S + 1]
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
+  const long p = (long)ray * S + i;
+  float q[32];
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
+    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
+    q[d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;
+  }
+  __syncthreads();
+  const bool live = nvalid[p] > 1.0f;
+  float* pr = ps + i * SP;
+  float mx = -INFINITY;
+  for (int j = 0; j < S; ++j) {
+    float sc = 0.f;
+    for (int d = 0; d < 32; ++d) sc += q[d] * ks[j * 33 + d];
+    if (!live) sc = -1e9f;
+    pr[j] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  float den = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float e = expf(pr[j] - mx);
+    pr[j] = e;
+    den += e;
+  }
+  float o[32];
+  for (int d = 0; d < 32; ++d) o[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float a = pr[j] / den;
+    pr[j] = a;
+    for (int d = 0; d < 32; ++d) o[d] += a * vs[j * 33 + d];
+  }
+  for (int d = 0; d < 32; ++d) out[p * 128 + head * 32 + d] = o[d];
+  __syncthreads();
+  float* g = prob + (long)blockIdx.x * S * S;
+  for (int r = 0; r < S; ++r) g[(long)r * S + i] = ps[r * SP + i];  // coalesced rows
+}
+__global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, const float* __restrict__ prob,
+                                     const float* __restrict__ dout, float* __restrict__ dqkv) {
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]: K, later Q / sqrt(d)
+  float* vs = ks + S * 33;                         // [S][33]: V, later dO
+  float* ps = vs + S * 33;                         // [S][S + 1]: probabilities
+  float* db = ps + S * (S + 1);                    // [S][S + 1]: score gradients
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
+  const long p = (long)ray * S + i;
+  float dO[32], q[32];
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
+    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
+    dO[d] = dout[p * 128 + head * 32 + d];
+    q[d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;
+  }
+  const float* g = prob + (long)blockIdx.x * S * S;
+  for (int r = 0; r < S; ++r) ps[r * SP + i] = g[(long)r * S + i];
+  __syncthreads();
+  const bool live = nvalid[p] > 1.0f;
+  float dot = 0.f;
+  for (int j = 0; j < S; ++j) {
+    float dp = 0.f;
+    for (int d = 0; d < 32; ++d) dp += dO[d] * vs[j * 33 + d];
+    db[i * SP + j] = dp;
+    dot += dp * ps[i * SP + j];
+  }
+  float dq[32];
+  for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float ds = live ? ps[i * SP + j] * (db[i * SP + j] - dot) : 0.f;
+    db[i * SP + j] = ds;
+    for (int d = 0; d < 32; ++d) dq[d] += ds * ks[j * 33 + d];
+  }
+  for (int d = 0; d < 32; ++d) dqkv[p * 384 + head * 32 + d] = dq[d] / 5.656854249492381f;
+  __syncthreads();  // every thread is done with K and V
+  for (int d = 0; d < 32; ++d) {
+    ks[i * 33 + d] = q[d];
+    vs[i * 33 + d] = dO[d];
+  }
+  __syncthreads();
+  float dk[32], dv[32];
+  for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int qi = 0; qi < S; ++qi) {
+    const float a = ps[qi * SP + i], ds = db[qi * SP + i];
+    for (int d = 0; d < 32; ++d) {
+      dk[d] += ds * ks[qi * 33 + d];
+      dv[d] += a * vs[qi * 33 + d];
+    }
+  }
+  for (int d = 0; d < 32; ++d) {
+    dqkv[p * 384 + 128 + head * 32 + d] = dk[d];
+    dqkv[p * 384 + 256 + head * 32 + d] = dv[d];
+  }
+}
+#define TR_ATTN_LDS_MAX_S 112
+
 extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int S, float* out, float* prob, void* stream) {
   DYN_REQUIRE(qkv && nvalid && out && prob && R > 0 && S > 0 && S <= 256, "dyn_train_attn: bad arguments (S <= 256)");
+  if (S <= TR_ATTN_LDS_MAX_S) {
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 66 + S * (S + 1)) * 4, (hipStream_t)stream,
+               qkv, nvalid, S, out, prob);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn, dim3((unsigned)R * 4), dim3(S), (size_t)S * 33 * 8, (hipStream_t)stream, qkv, nvalid, S,
              out, prob);
   return 0;
@@ -1021,6 +1149,11 @@ extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int 
 extern "C" int dyn_train_attn_bwd(const float* qkv, const float* nvalid, int R, int S, const float* prob, const float* dout, float* dscore,
                                   float* dqkv, void* stream) {
   DYN_REQUIRE(qkv && nvalid && prob && dout && dscore && dqkv && R > 0 && S > 0 && S <= 256, "dyn_train_attn_bwd: bad arguments (S <= 256)");
+  if (S <= TR_ATTN_LDS_MAX_S) {
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 66 + 2 * S * (S + 1)) * 4,
+               (hipStream_t)stream, qkv, nvalid, S, prob, dout, dqkv);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd, dim3((unsigned)R * 4), dim3(S), (size_t)S * 33 * 8, (hipStream_t)stream, qkv,
              nvalid, S, prob, dout, dscore, dqkv);
   return 0;
