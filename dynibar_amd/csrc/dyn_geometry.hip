@@ -810,6 +810,40 @@ __global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __re
   }
 }
 
+// F == 32 (the only width the encoder produces): lane = channel, so one atomic instruction adds two complete 128-byte pixel records
+// (32 lanes each) instead of 4-byte pieces of eight records -- the L2 atomic units work per line.
+__global__ void __launch_bounds__(256) k_gather_bwd32(PGShape q, const float* __restrict__ pts_st, const float* __restrict__ xyz,
+                                                      const float4* __restrict__ proj4, const float* __restrict__ drgb_feat, long ld_d, int col0,
+                                                      float* __restrict__ dfeat) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = idx >> 5;
+  const int c = (int)(idx & 31);
+  if (row >= q.N) return;
+  const long rs = row / q.V;
+  const int v = (int)(row - rs * q.V);
+  const float* pt = xyz != nullptr ? xyz + ((long)v * q.R * q.S + rs) * 3 : pts_st + rs * 3;
+  const float x = pt[0], y = pt[1], z3 = pt[2];
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  const float izc = __builtin_amdgcn_rcpf(zc);
+  float px = hx * izc, py = hy * izc;
+  px = fminf(fmaxf(px, -1e6f), 1e6f);
+  py = fminf(fmaxf(py, -1e6f), 1e6f);
+  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
+  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const Taps t = make_taps(nx, ny, q.Wf, q.Hf);
+  const float d = drgb_feat[row * ld_d + col0 + c];
+  float* base = dfeat + (long)v * q.Hf * q.Wf * 32 + c;
+  const float wts[4] = {t.w_nw, t.w_ne, t.w_sw, t.w_se};
+  const int offs[4] = {t.y0 * q.Wf + t.x0, t.y0 * q.Wf + t.x1, t.y1 * q.Wf + t.x0, t.y1 * q.Wf + t.x1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (wts[k] != 0.f) atomicAdd(base + (long)offs[k] * 32, wts[k] * d);
+}
+
 extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
                               const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream) {
   DYN_REQUIRE((pts_st || xyz) && proj && drgb_feat && dfeat_cl, "dyn_gather_bwd: null pointer");
@@ -820,6 +854,11 @@ extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float
   q.inv_wm1 = 1.0f / (img_w - 1.0f); q.inv_hm1 = 1.0f / (img_h - 1.0f);
   q.N = (long)R * S * V;
   q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
+  if (F == 32) {
+    DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd32, dim3((unsigned)((q.N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q,
+               pts_st, xyz, reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);
+    return 0;
+  }
   const long n = q.N * (F / 4);
   DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, pts_st, xyz,
              reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);

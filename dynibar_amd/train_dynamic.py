@@ -253,6 +253,8 @@ class DynamicNetFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, draw):
+    if ctx.step is None:
+      raise RuntimeError('DynamicNetFunction: the saved activations were released by the first backward pass; call the renderer again instead of backward(retain_graph=True)')
     s = ctx.step
     g, dF = _backward(s, draw.float())
     gr = dF[:, :35].reshape(ctx.fshape) if ctx.needs_input_grad[0] else None

@@ -208,6 +208,8 @@ class MotionMLPFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, g):
+    if ctx.H is None:
+      raise RuntimeError('MotionMLPFunction: the saved activations were released by the first backward pass; call the renderer again instead of backward(retain_graph=True)')
     R, S, P, C = ctx.dims
     w, L, H, X0 = ctx.w, ctx.L, ctx.H, ctx.X0
     dev = g.device

@@ -314,6 +314,8 @@ class StaticNetFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, draw):
+    if ctx.step is None:
+      raise RuntimeError('StaticNetFunction: the saved activations were released by the first backward pass; call the renderer again instead of backward(retain_graph=True)')
     g, dF = _backward(ctx.step, draw.float())
     ctx.step = None  # the saved activations are released with the step
     gr = dF[:, :35].reshape(ctx.fshape) if ctx.needs_input_grad[0] else None  # a column-slice view: the gather's backward reads it in place
