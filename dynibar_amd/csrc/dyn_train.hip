@@ -372,58 +372,57 @@ __device__ __forceinline__ float tr_sigmoid(float v) { return 1.0f / (1.0f + exp
 
 // dZ = dY * act'(Y) in place (ELU: y > 0 ? 1 : y + 1, from the saved OUTPUT), plus the bias gradient (column sums, atomics) and the
 // gradient of a per-point addend (sums over the seg rows of a point).  A thread owns one column of a run of rows.
+// U consecutive rows of one column: all loads first (they are in flight together), then the derivative, the stores and the sums
+template <int U>
+__device__ __forceinline__ float tr_act_rows(float* __restrict__ dy, const float* __restrict__ y, long r, int c, long ld_dy, long ld_y, int act, float& amax) {
+  float d[U], yv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) d[u] = dy[(r + u) * ld_dy + c];
+  if (act != 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) yv[u] = y[(r + u) * ld_y + c];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d[u] = yv[u] > 0.f ? d[u] : (act == 1 ? d[u] * (yv[u] + 1.0f) : 0.f);  // ELU' = y + 1 below zero; ReLU' = 0
+      dy[(r + u) * ld_dy + c] = d[u];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    s += d[u];
+    amax = fmaxf(amax, fabsf(d[u]));
+  }
+  return s;
+}
+__device__ __forceinline__ float tr_act_span(float* __restrict__ dy, const float* __restrict__ y, long ra, long rb, int c, long ld_dy, long ld_y, int act,
+                                             float& amax) {
+  float s = 0.f;
+  long r = ra;
+  for (; r + 7 < rb; r += 8) s += tr_act_rows<8>(dy, y, r, c, ld_dy, ld_y, act, amax);
+  for (; r + 3 < rb; r += 4) s += tr_act_rows<4>(dy, y, r, c, ld_dy, ld_y, act, amax);
+  for (; r < rb; ++r) s += tr_act_rows<1>(dy, y, r, c, ld_dy, ld_y, act, amax);
+  return s;
+}
+
 __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, const float* __restrict__ y, long rows, int cols, long ld_dy, long ld_y,
                                                        int act, float* __restrict__ dbias, int seg, float* __restrict__ dseg, long ld_seg, int ct,
                                                        int run, float* __restrict__ absmax) {
   const int cx = threadIdx.x % ct, cy = threadIdx.x / ct;
   const long chunk = (long)blockIdx.x * (256 / ct) + cy;
   const long r0 = chunk * run;
+  const long rend = r0 + run < rows ? r0 + run : rows;
   float amax = 0.f;
   for (int c = cx; c < cols; c += ct) {
-    float colsum = 0.f, segsum = 0.f;
-    int in_seg = 0;  // r0 is a multiple of seg (run is)
-    long sidx = dseg != nullptr ? r0 / seg : 0;
-    const long rend = r0 + run < rows ? r0 + run : rows;
-    long r = r0;
+    float colsum = 0.f;
     if (dseg == nullptr) {
-      // four independent rows per trip: the loop carries only the sums, so the loads of a trip are in flight together
-      float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
-      for (; r + 3 < rend; r += 4) {
-        float d0 = dy[r * ld_dy + c], d1 = dy[(r + 1) * ld_dy + c], d2 = dy[(r + 2) * ld_dy + c], d3 = dy[(r + 3) * ld_dy + c];
-        if (act != 0) {
-          const float y0 = y[r * ld_y + c], y1 = y[(r + 1) * ld_y + c], y2 = y[(r + 2) * ld_y + c], y3 = y[(r + 3) * ld_y + c];
-          if (act == 1) {
-            d0 = y0 > 0.f ? d0 : d0 * (y0 + 1.0f); d1 = y1 > 0.f ? d1 : d1 * (y1 + 1.0f);
-            d2 = y2 > 0.f ? d2 : d2 * (y2 + 1.0f); d3 = y3 > 0.f ? d3 : d3 * (y3 + 1.0f);
-          } else {
-            d0 = y0 > 0.f ? d0 : 0.f; d1 = y1 > 0.f ? d1 : 0.f; d2 = y2 > 0.f ? d2 : 0.f; d3 = y3 > 0.f ? d3 : 0.f;
-          }
-          dy[r * ld_dy + c] = d0; dy[(r + 1) * ld_dy + c] = d1; dy[(r + 2) * ld_dy + c] = d2; dy[(r + 3) * ld_dy + c] = d3;
-        }
-        colsum += d0; cs1 += d1; cs2 += d2; cs3 += d3;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
-      }
-      colsum += (cs1 + cs2) + cs3;
-    }
-    for (; r < rend; ++r) {
-      float d = dy[r * ld_dy + c];
-      if (act == 1) {
-        const float yv = y[r * ld_y + c];
-        d = yv > 0.f ? d : d * (yv + 1.0f);
-        dy[r * ld_dy + c] = d;
-      } else if (act == 2) {  // ReLU
-        d = y[r * ld_y + c] > 0.f ? d : 0.f;
-        dy[r * ld_dy + c] = d;
-      }
-      colsum += d;
-      amax = fmaxf(amax, fabsf(d));
-      if (dseg != nullptr) {
-        segsum += d;
-        if (++in_seg == seg) {
-          dseg[sidx++ * ld_seg + c] = segsum;
-          segsum = 0.f;
-          in_seg = 0;
-        }
+      colsum = tr_act_span(dy, y, r0, rend, c, ld_dy, ld_y, act, amax);
+    } else {  // r0 and rows are multiples of seg (run is): whole segments, one sum stored per segment
+      long sidx = r0 / seg;
+      for (long r = r0; r < rend; r += seg) {
+        const float segsum = tr_act_span(dy, y, r, r + seg, c, ld_dy, ld_y, act, amax);
+        dseg[sidx++ * ld_seg + c] = segsum;
+        colsum += segsum;
       }
     }
     if (dbias != nullptr && r0 < rows) atomicAdd(dbias + c, colsum);
@@ -453,22 +452,36 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
 }
 
 // largest |x| of a [rows, cols] matrix (leading dimension ld): the scale of a gradient tensor that no activation-derivative pass produced
-__global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ x, long rows, int cols, long ld, float* __restrict__ absmax) {
-  const long n = rows * cols;
+__global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ x, long rows, int cols, long ld, int ct, float* __restrict__ absmax) {
   float amax = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols;
-    amax = fmaxf(amax, fabsf(x[r * ld + (i - r * cols)]));
+  if (ld == cols) {  // contiguous: one flat stream, four independent loads per trip
+    const long n = rows * cols, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
+      const long i1 = i + stride < n ? i + stride : i, i2 = i + 2 * stride < n ? i + 2 * stride : i, i3 = i + 3 * stride < n ? i + 3 * stride : i;
+      const float a0 = x[i], a1 = x[i1], a2 = x[i2], a3 = x[i3];
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a0), fabsf(a1))), fmaxf(fabsf(a2), fabsf(a3)));
+    }
+  } else {  // a column window of a wider matrix: a thread keeps its column, the block walks rows (no per-element division); re-reading
+            // a valid row past the end is harmless for a maximum, so the four loads of a trip are issued without branches
+    const int cx = threadIdx.x % ct, cy = threadIdx.x / ct;
+    const long stride = (long)gridDim.x * (256 / ct);
+    for (long r = (long)blockIdx.x * (256 / ct) + cy; r < rows; r += 4 * stride) {
+      const long r1 = r + stride < rows ? r + stride : r, r2 = r + 2 * stride < rows ? r + 2 * stride : r, r3 = r + 3 * stride < rows ? r + 3 * stride : r;
+      for (int c = cx; c < cols; c += ct) {
+        const float a0 = x[r * ld + c], a1 = x[r1 * ld + c], a2 = x[r2 * ld + c], a3 = x[r3 * ld + c];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a0), fabsf(a1))), fmaxf(fabsf(a2), fabsf(a3)));
+      }
+    }
   }
   amax = wave_max(amax);
   if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
 }
 extern "C" int dyn_train_absmax(const float* x, long rows, int cols, long ld, float* absmax, void* stream) {
-  DYN_REQUIRE(x && absmax && rows > 0 && cols > 0, "dyn_train_absmax: bad arguments");
-  const long n = rows * cols;
-  const long blocks = (n + 255) / 256;
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_absmax", k_train_absmax, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, x,
-             rows, cols, ld, absmax);
+  DYN_REQUIRE(x && absmax && rows > 0 && cols > 0 && ld >= cols, "dyn_train_absmax: bad arguments");
+  const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
+  const long blocks = ld == cols ? (rows * cols + 1023) / 1024 : (rows + 4 * (256 / ct) - 1) / (4 * (256 / ct));
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_absmax", k_train_absmax, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x,
+             rows, cols, ld, ct, absmax);
   return 0;
 }
 

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
-from .train_static import ELU, NONE, _Lin, _act_bwd, _p
+from .train_static import ELU, NONE, _Lin, _act_bwd, _p, zero_grads
 
 PARAM_NAMES = ops.DYNAMIC_TENSORS
 
@@ -141,8 +141,8 @@ def _backward(s, draw):
   dev = draw.device
   st = stream_of(draw)
   new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-  g = {n: torch.zeros_like(t) for n, t in w.items()}
-  gqkv = torch.zeros_like(s.Wqkv)
+  g = zero_grads(dict(w, **{'__qkv': s.Wqkv}))
+  gqkv = g.pop('__qkv')
   draw = draw.contiguous()
   dCL, dSIG = new(P, 4), new(P)
   call('dyn_train_dynamic_head_bwd', _p(draw), _p(s.raw), _p(s.nvalid), P, _p(dCL), 4, _p(dSIG), st)

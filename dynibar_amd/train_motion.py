@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
-from .train_static import NONE, _Lin, _act_bwd, _p
+from .train_static import NONE, _Lin, _act_bwd, _p, zero_grads
 
 RELU = 2
 MOTION_FREQS = np.linspace(1.0, 17.0, 16).astype(np.float32)   # PeriodicEmbed(max_freq=16, N_freq=16, linspace=True): mlp_network.py:589
@@ -215,7 +215,7 @@ class MotionMLPFunction(torch.autograd.Function):
     dev = g.device
     st = stream_of(g)
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    grads = {n: torch.zeros_like(t) for n, t in w.items()}
+    grads = zero_grads(w)
     dC = g.float().contiguous().clone()
     call('dyn_train_zero_tail', _p(dC), R, S, C, ctx.n_zero, 1.0 / ctx.sf_div, st)
     _act_bwd(st, dC, 0, C, None, 0, C, P, C, NONE, grads['coeff_linear.bias'])

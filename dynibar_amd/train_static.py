@@ -33,6 +33,31 @@ def _p(t, off=0):
   return ctypes.c_void_p(t.data_ptr() + 4 * int(off))
 
 
+class _Scalars:
+  """Zero-initialised device scalars handed out from 512-element blocks (one fill kernel per block instead of one per scalar); an
+  element is handed out once, so it is still zero when the kernel that accumulates into it runs."""
+  blocks = {}
+
+  @classmethod
+  def take(cls, device):
+    blk = cls.blocks.get(device)
+    if blk is None or blk[1] >= blk[0].numel():
+      blk = cls.blocks[device] = [torch.zeros(512, dtype=torch.float32, device=device), 0]
+    blk[1] += 1
+    return blk[0][blk[1] - 1:blk[1]]
+
+
+def zero_grads(w):
+  """{name: zero tensor shaped like w[name]} as 256-byte aligned views of ONE zero-filled buffer (a step has ~40 parameter tensors)."""
+  offs, total = {}, 0
+  for n, t in w.items():
+    offs[n] = total
+    total += (t.numel() + 63) // 64 * 64
+  dev = next(iter(w.values())).device
+  flat = torch.zeros(total, dtype=torch.float32, device=dev)
+  return {n: flat[offs[n]:offs[n] + t.numel()].view(t.shape) for n, t in w.items()}
+
+
 GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} to total the algorithmic traffic / work of the GEMM launches
 
 
@@ -67,7 +92,7 @@ class _Lin:
     if tag is not None and tag[0] == (dz_off, ld_dz, M, self.n_out):
       am = tag[1]
     else:
-      am = torch.zeros(1, dtype=torch.float32, device=dZ.device)
+      am = _Scalars.take(dZ.device)
       call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
       dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
     ks = max(1, min(512, M // 1024))
@@ -79,7 +104,7 @@ class _Lin:
 
 
 def _act_bwd(st, dY, dy_off, ld_dy, Y, y_off, ld_y, rows, cols, act, dbias=None, seg=1, dseg=None, ld_seg=0):
-  am = torch.zeros(1, dtype=torch.float32, device=dY.device)
+  am = _Scalars.take(dY.device)
   call('dyn_train_act_bwd', _p(dY, dy_off), _p(Y, y_off) if Y is not None else None, rows, cols, ld_dy, ld_y, act,
        _p(dbias) if dbias is not None else None, seg, _p(dseg) if dseg is not None else None, ld_seg, _p(am), st)
   dY._dyn_absmax = ((dy_off, ld_dy, rows, cols), am)  # largest |dZ|: the scale of the backward GEMMs that consume this tensor
@@ -215,8 +240,8 @@ def _backward(s, draw):
   dev = draw.device
   st = stream_of(draw)
   new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-  g = {n: torch.zeros_like(t) for n, t in w.items()}
-  gqkv = torch.zeros_like(s.Wqkv)
+  g = zero_grads(dict(w, **{'__qkv': s.Wqkv}))
+  gqkv = g.pop('__qkv')
   draw = draw.contiguous()
   # blending softmax / density fill
   dRL, dSIG = new(N), new(P)
