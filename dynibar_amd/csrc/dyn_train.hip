@@ -433,11 +433,102 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
   }
 }
 
+// The same pass with 16-byte accesses (cols, both leading dimensions and ld_seg multiples of four, 16-byte aligned bases: the 64 / 128 /
+// 256-wide hidden layers, i.e. nearly all of the traffic).  L = cols / 4 lanes span a row, the block's G = 256 / L lane groups own
+// consecutive spans of `span` rows (whole segments), four rows per trip; the G partial column sums meet in LDS, so a block still issues one
+// atomic per column.
+__device__ __forceinline__ float4 tr_act4(float4 d, float4 y, int act) {
+  if (act == 1) {
+    d.x = y.x > 0.f ? d.x : d.x * (y.x + 1.0f); d.y = y.y > 0.f ? d.y : d.y * (y.y + 1.0f);
+    d.z = y.z > 0.f ? d.z : d.z * (y.z + 1.0f); d.w = y.w > 0.f ? d.w : d.w * (y.w + 1.0f);
+  } else {
+    d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f; d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+  }
+  return d;
+}
+template <int U>
+__device__ __forceinline__ void tr_act_rows4(float4* __restrict__ dy, const float4* __restrict__ y, long r, long ld_dy4, long ld_y4, int act, float4& sum,
+                                             float& amax) {
+  float4 d[U], yv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) d[u] = dy[(r + u) * ld_dy4];
+  if (act != 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) yv[u] = y[(r + u) * ld_y4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d[u] = tr_act4(d[u], yv[u], act);
+      dy[(r + u) * ld_dy4] = d[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    sum.x += d[u].x; sum.y += d[u].y; sum.z += d[u].z; sum.w += d[u].w;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d[u].x), fabsf(d[u].y))), fmaxf(fabsf(d[u].z), fabsf(d[u].w)));
+  }
+}
+__device__ __forceinline__ void tr_act_span4(float4* __restrict__ dy, const float4* __restrict__ y, long ra, long rb, long ld_dy4, long ld_y4, int act,
+                                             float4& sum, float& amax) {
+  long r = ra;
+  for (; r + 3 < rb; r += 4) tr_act_rows4<4>(dy, y, r, ld_dy4, ld_y4, act, sum, amax);
+  for (; r < rb; ++r) tr_act_rows4<1>(dy, y, r, ld_dy4, ld_y4, act, sum, amax);
+}
+__global__ void __launch_bounds__(256) k_train_act_bwd4(float4* __restrict__ dy, const float4* __restrict__ y, long rows, int L, long ld_dy4, long ld_y4,
+                                                        int act, float* __restrict__ dbias, int seg, float4* __restrict__ dseg, long ld_seg4, int span,
+                                                        float* __restrict__ absmax) {
+  float4* part = dyn_smem;  // [G][L] partial column sums (4 KiB)
+  const int G = 256 / L, g = threadIdx.x / L, q = threadIdx.x - g * L;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amax = 0.f;
+  if (g < G) {
+    const long ra = ((long)blockIdx.x * G + g) * span;
+    const long rb = ra + span < rows ? ra + span : rows;
+    float4* dq = dy + q;
+    const float4* yq = y != nullptr ? y + q : nullptr;
+    if (dseg == nullptr) {
+      if (ra < rb) tr_act_span4(dq, yq, ra, rb, ld_dy4, ld_y4, act, colsum, amax);
+    } else {  // ra, span and rows are multiples of seg
+      long sidx = ra / seg;
+      for (long r = ra; r < rb; r += seg) {
+        float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+        tr_act_span4(dq, yq, r, r + seg, ld_dy4, ld_y4, act, ss, amax);
+        dseg[sidx++ * ld_seg4 + q] = ss;
+        colsum.x += ss.x; colsum.y += ss.y; colsum.z += ss.z; colsum.w += ss.w;
+      }
+    }
+    part[g * L + q] = colsum;
+  }
+  __syncthreads();
+  if (dbias != nullptr && threadIdx.x < 4 * L) {  // column threadIdx.x: the G partial sums, then ONE atomic per column and block
+    const float* pf = reinterpret_cast<const float*>(part);
+    float s = 0.f;
+    for (int k = 0; k < G; ++k) s += pf[k * 4 * L + threadIdx.x];
+    atomicAdd(dbias + threadIdx.x, s);
+  }
+  if (absmax != nullptr) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+  }
+}
+
 extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg,
                                  float* dseg, long ld_seg, float* absmax, void* stream) {
   DYN_REQUIRE(dY != nullptr && rows > 0 && cols > 0, "dyn_train_act_bwd: bad arguments");
   DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_act_bwd: ELU / ReLU backward needs the saved output");
   DYN_REQUIRE(dseg == nullptr || (seg >= 1 && rows % seg == 0), "dyn_train_act_bwd: rows must be whole segments");
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if ((cols & 3) == 0 && cols >= 16 && cols <= 256 && (ld_dy & 3) == 0 && (act == 0 || (ld_y & 3) == 0) && al16(dY) && (act == 0 || al16(Y)) &&
+      (dseg == nullptr || ((ld_seg & 3) == 0 && al16(dseg)))) {
+    const int L = cols / 4, G = 256 / L;
+    const int unit = dseg != nullptr ? seg : 1;
+    const long want = (rows >= (1L << 20) ? 2048 : 256) / G;  // rows per block: as the scalar kernel's runs (same-address atomics per column)
+    const int span = (int)((want + unit - 1) / unit) * unit;
+    const long blocks = (rows + (long)G * span - 1) / ((long)G * span);
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd4, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float4), (hipStream_t)stream,
+               reinterpret_cast<float4*>(dY), reinterpret_cast<const float4*>(act != 0 ? Y : nullptr), rows, L, ld_dy / 4, ld_y / 4, act, dbias, seg,
+               reinterpret_cast<float4*>(dseg), ld_seg / 4, span, absmax);
+    return 0;
+  }
   const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
   int run = dseg != nullptr ? seg : 1;
   // rows per thread: the bias gradient costs one fp32 atomic per column and run, and same-address atomics are what this kernel waits for
