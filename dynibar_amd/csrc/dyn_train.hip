@@ -372,6 +372,20 @@ __device__ __forceinline__ float tr_sigmoid(float v) { return 1.0f / (1.0f + exp
 
 // dZ = dY * act'(Y) in place (ELU: y > 0 ? 1 : y + 1, from the saved OUTPUT), plus the bias gradient (column sums, atomics) and the
 // gradient of a per-point addend (sums over the seg rows of a point).  A thread owns one column of a run of rows.
+// Largest magnitude of a block into *absmax (non-negative floats order like their bit patterns): waves meet in LDS so that a block issues
+// ONE atomic -- same-address atomics serialise in L2 (thousands of waves on one word cost more than the streaming pass itself).
+// `red` = 4 floats of LDS not in use by anything else at this point.
+__device__ __forceinline__ void tr_block_absmax(float amax, float* red, float* __restrict__ absmax) {
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(m));
+  }
+}
+
 // U consecutive rows of one column: all loads first (they are in flight together), then the derivative, the stores and the sums
 template <int U>
 __device__ __forceinline__ float tr_act_rows(float* __restrict__ dy, const float* __restrict__ y, long r, int c, long ld_dy, long ld_y, int act, float& amax) {
@@ -427,10 +441,7 @@ __global__ void __launch_bounds__(256) k_train_act_bwd(float* __restrict__ dy, c
     }
     if (dbias != nullptr && r0 < rows) atomicAdd(dbias + c, colsum);
   }
-  if (absmax != nullptr) {  // largest |dZ| of the tensor (non-negative floats order like their bit patterns): scales the backward GEMMs
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
-  }
+  if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem), absmax);  // largest |dZ|: scales the backward GEMMs
 }
 
 // The same pass with 16-byte accesses (cols, both leading dimensions and ld_seg multiples of four, 16-byte aligned bases: the 64 / 128 /
@@ -505,10 +516,7 @@ __global__ void __launch_bounds__(256) k_train_act_bwd4(float4* __restrict__ dy,
     for (int k = 0; k < G; ++k) s += pf[k * 4 * L + threadIdx.x];
     atomicAdd(dbias + threadIdx.x, s);
   }
-  if (absmax != nullptr) {
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
-  }
+  if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
 }
 
 extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols, long ld_dy, long ld_y, int act, float* dbias, int seg,
@@ -524,7 +532,7 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
     const long want = (rows >= (1L << 20) ? 2048 : 256) / G;  // rows per block: as the scalar kernel's runs (same-address atomics per column)
     const int span = (int)((want + unit - 1) / unit) * unit;
     const long blocks = (rows + (long)G * span - 1) / ((long)G * span);
-    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd4, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float4), (hipStream_t)stream,
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd4, dim3((unsigned)blocks), dim3(256), 257 * sizeof(float4), (hipStream_t)stream,
                reinterpret_cast<float4*>(dY), reinterpret_cast<const float4*>(act != 0 ? Y : nullptr), rows, L, ld_dy / 4, ld_y / 4, act, dbias, seg,
                reinterpret_cast<float4*>(dseg), ld_seg / 4, span, absmax);
     return 0;
@@ -537,15 +545,24 @@ extern "C" int dyn_train_act_bwd(float* dY, const float* Y, long rows, int cols,
   while (run < target) run += (dseg != nullptr ? seg : 1);
   const long chunks = (rows + run - 1) / run;
   const int per_block = 256 / ct;
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), 0,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_act_bwd", k_train_act_bwd, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(256), sizeof(float4),
              (hipStream_t)stream, dY, Y, rows, cols, ld_dy, ld_y, act, dbias, seg, dseg, ld_seg, ct, run, absmax);
   return 0;
 }
 
 // largest |x| of a [rows, cols] matrix (leading dimension ld): the scale of a gradient tensor that no activation-derivative pass produced
-__global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ x, long rows, int cols, long ld, int ct, float* __restrict__ absmax) {
+__global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ x, long rows, int cols, long ld, int ct, int vec, float* __restrict__ absmax) {
   float amax = 0.f;
-  if (ld == cols) {  // contiguous: one flat stream, four independent loads per trip
+  if (vec) {  // contiguous, a multiple of four elements, 16-byte aligned: two independent 16-byte loads per trip
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const long n = rows * cols / 4, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+      const long i1 = i + stride < n ? i + stride : i;
+      const float4 a = x4[i], b = x4[i1];
+      amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+    }
+  } else if (ld == cols) {  // contiguous: one flat stream, four independent loads per trip
     const long n = rows * cols, stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
       const long i1 = i + stride < n ? i + stride : i, i2 = i + 2 * stride < n ? i + 2 * stride : i, i3 = i + 3 * stride < n ? i + 3 * stride : i;
@@ -564,15 +581,15 @@ __global__ void __launch_bounds__(256) k_train_absmax(const float* __restrict__ 
       }
     }
   }
-  amax = wave_max(amax);
-  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+  tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem), absmax);
 }
 extern "C" int dyn_train_absmax(const float* x, long rows, int cols, long ld, float* absmax, void* stream) {
   DYN_REQUIRE(x && absmax && rows > 0 && cols > 0 && ld >= cols, "dyn_train_absmax: bad arguments");
   const int ct = cols <= 32 ? 32 : cols <= 64 ? 64 : cols <= 128 ? 128 : 256;
-  const long blocks = ld == cols ? (rows * cols + 1023) / 1024 : (rows + 4 * (256 / ct) - 1) / (4 * (256 / ct));
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_absmax", k_train_absmax, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x,
-             rows, cols, ld, ct, absmax);
+  const int vec = ld == cols && ((rows * cols) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const long blocks = vec ? (rows * cols / 4 + 511) / 512 : ld == cols ? (rows * cols + 1023) / 1024 : (rows + 4 * (256 / ct) - 1) / (4 * (256 / ct));
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_absmax", k_train_absmax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), sizeof(float4),
+             (hipStream_t)stream, x, rows, cols, ld, ct, vec, absmax);
   return 0;
 }
 
