@@ -38,15 +38,23 @@ typedef _Float16 tr_f16x8 __attribute__((ext_vector_type(8)));
 // written as a half by the mixed-precision fma (three instructions per pair, the inference engine's form; dyn_mlp.h)
 template <bool SCALED>
 __device__ __forceinline__ void tr_split2_pair(float x0, float x1, float scale, unsigned& h, unsigned& m) {
+#if defined(__AMDGCN__)
+  unsigned hh, mm;
+  if (SCALED) {  // both parts straight from the mixed-precision fma: hi = half(x s), mid = half(x s - hi) -- two instructions per value
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(mm) : "v"(x0), "v"(scale), "v"(hh));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(mm) : "v"(x1), "v"(scale), "v"(hh));
+  } else {       // truncating pack-convert for the pair, then the exact residuals: three instructions per pair
+    hh = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(mm) : "v"(hh), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mm) : "v"(hh), "v"(x1));
+  }
+  h = hh; m = mm;
+#else  /* the wave-level emulator of tests/emu: the same two residuals, converted like the first part */
   if (SCALED) { x0 *= scale; x1 *= scale; }
   const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
   h = __builtin_bit_cast(unsigned, hh);
-#if defined(__AMDGCN__)
-  unsigned mm;
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(mm) : "v"(h), "v"(x0));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mm) : "v"(h), "v"(x1));
-  m = mm;
-#else  /* the wave-level emulator of tests/emu: the same two residuals, converted like the first part */
   m = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]));
 #endif
 }
@@ -215,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
   }
   // Two register stages of raw global loads: the tile of k-step t + 2 is requested while step t feeds the matrix pipe; the barrier of
   // a step publishes LDS writes only (tr_barrier_lds), so those loads stay in flight across it.
+  const bool a_edge = m0 + TG_BM > g.a.nrows, b_edge = n0 + TG_BM > g.b.nrows, scaled = g.a_absmax != nullptr;
   float4 sa0[4], sb0[4], sa1[4], sb1[4];
   tr_load_tile<A_MODE>(g.a, m0, kbeg, kend, sa0, tid);
   tr_load_tile<B_MODE>(g.b, n0, kbeg, kend, sb0, tid);
@@ -223,9 +232,12 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     tr_load_tile<B_MODE>(g.b, n0, kbeg + TG_BK, kend, sb1, tid);
   }
   auto body = [&](float4 (&sa)[4], float4 (&sb)[4], int k0) {
-    tr_mask_tile<A_MODE>(g.a, m0, k0, kend, sa, tid);
-    tr_mask_tile<B_MODE>(g.b, n0, k0, kend, sb, tid);
-    tr_store_tile<A_KMINOR, true>(As, sa, a_scale, tid);
+    // interior tiles (nearly all of them) need no bounds masks: a uniform branch skips the 32 selects of a k-step
+    const bool k_edge = k0 + TG_BK > kend;
+    if (a_edge || k_edge) tr_mask_tile<A_MODE>(g.a, m0, k0, kend, sa, tid);
+    if (b_edge || k_edge) tr_mask_tile<B_MODE>(g.b, n0, k0, kend, sb, tid);
+    if (scaled) tr_store_tile<A_KMINOR, true>(As, sa, a_scale, tid);
+    else tr_store_tile<A_KMINOR, false>(As, sa, 1.0f, tid);
     tr_store_tile<B_KMINOR, false>(Bs, sb, 1.0f, tid);
     tr_barrier_lds();
     if (k0 + 2 * TG_BK < kend) {
