@@ -28,6 +28,9 @@ typedef unsigned tr_u32x2 __attribute__((ext_vector_type(2)));
 #define TG_BM 128
 #define TG_BN 128
 #define TG_BK 32
+#ifndef TR_EXP
+#define TR_EXP 0  /* developer decomposition builds (tools/gemm_decompose.sh): 1 no MFMA, 2 no loads inside the k loop, 4 no result stores, 8 no conversions */
+#endif
 #define TG_ROW 40                        // half elements per LDS row (32 used + 8 pad: 80-byte stride, conflict-free b128 reads)
 #define TG_PART (TG_BM * TG_ROW)         // elements of one part image
 #define TG_LDS_BYTES (2 * 2 * TG_PART * 2)  // (A | B) x two parts x 2 bytes = 40 KiB
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     else tr_store_tile<A_KMINOR, false>(As, sa, 1.0f, tid);
     tr_store_tile<B_KMINOR, false>(Bs, sb, 1.0f, tid);
     tr_barrier_lds();
-    if (k0 + 2 * TG_BK < kend) {
+    if (!(TR_EXP & 2) && k0 + 2 * TG_BK < kend) {
       tr_load_tile<A_MODE>(g.a, m0, k0 + 2 * TG_BK, kend, sa, tid);
       tr_load_tile<B_MODE>(g.b, n0, k0 + 2 * TG_BK, kend, sb, tid);
     }
@@ -262,7 +265,10 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = tr_mfma(a[i][pa], b[j][pb], acc[i][j]);
+          for (int j = 0; j < 2; ++j) {
+            if (TR_EXP & 1) acc[i][j][term] += __uint_as_float(a[i][pa][0] ^ b[j][pb][0]);
+            else acc[i][j] = tr_mfma(a[i][pa], b[j][pb], acc[i][j]);
+          }
       }
     }
     tr_barrier_lds();
@@ -333,6 +339,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     for (int r = 0; r < 16; ++r) {
       const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
       if (m >= g.M) continue;
+      if ((TR_EXP & 4) && acc[i][0][r] != 12345.678f) continue;
       float* crow = g.c + (long)m * g.ldc;
       if (g.accumulate == 0) {
         if (okA) crow[nA] = acc[i][0][r];
