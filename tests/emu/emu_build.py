@@ -23,15 +23,22 @@ def build(opt='-O2', sanitize=False):
   if sanitize:
     common += ['-fsanitize=address', '-fno-omit-frame-pointer']
   objs, procs = [], []
+  shared = [d for d in deps if not d.endswith('.hip')]  # headers and the emulator runtime: every unit depends on them
+
+  def fresh(obj, *srcs):  # an object newer than its own source and every shared header is reused (only the changed unit recompiles)
+    return os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in list(srcs) + shared)
+
   for src, flags in UNITS:  # the translation units compile side by side (dyn_nets.hip alone takes minutes at -O2)
     path = os.path.join(CSRC, src)
     if not os.path.exists(path):
       continue
     obj = os.path.join(OUT_DIR, src.replace('.hip', '_asan.o' if sanitize else '.o'))
-    procs.append((src, subprocess.Popen(common + flags + ['-x', 'c++', '-c', path, '-o', obj])))
+    if not fresh(obj, path):
+      procs.append((src, subprocess.Popen(common + flags + ['-x', 'c++', '-c', path, '-o', obj])))
     objs.append(obj)
   obj = os.path.join(OUT_DIR, 'emu_runtime_asan.o' if sanitize else 'emu_runtime.o')
-  procs.append(('emu_runtime.cpp', subprocess.Popen(common + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', obj])))
+  if not fresh(obj):
+    procs.append(('emu_runtime.cpp', subprocess.Popen(common + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', obj])))
   objs.append(obj)
   for src, pr in procs:
     if pr.wait() != 0:
