@@ -946,8 +946,101 @@ __global__ void __launch_bounds__(256) k_train_meanvar_bwd(const float* __restri
     }
   }
 }
+// The same two kernels for V <= 16 views (every configuration the reference ships) with a point's rows held in registers: one pass
+// over x, and all of a thread's loads issued before the first use (clamped rows with weight 0 stand in for the views beyond V).
+template <int VMAX>
+__global__ void __launch_bounds__(256) k_train_meanvar_reg(const float* __restrict__ x, long ldx, const float* __restrict__ w, long P, int V, int C,
+                                                           float* __restrict__ mean, float* __restrict__ var, long ld_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long p = idx / C;
+  const int c = (int)(idx - p * C);
+  if (p >= P) return;
+  const long r0 = p * V;
+  float xv[VMAX], wv[VMAX];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    const long row = r0 + (v < V ? v : 0);
+    xv[v] = x[row * ldx + c];
+    wv[v] = w[row];
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    wv[v] = v < V ? wv[v] : 0.f;
+    m += xv[v] * wv[v];
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    const float d = xv[v] - m;
+    sq += wv[v] * (d * d);
+  }
+  mean[p * ld_out + c] = m;
+  var[p * ld_out + c] = sq;
+}
+template <int VMAX, int Q>
+__global__ void __launch_bounds__(256) k_train_meanvar_bwd_reg(const float* __restrict__ x, long ldx, const float* __restrict__ w, long P, int V, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ dmean,
+                                                               const float* __restrict__ dvar, long ld_stat, float* __restrict__ dx, long ld_dx,
+                                                               int accumulate, float* __restrict__ dw, int dw_accumulate) {
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= P) return;
+  const long r0 = p * V;
+  float xv[Q][VMAX], old[Q][VMAX], wv[VMAX], m[Q], dmn[Q], dv[Q];
+  int cc[Q];
+  bool ok[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    ok[q] = lane + 64 * q < C;
+    cc[q] = ok[q] ? lane + 64 * q : 0;  // idle lanes shadow column 0 (their results are dropped)
+    m[q] = mean[p * ld_stat + cc[q]];
+    dv[q] = dvar[p * ld_stat + cc[q]];
+    dmn[q] = dmean[p * ld_stat + cc[q]];
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      const long row = r0 + (v < V ? v : 0);
+      xv[q][v] = x[row * ldx + cc[q]];
+      old[q][v] = accumulate ? dx[row * ld_dx + cc[q]] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) wv[v] = v < V ? w[r0 + v] : 0.f;
+  float dmt[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    float sw = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) sw += wv[v] * (xv[q][v] - m[q]);
+    dmt[q] = dmn[q] - 2.0f * dv[q] * sw;
+  }
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    if (v < V) {
+      float part = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float d = xv[q][v] - m[q];
+        const float g = wv[v] * (dmt[q] + 2.0f * d * dv[q]);
+        if (ok[q]) {
+          dx[(r0 + v) * ld_dx + cc[q]] = old[q][v] + g;
+          part += xv[q][v] * dmt[q] + d * d * dv[q];
+        }
+      }
+      part = wave_sum(part);
+      if (lane == 0) {
+        if (dw_accumulate) dw[r0 + v] += part; else dw[r0 + v] = part;
+      }
+    }
+  }
+}
 extern "C" int dyn_train_meanvar(const float* x, long ldx, const float* w, long P, int V, int C, float* mean, float* var, long ld_out, void* stream) {
   DYN_REQUIRE(x && w && mean && var && P > 0 && V > 0 && C > 0, "dyn_train_meanvar: bad arguments");
+  if (V <= 16) {
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar", k_train_meanvar_reg<16>, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+               x, ldx, w, P, V, C, mean, var, ld_out);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar", k_train_meanvar, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
              P, V, C, mean, var, ld_out);
   return 0;
@@ -956,6 +1049,11 @@ extern "C" int dyn_train_meanvar_bwd(const float* x, long ldx, const float* w, l
                                      const float* dvar, long ld_stat, float* dx, long ld_dx, int accumulate, float* dw, int dw_accumulate,
                                      void* stream) {
   DYN_REQUIRE(x && w && mean && dmean && dvar && dx && dw && P > 0 && V > 0 && C > 0 && C <= 256, "dyn_train_meanvar_bwd: bad arguments (C <= 256)");
+  if (V <= 16 && C <= 128) {
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar_bwd", (k_train_meanvar_bwd_reg<16, 2>), dim3((unsigned)((P + 3) / 4)), dim3(256), 0,
+               (hipStream_t)stream, x, ldx, w, P, V, C, mean, dmean, dvar, ld_stat, dx, ld_dx, accumulate, dw, dw_accumulate);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_meanvar_bwd", k_train_meanvar_bwd, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
              w, P, V, C, mean, dmean, dvar, ld_stat, dx, ld_dx, accumulate, dw, dw_accumulate);
   return 0;
