@@ -1112,9 +1112,41 @@ extern "C" int dyn_train_rowscale(const float* x, long ldx, const float* s, long
              s_stride, N, C, y, ldy);
   return 0;
 }
+// 16-byte accesses: L = C / 4 lanes (a power of two) span a row, so a wave covers 64 / L rows per instruction and the row's dot product is
+// a shuffle reduction inside its lane group
+__global__ void __launch_bounds__(256) k_train_rowscale_bwd4(const float4* __restrict__ dy, long ld_dy4, const float4* __restrict__ x, long ldx4,
+                                                             const float* __restrict__ s, long s_stride, long N, int sh, float4* __restrict__ dx,
+                                                             long ld_dx4, int accumulate, float* __restrict__ ds, long ds_stride, int ds_accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row_raw = idx >> sh;
+  const bool live = row_raw < N;
+  const long row = live ? row_raw : N - 1;  // every lane takes part in the shuffles
+  const int L = 1 << sh, q = (int)(idx & (L - 1));
+  const float4 d = dy[row * ld_dy4 + q], xv = x[row * ldx4 + q];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (accumulate) o = dx[row * ld_dx4 + q];
+  const float sv = s[row * s_stride];
+  float dsv = 0.f;
+  if (ds_accumulate) dsv = ds[row * ds_stride];
+  o.x += d.x * sv; o.y += d.y * sv; o.z += d.z * sv; o.w += d.w * sv;
+  if (live) dx[row * ld_dx4 + q] = o;
+  float acc = (d.x * xv.x + d.y * xv.y) + (d.z * xv.z + d.w * xv.w);
+  for (int off = L >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (live && q == 0) ds[row * ds_stride] = dsv + acc;
+}
 extern "C" int dyn_train_rowscale_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, int C, float* dx,
                                       long ld_dx, int accumulate, float* ds, long ds_stride, int ds_accumulate, void* stream) {
   DYN_REQUIRE(dy && x && s && dx && ds && N > 0 && C > 0, "dyn_train_rowscale_bwd: bad arguments");
+  const int c4 = C / 4;
+  if ((C & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0 && ((ld_dy | ldx | ld_dx) & 3) == 0 &&
+      (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0) {
+    int sh = 0;
+    while ((1 << sh) < c4) ++sh;
+    DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale_bwd", k_train_rowscale_bwd4, dim3((unsigned)((N * c4 + 255) / 256)), dim3(256), 0,
+               (hipStream_t)stream, reinterpret_cast<const float4*>(dy), ld_dy / 4, reinterpret_cast<const float4*>(x), ldx / 4, s, s_stride, N, sh,
+               reinterpret_cast<float4*>(dx), ld_dx / 4, accumulate, ds, ds_stride, ds_accumulate);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale_bwd", k_train_rowscale_bwd, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy,
              x, ldx, s, s_stride, N, C, dx, ld_dx, accumulate, ds, ds_stride, ds_accumulate);
   return 0;
