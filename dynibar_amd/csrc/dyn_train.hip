@@ -179,6 +179,10 @@ struct TrGemmArgs {
   int act;               // 0 none, 1 ELU
   int accumulate;        // 0 store, 1 c += result, 2 atomicAdd
   const float* a_absmax; // device: largest |a| (a gradient tensor: scaled into the half range), or null (operands of order one)
+  const float* act_y;    // saved output of the layer whose activation derivative multiplies the result (data gradient), or null
+  long ld_y;
+  int act_y_kind;        // 1 ELU, 2 ReLU
+  int act_y_vec;         // act_y rows 16-byte aligned and N a multiple of four: the tile is staged through LDS
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -290,6 +294,53 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= a_unscale;
   }
+  if (g.act_y != nullptr) {  // dZ = dX * act'(Y): the activation-derivative pass folded into the data gradient that feeds it
+    const bool elu = g.act_y_kind == 1;
+    if (g.act_y_vec) {
+      // the Y tile through LDS (free after the k loop): 16-byte coalesced global reads, all of a thread's eight in flight, 64 rows per pass;
+      // the waves of row half `pass` then read their elements in accumulator layout (row stride 132 floats)
+      float* Yt = reinterpret_cast<float*>(dyn_smem);
+      const int n4max = (g.N >> 2) - 1;
+      for (int pass = 0; pass < 2; ++pass) {
+        float4 yv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int idx = tid + 256 * j, row = idx >> 5, c4 = idx & 31;
+          const int m = m0 + pass * 64 + row, n4 = (n0 >> 2) + c4;
+          yv[j] = *reinterpret_cast<const float4*>(g.act_y + (long)(m < g.M ? m : g.M - 1) * g.ld_y + 4 * (n4 < n4max ? n4 : n4max));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int idx = tid + 256 * j, row = idx >> 5, c4 = idx & 31;
+          *reinterpret_cast<float4*>(Yt + row * 132 + 4 * c4) = yv[j];
+        }
+        __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* yrow = Yt + (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 132 + wn * 64 + (lane & 31);
+              const float yA = yrow[0], yB = yrow[32];
+              acc[i][0][r] = yA > 0.f ? acc[i][0][r] : (elu ? acc[i][0][r] * (yA + 1.0f) : 0.f);
+              acc[i][1][r] = yB > 0.f ? acc[i][1][r] : (elu ? acc[i][1][r] * (yB + 1.0f) : 0.f);
+            }
+        }
+        __syncthreads();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float* yrow = g.act_y + (long)(m < g.M ? m : g.M - 1) * g.ld_y;
+          const float yA = yrow[nAc], yB = yrow[nBc];
+          acc[i][0][r] = yA > 0.f ? acc[i][0][r] : (elu ? acc[i][0][r] * (yA + 1.0f) : 0.f);
+          acc[i][1][r] = yB > 0.f ? acc[i][1][r] : (elu ? acc[i][1][r] * (yB + 1.0f) : 0.f);
+        }
+    }
+  }
   if (g.addend != nullptr) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -368,6 +419,10 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   const int nz = (p->K + chunk - 1) / chunk;
   g.bias = p->bias; g.addend = p->addend; g.ld_add = p->ld_add; g.add_div = p->add_div > 0 ? p->add_div : 1;
   g.act = p->act; g.accumulate = p->accumulate; g.a_absmax = p->a_absmax;
+  DYN_REQUIRE(p->act_y == nullptr || (p->accumulate == 0 && p->k_split == 1 && (p->act_y_kind == 1 || p->act_y_kind == 2)),
+              "dyn_train_gemm: act_y needs accumulate = 0, k_split = 1 and act_y_kind 1 (ELU) or 2 (ReLU)");
+  g.act_y = p->act_y; g.ld_y = p->ld_y; g.act_y_kind = p->act_y_kind;
+  g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major

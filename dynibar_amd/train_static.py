@@ -62,13 +62,14 @@ GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} 
 
 
 def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
-          a_absmax=None):
+          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0):
   if GEMM_STATS is not None:  # algorithmic: every operand element read once, every result element written once
-    GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N)
+    GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N + (M * N if act_y is not None else 0))
     GEMM_STATS['flops'] += 2 * M * N * K
     GEMM_STATS['calls'] += 1
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
-             ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax)
+             ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax, act_y=act_y, ld_y=ld_y,
+             act_y_kind=act_y_kind)
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
@@ -85,7 +86,8 @@ class _Lin:
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
           ld_add=ld_add, add_div=add_div, act=act)
 
-  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0):
+  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None):
+    # act_y = (Y, y_off, ld_y, kind): X is the output Y of an ELU / ReLU layer and dX comes out already multiplied by act'(Y)
     """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K].  dZ is the GEMMs' scaled operand:
     its largest magnitude comes from the activation-derivative pass that made it (_act_bwd leaves it on the tensor) or is measured here."""
     tag = getattr(dZ, '_dyn_absmax', None)
@@ -99,8 +101,9 @@ class _Lin:
     _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
           a_absmax=_p(am))
     if dX is not None:
+      fy = {} if act_y is None else dict(act_y=_p(act_y[0], act_y[1]), ld_y=act_y[2], act_y_kind=act_y[3])
       _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
-            a_absmax=_p(am))
+            a_absmax=_p(am), **fy)
 
 
 def _act_bwd(st, dY, dy_off, ld_dy, Y, y_off, ld_y, rows, cols, act, dbias=None, seg=1, dseg=None, ld_seg=0):
@@ -249,11 +252,11 @@ def _backward(s, draw):
   # rgb_fc.4 / .2 / .0
   dR2, dR1 = new(N, 64), new(N, 128)
   _act_bwd(st, dRL, 0, 1, None, 0, 1, N, 1, NONE, g['rgb_fc.4.bias'])
-  L['r4'].bwd(st, dRL, 0, 1, s.R2, 0, 64, g['rgb_fc.4.weight'], N, dR2, 0, 64)
-  _act_bwd(st, dR2, 0, 64, s.R2, 0, 64, N, 64, ELU, g['rgb_fc.2.bias'])
-  L['r2'].bwd(st, dR2, 0, 64, s.R1, 0, 128, g['rgb_fc.2.weight'], N, dR1, 0, 128)
+  L['r4'].bwd(st, dRL, 0, 1, s.R2, 0, 64, g['rgb_fc.4.weight'], N, dR2, 0, 64, act_y=(s.R2, 0, 64, ELU))  # dR2 arrives times ELU'(R2)
+  _act_bwd(st, dR2, 0, 64, None, 0, 64, N, 64, NONE, g['rgb_fc.2.bias'])
+  L['r2'].bwd(st, dR2, 0, 64, s.R1, 0, 128, g['rgb_fc.2.weight'], N, dR1, 0, 128, act_y=(s.R1, 0, 128, ELU))
   dPP2 = new(P, 128)
-  _act_bwd(st, dR1, 0, 128, s.R1, 0, 128, N, 128, ELU, g['rgb_fc.0.bias'], V, dPP2, 128)
+  _act_bwd(st, dR1, 0, 128, None, 0, 128, N, 128, NONE, g['rgb_fc.0.bias'], V, dPP2, 128)
   dRIN = new(N, 136)  # gradient of [x2 | vis | ray_diff]; its first 128 columns go on to collect every gradient of x2, then of x1
   L['r0x'].bwd(st, dR1, 0, 128, s.RIN, 0, 136, g['rgb_fc.0.weight'], N, dRIN, 0, 136)
   dG3 = new(P, 128)
@@ -261,8 +264,8 @@ def _backward(s, draw):
   # out_geometry_fc
   dO1 = new(P, 128)
   _act_bwd(st, dSIG, 0, 1, None, 0, 1, P, 1, NONE, g['out_geometry_fc.2.bias'])
-  L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128)
-  _act_bwd(st, dO1, 0, 128, s.O1, 0, 128, P, 128, ELU, g['out_geometry_fc.0.bias'])
+  L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128, act_y=(s.O1, 0, 128, ELU))
+  _act_bwd(st, dO1, 0, 128, None, 0, 128, P, 128, NONE, g['out_geometry_fc.0.bias'])
   L['o0'].bwd(st, dO1, 0, 128, s.G3, 0, 128, g['out_geometry_fc.0.weight'], P, dG3, 0, 128, acc_dx=1)
   # LayerNorm(fc(attention) + g2): dY is the gradient of both summands; it then collects the rest of g2's gradient
   dY = new(P, 128)
@@ -276,8 +279,8 @@ def _backward(s, draw):
   # geometry_fc
   dGH1, dG0 = new(P, 256), new(P, 260)
   _act_bwd(st, dY, 0, 128, s.G2, 0, 128, P, 128, ELU, g['geometry_fc.2.bias'])
-  L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256)
-  _act_bwd(st, dGH1, 0, 256, s.GH1, 0, 256, P, 256, ELU, g['geometry_fc.0.bias'])
+  L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256, act_y=(s.GH1, 0, 256, ELU))
+  _act_bwd(st, dGH1, 0, 256, None, 0, 256, P, 256, NONE, g['geometry_fc.0.bias'])
   L['g0'].bwd(st, dGH1, 0, 256, s.G0, 0, 260, g['geometry_fc.0.weight'], P, dG0, 0, 260)
   # pooled statistics of x2 under the visibility weights; the weights themselves
   dw2, dVL = new(N), new(N)
@@ -287,24 +290,24 @@ def _backward(s, draw):
   # vis_fc2
   dH4, dXS, dvis0 = new(N, 128), new(N, 128), new(N)
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
-  L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128)
-  _act_bwd(st, dH4, 0, 128, s.H4, 0, 128, N, 128, ELU, g['vis_fc2.0.bias'])
+  L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU))
+  _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
   # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
   dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
   call('dyn_train_vis_split_bwd', _p(dRIN), 136, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
   _act_bwd(st, dXV, 0, 132, s.XV, 0, 132, N, 129, ELU, g['vis_fc.2.bias'])
-  L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128)
-  _act_bwd(st, dH3, 0, 128, s.H3, 0, 128, N, 128, ELU, g['vis_fc.0.bias'])
+  L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU))
+  _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
   dw1 = new(N)
   call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dRIN), 136, 1, _p(dw1), 1, 0, st)
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 72), new(P, 140)
   _act_bwd(st, dRIN, 0, 136, s.X1, 0, 128, N, 128, ELU, g['base_fc.2.bias'])
-  L['b2'].bwd(st, dRIN, 0, 136, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256)
-  _act_bwd(st, dH2, 0, 256, s.H2, 0, 256, N, 256, ELU, g['base_fc.0.bias'], V, dPP1, 256)
+  L['b2'].bwd(st, dRIN, 0, 136, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
+  _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 72, g['base_fc.0.weight'], N, dF, 0, 72)
   L['b0g'].bwd(st, dPP1, 0, 256, s.G1, 0, 140, g['base_fc.0.weight'], P, dG1, 0, 140)
   call('dyn_train_meanvar_bwd', _p(s.F), 72, _p(s.w1), P, V, 70, _p(s.G1), _p(dG1), _p(dG1, 70), 140, _p(dF), 72, 1, _p(dw1), 1, st)
@@ -317,8 +320,8 @@ def _backward(s, draw):
   _act_bwd(st, dREFF, 0, 36, None, 0, 36, R, 35, NONE, g['ref_feature_fc.0.bias'])
   L['ref'].bwd(st, dREFF, 0, 36, s.REFPE, 0, 68, g['ref_feature_fc.0.weight'], R)
   _act_bwd(st, dSRCF, 0, 36, None, 0, 36, N, 35, NONE, g['ray_dir_fc.2.bias'])
-  L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256)
-  _act_bwd(st, dH1, 0, 256, s.H1, 0, 256, N, 256, ELU, g['ray_dir_fc.0.bias'])
+  L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(s.H1, 0, 256, ELU))
+  _act_bwd(st, dH1, 0, 256, None, 0, 256, N, 256, NONE, g['ray_dir_fc.0.bias'])
   L['rd0'].bwd(st, dH1, 0, 256, s.A0, 0, 104, g['ray_dir_fc.0.weight'], N)
   return g, dF  # dF[:, 0:35] = d rgb_feat (the gather's backward, train_motion.GatherFunction, carries it on into the maps)
 

@@ -291,6 +291,11 @@ typedef struct {
   int accumulate;
   int k_split;
   const float* a_absmax; /* DEVICE scalar: largest |A| when A is a gradient tensor (scaled into the half range), NULL for operands of order one */
+  const float* act_y;    /* data gradient through the PRODUCING layer's activation: C = (A . B) * act'(act_y[m ld_y + n]) from that layer's saved
+                          * OUTPUT (ELU' = y > 0 ? 1 : y + 1; ReLU' = y > 0): the autograd of nn.ELU / nn.ReLU fused into the Linear's backward
+                          * (mlp_network.py:342-397, 587-603).  NULL to skip; needs accumulate = 0 */
+  long ld_y;
+  int act_y_kind;        /* 1 ELU, 2 ReLU */
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
 
