@@ -183,6 +183,7 @@ struct TrGemmArgs {
   long ld_y;
   int act_y_kind;        // 1 ELU, 2 ReLU
   int act_y_vec;         // act_y rows 16-byte aligned and N a multiple of four: the tile is staged through LDS
+  int c_vec;             // plain stores (accumulate 0) of 16-byte-aligned result rows, N a multiple of four: the tile leaves through LDS
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -384,6 +385,33 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
   }
   const bool okA = nA < g.N, okB = nB < g.N;
+  if (g.c_vec && !(TR_EXP & 4)) {
+    // plain stores of 16-byte-aligned rows: the tile leaves through LDS (64 rows per pass, accumulator layout in, row-major float4 out), so a
+    // store instruction writes four complete 512-byte rows instead of two 128-byte pieces
+    float* Ct = reinterpret_cast<float*>(dyn_smem);
+    const int n4lim = g.N >> 2;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* crow = Ct + (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 132 + wn * 64 + (lane & 31);
+            crow[0] = acc[i][0][r];
+            crow[32] = acc[i][1][r];
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, c4 = idx & 31;
+        const int m = m0 + pass * 64 + row, n4 = (n0 >> 2) + c4;
+        if (m < g.M && n4 < n4lim) *reinterpret_cast<float4*>(g.c + (long)m * g.ldc + 4 * n4) = *reinterpret_cast<const float4*>(Ct + row * 132 + 4 * c4);
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -422,6 +450,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   DYN_REQUIRE(p->act_y == nullptr || (p->accumulate == 0 && p->k_split == 1 && (p->act_y_kind == 1 || p->act_y_kind == 2)),
               "dyn_train_gemm: act_y needs accumulate = 0, k_split = 1 and act_y_kind 1 (ELU) or 2 (ReLU)");
   g.act_y = p->act_y; g.ld_y = p->ld_y; g.act_y_kind = p->act_y_kind;
+  g.c_vec = p->accumulate == 0 && (p->N & 3) == 0 && (p->ldc & 3) == 0 && ((uintptr_t)p->C & 15) == 0;
   g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
