@@ -1040,6 +1040,23 @@ def check_train_gemm(device):
     big = float(dZ.abs().max())
     assert_close(dX[:, :K], dZ[:, :N].double().cpu() @ W.double().cpu(), 3e-6 * big, 4e-6, f'train gemm data gradient (scale {scale:g})')
     assert_close(dW, dZ[:, :N].double().cpu().T @ X[:, :K].double().cpu(), 1e-5 * big, 4e-6, f'train gemm weight gradient (scale {scale:g})')
+  # data gradient with the producing layer's activation derivative folded into the epilogue (act_y): the 4-byte path (103 columns) and
+  # the LDS-staged 16-byte path (128 columns), ELU and ReLU, on a row count that is not a multiple of the tile
+  for Kin in (103, 128):
+    ld = (Kin + 3) // 4 * 4
+    Xs = torch.randn(M, ld, generator=g).to(device)          # the saved OUTPUT of the previous layer = this layer's input
+    Ws = (torch.randn(N, Kin, generator=g) * 0.3).to(device)
+    dZ = torch.randn(M, 40, generator=g).to(device)
+    lin = TS._Lin(Ws)
+    for kind, name in ((TS.ELU, 'ELU'), (2, 'ReLU')):
+      Ys = Xs if kind == 2 else torch.where(Xs > 0, Xs, torch.expm1(Xs))  # a plausible saved output (ELU outputs are > -1)
+      dW = torch.zeros_like(Ws)
+      dX = torch.full((M, ld), float('nan'), device=device)
+      lin.bwd(TS.stream_of(Xs), dZ, 0, 40, Ys, 0, ld, dW, M, dX, 0, ld, act_y=(Ys, 0, ld, kind))
+      y = Ys[:, :Kin].double().cpu()
+      der = torch.where(y > 0, torch.ones_like(y), (y + 1.0) if kind == TS.ELU else torch.zeros_like(y))
+      big = float(dZ.abs().max())
+      assert_close(dX[:, :Kin], (dZ[:, :N].double().cpu() @ Ws.double().cpu()) * der, 3e-6 * big, 4e-6, f"train gemm data gradient x {name}' ({Kin} columns)")
   # split reduction over many rows
   M = 5000
   X = torch.randn(M, 64, generator=g).to(device)
