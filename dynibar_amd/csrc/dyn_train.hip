@@ -184,6 +184,9 @@ struct TrGemmArgs {
   int act_y_kind;        // 1 ELU, 2 ReLU
   int act_y_vec;         // act_y rows 16-byte aligned and N a multiple of four: the tile is staged through LDS
   int c_vec;             // plain stores (accumulate 0) of 16-byte-aligned result rows, N a multiple of four: the tile leaves through LDS
+  float* colsum_part;    // [row tiles, ld_part] per-workgroup column sums of the result (the bias gradient's partial sums), or null (needs c_vec)
+  long ld_part;
+  float* amax_part;      // [row tiles * column tiles] per-workgroup largest |result| (with colsum_part)
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -390,6 +393,8 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     // store instruction writes four complete 512-byte rows instead of two 128-byte pieces
     float* Ct = reinterpret_cast<float*>(dyn_smem);
     const int n4lim = g.N >> 2;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cmax = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
       if (wm == pass) {
 #pragma unroll
@@ -406,9 +411,29 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
       for (int j = 0; j < 8; ++j) {
         const int idx = tid + 256 * j, row = idx >> 5, c4 = idx & 31;
         const int m = m0 + pass * 64 + row, n4 = (n0 >> 2) + c4;
-        if (m < g.M && n4 < n4lim) *reinterpret_cast<float4*>(g.c + (long)m * g.ldc + 4 * n4) = *reinterpret_cast<const float4*>(Ct + row * 132 + 4 * c4);
+        if (m < g.M && n4 < n4lim) {
+          const float4 v = *reinterpret_cast<const float4*>(Ct + row * 132 + 4 * c4);
+          *reinterpret_cast<float4*>(g.c + (long)m * g.ldc + 4 * n4) = v;
+          csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;  // a thread keeps its four columns (c4 = tid & 31) over all its rows
+          cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
       }
       __syncthreads();
+    }
+    if (g.colsum_part != nullptr) {
+      // the bias gradient's share of this tile and the largest |dZ| (the next GEMMs' scale): the eight row groups meet in LDS and the workgroup
+      // writes ONE partial row / value (no atomics; k_train_colsum_reduce adds the partials)
+      *reinterpret_cast<float4*>(Ct + (tid >> 5) * 128 + 4 * (tid & 31)) = csum;
+      cmax = wave_max(cmax);
+      if (lane == 0) Ct[1024 + wave] = cmax;
+      __syncthreads();
+      if (tid < 128 && n0 + tid < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += Ct[k * 128 + tid];
+        g.colsum_part[(long)blockIdx.x * g.ld_part + n0 + tid] = t;
+      }
+      if (tid == 0) g.amax_part[(long)blockIdx.x * gridDim.y + blockIdx.y] = fmaxf(fmaxf(Ct[1024], Ct[1025]), fmaxf(Ct[1026], Ct[1027]));
     }
     return;
   }
@@ -451,6 +476,9 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
               "dyn_train_gemm: act_y needs accumulate = 0, k_split = 1 and act_y_kind 1 (ELU) or 2 (ReLU)");
   g.act_y = p->act_y; g.ld_y = p->ld_y; g.act_y_kind = p->act_y_kind;
   g.c_vec = p->accumulate == 0 && (p->N & 3) == 0 && (p->ldc & 3) == 0 && ((uintptr_t)p->C & 15) == 0;
+  DYN_REQUIRE(p->colsum_part == nullptr || (g.c_vec && p->amax_part != nullptr && p->ld_part >= p->N),
+              "dyn_train_gemm: colsum_part needs plain 16-byte-aligned stores (accumulate 0, N and ldc multiples of 4), amax_part and ld_part >= N");
+  g.colsum_part = p->colsum_part; g.ld_part = p->ld_part; g.amax_part = p->amax_part;
   g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
@@ -465,6 +493,40 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   }
   TG_CASE(0, 0) TG_CASE(0, 1) TG_CASE(0, 2) TG_CASE(1, 0) TG_CASE(1, 1) TG_CASE(1, 2) TG_CASE(2, 0) TG_CASE(2, 1) TG_CASE(2, 2)
 #undef TG_CASE
+  return 0;
+}
+
+// dbias[n] += sum over the row tiles of colsum_part[tile, n];  *absmax = max(*absmax, amax_part[...]): the second stage of the sums the
+// data-gradient GEMM leaves per workgroup.  grid (column blocks of 64, row chunks): a block adds its chunk and issues one atomic per column.
+__global__ void __launch_bounds__(256) k_train_colsum_reduce(const float* __restrict__ part, long tiles, int N, long ld, float* __restrict__ dbias,
+                                                             const float* __restrict__ amax_part, long n_amax, float* __restrict__ absmax) {
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [4][64] + 4
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const long per = (tiles + gridDim.y - 1) / gridDim.y, t0 = (long)blockIdx.y * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+  float sum = 0.f;
+  if (c < N)
+    for (long t = t0 + rl; t < t1; t += 4) sum += part[t * ld + c];
+  red[rl * 64 + (threadIdx.x & 63)] = sum;
+  float m = 0.f;
+  if (blockIdx.x == 0) {
+    const long pa = (n_amax + gridDim.y - 1) / gridDim.y, a0 = (long)blockIdx.y * pa, a1 = a0 + pa < n_amax ? a0 + pa : n_amax;
+    for (long i = a0 + threadIdx.x; i < a1; i += 256) m = fmaxf(m, amax_part[i]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[256 + rl] = m;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < N && dbias != nullptr) atomicAdd(dbias + c, (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]));
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float mm = fmaxf(fmaxf(red[256], red[257]), fmaxf(red[258], red[259]));
+    if (mm > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(mm));
+  }
+}
+extern "C" int dyn_train_colsum_reduce(const float* colsum_part, long tiles, int N, long ld_part, float* dbias, const float* amax_part, long n_amax,
+                                       float* absmax, void* stream) {
+  DYN_REQUIRE(colsum_part && amax_part && absmax && tiles > 0 && N > 0 && ld_part >= N && n_amax > 0, "dyn_train_colsum_reduce: bad arguments");
+  const unsigned chunks = (unsigned)(tiles < 64 ? tiles : 64);
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_colsum_reduce", k_train_colsum_reduce, dim3((unsigned)dyn_cdiv(N, 64), chunks), dim3(256), 260 * sizeof(float),
+             (hipStream_t)stream, colsum_part, tiles, N, ld_part, dbias, amax_part, n_amax, absmax);
   return 0;
 }
 

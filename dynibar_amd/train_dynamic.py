@@ -149,8 +149,8 @@ def _backward(s, draw):
   # colour head
   dC2, dC1, dDP, dG4 = new(P, 64), new(P, 128), new(R, 128), new(P, 128)
   _act_bwd(st, dCL, 0, 4, None, 0, 4, P, 3, NONE, g['rgb_fc.4.bias'])
-  L['r4'].bwd(st, dCL, 0, 4, s.C2, 0, 64, g['rgb_fc.4.weight'], P, dC2, 0, 64, act_y=(s.C2, 0, 64, ELU))  # dC2 arrives times ELU'(C2)
-  _act_bwd(st, dC2, 0, 64, None, 0, 64, P, 64, NONE, g['rgb_fc.2.bias'])
+  if not L['r4'].bwd(st, dCL, 0, 4, s.C2, 0, 64, g['rgb_fc.4.weight'], P, dC2, 0, 64, act_y=(s.C2, 0, 64, ELU), dbias=g['rgb_fc.2.bias']):  # dC2 arrives times ELU'(C2)
+    _act_bwd(st, dC2, 0, 64, None, 0, 64, P, 64, NONE, g['rgb_fc.2.bias'])
   L['r2'].bwd(st, dC2, 0, 64, s.C1, 0, 128, g['rgb_fc.2.weight'], P, dC1, 0, 128, act_y=(s.C1, 0, 128, ELU))
   _act_bwd(st, dC1, 0, 128, None, 0, 128, P, 128, NONE, g['rgb_fc.0.bias'], S, dDP, 128)
   L['r0g'].bwd(st, dC1, 0, 128, s.G4, 0, 128, g['rgb_fc.0.weight'], P, dG4, 0, 128)
@@ -158,14 +158,14 @@ def _backward(s, draw):
   # density head
   dO1 = new(P, 128)
   _act_bwd(st, dSIG, 0, 1, None, 0, 1, P, 1, NONE, g['out_geometry_fc.2.bias'])
-  L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128, act_y=(s.O1, 0, 128, ELU))
-  _act_bwd(st, dO1, 0, 128, None, 0, 128, P, 128, NONE, g['out_geometry_fc.0.bias'])
+  if not L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128, act_y=(s.O1, 0, 128, ELU), dbias=g['out_geometry_fc.0.bias']):
+    _act_bwd(st, dO1, 0, 128, None, 0, 128, P, 128, NONE, g['out_geometry_fc.0.bias'])
   L['o0'].bwd(st, dO1, 0, 128, s.G4, 0, 128, g['out_geometry_fc.0.weight'], P, dG4, 0, 128, acc_dx=1)
   # ref_pts_fc
   dQ1, dG3 = new(P, 256), new(P, 128)
   _act_bwd(st, dG4, 0, 128, s.G4, 0, 128, P, 128, ELU, g['ref_pts_fc.2.bias'])
-  L['p2'].bwd(st, dG4, 0, 128, s.Q1, 0, 256, g['ref_pts_fc.2.weight'], P, dQ1, 0, 256, act_y=(s.Q1, 0, 256, ELU))
-  _act_bwd(st, dQ1, 0, 256, None, 0, 256, P, 256, NONE, g['ref_pts_fc.0.bias'])
+  if not L['p2'].bwd(st, dG4, 0, 128, s.Q1, 0, 256, g['ref_pts_fc.2.weight'], P, dQ1, 0, 256, act_y=(s.Q1, 0, 256, ELU), dbias=g['ref_pts_fc.0.bias']):
+    _act_bwd(st, dQ1, 0, 256, None, 0, 256, P, 256, NONE, g['ref_pts_fc.0.bias'])
   L['p0g'].bwd(st, dQ1, 0, 256, s.G3, 0, 128, g['ref_pts_fc.0.weight'], P, dG3, 0, 128)
   s.dPPE = new(P, 36)
   L['p0p'].bwd(st, dQ1, 0, 256, s.PPE, 0, 36, g['ref_pts_fc.0.weight'], P, s.dPPE, 0, 36)  # d PE(pts): on into the points (anchor pass)
@@ -181,8 +181,8 @@ def _backward(s, draw):
   # geometry_fc (the positional table is a constant: d g2 = d (g2 + pos))
   dGH1, dG0 = new(P, 256), new(P, 260)
   _act_bwd(st, dY, 0, 128, s.G2, 0, 128, P, 128, ELU, g['geometry_fc.2.bias'])
-  L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256, act_y=(s.GH1, 0, 256, ELU))
-  _act_bwd(st, dGH1, 0, 256, None, 0, 256, P, 256, NONE, g['geometry_fc.0.bias'])
+  if not L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256, act_y=(s.GH1, 0, 256, ELU), dbias=g['geometry_fc.0.bias']):
+    _act_bwd(st, dGH1, 0, 256, None, 0, 256, P, 256, NONE, g['geometry_fc.0.bias'])
   L['g0'].bwd(st, dGH1, 0, 256, s.G0, 0, 260, g['geometry_fc.0.weight'], P, dG0, 0, 260)
   dX, dw2, dVL = new(N, 128), new(N), new(N)  # dX: gradient of x2, then of x1
   call('dyn_train_meanvar_bwd', _p(s.X2), 128, _p(s.w2), P, V, 128, _p(s.G0), _p(dG0), _p(dG0, 128), 260, _p(dX), 128, 0, _p(dw2), 0, st)
@@ -190,15 +190,15 @@ def _backward(s, draw):
        _p(dVL), 1, None, st)
   dH4, dXS, dvis0 = new(N, 128), new(N, 128), new(N)
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
-  L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU))
-  _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
+  if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
+    _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
   dXV, dH3, dXW, scratch = new(N, 132), new(N, 128), new(N, 128), new(N)
   call('dyn_train_vis_split_bwd', _p(dX), 128, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
   _act_bwd(st, dXV, 0, 132, s.XV, 0, 132, N, 129, ELU, g['vis_fc.2.bias'])
-  L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU))
-  _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
+  if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
+    _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
   call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dX), 128, 1, _p(scratch), 1, 0, st)  # w1 = mask / sum: no parameter behind it
   # base_fc

@@ -220,23 +220,27 @@ class MotionMLPFunction(torch.autograd.Function):
     call('dyn_train_zero_tail', _p(dC), R, S, C, ctx.n_zero, 1.0 / ctx.sf_div, st)
     _act_bwd(st, dC, 0, C, None, 0, C, P, C, NONE, grads['coeff_linear.bias'])
     dH = new(P, 256)
-    ctx.lc.bwd(st, dC, 0, C, H[7], 0, 256, grads['coeff_linear.weight'], P, dH, 0, 256, act_y=(H[7], 0, 256, RELU))
     dX0 = torch.zeros((P, 132), dtype=torch.float32, device=dev)
+    # dH arrives already multiplied by ReLU'(H[i]) and -- when its rows are 16-byte aligned -- with the bias gradient of layer i and its scale
+    # taken from the producing GEMM's tiles (summed); otherwise the read-only pass below does that
+    summed = ctx.lc.bwd(st, dC, 0, C, H[7], 0, 256, grads['coeff_linear.weight'], P, dH, 0, 256, act_y=(H[7], 0, 256, RELU),
+                        dbias=grads['pts_linears.7.bias'])
     for i in range(7, -1, -1):
-      # dH arrived already multiplied by ReLU'(H[i]) (folded into the data gradient that produced it): bias gradient and scale only
-      _act_bwd(st, dH, 0, 256, None, 0, 256, P, 256, NONE, grads[f'pts_linears.{i}.bias'])
+      if not summed:
+        _act_bwd(st, dH, 0, 256, None, 0, 256, P, 256, NONE, grads[f'pts_linears.{i}.bias'])
       gw = grads[f'pts_linears.{i}.weight']
       if i == 5:
         la, lb = L[5]
         dprev = new(P, 256)
-        lb.bwd(st, dH, 0, 256, H[4], 0, 256, gw, P, dprev, 0, 256, act_y=(H[4], 0, 256, RELU))
+        summed = lb.bwd(st, dH, 0, 256, H[4], 0, 256, gw, P, dprev, 0, 256, act_y=(H[4], 0, 256, RELU), dbias=grads['pts_linears.4.bias'])
         la.bwd(st, dH, 0, 256, X0, 0, 132, gw, P, dX0, 0, 132, acc_dx=1)
         dH = dprev
       elif i == 0:
         L[0].bwd(st, dH, 0, 256, X0, 0, 132, gw, P, dX0, 0, 132, acc_dx=1)
       else:
         dprev = new(P, 256)
-        L[i].bwd(st, dH, 0, 256, H[i - 1], 0, 256, gw, P, dprev, 0, 256, act_y=(H[i - 1], 0, 256, RELU))
+        summed = L[i].bwd(st, dH, 0, 256, H[i - 1], 0, 256, gw, P, dprev, 0, 256, act_y=(H[i - 1], 0, 256, RELU),
+                          dbias=grads[f'pts_linears.{i - 1}.bias'])
         dH = dprev
     gp = None
     if ctx.needs_input_grad[0]:

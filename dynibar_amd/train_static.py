@@ -62,14 +62,14 @@ GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} 
 
 
 def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
-          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0):
+          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0, colsum_part=None, ld_part=0, amax_part=None):
   if GEMM_STATS is not None:  # algorithmic: every operand element read once, every result element written once
     GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N + (M * N if act_y is not None else 0))
     GEMM_STATS['flops'] += 2 * M * N * K
     GEMM_STATS['calls'] += 1
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
              ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax, act_y=act_y, ld_y=ld_y,
-             act_y_kind=act_y_kind)
+             act_y_kind=act_y_kind, colsum_part=colsum_part, ld_part=ld_part, amax_part=amax_part)
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
@@ -86,8 +86,10 @@ class _Lin:
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
           ld_add=ld_add, add_div=add_div, act=act)
 
-  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None):
-    # act_y = (Y, y_off, ld_y, kind): X is the output Y of an ELU / ReLU layer and dX comes out already multiplied by act'(Y)
+  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None, dbias=None):
+    # act_y = (Y, y_off, ld_y, kind): X is the output Y of an ELU / ReLU layer and dX comes out already multiplied by act'(Y).
+    # dbias: the bias gradient of THAT layer (column sums of dX) and the scale of dX are taken from the result tiles on their way out;
+    # returns True when that happened (16-byte-aligned dX rows), False when the caller still has to run _act_bwd for them.
     """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K].  dZ is the GEMMs' scaled operand:
     its largest magnitude comes from the activation-derivative pass that made it (_act_bwd leaves it on the tensor) or is measured here."""
     tag = getattr(dZ, '_dyn_absmax', None)
@@ -102,8 +104,20 @@ class _Lin:
           a_absmax=_p(am))
     if dX is not None:
       fy = {} if act_y is None else dict(act_y=_p(act_y[0], act_y[1]), ld_y=act_y[2], act_y_kind=act_y[3])
+      sums = dbias is not None and acc_dx == 0 and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0
+      if sums:
+        tiles, ctiles = (M + 127) // 128, (self.K + 127) // 128
+        part = torch.empty((tiles, self.K), dtype=torch.float32, device=dX.device)
+        apart = torch.empty(tiles * ctiles, dtype=torch.float32, device=dX.device)
+        fy.update(colsum_part=_p(part), ld_part=self.K, amax_part=_p(apart))
       _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
             a_absmax=_p(am), **fy)
+      if sums:
+        am2 = _Scalars.take(dX.device)
+        call('dyn_train_colsum_reduce', _p(part), tiles, self.K, self.K, _p(dbias), _p(apart), tiles * ctiles, _p(am2), st)
+        dX._dyn_absmax = ((dx_off, ld_dx, M, self.K), am2)
+      return sums
+    return False
 
 
 def _act_bwd(st, dY, dy_off, ld_dy, Y, y_off, ld_y, rows, cols, act, dbias=None, seg=1, dseg=None, ld_seg=0):
@@ -252,8 +266,8 @@ def _backward(s, draw):
   # rgb_fc.4 / .2 / .0
   dR2, dR1 = new(N, 64), new(N, 128)
   _act_bwd(st, dRL, 0, 1, None, 0, 1, N, 1, NONE, g['rgb_fc.4.bias'])
-  L['r4'].bwd(st, dRL, 0, 1, s.R2, 0, 64, g['rgb_fc.4.weight'], N, dR2, 0, 64, act_y=(s.R2, 0, 64, ELU))  # dR2 arrives times ELU'(R2)
-  _act_bwd(st, dR2, 0, 64, None, 0, 64, N, 64, NONE, g['rgb_fc.2.bias'])
+  if not L['r4'].bwd(st, dRL, 0, 1, s.R2, 0, 64, g['rgb_fc.4.weight'], N, dR2, 0, 64, act_y=(s.R2, 0, 64, ELU), dbias=g['rgb_fc.2.bias']):  # dR2 arrives times ELU'(R2)
+    _act_bwd(st, dR2, 0, 64, None, 0, 64, N, 64, NONE, g['rgb_fc.2.bias'])
   L['r2'].bwd(st, dR2, 0, 64, s.R1, 0, 128, g['rgb_fc.2.weight'], N, dR1, 0, 128, act_y=(s.R1, 0, 128, ELU))
   dPP2 = new(P, 128)
   _act_bwd(st, dR1, 0, 128, None, 0, 128, N, 128, NONE, g['rgb_fc.0.bias'], V, dPP2, 128)
@@ -264,8 +278,8 @@ def _backward(s, draw):
   # out_geometry_fc
   dO1 = new(P, 128)
   _act_bwd(st, dSIG, 0, 1, None, 0, 1, P, 1, NONE, g['out_geometry_fc.2.bias'])
-  L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128, act_y=(s.O1, 0, 128, ELU))
-  _act_bwd(st, dO1, 0, 128, None, 0, 128, P, 128, NONE, g['out_geometry_fc.0.bias'])
+  if not L['o2'].bwd(st, dSIG, 0, 1, s.O1, 0, 128, g['out_geometry_fc.2.weight'], P, dO1, 0, 128, act_y=(s.O1, 0, 128, ELU), dbias=g['out_geometry_fc.0.bias']):
+    _act_bwd(st, dO1, 0, 128, None, 0, 128, P, 128, NONE, g['out_geometry_fc.0.bias'])
   L['o0'].bwd(st, dO1, 0, 128, s.G3, 0, 128, g['out_geometry_fc.0.weight'], P, dG3, 0, 128, acc_dx=1)
   # LayerNorm(fc(attention) + g2): dY is the gradient of both summands; it then collects the rest of g2's gradient
   dY = new(P, 128)
@@ -279,8 +293,8 @@ def _backward(s, draw):
   # geometry_fc
   dGH1, dG0 = new(P, 256), new(P, 260)
   _act_bwd(st, dY, 0, 128, s.G2, 0, 128, P, 128, ELU, g['geometry_fc.2.bias'])
-  L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256, act_y=(s.GH1, 0, 256, ELU))
-  _act_bwd(st, dGH1, 0, 256, None, 0, 256, P, 256, NONE, g['geometry_fc.0.bias'])
+  if not L['g2'].bwd(st, dY, 0, 128, s.GH1, 0, 256, g['geometry_fc.2.weight'], P, dGH1, 0, 256, act_y=(s.GH1, 0, 256, ELU), dbias=g['geometry_fc.0.bias']):
+    _act_bwd(st, dGH1, 0, 256, None, 0, 256, P, 256, NONE, g['geometry_fc.0.bias'])
   L['g0'].bwd(st, dGH1, 0, 256, s.G0, 0, 260, g['geometry_fc.0.weight'], P, dG0, 0, 260)
   # pooled statistics of x2 under the visibility weights; the weights themselves
   dw2, dVL = new(N), new(N)
@@ -290,16 +304,16 @@ def _backward(s, draw):
   # vis_fc2
   dH4, dXS, dvis0 = new(N, 128), new(N, 128), new(N)
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
-  L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU))
-  _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
+  if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
+    _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
   # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
   dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
   call('dyn_train_vis_split_bwd', _p(dRIN), 136, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
   _act_bwd(st, dXV, 0, 132, s.XV, 0, 132, N, 129, ELU, g['vis_fc.2.bias'])
-  L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU))
-  _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
+  if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
+    _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
   dw1 = new(N)
   call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dRIN), 136, 1, _p(dw1), 1, 0, st)
@@ -320,8 +334,8 @@ def _backward(s, draw):
   _act_bwd(st, dREFF, 0, 36, None, 0, 36, R, 35, NONE, g['ref_feature_fc.0.bias'])
   L['ref'].bwd(st, dREFF, 0, 36, s.REFPE, 0, 68, g['ref_feature_fc.0.weight'], R)
   _act_bwd(st, dSRCF, 0, 36, None, 0, 36, N, 35, NONE, g['ray_dir_fc.2.bias'])
-  L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(s.H1, 0, 256, ELU))
-  _act_bwd(st, dH1, 0, 256, None, 0, 256, N, 256, NONE, g['ray_dir_fc.0.bias'])
+  if not L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(s.H1, 0, 256, ELU), dbias=g['ray_dir_fc.0.bias']):
+    _act_bwd(st, dH1, 0, 256, None, 0, 256, N, 256, NONE, g['ray_dir_fc.0.bias'])
   L['rd0'].bwd(st, dH1, 0, 256, s.A0, 0, 104, g['ray_dir_fc.0.weight'], N)
   return g, dF  # dF[:, 0:35] = d rgb_feat (the gather's backward, train_motion.GatherFunction, carries it on into the maps)
 

@@ -296,8 +296,16 @@ typedef struct {
                           * (mlp_network.py:342-397, 587-603).  NULL to skip; needs accumulate = 0 */
   long ld_y;
   int act_y_kind;        /* 1 ELU, 2 ReLU */
+  float* colsum_part;    /* [ceil(M / 128), ld_part]: every workgroup leaves the column sums of its result tile here (the partial sums of the NEXT
+                          * bias gradient: autograd of nn.Linear's bias, mlp_network.py:342-397) -- NULL to skip; needs accumulate = 0 and
+                          * 16-byte-aligned result rows (N, ldc multiples of 4) */
+  long ld_part;
+  float* amax_part;      /* [ceil(M / 128) * ceil(N / 128)]: largest |result| per workgroup (required with colsum_part) */
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
+/* second stage of colsum_part / amax_part: dbias[n] += sum over the tiles (dbias may be NULL), *absmax = max(*absmax, all of amax_part) */
+int dyn_train_colsum_reduce(const float* colsum_part, long tiles, int N, long ld_part, float* dbias, const float* amax_part, long n_amax,
+                            float* absmax, void* stream);
 
 /* dZ = dY * act'(Y) in place (act 1: ELU, act 2: ReLU, both from the saved output Y; act 0: unchanged); dbias[c] += column sums (NULL to skip);
  * dseg[(row / seg), c] = sums over the seg rows of a point (gradient of a per-point addend; NULL to skip); absmax: see dyn_train_absmax. */
