@@ -1052,11 +1052,21 @@ def check_train_gemm(device):
       Ys = Xs if kind == 2 else torch.where(Xs > 0, Xs, torch.expm1(Xs))  # a plausible saved output (ELU outputs are > -1)
       dW = torch.zeros_like(Ws)
       dX = torch.full((M, ld), float('nan'), device=device)
-      lin.bwd(TS.stream_of(Xs), dZ, 0, 40, Ys, 0, ld, dW, M, dX, 0, ld, act_y=(Ys, 0, ld, kind))
+      db = torch.zeros(Kin, device=device)
+      summed = lin.bwd(TS.stream_of(Xs), dZ, 0, 40, Ys, 0, ld, dW, M, dX, 0, ld, act_y=(Ys, 0, ld, kind), dbias=db)
       y = Ys[:, :Kin].double().cpu()
       der = torch.where(y > 0, torch.ones_like(y), (y + 1.0) if kind == TS.ELU else torch.zeros_like(y))
       big = float(dZ.abs().max())
-      assert_close(dX[:, :Kin], (dZ[:, :N].double().cpu() @ Ws.double().cpu()) * der, 3e-6 * big, 4e-6, f"train gemm data gradient x {name}' ({Kin} columns)")
+      ref = (dZ[:, :N].double().cpu() @ Ws.double().cpu()) * der
+      assert_close(dX[:, :Kin], ref, 3e-6 * big, 4e-6, f"train gemm data gradient x {name}' ({Kin} columns)")
+      # the bias gradient / scale of the result from the GEMM's own tiles: only for 16-byte-aligned result rows (the caller's pass otherwise)
+      assert summed == (Kin % 4 == 0), (Kin, summed)
+      if summed:
+        assert_close(db, ref.sum(0), 3e-5 * big, 4e-6, f"train gemm column sums of the result ({name}, {Kin} columns)")
+        key, am = dX._dyn_absmax
+        assert key == (0, ld, M, Kin)
+        assert abs(float(am) - float(dX[:, :Kin].abs().max())) == 0.0, 'scale of the result'
+
   # split reduction over many rows
   M = 5000
   X = torch.randn(M, 64, generator=g).to(device)
