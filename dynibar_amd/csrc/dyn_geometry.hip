@@ -1085,6 +1085,63 @@ __global__ void __launch_bounds__(256) k_trajectory_bwd(const float* __restrict_
     if (row >= 0 && acc[e] != 0.f) atomicAdd(dbasis + (long)row * B + b, acc[e]);
   }
 }
+// B <= 8 basis functions (the reference ships 6): a point's coefficients and their gradients stay in registers (the generic kernel above
+// read-modify-writes 3 B floats of global memory per trajectory row with an 18-float stride between lanes), and the basis gradient is summed
+// over the wave before it touches the workgroup's LDS accumulators (one atomic per wave instead of 64 on the same address).
+__global__ void __launch_bounds__(256) k_trajectory_bwd8(const float* __restrict__ dseq, const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                         long n_pts, int B, TrajRows tr, float* __restrict__ dcoeff, float* __restrict__ dbasis,
+                                                         float* __restrict__ dpts) {
+  float* acc = reinterpret_cast<float*>(dyn_smem);  // [(n + 1)][B]: per trajectory row, last = the reference row
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int e = tid; e < (tr.n + 1) * B; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  const long p = (long)blockIdx.x * 256 + tid;
+  const bool live = p < n_pts;
+  const long pc = live ? p : n_pts - 1;
+  float co[3][8], dc[3][8], dp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      co[a][b] = b < B ? coeff[pc * 3 * B + a * B + b] : 0.f;
+      dc[a][b] = 0.f;
+    }
+  for (int v = 0; v < tr.n; ++v) {
+    const float* d = dseq + ((long)v * n_pts + pc) * 3;
+    const float d0 = live ? d[0] : 0.f, d1 = live ? d[1] : 0.f, d2 = live ? d[2] : 0.f;
+    dp[0] += d0; dp[1] += d1; dp[2] += d2;
+    const int row = tr.rows[v];
+    if (row >= 0) {  // uniform
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        if (b < B) {
+          const float db = basis[(long)row * B + b] - basis[(long)tr.ref * B + b];
+          dc[0][b] += d0 * db; dc[1][b] += d1 * db; dc[2][b] += d2 * db;
+          const float t = wave_sum(d0 * co[0][b] + d1 * co[1][b] + d2 * co[2][b]);
+          if (lane == 0) {
+            atomicAdd(acc + v * B + b, t);
+            atomicAdd(acc + tr.n * B + b, -t);
+          }
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b < B) dcoeff[p * 3 * B + a * B + b] = dc[a][b];
+    if (dpts != nullptr)
+      for (int a = 0; a < 3; ++a) dpts[p * 3 + a] = dp[a];
+  }
+  __syncthreads();
+  for (int e = tid; e < (tr.n + 1) * B; e += 256) {
+    const int v = e / B, b = e % B;
+    const int row = v < tr.n ? tr.rows[v] : tr.ref;
+    if (row >= 0 && acc[e] != 0.f) atomicAdd(dbasis + (long)row * B + b, acc[e]);
+  }
+}
 extern "C" int dyn_trajectory_bwd(const float* dseq, const float* coeff, const float* basis, long n_pts, int B, const int* rows, int n_rows,
                                   int row_ref, float* dcoeff, float* dbasis, float* dpts, void* stream) {
   DYN_REQUIRE(dseq && coeff && basis && rows && dcoeff && dbasis, "dyn_trajectory_bwd: null pointer");
@@ -1092,6 +1149,11 @@ extern "C" int dyn_trajectory_bwd(const float* dseq, const float* coeff, const f
   TrajRows tr;
   tr.n = n_rows; tr.ref = row_ref;
   for (int i = 0; i < 32; ++i) tr.rows[i] = i < n_rows ? rows[i] : -1;
+  if (B <= 8) {
+    DYN_LAUNCH(DYN_K_TRAJECTORY, "dyn_trajectory_bwd", k_trajectory_bwd8, dim3(dyn_cdiv(n_pts, 256)), dim3(256),
+               (size_t)(n_rows + 1) * B * sizeof(float), (hipStream_t)stream, dseq, coeff, basis, n_pts, B, tr, dcoeff, dbasis, dpts);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAJECTORY, "dyn_trajectory_bwd", k_trajectory_bwd, dim3(dyn_cdiv(n_pts, 256)), dim3(256), (size_t)(n_rows + 1) * B * sizeof(float),
              (hipStream_t)stream, dseq, coeff, basis, n_pts, B, tr, dcoeff, dbasis, dpts);
   return 0;
