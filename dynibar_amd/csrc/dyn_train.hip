@@ -860,13 +860,19 @@ extern "C" int dyn_train_static_embed(const float* pts, const float* ray_o, cons
 __global__ void __launch_bounds__(256) k_train_build_f(const float* __restrict__ rgb_feat, const float* __restrict__ src_feat, long ld_src,
                                                        const float* __restrict__ ref_feat, long ld_ref, long N, int rows_per_ray,
                                                        float* __restrict__ f) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long row = idx / 72;
-  const int c = (int)(idx - row * 72);
+  long row, ray;
+  int c;
+  if (N * 72 < (1L << 32)) {  // 32-bit index arithmetic (a 64-bit division costs ~100 instructions; this kernel had two per element)
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x, r = idx / 72u;
+    row = r; c = (int)(idx - r * 72u); ray = r / (unsigned)rows_per_ray;
+  } else {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    row = idx / 72; c = (int)(idx - row * 72); ray = row / rows_per_ray;
+  }
   if (row >= N) return;
   float v = 0.f;
   if (c < 35) v = rgb_feat[row * 35 + c];
-  else if (c < 70) v = src_feat[row * ld_src + c - 35] * ref_feat[(row / rows_per_ray) * ld_ref + c - 35];
+  else if (c < 70) v = src_feat[row * ld_src + c - 35] * ref_feat[ray * ld_ref + c - 35];
   f[row * 72 + c] = v;
 }
 __global__ void __launch_bounds__(256) k_train_build_f_bwd(const float* __restrict__ df, long ld_df, const float* __restrict__ src_feat, long ld_src,
@@ -1611,10 +1617,14 @@ __global__ void __launch_bounds__(256) k_train_layernorm_bwd(const float* __rest
     din[row * 128 + 64 + lane] = rs * (g1 - mg - x1 * mgx);
     dg0 += o0 * x0; dg1 += o1 * x1; db0 += o0; db1 += o1;
   }
-  if (w * rows_per_wave < P) {
-    atomicAdd(dgamma + lane, dg0); atomicAdd(dgamma + 64 + lane, dg1);
-    atomicAdd(dbeta + lane, db0); atomicAdd(dbeta + 64 + lane, db1);
-  }
+  // the block's four waves meet in LDS: one atomic per column and block (same-address atomics serialise in L2)
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [4 waves][256]
+  float* mine = red + (threadIdx.x >> 6) * 256;
+  mine[lane] = dg0; mine[64 + lane] = dg1; mine[128 + lane] = db0; mine[192 + lane] = db1;
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float sum = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+  atomicAdd((t < 128 ? dgamma : dbeta - 128) + t, sum);
 }
 extern "C" int dyn_train_layernorm(const float* a, const float* b, const float* gamma, const float* beta, long P, float* out, float* xhat, float* rstd,
                                    void* stream) {
@@ -1628,7 +1638,7 @@ extern "C" int dyn_train_layernorm_bwd(const float* dout, const float* xhat, con
   DYN_REQUIRE(dout && xhat && rstd && gamma && din && dgamma && dbeta && P > 0, "dyn_train_layernorm_bwd: bad arguments");
   const int rpw = 16;
   const long waves = (P + rpw - 1) / rpw;
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_layernorm_bwd", k_train_layernorm_bwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_layernorm_bwd", k_train_layernorm_bwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 1024 * sizeof(float), (hipStream_t)stream, dout,
              xhat, rstd, gamma, P, rpw, din, dgamma, dbeta);
   return 0;
 }
