@@ -123,18 +123,29 @@ def ptr(t, dtype=torch.float32):
   return ctypes.c_void_p(t.data_ptr())
 
 
+class _Stream(ctypes.c_void_p):
+  """A hipStream_t handle that remembers which device it belongs to (see call())."""
+  device_index = None
+
+
 def stream_of(t):
-  """torch's current stream on the tensor's device; that device is made current first (kernels launch on the current device, and the
-  C side refuses a stream of another device)."""
+  """torch's current stream on the tensor's device.  Kernels launch on the CURRENT device and the C side refuses a stream of another one, so
+  call() makes the stream's device current for the duration of the launch only -- the caller's current device is never changed."""
   if t is not None and t.is_cuda:
-    if torch.cuda.current_device() != t.device.index:
-      torch.cuda.set_device(t.device)
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    st = _Stream(torch.cuda.current_stream(t.device).cuda_stream)
+    st.device_index = t.device.index
+    return st
   return ctypes.c_void_p(0)
 
 
 def call(name, *args):
-  rc = getattr(lib(), name)(*args)
+  fn = getattr(lib(), name)
+  dev = next((a.device_index for a in args if isinstance(a, _Stream)), None)
+  if dev is not None and dev != torch.cuda.current_device():
+    with torch.cuda.device(dev):
+      rc = fn(*args)
+  else:
+    rc = fn(*args)
   if rc != 0:
     raise RuntimeError(f'{name} failed ({rc}): {lib().dyn_last_error().decode()}')
 

@@ -10,9 +10,11 @@
 // pack-time permutation of the reference's (results agree to fp32 round-off, not bitwise; tolerance 1e-4 per north_star).
 //
 // Two engines share that structure (selected at build time, DYN_ENGINE_B6):
-//  * the shipped one ("B6", second half of this file): fp32 operands split exactly into bf16 parts, products on the bf16 matrix pipe
-//    (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, 3 or 6 partial products per product (DYN_SPLIT_TERMS).  Weights are split and
-//    packed on the host (dyn_nets.hip: pack_layer_b6) into a stream of 48 KiB chunks in consumption order and DMA'd global->LDS
+//  * the shipped one ("B6", second half of this file): fp32 operands split exactly into two 16-bit parts, products on the 16-bit matrix
+//    pipe with fp32 accumulation.  Default build (DYN_SPLIT_F16 = 1): IEEE half parts (22 mantissa bits), three partial products
+//    hi.hi + hi.mid + mid.hi on v_mfma_f32_32x32x16_f16 -- fp32-class products.  Variant builds keep bf16 parts
+//    (v_mfma_f32_32x32x16_bf16; DYN_SPLIT_TERMS = 3 or 6 partial products).  Weights are split and packed on the host
+//    (dyn_nets.hip: pack_layer_b6) into a stream of 48 KiB chunks in consumption order and DMA'd global->LDS
 //    (global_load_lds_dwordx4) into a ring shared by the 4 or 8 waves of a workgroup: chunk c+1 in flight while chunk c feeds the
 //    MFMAs, one workgroup barrier per chunk.  Biases are accumulator initial values (LDS tables) or one extra k-slot fed with 1.
 //  * the first one (kept for A/B builds, -DDYN_ENGINE_B6=0; first half of this file): native fp32 MFMA (v_mfma_f32_32x32x2_f32),

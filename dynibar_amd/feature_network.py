@@ -43,6 +43,51 @@ class ResNet(object):
   def eval(self):
     return self
 
+  # ---- the nn.Module surface the reference's own model container touches (model.py:117-131 switch_to_train / switch_to_eval,
+  # :177-190 save_model -> state_dict, :85-115 optimizer construction -> parameters): delegated to the wrapped module, so an object of
+  # this class can sit where `model.feature_net` sits without AttributeError.
+  def train(self, mode=True):
+    src = _unwrap(self._source)
+    if hasattr(src, 'train'):
+      src.train(mode)
+    return self
+
+  def state_dict(self, *a, **kw):
+    src = _unwrap(self._source)
+    if src is None:
+      raise RuntimeError('dynibar_amd.feature_network.ResNet has no weights')
+    return src.state_dict(*a, **kw) if hasattr(src, 'state_dict') else dict(src)
+
+  def parameters(self, recurse=True):
+    src = _unwrap(self._source)
+    return src.parameters(recurse) if hasattr(src, 'parameters') else iter(())
+
+  def named_parameters(self, *a, **kw):
+    src = _unwrap(self._source)
+    return src.named_parameters(*a, **kw) if hasattr(src, 'named_parameters') else iter(())
+
+  def to(self, *a, **kw):
+    src = _unwrap(self._source)
+    if hasattr(src, 'to') and not isinstance(src, dict):
+      src.to(*a, **kw)
+    elif isinstance(src, dict):
+      self._source = {k: (v.to(*a, **kw) if torch.is_tensor(v) else v) for k, v in src.items()}
+    self._packed = {}
+    return self
+
+  def cuda(self, device=None):
+    return self.to('cuda' if device is None else device)
+
+  def _refuse_training(self):
+    """The HIP encoder is forward-only: its maps carry no autograd graph.  Left in place of `model.feature_net` during training the
+    encoder would silently stop learning (the reference trains it, train.py:272-281), so a forward under grad mode over a module that
+    still has trainable parameters is refused."""
+    src = _unwrap(self._source)
+    if torch.is_grad_enabled() and hasattr(src, 'parameters') and any(p.requires_grad for p in src.parameters()):
+      raise RuntimeError('dynibar_amd.feature_network.ResNet is forward-only: called under grad mode on an encoder with trainable parameters. '
+                         'Keep the reference nn.Module as model.feature_net while training (its maps carry the graph our feature-map gradients '
+                         'flow into), or call under torch.no_grad() / freeze the encoder for evaluation.')
+
   def _state(self):
     src = _unwrap(self._source)
     if src is None:
@@ -64,6 +109,7 @@ class ResNet(object):
   def forward(self, x):
     """x [N,3,H,W] -> (x_coarse [N,32,Hf,Wf], x_fine [N,32,Hf,Wf])."""
     assert x.dim() == 4 and x.shape[1] == 3
+    self._refuse_training()
     img = x.permute(0, 2, 3, 1)
     if img.dtype != torch.float32 or not img.is_contiguous():
       img = img.float().contiguous()

@@ -22,7 +22,10 @@ class Projector(object):
     key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (query_camera, train_imgs, train_cameras, featmaps))
     v = self._views.get(key)
     if v is None:
-      if len(self._views) > 16:
+      # Training hands over NEW featmaps tensors every iteration (the encoder's outputs under grad mode; an iteration uses three or four
+      # view sets): entries of earlier iterations can never be hit again, so under grad mode the cache is bounded to about one iteration's
+      # sets instead of keeping up to 17 (maps, repacked copy) pairs alive.
+      if len(self._views) > (5 if featmaps.requires_grad else 16):
         self._views.clear()
       v = ops.SourceViews(query_camera, train_imgs, train_cameras, featmaps)
       # keep the keyed tensors alive so that a recycled address cannot alias a stale entry

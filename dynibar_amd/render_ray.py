@@ -377,8 +377,9 @@ def render_rays_mv(frame_idx, time_embedding, time_offset, ray_batch, model, pro
 def render_rays_mono(frame_idx, time_embedding, time_offset, ray_batch, model, featmaps, projector, N_samples, args, inv_uniform=False,
                      N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True, num_vv=2):
   """Reference render_ray.py:870-1277: outputs_coarse_ref, outputs_coarse_ref_dy, outputs_coarse_st and, with is_train=True, the
-  cross-time rendering at the anchor frame (outputs_coarse_anchor, outputs_coarse_anchor_dy; :1099-1270) -- forward values only:
-  the returned tensors carry no autograd graph (the backward kernels are SURVEY section 8f)."""
+  cross-time rendering at the anchor frame (outputs_coarse_anchor, outputs_coarse_anchor_dy; :1099-1270).  Under grad mode the
+  returned tensors carry the autograd graph train.py differentiates (its nodes are the backward kernels of train_static / train_dynamic /
+  train_motion); under torch.no_grad() the forward-only inference kernels run."""
   ref_frame_idx, ref_time_embedding, ref_time_offset = frame_idx[0], time_embedding[0], time_offset[0]
   ray_o, ray_d = ray_batch['ray_o'], ray_batch['ray_d']
   pts, z_vals, s_vals = sample_along_camera_ray(ray_o, ray_d, ray_batch['depth_range'], N_samples, inv_uniform, det)

@@ -27,7 +27,17 @@ def trainable_parameters(model, names=('net_coarse_st', 'net_coarse_dy', 'motion
     obj = getattr(model, n, None)
     if obj is None:
       continue
-    ps = [obj] if isinstance(obj, torch.Tensor) else list(obj.parameters())
+    if isinstance(obj, torch.Tensor):
+      ps = [obj]
+    elif hasattr(obj, 'parameters'):
+      ps = list(obj.parameters())
+    elif isinstance(obj, dict):  # a state dict (checkpoint.load_model keeps the nets that way): its tensors are the parameters
+      ps = [v for v in obj.values() if isinstance(v, torch.Tensor)]
+      if ps and not any(p.requires_grad for p in ps):
+        raise RuntimeError(f'trainable_parameters: model.{n} is an inference-only state dict (no tensor requires grad); build the model from '
+                           'nn.Modules (or call requires_grad_() on its tensors) before training')
+    else:
+      raise RuntimeError(f'trainable_parameters: model.{n} ({type(obj).__name__}) has no parameters(); it is an inference-only object')
     for p in ps:
       if p.requires_grad and id(p) not in seen:
         seen.add(id(p))

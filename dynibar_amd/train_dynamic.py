@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
-from .train_static import ELU, NONE, _Lin, _act_bwd, _p, zero_grads
+from .train_static import ELU, NONE, _Lin, _act_bwd, _p, _untag, zero_grads
 
 PARAM_NAMES = ops.DYNAMIC_TENSORS
 
@@ -193,6 +193,7 @@ def _backward(s, draw):
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  _untag(dX)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
   dXV, dH3, dXW, scratch = new(N, 132), new(N, 128), new(N, 128), new(N)
   call('dyn_train_vis_split_bwd', _p(dX), 128, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
@@ -200,6 +201,7 @@ def _backward(s, draw):
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
+  _untag(dX)
   call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dX), 128, 1, _p(scratch), 1, 0, st)  # w1 = mask / sum: no parameter behind it
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 36), new(P, 72)
@@ -208,6 +210,7 @@ def _backward(s, draw):
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 36, g['base_fc.0.weight'], N, dF, 0, 36)
   L['b0g'].bwd(st, dPP1, 0, 256, s.G1, 0, 72, g['base_fc.0.weight'], P, dG1, 0, 72)
+  _untag(dF)
   call('dyn_train_meanvar_bwd', _p(s.F), 36, _p(s.w1), P, V, 35, _p(s.G1), _p(dG1), _p(dG1, 35), 72, _p(dF), 36, 1, _p(scratch), 0, st)
   # time feature: its gradient is the column sum of d(rgb_feat + feature) over all rows, then back through ray_dir_fc
   dDIRF, dDH1 = torch.zeros((1, 36), dtype=torch.float32, device=dev), new(1, 256)

@@ -73,6 +73,14 @@ def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=N
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
+def _untag(t):
+  """Drop the cached largest-magnitude tag of a gradient tensor that a kernel is about to ACCUMULATE into in place: the tag (set by
+  whatever produced the tensor) is the power-of-two scale of the split-half backward GEMMs, and a stale, too-small scale overflows
+  their f16 operands.  The next consumer re-measures (dyn_train_absmax)."""
+  if t is not None:
+    t.__dict__.pop('_dyn_absmax', None)
+
+
 class _Lin:
   """Columns [col0, col0 + K) of an nn.Linear weight [n_out, k_full] (+ its bias): one GEMM operand."""
 
@@ -110,6 +118,8 @@ class _Lin:
         part = torch.empty((tiles, self.K), dtype=torch.float32, device=dX.device)
         apart = torch.empty(tiles * ctiles, dtype=torch.float32, device=dX.device)
         fy.update(colsum_part=_p(part), ld_part=self.K, amax_part=_p(apart))
+      if acc_dx != 0:
+        _untag(dX)
       _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
             a_absmax=_p(am), **fy)
       if sums:
@@ -298,6 +308,7 @@ def _backward(s, draw):
   L['g0'].bwd(st, dGH1, 0, 256, s.G0, 0, 260, g['geometry_fc.0.weight'], P, dG0, 0, 260)
   # pooled statistics of x2 under the visibility weights; the weights themselves
   dw2, dVL = new(N), new(N)
+  _untag(dRIN)
   call('dyn_train_meanvar_bwd', _p(s.RIN), 136, _p(s.w2), P, V, 128, _p(s.G0), _p(dG0), _p(dG0, 128), 260, _p(dRIN), 136, 1, _p(dw2), 0, st)
   call('dyn_train_view_weights_bwd', 1, _p(s.VL), 1, _p(s.M), None, P, V, _p(s.w2), _p(dw2), _p(dRIN, 128), 136, _p(s.RIN, 128), 136,
        _p(dG0, 256), 260, _p(dVL), 1, None, st)
@@ -307,6 +318,7 @@ def _backward(s, draw):
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  _untag(dRIN)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
   # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
   dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
@@ -316,6 +328,7 @@ def _backward(s, draw):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
   dw1 = new(N)
+  _untag(dRIN)
   call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dRIN), 136, 1, _p(dw1), 1, 0, st)
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 72), new(P, 140)
@@ -324,6 +337,7 @@ def _backward(s, draw):
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 72, g['base_fc.0.weight'], N, dF, 0, 72)
   L['b0g'].bwd(st, dPP1, 0, 256, s.G1, 0, 140, g['base_fc.0.weight'], P, dG1, 0, 140)
+  _untag(dF)
   call('dyn_train_meanvar_bwd', _p(s.F), 72, _p(s.w1), P, V, 70, _p(s.G1), _p(dG1), _p(dG1, 70), 140, _p(dF), 72, 1, _p(dw1), 1, st)
   if s.aa:
     call('dyn_train_view_weights_bwd', 0, _p(s.ray_diff, 3), 4, _p(s.M), _p(w['s']), P, V, _p(s.w1), _p(dw1), None, 0, None, 0, None, 0, None, 0,
