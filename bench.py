@@ -11,7 +11,11 @@ Prints ONE JSON line (rank 0).  The CPU leg times the oracle (the reference algo
 sample of the same workload (median of 3); it is a reported baseline, not the target.  Extra legs in the same line (`extra`): the
 same step at the Nvidia eval's real static view count (11), one full 288x512 frame through render_single_image_nvi (on N > 1 GPUs:
 ray-tiled across the ranks -- a strong-scaling number next to the weak-scaling headline), and the HBM traffic of the network and
-gather kernels measured by rocprofv3 --pmc children of this same command.
+gather kernels measured by rocprofv3 --pmc children of this same command.  With N > 1 the line also carries every rank's own ms per step, the
+cost of the pixel all-gather alone and, for the frame leg, every rank's render and gather times.
+`--dry-run` rehearses exactly this control flow on CPU ranks over gloo with a stub of the kernel layer (tests/test_bench_dry_run.py launches it
+through torch.distributed.run with 2 ranks): the product has no CPU path, so the numbers of a dry run mean nothing -- the point is that the
+N > 1 command cannot fail on first contact with an 8-GPU node for a reason a CPU could have found.
 """
 import argparse
 import ctypes
@@ -87,16 +91,60 @@ class StaticStep:
     return ops.composite(raw, z, pm, per_sample=False)
 
 
+class DryStep:
+  """--dry-run: the shape of StaticStep without kernels (a per-ray function on the CPU); bench-only, never part of the product."""
+
+  def __init__(self, dev, R, S, V, rank=0):
+    g = torch.Generator().manual_seed(100 + rank)
+    self.R, self.ray_o = R, torch.rand(R, 3, generator=g)
+
+  def step(self):
+    return {'rgb': self.ray_o * 0.5 + 0.25, 'depth': self.ray_o.sum(dim=1)}
+
+
+def dry_render_rays_mv(frame_idx, time_embedding, time_offset, ray_batch, model, projector, coarse_featmaps, fine_featmaps, N_samples, args,
+                       inv_uniform=False, N_importance=0, raw_noise_std=0.0, det=False, white_bkgd=False, is_train=True):
+  """--dry-run: render_rays_mv's output structure from a per-ray function (what tests/test_distributed_cpu.py drives the frame code with)."""
+  o = ray_batch['ray_o']
+  s = torch.arange(N_samples, dtype=torch.float32)[None, :]
+  coarse = {'rgb': o * 2.0 + 1.0, 'depth': o.sum(dim=1), 'weights': o[:, :1] * s, 'mask': o[:, 0] > 0.3}
+  fine = {'rgb': o * 3.0, 'mask': o[:, 1] > 0.5, 'depth': o[:, 2], 'alpha': o[:, 1:2] * s}
+  return {'outputs_coarse_ref': coarse, 'outputs_fine_ref': fine, 'outputs_fine_anchor': None, 'outputs_fine_anchor_dy': None}
+
+
+class DryFrameCase:
+  """--dry-run: FrameCase's interface; render() is the REAL render_single_image_nvi (ray tiles, chunk slicing, packed all-gather) over the stub."""
+
+  def __init__(self, dev, H=36, W=64, chunk=512):
+    import types
+    from dynibar_amd import render_image
+    self.RI, self.H, self.W, self.chunk = render_image, H, W, chunk
+    render_image.render_rays_mv = dry_render_rays_mv
+    self.args = types.SimpleNamespace(frame_outputs=None)
+
+  def sampler(self):
+    import types
+    g = torch.Generator().manual_seed(5)
+    return types.SimpleNamespace(H=self.H, W=self.W), {'ray_o': torch.rand(self.H * self.W, 3, generator=g), 'camera': torch.zeros(1, 34), 'rgb': None}
+
+  def render(self, smp, rb):
+    return self.RI.render_single_image_nvi((0, None), (None, None), ([0], None), smp, rb, None, None, self.chunk, 4, self.args, N_importance=4, det=True,
+                                           is_train=False)
+
+
 def timed(lib, step, steps, warmup, fence):
   for _ in range(warmup):
     out = step()
   fence()
-  lib.dyn_profile_enable(1)
+  if lib is not None:
+    lib.dyn_profile_enable(1)
   t0 = time.perf_counter()
   for _ in range(steps):
     out = step()
   fence()
   dt = time.perf_counter() - t0
+  if lib is None:
+    return out, dt, {}
   lib.dyn_profile_enable(0)
   return out, dt, read_kernels(lib)
 
@@ -152,43 +200,57 @@ def main():
   ap.add_argument('--x6', action='store_true', help='also time the bf16 6-term split engine build (libdynibar_hip_x6.so)')
   ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (11 views, full frame)')
   ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc child runs that measure HBM traffic per launch')
+  ap.add_argument('--dry-run', action='store_true', help='rehearse the (multi-rank) control flow on CPU ranks over gloo with a stub of the kernel layer; numbers are meaningless')
   ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
   a = ap.parse_args()
   if a.child:
     a.cpu_rays, a.no_extra, a.no_traffic, a.x6 = 0, True, True, False
+  if a.dry_run:
+    a.cpu_rays, a.no_traffic, a.x6 = 0, True, False
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if a.gpus > 1 and world != a.gpus:
     raise SystemExit(f'--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})')
-  if not torch.cuda.is_available():
-    raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
-  dev = torch.device('cuda', local_rank)
-  torch.cuda.set_device(dev)
+  dry = a.dry_run
+  if not dry and not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path; --dry-run only rehearses the control flow)')
+  dev = torch.device('cpu') if dry else torch.device('cuda', local_rank)
+  if not dry:
+    torch.cuda.set_device(dev)
   dist = None
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=dev)
+    if dry:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=dev)
 
-  from dynibar_amd import _lib
-  lib = _lib.lib()
+  lib = None
+  if not dry:
+    from dynibar_amd import _lib
+    lib = _lib.lib()
+  sync = (lambda: None) if dry else torch.cuda.synchronize
 
   R, S, V = a.rays, a.samples, a.views
-  wl = StaticStep(dev, R, S, V, rank)
+  wl = (DryStep if dry else StaticStep)(dev, R, S, V, rank)
   gathered = torch.empty((world * R, 4), dtype=torch.float32, device=dev) if world > 1 else None
+
+  def pixels(out):
+    return torch.cat([out['rgb'], out['depth'][:, None]], dim=1)
 
   def step():
     out = wl.step()
     if world > 1:
-      dist.all_gather_into_tensor(gathered, torch.cat([out['rgb'], out['depth'][:, None]], dim=1))
+      dist.all_gather_into_tensor(gathered, pixels(out))
     return out
 
   def fence():
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
       dist.barrier()
-      torch.cuda.synchronize()
+      sync()
 
   def max_over_ranks(x):
     if world == 1:
@@ -197,35 +259,73 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
 
-  out, dt, kernels = timed(lib, step, a.steps, a.warmup, fence)
-  dt = max_over_ranks(dt)
+  def every_rank(x):
+    """x of every rank, in rank order (a list of one on a single GPU)."""
+    if world == 1:
+      return [float(x)]
+    tt = torch.zeros(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(tt, torch.tensor([x], dtype=torch.float64, device=dev))
+    return [float(v) for v in tt.tolist()]
+
+  out, dt_own, kernels = timed(lib, step, a.steps, a.warmup, fence)
+  dt = max_over_ranks(dt_own)
+  multi = None
+  if world > 1:
+    # what the collective alone costs (the same payload, the same stream, nothing to overlap with), and every rank's own clock
+    send = pixels(out).contiguous()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+      dist.all_gather_into_tensor(gathered, send)
+    fence()
+    ag = max_over_ranks(time.perf_counter() - t0)
+    multi = {'per_rank_ms_per_step': [round(v / a.steps * 1e3, 4) for v in every_rank(dt_own)], 'allgather_alone_ms_per_step': ag / a.steps * 1e3,
+             'allgather_bytes_per_rank_per_step': int(send.numel() * 4), 'backend': dist.get_backend()}
 
   # ---- extra legs (every rank takes part in the frame leg: the ray tiles are a collective effort) ----
   extra = {}
   if not a.no_extra:
     try:
-      from frame_case import FrameCase
-      fc = FrameCase(dev)
+      from dynibar_amd import render_image
+      if dry:
+        fc = DryFrameCase(dev)
+      else:
+        from frame_case import FrameCase
+        fc = FrameCase(dev)
       smp, rb = fc.sampler()
       fc.render(smp, rb)  # warm-up: packs the six networks, prepares the source views
       fence()
-      lib.dyn_profile_enable(1)
+      if lib is not None:
+        lib.dyn_profile_enable(1)
+      render_image.FRAME_STATS = {}  # opt-in stage clocks of the next frame (they synchronise the device between the stages)
       t0 = time.perf_counter()
       ret = fc.render(smp, rb)
       fence()
       fdt = max_over_ranks(time.perf_counter() - t0)
-      lib.dyn_profile_enable(0)
-      fk = read_kernels(lib)
+      fst, render_image.FRAME_STATS = render_image.FRAME_STATS, None
+      fk = {}
+      if lib is not None:
+        lib.dyn_profile_enable(0)
+        fk = read_kernels(lib)
+      n_frame_rays = rb['ray_o'].shape[0]
       extra['frame_nvi_288x512'] = {
           'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
                   + ('rays tiled over %d ranks, one packed [rays,5] all-gather: strong scaling' % world if world > 1 else 'one GPU'),
-          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': H * W / fdt,
+          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': n_frame_rays / fdt,
+          'per_rank': {'tile_rays': [int(v) for v in every_rank(fst.get('tile_rays', 0))],
+                       'render_ms': [round(v, 3) for v in every_rank(fst.get('render_ms', 0.0))],
+                       'gather_and_copy_ms': [round(v, 3) for v in every_rank(fst.get('gather_ms', 0.0))],
+                       'gather_payload_bytes_per_rank': int(fst.get('gather_bytes', 0)),
+                       'note': 'render_ms: the chunk loop over the rank\'s own ray tile; gather_and_copy_ms: the packed [rays,5] all-gather + the copy of the frame\'s pixels '
+                               'to the host (render_image.FRAME_STATS: the device is synchronised between the two stages for this frame only)'},
           'kernel_ms_per_frame_rank0': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},
           'pixels_check': [float(ret['outputs_fine_ref']['rgb'].mean()), float(ret['outputs_fine_ref']['depth'].mean())]}
+      if dry:
+        extra['frame_nvi_288x512']['what'] = 'DRY RUN: %d x %d stub rays through the real render_single_image_nvi on %d gloo rank(s)' % (fc.H, fc.W, world)
       del fc, smp, rb, ret
     except Exception as e:
       extra['frame_nvi_288x512'] = {'error': str(e)[:300]}
-    if world == 1:
+    if world == 1 and not dry:
       try:
         wl11 = StaticStep(dev, R, S, 11, rank)
         _, dt11, k11 = timed(lib, wl11.step, max(5, a.steps // 2), 2, fence)
@@ -237,7 +337,7 @@ def main():
       except Exception as e:
         extra['views_11'] = {'error': str(e)[:300]}
 
-    if world == 1:
+    if world == 1 and not dry:
       try:
         # section 8(f)1: the feature encoder on the 18 source images of one Balloon1 target view (7 dynamic + 11 static, eval_nvidia.py:335-358)
         from dynibar_amd import feature_network, synthetic as syn
@@ -448,6 +548,17 @@ def main():
     return
 
   value = world * R * a.steps / dt
+  if dry:
+    print(json.dumps({'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                      'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none (dry run)',
+                      'data': 'synthetic', 'dry_run': True,
+                      'config': {'workload': 'DRY RUN of the control flow on CPU ranks (gloo) over a stub of the kernel layer: not a measurement',
+                                 'rays_per_step_per_gpu': R, 'samples': S, 'src_views': V},
+                      'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': None, 'peak': split_peak(3), 'unit': 'TFLOP/s', 'frac': None, 'traffic': None},
+                      'multi_gpu': multi, 'extra': extra}))
+    if world > 1:
+      dist.destroy_process_group()
+    return
   terms, kind = int(lib.dyn_mlp_split_terms()), int(lib.dyn_mlp_split_kind())
   peak = split_peak(terms)
   dom = kernels['k_static_views']
@@ -485,6 +596,7 @@ def main():
                                   'algorithmic_bytes_per_launch': pg_bytes, 'traffic': tr('k_project_gather_tile')},
       'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()},
       'traffic_per_launch': traffic,
+      'multi_gpu': multi,
       'extra': extra,
   }
 

@@ -131,6 +131,30 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const float* ta
 // instead of a compare + select (which also hides worse under the matrix pipe, tools/ubench/mfma_valu_kind.hip)
 __device__ __forceinline__ float elu1(float v) { return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f); }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// ELU in the exponent's own domain (DYN_ELU3): a layer whose output only feeds ELUs is packed with weights and bias times log2(e), so its
+// accumulators hold u = v log2(e); elu_s(u) = log2(e) ELU(v) = med3(u, 2^u log2(e) - log2(e), 0) is three instructions (v_exp_f32 takes u as it
+// is: the multiply by log2(e) of __expf is gone; the subtraction rides in the fma), and the consumer -- always a Linear or a dot-product
+// table -- is packed times ln(2).  float(log2 e) float(ln 2) = 1 + 4e-9: invisible next to the split products' 2^-20.
+#ifndef DYN_ELU3
+#define DYN_ELU3 1
+#endif
+#define DYN_LOG2E 1.44269504088896340736
+#define DYN_LN2 0.69314718055994530942
+#if DYN_ELU3
+#define DYN_ELU_PRE DYN_LOG2E  /* pack-time factor of a layer (weights and bias) whose output goes through elu_s */
+#define DYN_ELU_POST DYN_LN2   /* pack-time factor of the weights that consume elu_s outputs */
+__device__ __forceinline__ float elu_s(float u) {
+#if defined(__AMDGCN__)
+  return __builtin_amdgcn_fmed3f(u, fmaf(__builtin_amdgcn_exp2f(u), (float)DYN_LOG2E, -(float)DYN_LOG2E), 0.0f);
+#else
+  return __builtin_amdgcn_fmed3f(u, fmaf(exp2f(u), (float)DYN_LOG2E, -(float)DYN_LOG2E), 0.0f);
+#endif
+}
+#else
+#define DYN_ELU_PRE 1.0
+#define DYN_ELU_POST 1.0
+__device__ __forceinline__ float elu_s(float u) { return elu1(u); }
+#endif
 
 template <int NT>
 __device__ __forceinline__ void acc_elu(f32x16 (&acc)[NT]) {
@@ -138,6 +162,13 @@ __device__ __forceinline__ void acc_elu(f32x16 (&acc)[NT]) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = elu1(acc[t][r]);
+}
+template <int NT>
+__device__ __forceinline__ void acc_elu_s(f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = elu_s(acc[t][r]);
 }
 
 // ---- reductions over the VSEG consecutive lanes (views, padded to a power of two) of one point ------------------------------
@@ -189,6 +220,30 @@ __device__ __forceinline__ float seg_sum(float v, int, int) {
 #pragma clang fp contract(off)
     return a + b;
   });
+}
+// four independent sums at once: the quad steps interleave (no DPP wait states between them) and the four half-mirror adds share ONE
+// s_nop instead of carrying one each (the statistics of the view chain are 400 such sums per row tile)
+template <int VSEG>
+__device__ __forceinline__ void seg_sum4(float& a, float& b, float& c, float& d) {
+#if defined(__AMDGCN__)
+  if (VSEG == 8) {
+    auto quad = [](float v) {
+      return seg_reduce<4>(v, [](float x, float y) {
+#pragma clang fp contract(off)
+        return x + y;
+      });
+    };
+    a = quad(a); b = quad(b); c = quad(c); d = quad(d);
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return;
+  }
+#endif
+  a = seg_sum<VSEG>(a, 0, 0); b = seg_sum<VSEG>(b, 0, 0); c = seg_sum<VSEG>(c, 0, 0); d = seg_sum<VSEG>(d, 0, 0);
 }
 template <int VSEG>
 __device__ __forceinline__ float seg_min(float v, int, int) {
@@ -457,7 +512,7 @@ __device__ __forceinline__ void b6_split_pairs(Feed& feed, int g, u32x4v& bh, u3
 #ifndef B6_VALU_PER_PAIR
 #define B6_VALU_PER_PAIR 1  // 1: the next k-group's B operand is produced in NT slices, one beside each tile; 0: all beside tile 0
 #endif
-template <int NT, int NSLOTS, class Feed>
+template <int NT, int NSLOTS, int AHEAD = B6_AHEAD, class Feed>
 __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], Feed&& feed) {
   constexpr int NG = (NSLOTS + 7) / 8;
   constexpr int GPC = B6_CHUNK_PAIRS / NT;
@@ -474,9 +529,9 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
     const float* buf = ring6_acquire(R);
     constexpr int NPC_MAX = B6_CHUNK_PAIRS;
     const int npc = (NG - c * GPC < GPC ? NG - c * GPC : GPC) * NT;  // pairs of this chunk (compile-time after unrolling)
-    B6A q[B6_AHEAD + 1];
+    B6A q[AHEAD + 1];
 #pragma unroll
-    for (int i = 0; i < B6_AHEAD; ++i)
+    for (int i = 0; i < AHEAD; ++i)
       if (i < npc) q[i] = b6_load_a(buf + i * B6_PAIR_FLOATS, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -484,7 +539,7 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
       if (pr < npc) {
         const int gi = pr / NT, t = pr % NT;
         const int g = c * GPC + gi;
-        if (pr + B6_AHEAD < npc) q[(pr + B6_AHEAD) % (B6_AHEAD + 1)] = b6_load_a(buf + (pr + B6_AHEAD) * B6_PAIR_FLOATS, lane);
+        if (pr + AHEAD < npc) q[(pr + AHEAD) % (AHEAD + 1)] = b6_load_a(buf + (pr + AHEAD) * B6_PAIR_FLOATS, lane);
         if (g + 1 < NG) {
 #if B6_VALU_PER_PAIR
           // this tile's share of the next k-group's operand: pairs [4 t / NT, 4 (t + 1) / NT)
@@ -503,7 +558,7 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
           if (t == 0) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
 #endif
         }
-        const B6A& cur = q[pr % (B6_AHEAD + 1)];
+        const B6A& cur = q[pr % (AHEAD + 1)];
         // smallest partial products first
 #if DYN_SPLIT_TERMS == 6
         acc[t] = mfma_bf16(cur.lo, bh, acc[t]);

@@ -93,10 +93,16 @@ SlotFn chained(const float* W, const float* b, int nout, int nin, int ld, int co
   };
 }
 
-// [2][n] table of a single-output Linear over a D-layout activation of n features
-void pack_rowtab(std::vector<float>& out, const float* w, int n) {
+// [2][n] table of a single-output Linear over a D-layout activation of n features (times `scale`: DYN_ELU_PRE / DYN_ELU_POST, dyn_mlp.h)
+void pack_rowtab(std::vector<float>& out, const float* w, int n, double scale = 1.0) {
   for (int h = 0; h < 2; ++h)
-    for (int k = 0; k < n / 2; ++k) out.push_back(w[chain_feature(k, h)]);
+    for (int k = 0; k < n / 2; ++k) out.push_back((float)((double)w[chain_feature(k, h)] * scale));
+}
+
+// a layer image times a constant (the scaled-domain ELU's pack-time factors, dyn_mlp.h: elu_s)
+SlotFn scaled(SlotFn fn, double scale) {
+  if (scale == 1.0) return fn;
+  return [=](int t, int i, int s, int h) -> float { return (float)((double)fn(t, i, s, h) * scale); };
 }
 
 }  // namespace
@@ -203,31 +209,32 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   // ---- A ----
   {
     const float *W = T[ST_RAYDIR0_W], *b = T[ST_RAYDIR0_B];
-    pack_net_layer(o, 8, SA_L1_STEPS, [=](int t, int i, int s, int h) -> float {
+    // (ELU_PRE / ELU_POST: the layers whose outputs only feed ELUs hold log2(e) times their value, their consumers ln(2) -- elu_s, dyn_mlp.h)
+    pack_net_layer(o, 8, SA_L1_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i, c = sa_l1_col(s, h);
       return c >= 0 ? W[n * 103 + c] : (c == -2 ? b[n] : 0.f);
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 2, SA_L2_STEPS, chained(T[ST_RAYDIR2_W], nullptr, 35, 256, 256));
+  pack_net_layer(o, 2, SA_L2_STEPS, scaled(chained(T[ST_RAYDIR2_W], nullptr, 35, 256, 256), DYN_ELU_POST));
   {
     // base_fc.0 (mlp_network.py:477-481, input [mean | var | x]): the [mean | var] columns act on per-point statistics and are
     // evaluated once per point for the whole workgroup, the x columns (+ bias) per view
     const float *W = T[ST_BASE0_W], *b = T[ST_BASE0_B];
-    pack_net_layer(o, 8, SA_L3P_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, SA_L3P_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int c = sa_c70(s % SA_NX, h);
       return c < 0 ? 0.f : W[(32 * t + i) * 210 + (s / SA_NX) * 70 + c];
-    });
-    pack_net_layer(o, 8, SA_L3V_STEPS, [=](int t, int i, int s, int h) -> float {
+    }, DYN_ELU_PRE));
+    pack_net_layer(o, 8, SA_L3V_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s == SA_NX) return h == 0 ? b[n] : 0.f;
       const int c = sa_c70(s, h);
       return c < 0 ? 0.f : W[n * 210 + 140 + c];
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[ST_BASE2_W], nullptr, 128, 256, 256));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS0_W], nullptr, 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VIS2_W], nullptr, 128, 128, 128));  // rows 0..127 = x_res
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[ST_VISB0_W], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, scaled(chained(T[ST_BASE2_W], nullptr, 128, 256, 256), DYN_ELU_POST));
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[ST_VIS0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[ST_VIS2_W], nullptr, 128, 128, 128), DYN_ELU_POST));  // rows 0..127 = x_res
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[ST_VISB0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == ST_OFF_B, "static pack: A stream size mismatch");
   // ---- B ----
   {
@@ -259,16 +266,16 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   pack_net_layer(o, 2, 64, chained(T[ST_RGB2_W], nullptr, 64, 128, 128));
   DYN_REQUIRE(o.size() == ST_OFF_CTA, "static pack: C stream size mismatch");
   // ---- constant tables ----
-  pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128);
-  pack_rowtab(o, T[ST_VISB2_W], 128);
+  pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128, DYN_ELU_POST);
+  pack_rowtab(o, T[ST_VISB2_W], 128, DYN_ELU_POST);
   o.push_back(T[ST_VIS2_B][128]);
   o.push_back(T[ST_VISB2_B][0]);
   o.push_back(fabsf(T[ST_S][0]));
   o.resize(ST_OFF_CTA + 272, 0.f);
   pack_rowtab(o, T[ST_BASE2_B], 128);
-  pack_rowtab(o, T[ST_VIS0_B], 128);
+  pack_rowtab(o, T[ST_VIS0_B], 128, DYN_ELU_PRE);
   pack_rowtab(o, T[ST_VIS2_B], 128);
-  pack_rowtab(o, T[ST_VISB0_B], 128);
+  pack_rowtab(o, T[ST_VISB0_B], 128, DYN_ELU_PRE);
   {
     float b64[64] = {0.f};
     for (int i = 0; i < 35; ++i) b64[i] = T[ST_RAYDIR2_B][i];
@@ -630,7 +637,22 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     // basic blocks and keep their lane moves from folding into the adds
     float pm[NX], pvr[NX];
 #pragma unroll
-    for (int q = 0; q < NX; ++q) {
+    for (int q0 = 0; q0 + 4 <= NX; q0 += 4) {  // four features at a time (seg_sum4)
+      float m4[4], v4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m4[e] = xin[q0 + e] * wgt;
+      seg_sum4<VSEG>(m4[0], m4[1], m4[2], m4[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = xin[q0 + e] - m4[e];
+        v4[e] = wgt * (d * d);
+      }
+      seg_sum4<VSEG>(v4[0], v4[1], v4[2], v4[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pm[q0 + e] = m4[e]; pvr[q0 + e] = v4[e]; }
+    }
+#pragma unroll
+    for (int q = NX & ~3; q < NX; ++q) {
       pm[q] = seg_sum<VSEG>(xin[q] * wgt, V, 0);
       const float d = xin[q] - pm[q];
       pvr[q] = seg_sum<VSEG>(wgt * (d * d), V, 0);
@@ -693,7 +715,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
   f32x16 x[4];
   {
     acc_init_bias<4>(x, ctab + 272);
-    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return elu1(a1[s / 16][s % 16]); });
+    net_layer<4, SA_L4_STEPS>(ring, x, [&](int s) { return elu_s(a1[s / 16][s % 16]); });
     DYN_PHASE(11);
   }
   float vis;
@@ -709,7 +731,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     DYN_PHASE(13);
     acc_init_bias<4>(a6, ctab + 528);
     net_layer<4, SA_L5_STEPS>(ring, a6, [&](int s) {
-      const float r = elu1(a5[s / 16][s % 16]);
+      const float r = elu_s(a5[s / 16][s % 16]);
       a5[s / 16][s % 16] = r;
       return r;
     });
@@ -727,7 +749,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     DYN_PHASE(15);
     net_layer<4, SA_L5_STEPS>(ring, a7, [&](int s) { return x[s / 16][s % 16] * vis; });
     DYN_PHASE(16);
-    acc_elu(a7);
+    acc_elu_s(a7);
     vis2 = sigmoid1(row_dot<4>(a7, ctab + 128) + ctab[257]) * msk;
   }
   DYN_PHASE(17);
@@ -831,11 +853,14 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     for (int q = 0; q < 4; ++q) {
       float m[4], vv[4];
 #pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = x[t][q * 4 + e] * w2;
+      seg_sum4<VSEG>(m[0], m[1], m[2], m[3]);
+#pragma unroll
       for (int e = 0; e < 4; ++e) {
-        m[e] = seg_sum<VSEG>(x[t][q * 4 + e] * w2, V, seg_base);
         const float d = x[t][q * 4 + e] - m[e];
-        vv[e] = seg_sum<VSEG>(w2 * (d * d), V, seg_base);
+        vv[e] = w2 * (d * d);
       }
+      seg_sum4<VSEG>(vv[0], vv[1], vv[2], vv[3]);
       const int g = t * 4 + q;
       const int sel = g & (VSEG - 1);  // spread the 32 row groups over the segment's real lanes
       const bool mine = valid && (view == (sel < V ? sel : 0));
@@ -866,6 +891,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   DYN_PHASE(0);
   // the per-point part of base_fc.0 (VSEG >= 8) is read straight from the stream by each wave, not through the ring
   constexpr int SA_POOLED_AT = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
+  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
 #if DYN_ENGINE_B6
   net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
@@ -876,7 +902,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // VSEG > 0: views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding.
   // VSEG == 0 (dense rows): the workgroup's 256 rows are the point-views of its PT = 256 / V points in order, no padding between points.
-  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
   const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
   const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
@@ -906,9 +931,16 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     float in1[SA_L1_STEPS];
 #pragma unroll
     for (int c = 0; c < 9; ++c) octave_embed<5>(c9[c], h, in1 + c * 5);
-    const float raw[14] = {c9[0], c9[1], c9[2], c9[3], c9[4], c9[5], c9[6], c9[7], c9[8], rd.x, rd.y, rd.z, rd.w, 1.0f};
-#pragma unroll
-    for (int k = 0; k < 7; ++k) in1[45 + k] = h == 0 ? raw[2 * k] : raw[2 * k + 1];
+    // raw inputs [pts | Pluecker | ray_diff | 1], even entries to half 0, odd ones to half 1.  Written as selects between scalars: a
+    // select between two elements of a local array becomes a lane-indexed load of the array from scratch memory (64 B per lane)
+    const bool h0 = h == 0;
+    in1[45] = h0 ? c9[0] : c9[1];
+    in1[46] = h0 ? c9[2] : c9[3];
+    in1[47] = h0 ? c9[4] : c9[5];
+    in1[48] = h0 ? c9[6] : c9[7];
+    in1[49] = h0 ? c9[8] : rd.x;
+    in1[50] = h0 ? rd.y : rd.z;
+    in1[51] = h0 ? rd.w : 1.0f;
     acc_zero(a1);
     DYN_PHASE(1);
     net_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
@@ -927,7 +959,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
           xin[q] = (valid && ch < 35) ? nt_load1<2>(p.rgb_feat + pv * 35 + ch) : 0.f;
         }
       }
-      return elu1(a1[s / 16][s % 16]);  // ELU of ray_dir_fc.0 where it is consumed
+      return elu_s(a1[s / 16][s % 16]);  // ELU of ray_dir_fc.0 where it is consumed
     });
     const float* rf = p.ws + p.o.off_ref + (valid ? (point / p.S) * 36 : 0);
 #pragma unroll
@@ -1572,21 +1604,21 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   o.reserve(DY_BLOB_FLOATS);
   {
     const float *W = T[DT_BASE0_W], *b = T[DT_BASE0_B];  // input [mean | var | x]  (mlp_network.py:262-266)
-    pack_net_layer(o, 8, DA_L3P_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, DA_L3P_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int c = da_c35(s % DA_NX, h);
       return c < 0 ? 0.f : W[(32 * t + i) * 105 + (s / DA_NX) * 35 + c];
-    });
-    pack_net_layer(o, 8, DA_L3V_STEPS, [=](int t, int i, int s, int h) -> float {
+    }, DYN_ELU_PRE));
+    pack_net_layer(o, 8, DA_L3V_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s == DA_NX) return h == 0 ? b[n] : 0.f;
       const int c = da_c35(s, h);
       return c < 0 ? 0.f : W[n * 105 + 70 + c];
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 4, SA_L4_STEPS, chained(T[DT_BASE2_W], nullptr, 128, 256, 256));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS0_W], nullptr, 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VIS2_W], nullptr, 128, 128, 128));
-  pack_net_layer(o, 4, SA_L5_STEPS, chained(T[DT_VISB0_W], nullptr, 128, 128, 128));
+  pack_net_layer(o, 4, SA_L4_STEPS, scaled(chained(T[DT_BASE2_W], nullptr, 128, 256, 256), DYN_ELU_POST));
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[DT_VIS0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[DT_VIS2_W], nullptr, 128, 128, 128), DYN_ELU_POST));
+  pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[DT_VISB0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
   {
     const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
@@ -1625,15 +1657,15 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   }
   pack_net_layer(o, 2, 65, chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128));
   DYN_REQUIRE(o.size() == DY_OFF_CTA, "dynamic pack: B stream size mismatch");
-  pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128);
-  pack_rowtab(o, T[DT_VISB2_W], 128);
+  pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128, DYN_ELU_POST);
+  pack_rowtab(o, T[DT_VISB2_W], 128, DYN_ELU_POST);
   o.push_back(T[DT_VIS2_B][128]);
   o.push_back(T[DT_VISB2_B][0]);
   o.resize(DY_OFF_CTA + 272, 0.f);
   pack_rowtab(o, T[DT_BASE2_B], 128);
-  pack_rowtab(o, T[DT_VIS0_B], 128);
+  pack_rowtab(o, T[DT_VIS0_B], 128, DYN_ELU_PRE);
   pack_rowtab(o, T[DT_VIS2_B], 128);
-  pack_rowtab(o, T[DT_VISB0_B], 128);
+  pack_rowtab(o, T[DT_VISB0_B], 128, DYN_ELU_PRE);
   o.resize(DY_OFF_CTB, 0.f);
   pack_rowtab(o, T[DT_LN_G], 128);
   pack_rowtab(o, T[DT_LN_B], 128);
@@ -1703,6 +1735,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
+  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
 #if DYN_ENGINE_B6
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, DA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 #else
@@ -1712,7 +1745,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // row -> (point, view): power-of-two lane segments (VSEG > 0) or dense rows (VSEG == 0), as in k_static_views
-  constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
   const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
   const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));

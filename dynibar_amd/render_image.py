@@ -32,6 +32,15 @@ _PER_VIEW_KEYS = ('camera', 'anchor_camera', 'render_camera', 'depth_range', 'sr
 FRAME_OUTPUTS = 'lazy'       # 'lazy' | 'all'
 TILE_ACROSS_RANKS = True     # False: every rank renders the whole frame by itself (no collective), e.g. when only one rank calls in
 _EAGER_KEYS = ('rgb', 'depth', 'mask')
+FRAME_STATS = None           # bench.py sets this to a dict for ONE frame: per-stage clocks (tile_rays, render_ms, gather_ms, gather_bytes); the device is
+                             # synchronised between the stages while it is set, never otherwise
+
+
+def _clock():
+  import time
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+  return time.perf_counter()
 
 
 def _dist():
@@ -223,8 +232,14 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank, count=None, eager=No
   now = [k for k in local if eager is None or k in eager]
 
   def fetch(ks):
+    t0 = _clock() if FRAME_STATS is not None else 0.0
     full = gather_rows(OrderedDict((k, local[k]) for k in ks), n_rays, dist, world, rank, count)
-    return OrderedDict((k, _shape_frame(t, Hs, Ws)) for k, t in _to_host(full).items())
+    host = OrderedDict((k, _shape_frame(t, Hs, Ws)) for k, t in _to_host(full).items())
+    if FRAME_STATS is not None and ks:
+      tile = ray_tile(n_rays, world, rank)[2]
+      FRAME_STATS['gather_ms'] = FRAME_STATS.get('gather_ms', 0.0) + (_clock() - t0) * 1e3
+      FRAME_STATS['gather_bytes'] = FRAME_STATS.get('gather_bytes', 0) + 4 * tile * sum(_rows(local[k])[0].shape[1] for k in ks)
+    return host
 
   def blank(rgb, mask):
     rgb[mask == 0] = 0.0  # render_image.py:162-164, :186-188: pixels whose ray mask is off are zeroed, in every group
@@ -259,11 +274,14 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
   if count == 0:
     lo, hi = 0, 1  # an empty tile still joins the collectives: render one placeholder ray for the key / shape structure, contribute none
   chunks = {g: [] for g in group_names}
+  t0 = _clock() if FRAME_STATS is not None else 0.0
   for i in range(lo, hi, chunk_size):
     ret = render_chunk(slice_ray_batch(ray_batch, i, min(i + chunk_size, hi)))
     for g in group_names:
       if ret.get(g) is not None:
         chunks[g].append(ret[g])
+  if FRAME_STATS is not None:
+    FRAME_STATS.update(tile_rays=count, render_ms=(_clock() - t0) * 1e3, gather_ms=0.0, gather_bytes=0)
   return chunks, n_rays, dist, world, rank, count
 
 

@@ -222,7 +222,7 @@ def compute_projections(xyz, train_cameras):
   c2w = train_cameras[:, -16:].reshape(-1, 4, 4)
   xyz_h = torch.cat([xyz, torch.ones_like(xyz[..., :1])], dim=-1)
   if PROJECTION_MODE == 'double':
-    P = K.double().bmm(torch.inverse(c2w.double())).float()
+    P = K.double().bmm(torch.inverse(c2w.double())).to(torch.get_default_dtype())
     proj = P.bmm(xyz_h.permute(0, 2, 1)).permute(0, 2, 1)
   else:
     proj = K.bmm(torch.inverse(c2w)).bmm(xyz_h.permute(0, 2, 1)).permute(0, 2, 1)
@@ -266,7 +266,7 @@ def compute_with_motions(xyz_st, xyz, query_camera, train_imgs, train_cameras, f
   rgb_feat = torch.cat([rgb, feat], dim=-1)
   inb = (pix[..., 0] <= w - 1.0) & (pix[..., 0] >= 0) & (pix[..., 1] <= h - 1.0) & (pix[..., 1] >= 0)
   ray_diff = compute_angle(xyz_st, xyz, qcam, cams).permute(1, 2, 0, 3)
-  mask = (inb * in_front).float().permute(1, 2, 0)[..., None]
+  mask = (inb * in_front).to(torch.get_default_dtype()).permute(1, 2, 0)[..., None]
   return rgb_feat, ray_diff, mask
 
 
@@ -409,7 +409,7 @@ def posenc_table(d_hid, n_samples):
   tab = np.array([[pos / np.power(10000, 2 * (j // 2) / d_hid) for j in range(d_hid)] for pos in range(n_samples)])
   tab[:, 0::2] = np.sin(tab[:, 0::2])
   tab[:, 1::2] = np.cos(tab[:, 1::2])
-  return torch.from_numpy(tab).float().unsqueeze(0)
+  return torch.from_numpy(tab).to(torch.get_default_dtype()).unsqueeze(0)
 
 
 # ----------------------------------------------------------------------------
@@ -425,7 +425,7 @@ def _mlp2(sd, name, x, last_act=True):
 
 def dynamic_net(sd, pts_xyz, rgb_feat, glb_ray_dir, ray_diff, time_diff, mask, time, shift=0.0):
   V = rgb_feat.shape[2]
-  time_pe = periodic_embed(time, 10, 10, False)[..., None, :].repeat(1, 1, V, 1).float()
+  time_pe = periodic_embed(time, 10, 10, False)[..., None, :].repeat(1, 1, V, 1).to(torch.get_default_dtype())
   rgb_feat = rgb_feat + _mlp2(sd, 'ray_dir_fc', time_pe)
   weight = mask / (torch.sum(mask, dim=2, keepdim=True) + 1e-8)
   mean, var = fused_mean_variance(rgb_feat, weight)
@@ -442,11 +442,11 @@ def dynamic_net(sd, pts_xyz, rgb_feat, glb_ray_dir, ray_diff, time_diff, mask, t
   g = _mlp2(sd, 'geometry_fc', g)
   n_valid = torch.sum(mask, dim=2)
   g = g + posenc_table(128, g.shape[1]).to(g.device)
-  g = ray_attention(sd, g, (n_valid > 1).float())
+  g = ray_attention(sd, g, (n_valid > 1).to(torch.get_default_dtype()))
   g = _mlp2(sd, 'ref_pts_fc', torch.cat([g, periodic_embed(pts_xyz, 5, 5, False)], dim=-1))
   sigma = _lin(sd, 'out_geometry_fc.2', F.elu(_lin(sd, 'out_geometry_fc.0', g))) - shift
   sigma = sigma.masked_fill(n_valid < 1, -1e9)
-  dir_pe = periodic_embed(glb_ray_dir, 4, 4, False).float()
+  dir_pe = periodic_embed(glb_ray_dir, 4, 4, False).to(torch.get_default_dtype())
   h = torch.cat([g, dir_pe[:, None, :].repeat(1, g.shape[1], 1)], dim=-1)
   h = F.elu(_lin(sd, 'rgb_fc.0', h))
   h = F.elu(_lin(sd, 'rgb_fc.2', h))
@@ -474,7 +474,7 @@ def static_net(sd, pts, ref_rays_coords, src_rays_coords, rgb_feat, glb_ray_dir,
   ref_feat = _lin(sd, 'ref_feature_fc.0', ref_features)
   rgb_in = rgb_feat[..., :3]
   if mask_rgb:
-    mask = mask * (torch.sum(rgb_in, dim=-1, keepdim=True) > 1e-3).float()
+    mask = mask * (torch.sum(rgb_in, dim=-1, keepdim=True) > 1e-3).to(torch.get_default_dtype())
   rgb_feat = torch.cat([rgb_feat, src_feat * ref_feat], dim=-1)
   if anti_alias_pooling:
     dot = ray_diff[..., 3:4]
@@ -498,7 +498,7 @@ def static_net(sd, pts, ref_rays_coords, src_rays_coords, rgb_feat, glb_ray_dir,
   g = torch.cat([mean.squeeze(2), var.squeeze(2), weight.mean(dim=2)], dim=-1)
   g = _mlp2(sd, 'geometry_fc', g)
   n_valid = torch.sum(mask, dim=2)
-  g = ray_attention(sd, g, (n_valid > 1).float())
+  g = ray_attention(sd, g, (n_valid > 1).to(torch.get_default_dtype()))
   sigma = _lin(sd, 'out_geometry_fc.2', F.elu(_lin(sd, 'out_geometry_fc.0', g)))
   sigma = sigma.masked_fill(n_valid < 1, -1e9)
   x = torch.cat([g[:, :, None, :].expand(-1, -1, V, -1), x, vis, ray_diff], dim=-1)
@@ -537,7 +537,7 @@ def raw2outputs_vanilla(raw, z_vals, mask):
       ('rgb', torch.sum(weights.unsqueeze(2) * rgb, dim=1)),
       ('depth', torch.sum(weights * z_vals, dim=-1)),
       ('weights', weights),
-      ('mask', mask.float().sum(dim=1) > 8),
+      ('mask', mask.to(torch.get_default_dtype()).sum(dim=1) > 8),
       ('alpha', alpha),
       ('z_vals', z_vals),
   ])
@@ -564,7 +564,7 @@ def raw2outputs(raw_dy, raw_static, z_vals, mask_dy, mask_static):
       ('weights_st', w_st),
       ('alpha', alpha),
       ('weights', weights),
-      ('mask', torch.bitwise_or(mask_dy.float().sum(dim=1) > 8, mask_static.float().sum(dim=1) > 8)),
+      ('mask', torch.bitwise_or(mask_dy.to(torch.get_default_dtype()).sum(dim=1) > 8, mask_static.to(torch.get_default_dtype()).sum(dim=1) > 8)),
       ('z_vals', z_vals),
   ])
 
@@ -627,7 +627,7 @@ def dual_branch_stage(models, scene, featmaps_dy, featmaps_st, ray_o, ray_d, uv_
   R, S = pts.shape[:2]
   n_last = int(round(S * 0.1))
   t_emb = ref_time_embedding[None, None, :].repeat(R, S, 1)
-  xyzt = torch.cat([pts, t_emb], dim=-1).float()
+  xyzt = torch.cat([pts, t_emb], dim=-1).to(torch.get_default_dtype())
   coeff = motion_mlp(sd_mo, xyzt)
   coeff[:, -n_last:, :] *= 0.0
   traj = trajectory_points(coeff, basis, ref_frame_idx)
@@ -719,8 +719,8 @@ def render_rays_mono_train(models, scene, ray_o, ray_d, uv_grid, frame_idx, time
   traj = trajectory_points(st['coeff'], basis, ref_idx)                      # ref_traj_pts_dict, offsets -3..3 (:965-979)
   sf_seq = torch.stack([traj[o] - traj[o - 1] for o in (-2, -1, 0, 1, 2, 3)], 0)   # :1101-1105
   pts_anchor = pts + (traj[anc_idx - ref_idx] - traj[0])                      # :1109-1112
-  t_anc = anc_temb[None, None, :].repeat(R, S, 1).float()
-  coeff_a = motion_mlp(models['motion_mlp'], torch.cat([pts_anchor, t_anc], -1).float())
+  t_anc = anc_temb[None, None, :].repeat(R, S, 1).to(torch.get_default_dtype())
+  coeff_a = motion_mlp(models['motion_mlp'], torch.cat([pts_anchor, t_anc], -1).to(torch.get_default_dtype()))
   coeff_a[:, -n_last:, :] *= 0.0
   B = basis.shape[1]
   cx, cy, cz = coeff_a[..., :B], coeff_a[..., B:2 * B], coeff_a[..., 2 * B:3 * B]

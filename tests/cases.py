@@ -29,6 +29,9 @@ def scene_case(name):
       # configs/train_kid-running.txt shape: 7 time-offset + num_vv = 3 virtual dynamic views, 15 static views (render_monocular_bt.py:113-201)
       'kid': dict(seed=8, H=32, W=48, V=10, n_static=15, smooth=True, R=5),
       'stress': dict(seed=7, H=32, W=48, V=16, n_static=16, smooth=True, R=4),  # not 3 rays: torch.cross without dim (reference quirk)
+      # the training shape of configs/train_kid-running.txt at a size the oracle's autograd runs on the device in seconds: 64 samples,
+      # 7 + 3 dynamic views at the reference and at the anchor frame, 15 static views, hundreds of rays (tests/parity.check_train_mono_large)
+      'train_large': dict(seed=31, H=144, W=256, V=10, n_static=15, smooth=True, R=256),
   }[name]
   R = cfg.pop('R')
   seed = cfg['seed']

@@ -426,8 +426,80 @@ def mono_train_grad_goldens(name='few', S=16, R=4):
   print('mono_train_grad', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def camera_format_goldens():
+  """Section 8f-4, data side: the reference's OWN pose parsing (llff_data_utils.py) and benchmark dataset class (eval_nvidia.py:26-200) on a synthetic
+  scene directory (seeded poses_bounds_cvd.npy, dummy image files).  The packages they import for image decoding / metrics (cv2, imageio, skimage,
+  models, configargparse) are not installed here and are stubbed: imread returns a blank image of the scene's size -- only cameras, view ids and depth
+  ranges are pinned, never pixels."""
+  import shutil
+  import sys
+  import tempfile
+  import types
+  refimport.import_reference()
+  H, W, N = 288, 512, 36
+  blank = np.zeros((H, W, 3), np.uint8)
+  for name in ('cv2', 'imageio', 'imageio.v2', 'models', 'skimage', 'skimage.metrics', 'skimage.morphology', 'configargparse'):
+    if name not in sys.modules:
+      sys.modules[name] = types.ModuleType(name)
+      sys.modules[name].__path__ = []  # importable as a package (import skimage.morphology)
+  sys.modules['skimage'].morphology = sys.modules['skimage.morphology']
+  sys.modules['imageio'].imread = lambda f, **kw: blank
+  sys.modules['imageio'].v2 = sys.modules['imageio.v2']
+  sys.modules['imageio.v2'].imread = lambda f, **kw: blank
+  sys.modules['skimage'].metrics = sys.modules['skimage.metrics']
+  import importlib
+  llff = importlib.import_module('ibrnet.data_loaders.llff_data_utils')
+  ev = importlib.import_module('eval_nvidia')
+  rng = np.random.RandomState(7)
+  # a plausible forward-facing rig: 12 cameras on a shallow arc taking turns frame by frame (the Nvidia benchmark), LLFF axis convention
+  poses = np.zeros((N, 3, 5))
+  for i in range(N):
+    cam = i % 12
+    ang = (cam - 5.5) * 0.04 + rng.randn() * 0.003
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]) @ (np.eye(3) + rng.randn(3, 3) * 0.01)
+    poses[i, :, :3] = np.linalg.qr(R)[0]
+    poses[i, :, 3] = [(cam - 5.5) * 0.21 + rng.randn() * 0.01, rng.randn() * 0.02, rng.randn() * 0.02]
+    poses[i, :, 4] = [1080, 1920, 1480.0 + rng.rand()]
+  bds = np.stack([2.0 + rng.rand(N), 30.0 + 10 * rng.rand(N)], 1)
+  poses_arr = np.concatenate([poses.reshape(N, 15), bds], 1)
+  root = tempfile.mkdtemp(prefix='dynibar_cam_')
+  try:
+    dense = os.path.join(root, 'Scene', 'dense')
+    for sub in ('images', 'images_%dx%d' % (W, H)):
+      os.makedirs(os.path.join(dense, sub))
+      for i in range(N):
+        open(os.path.join(dense, sub, '%05d.png' % i), 'wb').close()
+    np.save(os.path.join(dense, 'poses_bounds_cvd.npy'), poses_arr)
+    out = {'poses_arr': poses_arr, 'image_hw': np.array([H, W])}
+    _, lposes, lbds, _, _, _, scale = llff.load_llff_data(dense, height=H, num_avg_imgs=12, render_idx=10, load_imgs=False)
+    out.update({'llff/poses': lposes, 'llff/bds': lbds, 'llff/scale': np.array(scale)})
+    K, C = llff.batch_parse_llff_poses(lposes)
+    out.update({'llff/intrinsics': K, 'llff/c2w': C})
+    vv = np.stack([lposes[:4], lposes[4:8]], 1)  # [T=4, Vv=2, 3, 5]
+    out['llff/vv_c2w'] = llff.batch_parse_vv_poses(vv)
+    out['llff/vv_in'] = vv
+    args = types.SimpleNamespace(folder_path=root, mask_static=False)
+    for render_idx in (10, 3, 32):
+      ds = ev.DynamicVideoDataset(render_idx, args, ['Scene'])
+      for view_idx in (0, 7):
+        item = ds[view_idx]
+        pre = 'item/%d/%d/' % (render_idx, view_idx)
+        for k in ('camera', 'src_cameras', 'static_src_cameras', 'depth_range'):
+          out[pre + k] = npy(item[k])
+        out[pre + 'nearest_pose_ids'] = np.asarray(item['nearest_pose_ids'])
+        out[pre + 'ref_time'] = np.array(item['ref_time'])
+        out[pre + 'n_static'] = np.array(item['static_src_rgbs'].shape[0])
+  finally:
+    shutil.rmtree(root, ignore_errors=True)
+  np.savez_compressed(os.path.join(HERE, 'camera_format.npz'), **out)
+  print('camera_format', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
   import sys
+  if 'camera_format' in sys.argv[1:]:
+    camera_format_goldens()
+    sys.exit(0)
   if 'mono_train_grad' in sys.argv[1:]:
     mono_train_grad_goldens()
     sys.exit(0)
@@ -462,3 +534,4 @@ if __name__ == '__main__':
   mono_train_goldens()
   mono_kid_goldens()
   encoder_goldens()
+  camera_format_goldens()

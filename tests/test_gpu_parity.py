@@ -221,3 +221,15 @@ def test_training_loop_reduces_the_loss(dev):
   h = train_loop.run(dev, iters=25, R=256, S=32, log_every=24, quiet=True)
   assert h['bootstrap'][-1] < 0.97 * h['bootstrap'][0], h
   assert h['main'][-1] < 0.97 * h['main'][0], h
+
+
+def test_checkpoint_files_to_rendered_frame(dev, golden_dir, tmp_path):
+  """Section 8f-4: torch.save files in the reference's two checkpoint formats -> checkpoint.load_model -> HIP encoders (vs the encoder golden) and
+  render_single_image_nvi with the loaded model (vs the real reference's frame)."""
+  parity.check_checkpoint_render_chain(dev, _golden(golden_dir, 'image_nvi.npz'), _golden(golden_dir, 'encoder.npz'), tmp_path)
+
+
+def test_training_iteration_at_the_training_shape(dev):
+  """Section 8f-3 at 256 rays x 64 samples x (7 + 3) / (7 + 3) / 15 views: the full train.py loss, every gradient as a full tensor vs autograd through
+  the oracle on the device (fp32) with its fp64 twin as the arbiter of conditioning; run-to-run spread of two identical steps."""
+  parity.check_train_mono_large(dev)
