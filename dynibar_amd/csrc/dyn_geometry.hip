@@ -288,13 +288,26 @@ __device__ __forceinline__ float safe_floor_coord(float x, float size) {
   return fminf(fmaxf(x, -2.0f), size + 1.0f);
 }
 
+// DYN_NORMALIZE_IEEE = 1 (measured, round 3): the gather kernel 88 -> 94.5 us (0.51 -> 0.475 of 8 TB/s) for three square roots and nine divisions per
+// point-view, and the result still is not bitwise ATen's (its norm reduces in another order); ray_diff is checked to 1e-6 either way.  The perspective
+// divide and normalize(), which decide the bilinear taps and make the gathered values bit-exact, are IEEE at no measurable cost.
+#ifndef DYN_NORMALIZE_IEEE
+#define DYN_NORMALIZE_IEEE 0
+#endif
 __device__ __forceinline__ void normalize3(float x, float y, float z, float& ox, float& oy, float& oz) {
-  // F.normalize(eps=1e-12): v / max(||v||_2, eps), as one reciprocal square root (1 ulp) and three multiplies.  ray_diff is
-  // checked to 1e-6, not bitwise: the projection matrices already differ from torch.inverse's in the last bits.
-  const float inv = fminf(rsqrtf(x * x + y * y + z * z), 1e12f);
+#if DYN_NORMALIZE_IEEE
+  // F.normalize(eps=1e-12) as written (projection.py:83-97): v / max(sqrt(x^2 + y^2 + z^2), eps) with a correctly rounded square root and IEEE
+  // divisions (this unit is built without contraction, so the sum of squares rounds like ATen's)
+  const float d = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  ox = x / d;
+  oy = y / d;
+  oz = z / d;
+#else
+  const float inv = fminf(rsqrtf(x * x + y * y + z * z), 1e12f);  // one reciprocal square root (1 ulp) and three multiplies
   ox = x * inv;
   oy = y * inv;
   oz = z * inv;
+#endif
 }
 
 // exact n / d for 32-bit n with the host-made multiplier m = ceil(2^32 / d): the estimate is q or q + 1
@@ -386,18 +399,15 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
   const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
-  // the pixel location is not bitwise the reference's in any case (K.inv(c2w) is inverted differently), so the perspective
-  // divide and normalize() use the 1-ulp hardware reciprocal instead of IEEE division sequences
   const float zc = fmaxf(hz, 1e-8f);
-  const float izc = __builtin_amdgcn_rcpf(zc);
-  float px = hx * izc, py = hy * izc;
+  float px = hx / zc, py = hy / zc;  // IEEE division, like the reference's tensor division (projection.py:53-55)
   px = fminf(fmaxf(px, -1e6f), 1e6f);
   py = fminf(fmaxf(py, -1e6f), 1e6f);
   const float wm1 = q.img_w - 1.0f, hm1 = q.img_h - 1.0f;
   const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
   // normalize() then grid_sample's align_corners=True un-normalisation (ATen CPU: (x + 1) * ((size - 1) / 2))
-  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
-  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;  // normalize(): 2 * pixel / [w - 1, h - 1] - 1 (projection.py:22-30), divisions as written there
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
   const Taps tf = make_taps(nx, ny, q.Wf, q.Hf);
   {
     // RGB taps of this row: four unconditional 12-byte loads
@@ -581,14 +591,13 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
   const float zc = fmaxf(hz, 1e-8f);
-  const float izc = __builtin_amdgcn_rcpf(zc);
-  float px = hx * izc, py = hy * izc;
+  float px = hx / zc, py = hy / zc;  // IEEE division, like the reference's tensor division (projection.py:53-55)
   px = fminf(fmaxf(px, -1e6f), 1e6f);
   py = fminf(fmaxf(py, -1e6f), 1e6f);
   const float wm1 = q.img_w - 1.0f, hm1 = q.img_h - 1.0f;
   const bool inb = (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f);
-  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
-  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;  // normalize(): 2 * pixel / [w - 1, h - 1] - 1 (projection.py:22-30), divisions as written there
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
   const Taps tf = make_taps(nx, ny, q.Wf, q.Hf);
   const int row = pl * V + vv;  // row of the tile in its final order
   float4 rd;
@@ -787,12 +796,11 @@ __global__ void __launch_bounds__(256) k_gather_bwd(PGShape q, const float* __re
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
   const float zc = fmaxf(hz, 1e-8f);
-  const float izc = __builtin_amdgcn_rcpf(zc);
-  float px = hx * izc, py = hy * izc;
+  float px = hx / zc, py = hy / zc;  // IEEE division, like the reference's tensor division (projection.py:53-55)
   px = fminf(fmaxf(px, -1e6f), 1e6f);
   py = fminf(fmaxf(py, -1e6f), 1e6f);
-  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
-  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;  // normalize(): 2 * pixel / [w - 1, h - 1] - 1 (projection.py:22-30), divisions as written there
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
   const Taps t = make_taps(nx, ny, q.Wf, q.Hf);
   const float* d = drgb_feat + row * ld_d + col0 + cg * 4;
   const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
@@ -828,12 +836,11 @@ __global__ void __launch_bounds__(256) k_gather_bwd32(PGShape q, const float* __
   const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
   const float zc = fmaxf(hz, 1e-8f);
-  const float izc = __builtin_amdgcn_rcpf(zc);
-  float px = hx * izc, py = hy * izc;
+  float px = hx / zc, py = hy / zc;  // IEEE division, like the reference's tensor division (projection.py:53-55)
   px = fminf(fmaxf(px, -1e6f), 1e6f);
   py = fminf(fmaxf(py, -1e6f), 1e6f);
-  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
-  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;  // normalize(): 2 * pixel / [w - 1, h - 1] - 1 (projection.py:22-30), divisions as written there
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
   const Taps t = make_taps(nx, ny, q.Wf, q.Hf);
   const float d = drgb_feat[row * ld_d + col0 + c];
   float* base = dfeat + (long)v * q.Hf * q.Wf * 32 + c;
@@ -912,10 +919,10 @@ __global__ void __launch_bounds__(256) k_gather_bwd_pts(PGShape q, const float* 
   const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
   const float zc = fmaxf(hz, 1e-8f);
   const float izc = 1.0f / zc;
-  const float pxu = hx * izc, pyu = hy * izc;
+  const float pxu = hx / zc, pyu = hy / zc;  // the forward's pixel (same taps); izc only scales the gradient
   const float px = fminf(fmaxf(pxu, -1e6f), 1e6f), py = fminf(fmaxf(pyu, -1e6f), 1e6f);
-  const float nx = 2.0f * px * q.inv_wm1 - 1.0f;
-  const float ny = 2.0f * py * q.inv_hm1 - 1.0f;
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;  // normalize(): 2 * pixel / [w - 1, h - 1] - 1 (projection.py:22-30), divisions as written there
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
   const float* d = drgb_feat + row * ld_d;
   float gnx = 0.f, gny = 0.f;
   tap_grad(src_rgb + (long)v * q.H * q.W * 3, q.W, q.H, 3, nx, ny, d, gnx, gny);
@@ -1043,6 +1050,45 @@ extern "C" int dyn_render_flows(const float* weights, const float* pts_seq, cons
   DYN_REQUIRE(weights && pts_seq && proj && uv && flows && R > 0 && S > 0 && V > 0, "dyn_render_flows: bad argument");
   DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_render_flows", k_render_flows, dim3(dyn_cdiv((long)V * R, 4)), dim3(256), 0, (hipStream_t)stream, weights,
              pts_seq, proj, uv, R, S, V, flows);
+  return 0;
+}
+
+// Projector.compute_projections / compute_angle (projection.py:32-101) as stand-alone exports: the render path fuses them into the gather
+// kernel; these serve callers of the reference's helper methods.  One thread per (view, point).
+__global__ void __launch_bounds__(256) k_project_points(const float* __restrict__ xyz, const float* __restrict__ xyz_st, const float* __restrict__ proj,
+                                                        const float* __restrict__ query_center, int V, long n_pts, float* __restrict__ pix,
+                                                        float* __restrict__ in_front, float* __restrict__ ray_diff) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)V * n_pts) return;
+  const int v = (int)(i / n_pts);
+  const float x = xyz[i * 3], y = xyz[i * 3 + 1], z3 = xyz[i * 3 + 2];
+  const float4* proj4 = reinterpret_cast<const float4*>(proj);
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2], P3 = proj4[v * 4 + 3];
+  if (pix != nullptr) {
+    const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+    const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+    const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+    const float zc = fmaxf(hz, 1e-8f);
+    pix[i * 2] = fminf(fmaxf(hx / zc, -1e6f), 1e6f);
+    pix[i * 2 + 1] = fminf(fmaxf(hy / zc, -1e6f), 1e6f);
+    in_front[i] = hz > 0.f ? 1.0f : 0.0f;
+  }
+  if (ray_diff != nullptr) {
+    const float sx = xyz_st[i * 3], sy = xyz_st[i * 3 + 1], sz = xyz_st[i * 3 + 2];
+    float ax, ay, az, bx, by, bz, dx, dy, dz;
+    normalize3(query_center[0] - sx, query_center[1] - sy, query_center[2] - sz, ax, ay, az);
+    normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
+    normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
+    reinterpret_cast<float4*>(ray_diff)[i] = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
+  }
+}
+extern "C" int dyn_project_points(const float* xyz, const float* xyz_st, const float* proj, const float* query_center, int V, long n_pts, float* pix,
+                                  float* in_front, float* ray_diff, void* stream) {
+  DYN_REQUIRE(xyz && proj && V > 0 && n_pts > 0, "dyn_project_points: bad argument");
+  DYN_REQUIRE((pix == nullptr) == (in_front == nullptr), "dyn_project_points: pix and in_front go together");
+  DYN_REQUIRE(ray_diff == nullptr || (xyz_st != nullptr && query_center != nullptr), "dyn_project_points: ray_diff needs xyz_st and query_center");
+  DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_project_points", k_project_points, dim3(dyn_cdiv((long)V * n_pts, 256)), dim3(256), 0, (hipStream_t)stream, xyz, xyz_st,
+             proj, query_center, V, n_pts, pix, in_front, ray_diff);
   return 0;
 }
 

@@ -426,6 +426,32 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   return R.buf + (c & 1) * B6_CHUNK;
 }
 
+// Issue-priority experiments of round 3 (measured on k_static_views, 4096 rays x 64 x 8 views, two rounds each against the same build without):
+//   B6_PRIO_FLIP = n: the two waves of a SIMD swap issue priority every n (k-group, tile) pairs.  n = 1: -1.1 %, n = 2: -1.4 % (kept), 4: -0.7 %,
+//     6: -0.8 %, 12: +7 %.  Without it the older wave wins every arbitration, reaches each chunk barrier ~2 k cycles early and parks while its
+//     partner finishes alone; fine-grained alternation keeps the pair closer together at no cost in registers.
+//   B6_PRIO_STATIC (one half of the workgroup permanently at priority 1, either half): +7 %.
+//   A feedback scheme (progress counters in LDS, the wave ahead lowers its priority): +6 % -- its bookkeeping costs more than it returns.
+//   B6_SPREAD (first MFMA of a triple ahead of the pair's VALU slice): +1..2 %, although the same change hides more fillers in a synthetic loop
+//     (tools/ubench/mfma_acc_file.hip): the engine's slices are LDS reads and dependent ELU chains, not independent FMAs.
+#ifndef B6_SPREAD
+#define B6_SPREAD 0
+#endif
+#ifndef B6_PRIO_STATIC
+#define B6_PRIO_STATIC 0
+#endif
+#ifndef B6_PRIO_FLIP
+#define B6_PRIO_FLIP 2
+#endif
+// the two waves of a SIMD (wave w and w + 4 of an 8-wave workgroup) take turns at the higher issue priority
+__device__ __forceinline__ void ring6_prio_flip(const WeightRing6& R, int phase) {
+#if defined(__AMDGCN__)
+  if (R.round != 8 * 256) return;
+  if ((((int)threadIdx.x >> 8) ^ phase) & 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // exact three-way bf16 split of two fp32 values, each part packed as (first in the low half, second in the high half)
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
 #if DYN_SPLIT_F16
@@ -539,6 +565,19 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
       if (pr < npc) {
         const int gi = pr / NT, t = pr % NT;
         const int g = c * GPC + gi;
+#if B6_PRIO_FLIP
+        // alternate the issue priority of the two waves of a SIMD every B6_PRIO_FLIP pairs (see ring6_prio_flip)
+        if (pr % B6_PRIO_FLIP == 0) ring6_prio_flip(R, (pr / B6_PRIO_FLIP) & 1);
+#endif
+#if B6_PRIO_STATIC
+        if (pr == 0 && c == 0) ring6_prio_flip(R, B6_PRIO_STATIC & 1);  // 1: the older half (waves 0-3) high, 2: the younger half high
+#endif
+#if B6_SPREAD
+        // B6_SPREAD: the first of the three dependent MFMAs goes out BEFORE this pair's VALU slice and the A prefetch, which then issue under it
+        const B6A& cur0 = q[pr % (AHEAD + 1)];
+        acc[t] = mfma_bf16(cur0.mid, bh, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (pr + AHEAD < npc) q[(pr + AHEAD) % (AHEAD + 1)] = b6_load_a(buf + (pr + AHEAD) * B6_PAIR_FLOATS, lane);
         if (g + 1 < NG) {
 #if B6_VALU_PER_PAIR
@@ -565,7 +604,11 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         acc[t] = mfma_bf16(cur.hi, bl, acc[t]);
         acc[t] = mfma_bf16(cur.mid, bm, acc[t]);
 #endif
+#if B6_SPREAD
+        __builtin_amdgcn_sched_barrier(0);
+#else
         acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
+#endif
         acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
         if (t == NT - 1) { bh = nh; bm = nm; bl = nl; }

@@ -1240,26 +1240,31 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
           }
         }
       // softmax over the keys; register r of half h is key kt*32 + fi(r,h)
+      // (key tiles beyond the ray's own -- kt >= TPR, a uniform condition -- are skipped altogether: a 64-sample ray has two of the four)
       float mx = -3.0e38f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool key_ok = (kt < TPR) && (kt * 32 + dyn_fi(r, h) < p.S);
-          float v = q_ok ? sc[kt][r] : -1e9f;
-          v = key_ok ? v : -3.0e38f;
-          sc[kt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 16; ++r) {
+            const bool key_ok = kt * 32 + dyn_fi(r, h) < p.S;
+            float v = q_ok ? sc[kt][r] : -1e9f;
+            v = key_ok ? v : -3.0e38f;
+            sc[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
+        if (kt < TPR) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
-          sc[kt][r] = e;
-          sum += e;
+          for (int r = 0; r < 16; ++r) {
+            const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
+            sc[kt][r] = e;
+            sum += e;
+          }
         }
       sum += __shfl_xor(sum, 32);
       const float inv = 1.0f / sum;

@@ -52,7 +52,10 @@ class SourceViews:
   Built once per (target view, branch) and reused by every ray chunk, like the reference reuses ``featmaps`` /
   ``src_cameras`` across the chunk loop (render_image.py:68-117)."""
 
-  def __init__(self, query_camera, src_rgbs, src_cameras, featmaps):
+  def __init__(self, query_camera, src_rgbs, src_cameras, featmaps, proj_matrices=None):
+    """proj_matrices: optional [V,4,4] fp32 ``K . inv(c2w)`` of the source views formed by the caller (``Projector(matrix_mode='torch')``
+    forms them exactly as the reference does, torch.inverse + bmm on the tensors' device, projection.py:42-47); default: formed in double
+    by k_prepare_cameras and rounded once."""
     assert query_camera.shape[0] == 1 and src_rgbs.shape[0] == 1 and src_cameras.shape[0] == 1, \
         'only support batch_size=1 for now'  # projection.py:122-126
     dev = src_rgbs.device
@@ -74,6 +77,10 @@ class SourceViews:
     self.proj = torch.empty((self.V, 16), dtype=torch.float32, device=dev)
     self.query_center = torch.empty((4,), dtype=torch.float32, device=dev)
     call('dyn_prepare_cameras', ptr(self.cams), self.V, ptr(self.query), ptr(self.proj), ptr(self.query_center), st)
+    if proj_matrices is not None:
+      P = _f32c(proj_matrices.to(dev))
+      assert tuple(P.shape) == (self.V, 4, 4), 'proj_matrices must be [V,4,4]'
+      self.proj[:, :12] = P[:, :3, :].reshape(self.V, 12)  # rows 0..2 of K . inv(c2w); the camera centres at [12..14] stay
     # normalize()/inbound() use h, w from train_cameras[0][:2] (projection.py:136); read once on the host
     hw = self.cams[0, :2].tolist()
     self.img_h, self.img_w = float(hw[0]), float(hw[1])
@@ -103,6 +110,32 @@ def points_from_z(ray_o, ray_d, z_vals, depth_range=None, want_pts=True):
   dr = _f32c(depth_range.reshape(-1)) if depth_range is not None else None
   call('dyn_points_from_z', ptr(ray_o), ptr(ray_d), ptr(z_vals), ptr(dr), R, S, ptr(pts), ptr(s), stream_of(z_vals))
   return pts, s
+
+
+def project_points(cams, xyz, xyz_st=None, query_camera=None, proj_matrices=None, want_pix=True):
+  """k_project_points: Projector.compute_projections / compute_angle as stand-alone calls.  cams [V,34], xyz [V,...,3] (+ xyz_st [V,...,3] and
+  query_camera [34] for the viewing-angle differences) -> (pix [V,...,2], in_front [V,...] bool) and / or ray_diff [V,...,4]."""
+  cams, xyz = _f32c(cams), _f32c(xyz)
+  V = cams.shape[0]
+  assert xyz.shape[0] == V and xyz.shape[-1] == 3
+  shp = tuple(xyz.shape[:-1])
+  n = xyz[0].numel() // 3
+  dev = xyz.device
+  proj = torch.empty((V, 16), dtype=torch.float32, device=dev)
+  qc = torch.zeros((4,), dtype=torch.float32, device=dev)
+  q = _f32c(query_camera.reshape(-1)) if query_camera is not None else None
+  st = stream_of(xyz)
+  call('dyn_prepare_cameras', ptr(cams), V, ptr(q), ptr(proj), ptr(qc), st)
+  if proj_matrices is not None:
+    proj[:, :12] = _f32c(proj_matrices.to(dev))[:, :3, :].reshape(V, 12)
+  pix = torch.empty(shp + (2,), dtype=torch.float32, device=dev) if want_pix else None
+  front = torch.empty(shp, dtype=torch.float32, device=dev) if want_pix else None
+  rd = xs = None
+  if xyz_st is not None:
+    xs = _f32c(xyz_st.expand(xyz.shape))
+    rd = torch.empty(shp + (4,), dtype=torch.float32, device=dev)
+  call('dyn_project_points', ptr(xyz), ptr(xs), ptr(proj), ptr(qc), V, n, ptr(pix), ptr(front), ptr(rd), st)
+  return pix, (front > 0 if front is not None else None), rd
 
 
 def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None, pix_mask_thresh=None):

@@ -14,9 +14,41 @@ from . import ops
 
 class Projector(object):
 
-  def __init__(self, device):
+  def __init__(self, device, matrix_mode='exact'):
+    """matrix_mode -- how the per-view projection matrix K . inv(c2w) (projection.py:42-47) is formed, once per source-view set:
+    'exact' (default): in double inside k_prepare_cameras, rounded once to fp32;
+    'torch': by ``torch.inverse`` + ``bmm`` in fp32 on the cameras' device, i.e. by the very library call the reference makes, so the matrices
+    are bit-for-bit what a reference run on this device computes.  (The fp32 inverse is not canonical: LAPACK on a CPU, MAGMA / rocSOLVER on
+    a GPU and the exact inverse differ in the last bits; everything downstream of the matrix follows the reference's arithmetic.)"""
+    assert matrix_mode in ('exact', 'torch') or callable(matrix_mode)  # a callable(train_cameras [V,34]) -> [V,4,4] supplies the matrices (tests)
     self.device = device
+    self.matrix_mode = matrix_mode
     self._views = {}
+
+  # ---- the reference's helper methods (projection.py:13-101); the render path does not call them (the gather kernel fuses all four) ----
+  def _matrices(self, train_cameras):
+    cams = train_cameras.reshape(-1, 34).float()
+    if self.matrix_mode == 'torch':
+      return cams[:, 2:18].reshape(-1, 4, 4).bmm(torch.inverse(cams[:, -16:].reshape(-1, 4, 4)))
+    return self.matrix_mode(cams) if callable(self.matrix_mode) else None
+
+  def inbound(self, pixel_locations, h, w):
+    """projection.py:13-20 (a comparison of the caller's tensor: plain tensor expressions, no kernel needed)"""
+    return (pixel_locations[..., 0] <= w - 1.0) & (pixel_locations[..., 0] >= 0) & (pixel_locations[..., 1] <= h - 1.0) & (pixel_locations[..., 1] >= 0)
+
+  def normalize(self, pixel_locations, h, w):
+    """projection.py:22-30"""
+    resize_factor = torch.tensor([w - 1.0, h - 1.0]).to(pixel_locations.device)[None, None, :]
+    return 2 * pixel_locations / resize_factor - 1.0
+
+  def compute_projections(self, xyz, train_cameras):
+    """projection.py:32-59: xyz [V,...,3], train_cameras [V,34] -> (pixel_locations [V,...,2], in-front mask [V,...] bool); k_project_points"""
+    pix, front, _ = ops.project_points(train_cameras, xyz, proj_matrices=self._matrices(train_cameras))
+    return pix, front
+
+  def compute_angle(self, xyz_st, xyz, query_camera, train_cameras):
+    """projection.py:61-101: -> [V,...,4] = [unit(a - b), a . b]; k_project_points"""
+    return ops.project_points(train_cameras, xyz, xyz_st=xyz_st, query_camera=query_camera, want_pix=False)[2]
 
   def source_views(self, query_camera, train_imgs, train_cameras, featmaps):
     key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (query_camera, train_imgs, train_cameras, featmaps))
@@ -27,7 +59,8 @@ class Projector(object):
       # sets instead of keeping up to 17 (maps, repacked copy) pairs alive.
       if len(self._views) > (5 if featmaps.requires_grad else 16):
         self._views.clear()
-      v = ops.SourceViews(query_camera, train_imgs, train_cameras, featmaps)
+      P = self._matrices(train_cameras[0])
+      v = ops.SourceViews(query_camera, train_imgs, train_cameras, featmaps, proj_matrices=P)
       # keep the keyed tensors alive so that a recycled address cannot alias a stale entry
       v._key_refs = (query_camera, train_imgs, train_cameras, featmaps)
       self._views[key] = v

@@ -216,6 +216,10 @@ int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* 
 int dyn_sample_pdf(const float* bins, float* weights, const float* u, int R, int M, int N, float* samples, void* stream);
 int dyn_plucker_ref(const float* ray_o, const float* ray_d, int R, float* out, void* stream);
 int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, long n_pts, int V, float* out, void* stream);
+/* Projector.compute_projections (projection.py:32-59) and Projector.compute_angle (:61-101): xyz [V,n_pts,3] (+ xyz_st [V,n_pts,3], query_center [4] for
+ * the angles), proj [V,16] from dyn_prepare_cameras -> pix [V,n_pts,2], in_front [V,n_pts] (0 / 1), ray_diff [V,n_pts,4]; either output group may be NULL. */
+int dyn_project_points(const float* xyz, const float* xyz_st, const float* proj, const float* query_center, int V, long n_pts, float* pix,
+                       float* in_front, float* ray_diff, void* stream);
 
 /* ---- section 8(f)1: the 2-D feature encoder that feeds the path (feature_network.py:179-311, the executed part of ResNet.forward:
  * conv 7x7/2 -> InstanceNorm -> ReLU -> layer1 (3 BasicBlocks, reflect padding) -> 1x1 conv; 32 coarse + 32 fine channels at 1/4 resolution).

@@ -32,3 +32,12 @@ def test_fine_samples(emu, golden_dir):
 def test_module_helper_exports(emu, golden_dir):
   g = dict(np.load(os.path.join(golden_dir, 'stages_small.npz')))
   parity.check_module_helpers(emu, g, 'small', with_fine=False)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_project_gather_same_matrix(emu, name):
+  parity.check_project_gather_same_matrix(emu, name)
+
+
+def test_projector_helper_methods(emu):
+  print('  compute_angle max |err| vs oracle:', parity.check_projector_helpers(emu, 'small'))

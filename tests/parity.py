@@ -7,6 +7,7 @@ rounding times the map gradient); network outputs and rendered colours within 1e
 reference's own arithmetic is ill-conditioned (white-noise maps: a 1e-4 px shift of a tap is visible; anti-alias pooling weights: a
 cancellation) the allowance added is MEASURED on the oracle per element (projection_sensitivity, check_static_net's exp jitter), not
 a blanket factor.  Every check records the fraction of its limit it used (MARGINS, printed by tests/conftest.py)."""
+import math
 import os
 
 import numpy as np
@@ -162,6 +163,76 @@ def check_project_gather(device, name='small', S=64):
   return nflip
 
 
+def reference_proj_matrices(cams):
+  """K . inv(c2w) [V,4,4] as the reference forms it (projection.py:42-47: torch.inverse + bmm in fp32), on the CPU like the goldens"""
+  cams = cams.reshape(-1, 34).float().cpu()
+  return cams[:, 2:18].reshape(-1, 4, 4).bmm(torch.inverse(cams[:, -16:].reshape(-1, 4, 4)))
+
+
+def check_project_gather_same_matrix(device, name='small', S=64):
+  """The gather with the projection matrices handed in (ops.SourceViews(proj_matrices=...), what Projector(matrix_mode='torch') does): the kernel then
+  starts from the SAME fp32 K.inv(c2w) as the oracle, and what is left between them is the rounding of a 4-term dot product and IEEE-identical
+  divisions.  No conditioning allowance, no ray is dropped: masks are compared on every point-view (flips are counted and must be isolated ties on a
+  frustum edge), colours / features wherever both masks agree."""
+  scene, o, d, uv, _ = cases.scene_case(name)
+  pts_r, z_r, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  R = o.shape[0]
+  sd = to_dev(scene, device)
+  g = torch.Generator().manual_seed(9)
+  total, flips, worst = 0, 0, 0.0
+  for branch in ('static', 'dynamic'):
+    if branch == 'static':
+      rgbs, cams, fm = scene['static_src_rgbs'], scene['static_src_cameras'], scene['static_featmaps']
+      xyz = pts_r[None].repeat(rgbs.shape[1], 1, 1, 1)
+    else:
+      rgbs, cams, fm = scene['src_rgbs'], scene['src_cameras'], scene['featmaps']
+      xyz = pts_r[None] + 0.05 * torch.randn(rgbs.shape[1], R, S, 3, generator=g)
+    rf_r, rd_r, mk_r = O.compute_with_motions(pts_r, xyz, scene['camera'], rgbs, cams, fm)
+    views = ops.SourceViews(sd['camera'], rgbs.to(device), cams.to(device), fm.to(device), proj_matrices=reference_proj_matrices(cams[0]))
+    rf, rd, mk = ops.project_gather(views, R, S, pts_st=pts_r.to(device), xyz=xyz.to(device))
+    same = (cpu(mk) == mk_r)
+    nf = int((~same).sum())
+    flips += nf
+    total += mk_r.numel()
+    if nf:
+      # a flip is legitimate only as a tie: the oracle's own pixel sits within an ulp-scale distance of an inbound() edge / the z = 0 plane
+      tie = boundary_margin(xyz, cams[0], tol=1e-4)
+      assert bool(tie[(~same)[..., 0]].all()), f'{name} {branch}: mask differs away from a frustum edge'
+    # measured on the MI355X and under the emulator: IDENTICAL bits (the dot product, the two IEEE divisions and the bilinear blend round alike)
+    assert_bitexact(cpu(rf) * same, rf_r * same, f'{name} {branch} rgb_feat from the reference\'s own projection matrices')
+    worst = max(worst, float(((cpu(rf) - rf_r).abs() * same).max()))
+    check_ray_diff(rd, rd_r, pts_r, xyz, scene['camera'][0], cams[0], f'{name} {branch} ray_diff (same matrices)')
+  print(f'  gather with the reference\'s own K.inv(c2w) [{name}]: {flips} of {total} mask bits differ; worst |rgb_feat| difference {worst:.2e}')
+  return flips, worst
+
+
+def check_projector_helpers(device, name='small', S=16):
+  """Projector.inbound / normalize / compute_projections / compute_angle (projection.py:13-101) against the oracle's restatements."""
+  from dynibar_amd import projection
+  scene, o, d, uv, _ = cases.scene_case(name)
+  pts, z, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  cams = scene['src_cameras'][0]
+  V = cams.shape[0]
+  g = torch.Generator().manual_seed(4)
+  xyz = pts[None] + 0.05 * torch.randn(V, pts.shape[0], S, 3, generator=g)
+  pj = projection.Projector(device, matrix_mode=reference_proj_matrices)
+  pix, front = pj.compute_projections(xyz.to(device), cams.to(device))
+  pix_r, front_r = O.compute_projections(xyz, cams)
+  assert tuple(pix.shape) == tuple(pix_r.shape) and front.dtype == torch.bool
+  assert_bitexact(front, front_r, f'{name} compute_projections in-front mask')
+  assert_close(pix, pix_r, 0.0, 1e-6, f'{name} compute_projections pixel locations (relative: one rounding of a 4-term dot product)')
+  rd = pj.compute_angle(pts[None].expand(V, -1, -1, -1).to(device), xyz.to(device), scene['camera'][0].to(device), cams.to(device))
+  rd_r = O.compute_angle(pts[None].expand(V, -1, -1, -1), xyz, scene['camera'][0], cams)
+  assert tuple(rd.shape) == tuple(rd_r.shape)
+  check_ray_diff(rd.permute(1, 2, 0, 3), rd_r.permute(1, 2, 0, 3), pts, xyz, scene['camera'][0], cams, f'{name} compute_angle')
+  h, w = cams[0][:2]
+  assert_bitexact(pj.inbound(pix_r.to(device), h, w), (pix_r[..., 0] <= w - 1.0) & (pix_r[..., 0] >= 0) & (pix_r[..., 1] <= h - 1.0) & (pix_r[..., 1] >= 0),
+                  f'{name} inbound')
+  nrm = pj.normalize(pix.reshape(V, -1, 2), h, w)
+  assert_bitexact(nrm, 2 * cpu(pix).reshape(V, -1, 2) / torch.tensor([w - 1.0, h - 1.0])[None, None, :] - 1.0, f'{name} normalize')
+  return float((cpu(rd) - rd_r).abs().max())
+
+
 def check_composite(device, R=37, S=64, seed=0):
   g = torch.Generator().manual_seed(seed)
   raw_dy = torch.randn(R, S, 4, generator=g) * torch.tensor([1, 1, 1, 3.0])
@@ -261,9 +332,10 @@ def check_static_net(device, name='small', S=64, R=None, aa=True, mask_rgb=False
   return float(err[..., :3].max()), float(err[..., 3].max()), float(sens.max())
 
 
-def run_static_pass(device, scene_dev, net, o, d, S, inv_uniform=True):
+def run_static_pass(device, scene_dev, net, o, d, S, inv_uniform=True, same_matrix=False):
   """BASELINE config 2 on the HIP path: sample -> project/gather -> DynibarStatic -> composite."""
-  views = ops.SourceViews(scene_dev['camera'], scene_dev['static_src_rgbs'], scene_dev['static_src_cameras'], scene_dev['static_featmaps'])
+  P = reference_proj_matrices(scene_dev['static_src_cameras'][0]) if same_matrix else None
+  views = ops.SourceViews(scene_dev['camera'], scene_dev['static_src_rgbs'], scene_dev['static_src_cameras'], scene_dev['static_featmaps'], proj_matrices=P)
   R = o.shape[0]
   pts, z, s = ops.sample_along_ray(o, d, scene_dev['depth_range'], S, inv_uniform)
   rgb_feat, ray_diff, mask, pm = ops.project_gather(views, R, S, ray_o=o, ray_d=d, z_vals=z, pix_mask_thresh=1.0)
@@ -271,10 +343,28 @@ def run_static_pass(device, scene_dev, net, o, d, S, inv_uniform=True):
   return ops.composite(raw, z, pm), raw
 
 
-def check_static_pass(device, name='small', S=64, R=None, atol=1e-4, weights='init'):
+def check_static_pass(device, name='small', S=64, R=None, atol=1e-4, weights='init', same_matrix=False):
+  """same_matrix: the kernels start from the reference's own fp32 K.inv(c2w) (ops.SourceViews(proj_matrices=...)): then NO ray is dropped and NO
+  conditioning allowance is added -- every ray, 1e-4."""
   scene, o, d, sd, out_ref, st = static_inputs(name, S, R, weights)
   net = ops.StaticNet(_weights(weights)['net_coarse_st'], device, True, False)
-  out, raw = run_static_pass(device, to_dev(scene, device), net, o.to(device), d.to(device), S)
+  out, raw = run_static_pass(device, to_dev(scene, device), net, o.to(device), d.to(device), S, same_matrix=same_matrix)
+  # the anti-alias pooling weights (e - min_v e) are a cancellation (see check_static_net): 4 x how far +-1 ulp on exp() moves the ORACLE's own
+  # outputs, per element -- negligible at initialisation scale, up to several 1e-4 with trained-scale density heads
+  jit = {k: torch.zeros_like(out_ref[k]) for k in ('rgb', 'depth', 'weights')}
+  Vs_ = scene['static_src_rgbs'].shape[1]
+  for js in range(3):
+    ej = (torch.randint(0, 3, (o.shape[0], S, Vs_, 1), generator=torch.Generator().manual_seed(50 + js)).float() - 1.0) * 6e-8
+    oj = _oracle_static_graph(sd, scene, o, d, S, True, False, ej)[0]
+    for k in jit:
+      jit[k] = torch.maximum(jit[k], 4.0 * (oj[k] - out_ref[k]).abs())
+  if same_matrix:
+    tag = f'{name} static pass, reference matrices, all rays'
+    assert_close(cpu(out['rgb']), out_ref['rgb'], atol, 0.0, f'{tag}: rgb', extra=jit['rgb'])
+    assert_close(cpu(out['depth']), out_ref['depth'], 0.0, 2e-4, f'{tag}: depth', extra=jit['depth'])
+    assert_close(cpu(out['weights']), out_ref['weights'], atol, 0.0, f'{tag}: weights', extra=jit['weights'])
+    assert_bitexact(cpu(out['mask']) > 0, out_ref['mask'], f'{tag}: ray mask')
+    return float((cpu(out['rgb']) - out_ref['rgb']).abs().max())
   # a sample whose projection sits on the frustum boundary may flip its mask (fp32 tie, see _mask_check); rays touching one are skipped
   Vs = scene['static_src_rgbs'].shape[1]
   margin = boundary_margin(st['pts'][None].repeat(Vs, 1, 1, 1), scene['static_src_cameras'][0]).any(dim=2).any(dim=1)
@@ -282,7 +372,7 @@ def check_static_pass(device, name='small', S=64, R=None, atol=1e-4, weights='in
   assert int(keep.sum()) > 0
   # white-noise maps amplify the last-bit differences of the projection matrices: measured on the oracle, per element
   sens = projection_sensitivity(lambda: O.static_branch_pass(sd, scene, o, d, S, True, True, True, False))
-  ex = lambda k: SENS_FACTOR * sens[k][keep]
+  ex = lambda k: SENS_FACTOR * sens[k][keep] + jit[k][keep]
   assert_close(cpu(out['rgb'])[keep], out_ref['rgb'][keep], atol, 0.0, f'{name} static pass rgb', extra=ex('rgb'))
   assert_close(cpu(out['depth'])[keep], out_ref['depth'][keep], 0.0, 2e-4, f'{name} static pass depth', extra=ex('depth'))
   assert_close(cpu(out['weights'])[keep], out_ref['weights'][keep], atol, 0.0, f'{name} static pass weights', extra=ex('weights'))
@@ -385,10 +475,10 @@ def _group_tol(key, name=None):
   # No blanket loosening for ill-conditioned scenes: their allowance is measured per element (projection_sensitivity).
   if key in ('depth', 'z_vals', 's_vals'):
     return dict(atol=2e-4, rtol=2e-4)
-  if key in ('render_flows',):
-    return dict(atol=2e-2, rtol=1e-3)
-  if key in ('exp_sf',):
-    return dict(atol=2e-5, rtol=1e-3)
+  if key in ('render_flows',):  # pixel differences of projected expected points (values up to the image width): measured 1.5e-5 px at worst
+    return dict(atol=2e-4, rtol=1e-5)
+  if key in ('exp_sf',):        # measured 6e-8
+    return dict(atol=1e-6, rtol=1e-4)
   return dict(atol=1e-4, rtol=1e-4)
 
 
@@ -447,27 +537,29 @@ def oracle_models():
   return W
 
 
-def check_render_rays_mv(device, golden, name='small', S=64):
-  """render_rays_mv (coarse 64 + fine 64, dynamic + static, det=True, inv_uniform=True) against the real reference's outputs."""
+def check_render_rays_mv(device, golden, name='small', S=64, same_matrix=False):
+  """render_rays_mv (coarse 64 + fine 64, dynamic + static, det=True, inv_uniform=True) against the real reference's outputs.
+  same_matrix: the projector is handed the reference's own fp32 K.inv(c2w) (Projector(matrix_mode=...)); no conditioning allowance is added then,
+  not even on the white-noise scene."""
   import types
   from dynibar_amd import projection, render_ray
   scene, o, d, uv, _ = cases.scene_case(name)
   fidx, temb, toff = cases.time_args(scene['src_rgbs'].shape[1])
   model = make_model(device)
   args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0)
-  proj = projection.Projector(device)
+  proj = projection.Projector(device, matrix_mode=reference_proj_matrices) if same_matrix else projection.Projector(device)
   batch = make_ray_batch(scene, o, d, uv, device)
   cfeat = (scene['featmaps'].to(device), None, scene['static_featmaps'].to(device))
   ffeat = (scene['featmaps_fine'].to(device), None, scene['static_featmaps_fine'].to(device))
   ret = render_ray.render_rays_mv((fidx, None), (temb.to(device), None), (toff, None), batch, model, proj, cfeat, ffeat, S, args,
                                   inv_uniform=True, N_importance=S, det=True, is_train=False)
   sens = {}
-  if name == 'noise':  # white-noise maps: the reference's own conditioning w.r.t. the projection matrices' last bits, per element
+  if name == 'noise' and not same_matrix:  # white-noise maps: the reference's own conditioning w.r.t. the projection matrices' last bits, per element
     W = oracle_models()
     sens = projection_sensitivity(lambda: O.render_rays_mv(W, dict(scene), o, d, uv, fidx, temb, toff, S, S))
   n = 0
   for grp in ('outputs_coarse_ref', 'outputs_fine_ref', 'outputs_fine_ref_dy'):
-    n += check_group_vs_golden(f'mv/{grp}/', ret[grp], golden, name, sens=sens.get(grp))
+    n += check_group_vs_golden(f'mv/{grp}/' , ret[grp], golden, name + (' [reference matrices]' if same_matrix else ''), sens=sens.get(grp))
   assert n == sum(1 for k in golden if k.startswith('mv/')), 'render_rays_mv output key set differs from the reference'
   assert ret['outputs_fine_anchor'] is None and ret['outputs_fine_anchor_dy'] is None
   # chain-level index exactness (SURVEY section 7, protocol b): the inverse-CDF indices the HIP chain derives from ITS OWN coarse
@@ -1133,6 +1225,24 @@ def check_train_gemm(device):
         key, am = dX._dyn_absmax
         assert key == (0, ld, M, Kin)
         assert abs(float(am) - float(dX[:, :Kin].abs().max())) == 0.0, 'scale of the result'
+
+  # the half-float range of the FORWARD operands (only the gradient operand of the backward GEMMs is rescaled): activations beyond the largest half
+  # (65504) are carried by the second part up to 2 x 65504 with the precision of that part alone, and residuals below the smallest normal half
+  # (6.1e-5) sit on an absolute floor of 2^-25 per operand.  Pinned here so that the limits are measured facts, not assumptions.
+  report = {}
+  for tag, lo, hi_, rtol, atol_of_max in (('activations 1e3..6e4', 1e3, 6e4, 4e-6, 2e-6), ('activations 7e4..1.2e5 (second part carries the excess)', 7e4, 1.2e5, 0.0, 2e-4),
+                                          ('activations 1e-6..6e-5 (subnormal halves)', 1e-6, 6e-5, 0.0, 2e-3)):
+    mag = torch.exp(torch.rand(M, 104, generator=g) * (math.log(hi_) - math.log(lo)) + math.log(lo))
+    X = (mag * torch.sign(torch.randn(M, 104, generator=g))).to(device)
+    W = (torch.randn(N, K, generator=g) * 0.3).to(device)
+    Y = torch.full((M, 40), float('nan'), device=device)
+    TS._Lin(W).fwd(TS.stream_of(X), X, 0, 104, Y, 0, 40, M, 0)
+    ref = X[:, :K].double().cpu() @ W.double().cpu().T
+    assert bool(torch.isfinite(Y[:, :N]).all()), f'train gemm forward, {tag}: non-finite result'
+    big = float(ref.abs().max())
+    assert_close(Y[:, :N], ref, atol_of_max * big, rtol, f'train gemm forward, {tag}')
+    report[tag] = float((cpu(Y[:, :N]).double() - ref).abs().max()) / big
+  print('  train gemm forward operand range (max error / largest result): ' + '; '.join(f'{k}: {v:.1e}' for k, v in report.items()))
 
   # split reduction over many rows
   M = 5000

@@ -233,3 +233,19 @@ def test_training_iteration_at_the_training_shape(dev):
   """Section 8f-3 at 256 rays x 64 samples x (7 + 3) / (7 + 3) / 15 views: the full train.py loss, every gradient as a full tensor vs autograd through
   the oracle on the device (fp32) with its fp64 twin as the arbiter of conditioning; run-to-run spread of two identical steps."""
   parity.check_train_mono_large(dev)
+
+
+@pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
+def test_gather_and_passes_from_the_reference_matrices(dev, golden_dir, name):
+  """With the reference's own fp32 K.inv(c2w) handed in (Projector(matrix_mode=...) / SourceViews(proj_matrices=...)) nothing separates the gather from
+  the reference but a 4-term dot product: no conditioning allowance, no dropped frustum-edge rays -- gather, static pass and render_rays_mv on every ray."""
+  flips, worst = parity.check_project_gather_same_matrix(dev, name)
+  assert flips == 0
+  parity.check_static_pass(dev, name, same_matrix=True)
+  parity.check_render_rays_mv(dev, _golden(golden_dir, f'stages_{name}.npz'), name, same_matrix=True)
+
+
+def test_projector_helper_methods(dev):
+  """Projector.inbound / normalize / compute_projections / compute_angle (projection.py:13-101): the reference's helper surface, kernel-backed"""
+  parity.check_projector_helpers(dev, 'small')
+  parity.check_projector_helpers(dev, 'harsh')
