@@ -340,6 +340,11 @@ extern "C" int dyn_debug_phases(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 1;
 }
 #define DYN_PHASE_T0 const unsigned long long phase_t0 = __builtin_readcyclecounter();
+#ifdef DYN_PHASE_SKEW
+__device__ unsigned long long g_skew[8][4];
+extern "C" int dyn_debug_skew(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_skew), sizeof(g_skew)) == hipSuccess ? 0 : 1; }
+extern "C" int dyn_debug_skew_reset(void) { unsigned long long z[32] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_skew), z, sizeof(z)) == hipSuccess ? 0 : 1; }
+#endif
 #define DYN_PHASE_WAIT(R, c)                                                                          \
   do {                                                                                                \
     if (DYN_PHASE_ON && (c) < 64) {                                                                   \
@@ -419,8 +424,20 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
     return R.buf;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#ifdef DYN_PHASE_SKEW
+  const unsigned long long skew_t1 = __builtin_readcyclecounter();
+#endif
   __syncthreads();
   const int c = R.next++;
+#ifdef DYN_PHASE_SKEW
+  // developer diagnostic (tools/phasebench.py built with PHASE_FLAGS=-DDYN_PHASE_SKEW): per wave of one workgroup, cycles spent waiting for the
+  // wave's own DMA pieces and cycles spent in the chunk barrier, summed over the chunks
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == gridDim.x / 2 && R.kid == 0) {
+    g_skew[threadIdx.x >> 6][0] += skew_t1 - phase_t0;
+    g_skew[threadIdx.x >> 6][1] += __builtin_readcyclecounter() - skew_t1;
+    g_skew[threadIdx.x >> 6][2] += 1;
+  }
+#endif
   DYN_PHASE_WAIT(R, c);
   if (c + 1 < R.total) ring6_issue(R, c + 1);
   return R.buf + (c & 1) * B6_CHUNK;

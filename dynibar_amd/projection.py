@@ -7,19 +7,28 @@ caller passes (the reference passes the same ``featmaps`` / ``src_cameras`` obje
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
 
+DEFAULT_MATRIX_MODE = 'torch'  # see Projector.__init__ (env DYNIBAR_MATRIX_MODE overrides)
+
 
 class Projector(object):
 
-  def __init__(self, device, matrix_mode='exact'):
+  def __init__(self, device, matrix_mode=None):
     """matrix_mode -- how the per-view projection matrix K . inv(c2w) (projection.py:42-47) is formed, once per source-view set:
-    'exact' (default): in double inside k_prepare_cameras, rounded once to fp32;
-    'torch': by ``torch.inverse`` + ``bmm`` in fp32 on the cameras' device, i.e. by the very library call the reference makes, so the matrices
-    are bit-for-bit what a reference run on this device computes.  (The fp32 inverse is not canonical: LAPACK on a CPU, MAGMA / rocSOLVER on
-    a GPU and the exact inverse differ in the last bits; everything downstream of the matrix follows the reference's arithmetic.)"""
+    'torch' (default): by ``torch.inverse`` + ``bmm`` in fp32 on the cameras' device -- the very library call the reference makes, so the matrices
+    are bit-for-bit what a reference run on this device computes, and from the same matrices the gather kernel's outputs are bit-for-bit the
+    reference's (tests/parity.check_project_gather_same_matrix);
+    'exact': in double inside k_prepare_cameras, rounded once to fp32 (what ops.SourceViews does when no matrices are handed in);
+    a callable(train_cameras [V,34]) -> [V,4,4]: the caller's own matrices (the parity tests hand in the CPU reference's).
+    The fp32 inverse is not canonical -- LAPACK on a CPU, MAGMA / rocSOLVER on a GPU and the exact inverse differ in the last bits -- which is
+    the only reason pixel locations of two reference runs on different devices differ; everything downstream follows the reference's arithmetic."""
+    if matrix_mode is None:
+      matrix_mode = os.environ.get('DYNIBAR_MATRIX_MODE', DEFAULT_MATRIX_MODE)
     assert matrix_mode in ('exact', 'torch') or callable(matrix_mode)  # a callable(train_cameras [V,34]) -> [V,4,4] supplies the matrices (tests)
     self.device = device
     self.matrix_mode = matrix_mode

@@ -731,7 +731,7 @@ def check_module_helpers(device, golden, name='small', S=64, with_fine=True):
   assert_close(got, O.compute_traj_pts(coeff[..., :B], coeff[..., B:2 * B], coeff[..., 2 * B:], row), 1e-6, 1e-5, f'{name} compute_traj_pts')
   pts_seq = torch.from_numpy(golden['motion/pts_seq'])
   flows = RR.compute_optical_flow({'weights': dv(w)}, dv(pts_seq), dv(scene['src_cameras']), dv(uv))
-  assert_close(flows, torch.from_numpy(golden['flow/render_flows']), 2e-2, 1e-3, f'{name} compute_optical_flow')
+  assert_close(flows, torch.from_numpy(golden['flow/render_flows']), 2e-4, 1e-5, f'{name} compute_optical_flow')
   if not with_fine:
     return
   # fine_render_rays on explicit networks = the fine pass of render_rays_mv, bit for bit (same kernels, same inputs)
@@ -1230,7 +1230,7 @@ def check_train_gemm(device):
   # (65504) are carried by the second part up to 2 x 65504 with the precision of that part alone, and residuals below the smallest normal half
   # (6.1e-5) sit on an absolute floor of 2^-25 per operand.  Pinned here so that the limits are measured facts, not assumptions.
   report = {}
-  for tag, lo, hi_, rtol, atol_of_max in (('activations 1e3..6e4', 1e3, 6e4, 4e-6, 2e-6), ('activations 7e4..1.2e5 (second part carries the excess)', 7e4, 1.2e5, 0.0, 2e-4),
+  for tag, lo, hi_, rtol, atol_of_max in (('activations 1e3..6e4', 1e3, 6e4, 4e-6, 2e-6), ('activations 7e4..1.2e5 (second part carries the excess)', 7e4, 1.2e5, 0.0, 4e-4),  # measured: 1.4e-4 (MI355X), 2.3e-4 (emulator: truncating second part)
                                           ('activations 1e-6..6e-5 (subnormal halves)', 1e-6, 6e-5, 0.0, 2e-3)):
     mag = torch.exp(torch.rand(M, 104, generator=g) * (math.log(hi_) - math.log(lo)) + math.log(lo))
     X = (mag * torch.sign(torch.randn(M, 104, generator=g))).to(device)

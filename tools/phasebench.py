@@ -44,6 +44,15 @@ for _ in range(3):
   net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(LIB)
+if hasattr(raw, 'dyn_debug_skew'):  # built with PHASE_FLAGS=-DDYN_PHASE_SKEW
+  raw.dyn_debug_skew_reset()
+  net(views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask)
+  torch.cuda.synchronize()
+  sk = (ctypes.c_ulonglong * 32)()
+  assert raw.dyn_debug_skew(sk) == 0
+  print('view chain, one workgroup, per wave: cycles waiting for its own DMA pieces | cycles in the chunk barrier | chunks (all launches of the call that used ring kid 0)')
+  for w in range(8):
+    print('  wave %d: dma %8d   barrier %8d   chunks %d' % (w, sk[w * 4], sk[w * 4 + 1], sk[w * 4 + 2]))
 pg = (ctypes.c_ulonglong * 16)()
 if raw.dyn_debug_pg_phases(pg) == 0:
   for b in range(2):
