@@ -149,7 +149,18 @@ def timed(lib, step, steps, warmup, fence):
   return out, dt, read_kernels(lib)
 
 
-def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE')):
+def pmc_clock(a):
+  """Effective shader clock and matrix-pipe occupancy of k_static_views from one more rocprofv3 --pmc child (GRBM_GUI_ACTIVE is summed over the 8
+  XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles: 32 per v_mfma_f32_32x32x16).  The dense MFMA peak of the guide is quoted at 2.4 GHz; the chip
+  clocks to its power budget (MI355X_MICROARCH.md, DVFS), so the fraction at the clock the kernel actually ran at is reported next to the nominal one."""
+  got, note = pmc_traffic(a, counters=('GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES',), raw=True)
+  if not got or 'k_static_views' not in got:
+    return None, note
+  v = got['k_static_views']
+  return {'grbm_gui_active': v.get('GRBM_GUI_ACTIVE'), 'mfma_busy_cycles': v.get('SQ_VALU_MFMA_BUSY_CYCLES'), 'avg_us_under_profiler': v.get('avg_us')}, note
+
+
+def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE'), raw=False):
   """HBM-side bytes per launch of every kernel of this bench, by rocprofv3 --pmc children of this same command (one counter per pass, as
   MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950: wide coalesced reads are tallied at half their bytes)."""
   import glob
@@ -163,21 +174,32 @@ def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE')):
   for c in counters:
     d = tempfile.mkdtemp(prefix='dynibar_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
     try:
-      cmd = [exe, '--kernel-trace', '--pmc', c, '-d', d, '--', sys.executable, os.path.abspath(__file__), '--child', '--steps', '4', '--warmup', '1',
+      cmd = [exe, '--kernel-trace', '--pmc'] + c.split() + ['-d', d, '--', sys.executable, os.path.abspath(__file__), '--child', '--steps', '4', '--warmup', '1',
              '--rays', str(a.rays), '--samples', str(a.samples), '--views', str(a.views)]
       r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=d, env=dict(os.environ, TMPDIR=d))
       dbs = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
       if not dbs:
         return None, f'rocprofv3 --pmc {c}: no database written (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}'
       cur = sqlite3.connect(dbs[0]).cursor()
-      for name, n, v in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (c,)):
-        key = name.replace('void ', '').split('<')[0].split('(')[0]
-        res.setdefault(key, {})[c + '_KB'] = v
-        res[key]['dispatches'] = n
+      for cn in c.split():
+        for name, n, v in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (cn,)):
+          key = name.replace('void ', '').split('<')[0].split('(')[0]
+          res.setdefault(key, {})[cn if raw else cn + '_KB'] = v
+          res[key]['dispatches'] = n
+      if raw:
+        try:  # counters_collection carries the dispatch's duration (ns) next to every counter value
+          for name, ns in cur.execute("select kernel_name, avg(duration) from counters_collection where counter_name = ? group by kernel_name", (c.split()[0],)):
+            key = name.replace('void ', '').split('<')[0].split('(')[0]
+            if key in res:
+              res[key]['avg_us'] = ns / 1000.0
+        except Exception:
+          pass
     except Exception as e:  # the profiler leg must never cost the main line
       return None, f'rocprofv3 --pmc {c} failed: {str(e)[:200]}'
     finally:
       shutil.rmtree(d, ignore_errors=True)
+  if raw:
+    return res, 'rocprofv3 --kernel-trace --pmc ' + ' '.join(counters) + ' child of this command (4 steps)'
   out = {}
   for k, v in res.items():
     if k.startswith('k_') and 'FETCH_SIZE_KB' in v and 'WRITE_SIZE_KB' in v:
@@ -570,9 +592,16 @@ def main():
   pg_bytes = gather_bytes(R, S, V)
   engine = 'f32' if terms == 0 else f'f32 ({KIND[kind]}x{terms} split-product MFMA: fp32 operands as exact sums of {KIND[kind]} parts, f32 accumulate)'
 
-  traffic, traffic_note = None, 'skipped (--no-traffic)'
+  traffic, traffic_note, clock = None, 'skipped (--no-traffic)', None
   if not a.no_traffic and world == 1:
     traffic, traffic_note = pmc_traffic(a)
+    ck, _ = pmc_clock(a)
+    if ck and ck.get('grbm_gui_active') and ck.get('avg_us_under_profiler'):
+      ghz = ck['grbm_gui_active'] / 8.0 / (ck['avg_us_under_profiler'] * 1e3)  # cycles per XCD / ns
+      clock = {'effective_shader_clock_ghz': ghz, 'nominal_ghz': 2.4,
+               'mfma_pipe_busy_frac': (ck['mfma_busy_cycles'] / (ck['grbm_gui_active'] / 8.0 * 1024.0)) if ck.get('mfma_busy_cycles') else None,
+               'note': 'k_static_views under the profiler: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs). '
+                       'The 2500 TFLOP/s dense peak assumes 2.4 GHz; frac_at_effective_clock rescales it to the clock the power budget allowed'}
   tr = lambda k: (traffic[k]['bytes'] if traffic and k in traffic else None)
 
   res = {
@@ -588,7 +617,8 @@ def main():
                    'algorithmic_flops_per_launch': flops_launch,
                    'peak_note': f'fp32 operands as exact sums of two {KIND[kind]} parts, {terms} partial products per product on the 16-bit matrix pipe, fp32 '
                                 f'accumulation: peak = 2500 TFLOP/s dense / {terms}; against the native fp32 MFMA peak (157.3 TFLOP/s) see frac_vs_fp32_mfma_peak',
-                   'frac_vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS},
+                   'frac_vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS, 'clock': clock,
+                   'frac_at_effective_clock': (achieved / (peak * clock['effective_shader_clock_ghz'] / 2.4)) if clock else None},
       'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': net_tflops / peak, 'avg_ms': net_ms,
                               'frac_vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS},
       'roofline_project_gather': {'kernel': 'k_project_gather_tile', 'bound': 'hbm', 'achieved': pg_bytes / (pg['avg_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
@@ -627,6 +657,8 @@ def main():
         runs.append(time.perf_counter() - t1)
     cpu_dt = float(np.median(runs))
     res['cpu_baseline'] = {'value': n / cpu_dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+                           'kind_note': 'the oracle (oracle/ibr_oracle.py: the reference algorithm restated on torch-CPU, pinned bit-for-bit to the real reference by '
+                                        'tests/golden) -- /root/reference does not exist on the GPU box, so the reference\'s own modules cannot be timed here',
                            'sample': f'{n} of the {R} rays of one step, same scene/weights, torch-CPU oracle, {cores} threads (best of 8/32/64/all on a 32-ray probe; '
                                      f'host has {os.cpu_count()} hardware threads), median of 3 runs after warm-up ({", ".join("%.2f s" % r for r in runs)})'}
     err = (out['rgb'][:n].cpu() - ref['rgb']).abs()

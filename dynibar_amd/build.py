@@ -27,11 +27,29 @@ def _deps():
       os.path.join(os.path.dirname(HERE), 'include', 'dynibar_hip.h')]
 
 
+STAMP = os.path.join(CSRC, '.build_stamp')
+
+
+def _stamp():
+  """sha256 over the sources, headers and flags the libraries are made from.  (Modification times are not enough: a build that was started before
+  an edit finishes after it and leaves a stale library that is newer than its sources.)"""
+  import hashlib
+  h = hashlib.sha256(repr((COMMON, UNITS)).encode())
+  for d in sorted(_deps()):
+    h.update(os.path.basename(d).encode())
+    with open(d, 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()
+
+
 def build(force=False, verbose=True):
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
   units = [(s, f) for s, f in UNITS if os.path.exists(os.path.join(CSRC, s))]
-  if not force and os.path.exists(OUT) and os.path.exists(OUT_X6) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
+  stamp = _stamp()
+  if not force and os.path.exists(OUT) and os.path.exists(OUT_X6) and os.path.exists(STAMP) and open(STAMP).read().strip() == stamp:
     return OUT
+  if os.path.exists(STAMP):
+    os.remove(STAMP)
   objs = []
   for src, flags in units:
     obj = os.path.join(CSRC, src.replace('.hip', '.o'))
@@ -52,6 +70,9 @@ def build(force=False, verbose=True):
   subprocess.check_call(cmd)
   cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6] + objs[2:] + ['-o', OUT_X6]
   subprocess.check_call(cmd)
+  if _stamp() == stamp:  # the sources did not change while the compilers ran
+    with open(STAMP, 'w') as f:
+      f.write(stamp + '\n')
   return OUT
 
 

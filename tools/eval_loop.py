@@ -75,7 +75,10 @@ def run(dev='cuda:0', views=2):
                   'fine nets), render_single_image_nvi (288x512, 64 + 64 samples, 7 + 11 views), pixels to the host, masked PSNR',
           'ms_per_view': total, 'ms': {k: round(v, 2) for k, v in acc.items()}, 'views_timed': views,
           'balloon1_views': '(num_frames - 6) x 11 target views per scene (eval_nvidia.py:305-316)',
-          'balloon1_eval_minutes_at_24_frames': 18 * 11 * total / 6e4, 'psnr_vs_random_target_db': float(np.mean(ps))}
+          'balloon1_gpu_path_minutes_at_24_frames': 18 * 11 * total / 6e4,
+          'scope': 'GPU-PATH TIME ON SYNTHETIC DATA with random weights: what the loop does on the device + the pixel copy.  Not an evaluation wall-clock: image '
+                   'decoding, SSIM / LPIPS (eval_nvidia.py:383-400) and checkpoint loading are outside it, and no trained weights or dataset are available offline',
+          'psnr_vs_random_target_db': float(np.mean(ps))}
 
 
 if __name__ == '__main__':
