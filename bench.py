@@ -217,7 +217,7 @@ def main():
   ap.add_argument('--rays', type=int, default=4096, help='rays per step per GPU (N_rand / chunk)')
   ap.add_argument('--samples', type=int, default=64)
   ap.add_argument('--views', type=int, default=8)
-  ap.add_argument('--cpu-rays', type=int, default=256, help='rays of the same workload timed on the host oracle (0 = skip)')
+  ap.add_argument('--cpu-rays', type=int, default=1024, help='rays of the same workload timed on the host oracle (0 = skip)')
   ap.add_argument('--no-x6', action='store_true', help='(kept for old command lines; the bf16 6-term leg is off unless --x6)')
   ap.add_argument('--x6', action='store_true', help='also time the bf16 6-term split engine build (libdynibar_hip_x6.so)')
   ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (11 views, full frame)')
