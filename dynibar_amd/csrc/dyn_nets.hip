@@ -99,6 +99,11 @@ void pack_rowtab(std::vector<float>& out, const float* w, int n, double scale = 
     for (int k = 0; k < n / 2; ++k) out.push_back((float)((double)w[chain_feature(k, h)] * scale));
 }
 
+// a chained layer whose weight slots (s < nsteps_w) and bias slot take different factors
+SlotFn scaled_wb(SlotFn fn, int nsteps_w, double kw, double kb) {
+  return [=](int t, int i, int s, int h) -> float { return (float)((double)fn(t, i, s, h) * (s < nsteps_w ? kw : kb)); };
+}
+
 // a layer image times a constant (the scaled-domain ELU's pack-time factors, dyn_mlp.h: elu_s)
 SlotFn scaled(SlotFn fn, double scale) {
   if (scale == 1.0) return fn;
@@ -239,31 +244,31 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   // ---- B ----
   {
     const float *W = T[ST_GEO0_W], *b = T[ST_GEO0_B];
-    pack_net_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 129, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];  // mean | var
       return h == 0 ? W[n * 257 + 256] : b[n];                                          // mean of the weights | bias
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 4, 129, chained(T[ST_GEO2_W], T[ST_GEO2_B], 128, 256, 256));
+  pack_net_layer(o, 4, 129, scaled_wb(chained(T[ST_GEO2_W], T[ST_GEO2_B], 128, 256, 256), 128, DYN_ELU_POST, 1.0));
   pack_net_layer(o, 4, 64, chained(T[ST_WQ], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[ST_WK], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[ST_WV], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[ST_FC], nullptr, 128, 128, 128));
-  pack_net_layer(o, 4, 65, chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128));
-  pack_net_layer(o, 4, 65, chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261));  // columns 0..127 = globalfeat part
+  pack_net_layer(o, 4, 65, scaled(chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128), DYN_ELU_PRE));
+  pack_net_layer(o, 4, 65, scaled(chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261), DYN_ELU_PRE));  // columns 0..127 = globalfeat part
   DYN_REQUIRE(o.size() == ST_OFF_C, "static pack: B stream size mismatch");
   // ---- C ----
   {
     const float* W = T[ST_RGB0_W];
-    pack_net_layer(o, 4, SC_L11_STEPS, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 4, SC_L11_STEPS, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 261 + 128 + chain_feature(s, h)];
       const int k = (s - 64) * 2 + h;  // vis, ray_diff[0..3]
       return k < 5 ? W[n * 261 + 256 + k] : 0.f;
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 2, 64, chained(T[ST_RGB2_W], nullptr, 64, 128, 128));
+  pack_net_layer(o, 2, 64, scaled(chained(T[ST_RGB2_W], nullptr, 64, 128, 128), DYN_ELU_POST * DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == ST_OFF_CTA, "static pack: C stream size mismatch");
   // ---- constant tables ----
   pack_rowtab(o, T[ST_VIS2_W] + 128 * 128, 128, DYN_ELU_POST);
@@ -284,13 +289,13 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   o.resize(ST_OFF_CTB, 0.f);
   pack_rowtab(o, T[ST_LN_G], 128);
   pack_rowtab(o, T[ST_LN_B], 128);
-  pack_rowtab(o, T[ST_OG2_W], 128);
+  pack_rowtab(o, T[ST_OG2_W], 128, DYN_ELU_POST);
   o.push_back(T[ST_OG2_B][0]);
   o.resize(ST_OFF_CTC, 0.f);
-  pack_rowtab(o, T[ST_RGB4_W], 64);
+  pack_rowtab(o, T[ST_RGB4_W], 64, DYN_ELU_POST);
   o.push_back(T[ST_RGB4_B][0]);
   o.resize(ST_OFF_CTC + 80, 0.f);
-  pack_rowtab(o, T[ST_RGB2_B], 64);
+  pack_rowtab(o, T[ST_RGB2_B], 64, DYN_ELU_PRE);
   o.resize(ST_OFF_REF, 0.f);
   for (int i = 0; i < 35 * 66; ++i) o.push_back(T[ST_REFFEAT_W][i]);
   for (int i = 0; i < 35; ++i) o.push_back(T[ST_REFFEAT_B][i]);
@@ -1062,7 +1067,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       net_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
     }
     acc_zero(g);
-    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? elu1(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
+    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? elu_s(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
     acc_elu(g);
   }
   if (DYN && PHASE != 2) {
@@ -1399,7 +1404,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     f32x16 a[4];
     acc_zero(a);
     net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
-    acc_elu(a);
+    acc_elu_s(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384];
     if (nvalid < 1.0f) sigma = -1e9f;
     if (valid && h == 0) p.raw[point * 4 + 3] = sigma;
@@ -1427,7 +1432,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       acc_zero(a8);
       net_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
       acc_zero(g2);
-      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? elu1(a8[s / 16][s % 16]) : one_h0; });
+      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? elu_s(a8[s / 16][s % 16]) : one_h0; });
     }
     f32x16 a[4];
     acc_zero(a);
@@ -1437,7 +1442,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       g2[s / 16][s % 16] = r;
       return r;
     });
-    acc_elu(a);
+    acc_elu_s(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384] - p.shift;
     if (nvalid < 1.0f) sigma = -1e9f;
     // rgb_fc([globalfeat, PE(view dir)])   (mlp_network.py:299-313)
@@ -1454,8 +1459,8 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     net_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
     f32x16 b2[2];
     acc_zero(b2);
-    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? elu1(a[s / 16][s % 16]) : one_h0; });
-    acc_elu(b2);
+    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? elu_s(a[s / 16][s % 16]) : one_h0; });
+    acc_elu_s(b2);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1528,8 +1533,8 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
   }
   f32x16 b2[2];
   acc_init_bias<2>(b2, ctab + 80);
-  net_layer<2, 64>(ring, b2, [&](int s) { return elu1(a[s / 16][s % 16]); });
-  acc_elu(b2);
+  net_layer<2, 64>(ring, b2, [&](int s) { return elu_s(a[s / 16][s % 16]); });
+  acc_elu_s(b2);
   float logit = row_dot<2>(b2, ctab) + ctab[64];
   if (msk == 0.f) logit = -1e9f;
   if (VSEG == 0 ? p_local >= p.PT : view >= V) logit = -3.0e38f;  // padding rows take no share even when every real view is masked (uniform 1/V then)
@@ -1627,40 +1632,40 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
   {
     const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
-    pack_net_layer(o, 8, 129, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 129, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 128) return W[n * 257 + (s < 64 ? 0 : 128) + chain_feature(s % 64, h)];
       return h == 0 ? W[n * 257 + 256] : b[n];
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 4, 129, chained(T[DT_GEO2_W], T[DT_GEO2_B], 128, 256, 256));
+  pack_net_layer(o, 4, 129, scaled_wb(chained(T[DT_GEO2_W], T[DT_GEO2_B], 128, 256, 256), 128, DYN_ELU_POST, 1.0));
   pack_net_layer(o, 4, 64, chained(T[DT_WQ], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[DT_WK], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[DT_WV], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 64, chained(T[DT_FC], nullptr, 128, 128, 128));
   {
     const float *W = T[DT_REFPTS0_W], *b = T[DT_REFPTS0_B];  // [256, 128 + 33]
-    pack_net_layer(o, 8, 81, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 8, 81, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 161 + chain_feature(s, h)];
       if (s < 79) { const int c = (s - 64) / 5, f = (s - 64) % 5; return W[n * 161 + 128 + 3 + (h * 5 + f) * 3 + c]; }
       if (s == 79) return W[n * 161 + 128 + h];
       return h == 0 ? W[n * 161 + 128 + 2] : b[n];
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 4, 129, chained(T[DT_REFPTS2_W], T[DT_REFPTS2_B], 128, 256, 256));
-  pack_net_layer(o, 4, 65, chained(T[DT_OG0_W], T[DT_OG0_B], 128, 128, 128));
+  pack_net_layer(o, 4, 129, scaled_wb(chained(T[DT_REFPTS2_W], T[DT_REFPTS2_B], 128, 256, 256), 128, DYN_ELU_POST, 1.0));
+  pack_net_layer(o, 4, 65, scaled(chained(T[DT_OG0_W], T[DT_OG0_B], 128, 128, 128), DYN_ELU_PRE));
   {
     const float *W = T[DT_RGB0_W], *b = T[DT_RGB0_B];  // [128, 128 + 27]
-    pack_net_layer(o, 4, 78, [=](int t, int i, int s, int h) -> float {
+    pack_net_layer(o, 4, 78, scaled([=](int t, int i, int s, int h) -> float {
       const int n = 32 * t + i;
       if (s < 64) return W[n * 155 + chain_feature(s, h)];
       if (s < 76) { const int c = (s - 64) / 4, f = (s - 64) % 4; return W[n * 155 + 128 + 3 + (h * 4 + f) * 3 + c]; }
       if (s == 76) return W[n * 155 + 128 + h];
       return h == 0 ? W[n * 155 + 128 + 2] : b[n];
-    });
+    }, DYN_ELU_PRE));
   }
-  pack_net_layer(o, 2, 65, chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128));
+  pack_net_layer(o, 2, 65, scaled_wb(chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128), 64, DYN_ELU_POST * DYN_ELU_PRE, DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == DY_OFF_CTA, "dynamic pack: B stream size mismatch");
   pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128, DYN_ELU_POST);
   pack_rowtab(o, T[DT_VISB2_W], 128, DYN_ELU_POST);
@@ -1674,11 +1679,11 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   o.resize(DY_OFF_CTB, 0.f);
   pack_rowtab(o, T[DT_LN_G], 128);
   pack_rowtab(o, T[DT_LN_B], 128);
-  pack_rowtab(o, T[DT_OG2_W], 128);
+  pack_rowtab(o, T[DT_OG2_W], 128, DYN_ELU_POST);
   o.push_back(T[DT_OG2_B][0]);
   for (int c = 0; c < 3; ++c) o.push_back(T[DT_RGB4_B][c]);
   o.resize(DY_OFF_CTB + 400, 0.f);
-  for (int c = 0; c < 3; ++c) pack_rowtab(o, T[DT_RGB4_W] + c * 64, 64);
+  for (int c = 0; c < 3; ++c) pack_rowtab(o, T[DT_RGB4_W] + c * 64, 64, DYN_ELU_POST);
   o.resize(DY_OFF_POSENC, 0.f);
   // sinusoid table (mlp_network.py:218-234), evaluated in double like numpy, stored in D-layout order [pos][half][64]
   for (int pos = 0; pos < DYN_MAX_SAMPLES; ++pos)
