@@ -20,6 +20,9 @@
 // products halve both.  The split happens once per element when a tile is written to LDS, not per use.
 #include "dyn_device.h"
 #include "dyn_host.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 
 typedef unsigned tr_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short tr_u16;
@@ -171,7 +174,8 @@ struct TrGemmArgs {
   float* c;
   long ldc;
   int M, N, K;
-  int k_chunk;           // k range per blockIdx.z (multiple of TG_BK)
+  int k_chunk;           // k range per blockIdx.z / reduction chunk (multiple of TG_BK)
+  int mt, nt, nz;        // ring form: row tiles, column tiles, reduction chunks (mt * nz units of nt tiles each)
   const float* bias;     // [N] or null
   const float* addend;   // [(M / add_div), ld_add] or null
   long ld_add;
@@ -455,6 +459,433 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
     }
 }
 
+// =====================================================================================================================
+// Ring form of the GEMM (round 3).  What the tile kernel above could not do: keep HBM busy while the matrix pipe works.  Its operand
+// tiles pass through registers, and LLVM's s_waitcnt insertion gives up on a register-staged software pipeline (the loop's control-flow
+// merges and its own register renaming make it wait for vmcnt(0) at every k-step), so a tile was requested only after the previous one
+// had landed: measured, the kernel's HBM time ADDED to its LDS / MFMA time (profiles/r02_train_gemm_decomposition.txt; 0.40-0.50 of the
+// HBM peak).  Staging registers filled by inline-asm loads, waited for by hand, do not survive either -- the register allocator
+// spills or copies them while the loads are in flight (tried: r03).  Here no operand byte touches a register before it is needed:
+//   * tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, inline asm: the compiler neither sees nor waits for them) into a ring
+//     of two 32 KiB slots (A | B, raw fp32); the request for step t + 1 is issued at the start of step t and waited for, by count, at the
+//     start of step t + 1 -- across tile boundaries: a workgroup is PERSISTENT and walks a sequence of tiles, so the first tiles of the next
+//     tile land while the epilogue of this one runs;
+//   * the MFMA fragments are read straight from the raw tiles and split into their two half parts in registers (per use: twice the
+//     conversions of the tile kernel, which the matrix pipe hides; no image writes, ONE barrier per k-step instead of two);
+//   * k-minor tiles [128 rows][32 k] keep their 16-byte quads XOR-swizzled -- row r holds quad q at position q ^ ((r >> 1) & 7) -- so that
+//     the fragment reads (b128, 16 lanes = 16 consecutive rows) are bank-conflict free while a DMA instruction still fetches whole
+//     128-byte lines; k-major tiles [32 k][128 rows] are read with eight b32 per fragment (lanes = consecutive rows: conflict free);
+//   * epilogue, fast form (plain 16-byte-aligned result rows): the accumulators leave through the ring slot just consumed, 64 rows per
+//     pass, and bias / per-point addend / activation derivative of the saved output / activation / column sums are applied to the
+//     row-major float4 items on their way out (coalesced 16-byte loads and stores); general form: scalar code in accumulator layout.
+// Operands it takes: k-minor with aligned quads (the tile kernel's mode 0) or k-major with 16-byte-aligned rows; anything else (a weight
+// slice with an odd row stride, one-column outputs' gradients) stays on the tile kernel.
+// =====================================================================================================================
+#define TR_SLOT_FLOATS ((TG_BM + TG_BN) * TG_BK)  // A tile | B tile, raw fp32: 32 KiB
+#define TR_RING_BYTES (2 * TR_SLOT_FLOATS * 4)    // two slots, 64 KiB: two workgroups per CU
+
+typedef float tr_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef TR_ASM_DMA
+#define TR_ASM_DMA 1
+#endif
+#ifndef TR_RX
+#define TR_RX 0  /* developer decomposition builds (tools/gemm_decompose.sh; results wrong by construction): 1 no result stores, 2 no operand requests inside the loop, 4 no MFMAs, 8 no epilogue, 16 no fragment conversions */
+#endif
+
+// at most N vector-memory operations of this wave outstanding (they complete in issue order)
+template <int N>
+__device__ __forceinline__ void tr_wait_vm() {
+#if defined(__AMDGCN__) && TR_ASM_DMA
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit count");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// 16 bytes per lane, global -> LDS without passing through registers: lane l's quad lands at wave_base + 16 l (wave_base wave-uniform)
+__device__ __forceinline__ void tr_dma16(const float* gp, float* wave_base, int lane) {
+#if defined(__AMDGCN__) && TR_ASM_DMA
+  const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)wave_base);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(off) : "m0", "memory");
+#pragma clang diagnostic pop
+#else
+  reinterpret_cast<tr_f32x4*>(wave_base)[lane] = *reinterpret_cast<const tr_f32x4*>(gp);
+#endif
+}
+
+// request one operand tile into `dst` (4096 floats).  MODE 0: [128 rows][32 k] k-minor, swizzled quads; MODE 2: [32 k][128 rows] k-major.
+// Every address is clamped into the operand (rows beyond it only feed result rows / columns that are never stored; the k tail is
+// zeroed in the fragments).
+template <int MODE>
+__device__ __forceinline__ void tr_ring_request(const TrOperand& o, int row0, int k0, int kend, float* dst, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int L = j * 256 + tid;  // the quad's position in the tile
+    const float* gp;
+    if (MODE == 0) {
+      const int row = L >> 3, kq = (L & 7) ^ ((row >> 1) & 7);
+      const int r = row0 + row, rc = r < o.nrows ? r : o.nrows - 1;
+      const int k = k0 + 4 * kq, kc = k < kend ? k : 0;  // a row holds at least round_up4(kend) floats (checked by the host wrapper)
+      gp = o.p + (long)rc * o.rs + kc;
+    } else {
+      const int kk = L >> 5, fq = L & 31;
+      const int k = k0 + kk, kc = k < kend ? k : kend - 1;
+      const int f = row0 + 4 * fq, fmax = ((o.nrows + 3) & ~3) - 4;  // a k-row holds at least round_up4(nrows) floats (host wrapper)
+      gp = o.p + (long)kc * o.ks + (f < fmax ? f : fmax);
+    }
+    tr_dma16(gp, dst + 4 * (j * 256 + wave * 64), lane);
+  }
+}
+
+// the lane's eight consecutive k of tile row `row` for the 16-k group k16 (h = lane >> 5), raw
+template <int MODE>
+__device__ __forceinline__ void tr_ring_fragment(const float* tile, int row, int k16, int h, float (&v)[8]) {
+  if (MODE == 0) {
+    const int s = (row >> 1) & 7, kq = 4 * k16 + 2 * h;
+    const tr_f32x4 q0 = *reinterpret_cast<const tr_f32x4*>(tile + 4 * (row * 8 + (kq ^ s)));
+    const tr_f32x4 q1 = *reinterpret_cast<const tr_f32x4*>(tile + 4 * (row * 8 + ((kq + 1) ^ s)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = q0[e]; v[4 + e] = q1[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(16 * k16 + 8 * h + e) * TG_BM + row];
+  }
+}
+// eight raw values -> the two MFMA operand parts (hi | mid halves)
+template <bool SCALED>
+__device__ __forceinline__ void tr_ring_split(const float (&v)[8], float scale, tr_u32x4& hi, tr_u32x4& mid) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned h, m;
+    tr_split2_pair<SCALED>(v[2 * e], v[2 * e + 1], scale, h, m);
+    hi[e] = h; mid[e] = m;
+  }
+}
+
+struct TrCursor {
+  int unit, nt;          // position in the workgroup's sequence of tiles
+  int m0, n0, kend, z;   // the tile
+  int k0;                // next k-step
+};
+__device__ __forceinline__ void tr_cursor_tile(TrCursor& c, const TrGemmArgs& g) {
+  c.z = c.unit / g.mt;
+  c.m0 = (c.unit - c.z * g.mt) * TG_BM;
+  c.n0 = c.nt * TG_BN;
+  c.k0 = c.z * g.k_chunk;
+  c.kend = g.K < c.k0 + g.k_chunk ? g.K : c.k0 + g.k_chunk;
+}
+// -> false when the sequence is exhausted (the cursor then stays on a valid tile: a request issued from it is harmless)
+__device__ __forceinline__ bool tr_cursor_advance(TrCursor& c, const TrGemmArgs& g, int units, int stride) {
+  c.k0 += TG_BK;
+  if (c.k0 < c.kend) return true;
+  int nt = c.nt + 1, unit = c.unit;
+  if (nt == g.nt) { nt = 0; unit += stride; }
+  if (unit >= units) { c.k0 -= TG_BK; return false; }
+  c.nt = nt; c.unit = unit;
+  tr_cursor_tile(c, g);
+  return true;
+}
+
+__device__ __forceinline__ float tr_act(float v, int act) {
+  if (act == 1) {
+    // ELU: exp(v) - 1 (6e-8 absolute error) away from zero, the cubic Taylor polynomial (4e-8 relative) for -0.01 < v <= 0
+    const float e = __expf(v) - 1.0f, q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
+    return v > 0.f ? v : (v > -0.01f ? q : e);
+  }
+  if (act == 2) return fmaxf(v, 0.f);  // ReLU (MotionMLP)
+  return v;
+}
+
+// A workgroup walks units blockIdx.x, blockIdx.x + gridDim.x, ... (a unit = (reduction chunk z, row tile) with its column tiles back to
+// back, so that the second column tile finds the row tile's operand in this CU's caches); grid = the resident workgroups of the device.
+template <int A_MODE, int B_MODE, bool FAST>
+__global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
+  constexpr int THREADS = 256, PASSES = 2, ITEMS = 8;  // epilogue: 64 rows per pass, quads per thread and pass
+  float* ring = reinterpret_cast<float*>(dyn_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int units = g.mt * g.nz, stride = gridDim.x;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // power-of-two scale of the gradient operand: its largest magnitude goes to [2^14, 2^15) (exact; undone in the epilogue)
+  float a_scale = 1.0f, a_unscale = 1.0f;
+  if (g.a_absmax != nullptr) {
+    const unsigned mx = __float_as_uint(g.a_absmax[0]);
+    const int e = (int)((mx >> 23) & 0xff);              // biased exponent of the largest magnitude (0: zero / subnormal tensor)
+    if (e > 0 && e < 255) {
+      const int sh = (127 + 14) - e;                       // multiply by 2^sh
+      const int shc = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+      a_scale = __uint_as_float((unsigned)(127 + shc) << 23);
+      a_unscale = __uint_as_float((unsigned)(127 - shc) << 23);
+    }
+  }
+  const bool scaled = g.a_absmax != nullptr;
+  TrCursor cur, pf;
+  int newer_stores = 0;  // vector stores the epilogue just before certainly issued: they are newer than the request the next step waits for
+
+  // ---- epilogue, fast form; Ct = the ring slot the tile's last step consumed ----
+  auto epilogue_fast = [&](const TrCursor& t, float* Ct) __attribute__((always_inline)) {
+    const int m0 = t.m0, n0 = t.n0;
+    const int n4lim = g.N >> 2, c4 = tid & 31, n4 = (n0 >> 2) + c4, n4c = n4 < n4lim ? n4 : n4lim - 1;
+    const int side = g.act_y != nullptr ? 1 : (g.addend != nullptr ? 2 : 0);
+    const bool elu_y = g.act_y_kind == 1;
+    tr_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias != nullptr && t.z == 0) bias4 = *reinterpret_cast<const tr_f32x4*>(g.bias + 4 * n4c);
+    tr_f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    float cmax = 0.f;
+    for (int pass = 0; pass < PASSES; ++pass) {
+      // the side tile's quads of this pass, requested before the accumulators move: their latency hides behind the LDS round trip
+      tr_f32x4 sv[ITEMS];
+      if (side != 0) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const int row = (tid >> 5) + (THREADS / 32) * j;
+          const int m = m0 + pass * 64 + row, mc = m < g.M ? m : g.M - 1;
+          sv[j] = *reinterpret_cast<const tr_f32x4*>(side == 1 ? g.act_y + (long)mc * g.ld_y + 4 * n4c : g.addend + (long)(mc / g.add_div) * g.ld_add + 4 * n4c);
+        }
+      }
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* crow = Ct + (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * TG_BN + wn * 64 + (lane & 31);
+            crow[0] = acc[i][0][r] * a_unscale;
+            crow[32] = acc[i][1][r] * a_unscale;
+          }
+      }
+      tr_barrier_lds();
+      tr_f32x4 res[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int row = (tid >> 5) + (THREADS / 32) * j;
+        tr_f32x4 v = *reinterpret_cast<const tr_f32x4*>(Ct + row * TG_BN + 4 * c4);
+        if (side == 1) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = sv[j][c] > 0.f ? v[c] : (elu_y ? v[c] * (sv[j][c] + 1.0f) : 0.f);
+        } else if (side == 2) {
+          v += sv[j];
+        }
+        res[j] = v + bias4;
+      }
+      if (g.act != 0) {  // one uniform branch per pass, not per element
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) res[j][c] = tr_act(res[j][c], g.act);
+      }
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int m = m0 + pass * 64 + (tid >> 5) + (THREADS / 32) * j;
+        if (m < g.M && n4 < n4lim) {
+          const tr_f32x4 v = res[j];
+          if (!(TR_RX & 1) || v[0] == 1.2345f) *reinterpret_cast<tr_f32x4*>(g.c + (long)m * g.ldc + 4 * n4) = v;
+          if (g.colsum_part != nullptr) {
+            csum += v;  // a thread keeps its four columns (c4 = tid & 31) over all its rows
+            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          }
+        }
+      }
+      tr_barrier_lds();
+    }
+    if (g.colsum_part != nullptr) {
+      // the bias gradient's share of this tile and the largest |dZ| (the next GEMMs' scale): the eight row groups meet in LDS and the workgroup
+      // writes ONE partial row / value (no atomics; k_train_colsum_reduce adds the partials)
+      *reinterpret_cast<tr_f32x4*>(Ct + (tid >> 5) * 128 + 4 * c4) = csum;
+      cmax = wave_max(cmax);
+      if (lane == 0) Ct[(THREADS / 32) * 128 + wave] = cmax;
+      tr_barrier_lds();
+      if (tid < 128 && n0 + tid < g.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < THREADS / 32; ++k) s += Ct[k * 128 + tid];
+        g.colsum_part[(long)(m0 / TG_BM) * g.ld_part + n0 + tid] = s;
+      }
+      if (tid == 0) {
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < THREADS / 64; ++k) mx = fmaxf(mx, Ct[(THREADS / 32) * 128 + k]);
+        g.amax_part[(long)(m0 / TG_BM) * g.nt + t.nt] = mx;
+      }
+      tr_barrier_lds();  // the slot is the next request's target
+    }
+    newer_stores = (m0 + TG_BM <= g.M && n0 + TG_BN <= g.N) ? 16 : 0;
+  };
+
+  // ---- epilogue, general form: D layout -- lane (j = lane & 31: column n, h = lane >> 5), register r: row (r & 3) + 8 (r >> 2) + 4 h ----
+  auto epilogue_general = [&](const TrCursor& t) __attribute__((always_inline)) {
+    const int m0 = t.m0, n0 = t.n0;
+    const int nA = n0 + wn * 64 + (lane & 31), nB = nA + 32;
+    const int nAc = nA < g.N ? nA : g.N - 1, nBc = nB < g.N ? nB : g.N - 1;
+    const int mbase = m0 + wm * 64 + 4 * h;
+    const bool okA = nA < g.N, okB = nB < g.N;
+    const bool elu_y = g.act_y_kind == 1;
+    float bA = 0.f, bB = 0.f;
+    if (g.bias != nullptr && t.z == 0) { bA = g.bias[nAc]; bB = g.bias[nBc]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const int mc = m < g.M ? m : g.M - 1;
+        float vA = acc[i][0][r] * a_unscale, vB = acc[i][1][r] * a_unscale;
+        if (g.act_y != nullptr) {  // dZ = dX * act'(Y): the activation-derivative pass folded into the data gradient that feeds it
+          const float* yrow = g.act_y + (long)mc * g.ld_y;
+          const float yA = yrow[nAc], yB = yrow[nBc];
+          vA = yA > 0.f ? vA : (elu_y ? vA * (yA + 1.0f) : 0.f);
+          vB = yB > 0.f ? vB : (elu_y ? vB * (yB + 1.0f) : 0.f);
+        }
+        if (g.addend != nullptr) {
+          const float* add = g.addend + (long)(mc / g.add_div) * g.ld_add;
+          vA += add[nAc];
+          vB += add[nBc];
+        }
+        vA = tr_act(vA + bA, g.act);
+        vB = tr_act(vB + bB, g.act);
+        if (m < g.M) {
+          float* crow = g.c + (long)m * g.ldc;
+          if (g.accumulate == 0) {
+            if (okA) crow[nA] = vA;
+            if (okB) crow[nB] = vB;
+          } else {  // += : fire-and-forget fp32 atomics (no read latency in the epilogue)
+            if (okA) atomicAdd(crow + nA, vA);
+            if (okB) atomicAdd(crow + nB, vB);
+          }
+        }
+      }
+    newer_stores = 0;
+  };
+
+  cur.unit = blockIdx.x; cur.nt = 0;
+  tr_cursor_tile(cur, g);
+  pf = cur;
+  auto request = [&](int slot) __attribute__((always_inline)) {
+    float* dst = ring + slot * TR_SLOT_FLOATS;
+    tr_ring_request<A_MODE>(g.a, pf.m0, pf.k0, pf.kend, dst, tid);
+    tr_ring_request<B_MODE>(g.b, pf.n0, pf.k0, pf.kend, dst + TG_BM * TG_BK, tid);
+    tr_cursor_advance(pf, g, units, stride);
+  };
+  request(0);
+
+  // one k-step on ring slot SLOT
+  auto step = [&](auto slot_tag) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    float* At = ring + SLOT * TR_SLOT_FLOATS;
+    float* Bt = At + TG_BM * TG_BK;
+    // this step's tiles (the only request in flight; the stores of an epilogue just before are newer) have landed -- in every wave,
+    // after the barrier, which also says that every wave has finished reading the other slot: it takes the next request
+    if (newer_stores != 0) tr_wait_vm<16>();
+    else tr_wait_vm<0>();
+    newer_stores = 0;
+    tr_barrier_lds();
+    if (!(TR_RX & 2)) request(SLOT ^ 1);
+    else tr_cursor_advance(pf, g, units, stride);
+    const bool k_edge = cur.k0 + TG_BK > cur.kend;
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16) {
+      tr_u32x4 a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float va[8], vb[8];
+        tr_ring_fragment<A_MODE>(At, wm * 64 + i * 32 + (lane & 31), k16, h, va);
+        tr_ring_fragment<B_MODE>(Bt, wn * 64 + i * 32 + (lane & 31), k16, h, vb);
+        if (k_edge) {  // the k tail of a tile (its last step only): both operands, a zero times a stray NaN is a NaN
+          const int kb = cur.k0 + 16 * k16 + 8 * h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            va[e] = kb + e < cur.kend ? va[e] : 0.f;
+            vb[e] = kb + e < cur.kend ? vb[e] : 0.f;
+          }
+        }
+        if (TR_RX & 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[i][0][e] = __float_as_uint(va[e]); a[i][1][e] = __float_as_uint(va[4 + e]); b[i][0][e] = __float_as_uint(vb[e]); b[i][1][e] = __float_as_uint(vb[4 + e]); }
+        } else {
+          if (scaled) tr_ring_split<true>(va, a_scale, a[i][0], a[i][1]);
+          else tr_ring_split<false>(va, 1.0f, a[i][0], a[i][1]);
+          tr_ring_split<false>(vb, 1.0f, b[i][0], b[i][1]);
+        }
+      }
+      // the three partial products of a tile form a dependent chain through its accumulator: issue them term by term ACROSS the four
+      // tiles so that consecutive MFMAs are independent (smallest partial products first: mid.hi, hi.mid, hi.hi)
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (TR_RX & 4) acc[i][j][term] += __uint_as_float(a[i][pa][0] ^ b[j][pb][0]);
+            else acc[i][j] = tr_mfma(a[i][pa], b[j][pb], acc[i][j]);
+          }
+      }
+    }
+    if ((TR_RX & 8) && cur.k0 + TG_BK >= cur.kend) {
+      if (acc[0][0][0] == 1.2345f) g.c[tid] = acc[1][1][3];
+    } else if (cur.k0 + TG_BK >= cur.kend) {  // the tile's last step
+      if (FAST) {
+        tr_barrier_lds();  // every wave has finished reading the slot: it takes the result tile (64 rows x 128 floats per pass)
+        epilogue_fast(cur, At);
+      } else {
+        epilogue_general(cur);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+  };
+  for (;;) {
+    step(std::integral_constant<int, 0>{});
+    if (!tr_cursor_advance(cur, g, units, stride)) break;
+    step(std::integral_constant<int, 1>{});
+    if (!tr_cursor_advance(cur, g, units, stride)) break;
+  }
+  tr_wait_vm<0>();  // the request past the end of the sequence must land before the workgroup's LDS is released
+}
+
+// resident workgroups of k_train_gemm_ring<A, B, F> per device: the persistent kernel's grid (queried once per instantiation and device)
+template <int A_MODE, int B_MODE, bool FAST>
+static int tr_ring_slots() {
+  static int slots[DYN_MAX_DEVICES] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int d = (dev >= 0 && dev < DYN_MAX_DEVICES) ? dev : 0;
+  if (slots[d] == 0) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_gemm_ring<A_MODE, B_MODE, FAST>, 256, TR_RING_BYTES) != hipSuccess || per_cu < 1) per_cu = 2;
+    const int n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    slots[d] = per_cu * n_cu;
+  }
+  return slots[d];
+}
+// which form takes a product: 0 automatic -- the ring form for the backward products (weight gradient: both operands stream from HBM,
+// +25-35 % measured; data gradient: +0-10 %), the tile kernel for the forward ones (ring: -8 %; four workgroups per CU hide its long
+// epilogue better than the ring's two) --, 1 tile kernel only, 2 ring form wherever the operands allow it.  DYNIBAR_TRAIN_GEMM = auto | tile |
+// ring sets the initial value; dyn_train_gemm_mode() changes it (A/B timing, tests).
+static int g_tr_gemm_mode = -1;
+static int tr_gemm_mode() {
+  if (g_tr_gemm_mode < 0) {
+    const char* e = getenv("DYNIBAR_TRAIN_GEMM");
+    g_tr_gemm_mode = e == nullptr ? 0 : (strcmp(e, "tile") == 0 ? 1 : (strcmp(e, "ring") == 0 ? 2 : 0));
+  }
+  return g_tr_gemm_mode;
+}
+extern "C" int dyn_train_gemm_mode(int mode) {
+  DYN_REQUIRE(mode >= 0 && mode <= 2, "dyn_train_gemm_mode: mode %d (0 automatic, 1 tile, 2 ring)", mode);
+  g_tr_gemm_mode = mode;
+  return 0;
+}
+
 extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   DYN_REQUIRE(p != nullptr && p->A && p->B && p->C, "dyn_train_gemm: null pointer");
   DYN_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "dyn_train_gemm: empty problem (M %d N %d K %d)", p->M, p->N, p->K);
@@ -480,6 +911,34 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
               "dyn_train_gemm: colsum_part needs plain 16-byte-aligned stores (accumulate 0, N and ldc multiples of 4), amax_part and ld_part >= N");
   g.colsum_part = p->colsum_part; g.ld_part = p->ld_part; g.amax_part = p->amax_part;
   g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
+  g.mt = dyn_cdiv(p->M, TG_BM); g.nt = dyn_cdiv(p->N, TG_BN); g.nz = nz;
+  {
+    // ring form: each operand k-minor with aligned quads (the tile kernel's mode 0) or k-major with 16-byte-aligned k-rows
+    const int k4r = (p->K + 3) & ~3;
+    auto ring_mode = [&](const TrOperand& o) -> int {
+      if (!o.aligned) return -1;
+      if (o.ks == 1) return ((o.rs & 3) == 0 && o.rs >= k4r) ? 0 : -1;
+      return ((o.ks & 3) == 0 && o.ks >= ((o.nrows + 3) & ~3)) ? 2 : -1;
+    };
+    const int ra = ring_mode(g.a), rb = ring_mode(g.b);
+    const bool add_vec = p->addend == nullptr || ((p->ld_add & 3) == 0 && ((uintptr_t)p->addend & 15) == 0);
+    const bool fast = g.c_vec && (p->bias == nullptr || ((uintptr_t)p->bias & 15) == 0) && (p->act_y == nullptr || g.act_y_vec) && add_vec &&
+                      !(p->act_y != nullptr && p->addend != nullptr);
+    const int mode = tr_gemm_mode();
+    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)))) {
+      const long units = (long)g.mt * g.nz;
+#define TG_RING(A, B, F)                                                                                                                   \
+  if (ra == A && rb == B && fast == F) {                                                                                                   \
+    const long slots = tr_ring_slots<A, B, F>();                                                                                           \
+    const dim3 rgrid((unsigned)(units < slots ? units : slots));                                                                           \
+    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm_ring<A, B, F>), rgrid, dim3(256), TR_RING_BYTES, (hipStream_t)stream, g);  \
+    return 0;                                                                                                                              \
+  }
+      TG_RING(0, 0, true) TG_RING(0, 0, false) TG_RING(0, 2, true) TG_RING(0, 2, false)
+      TG_RING(2, 0, true) TG_RING(2, 0, false) TG_RING(2, 2, true) TG_RING(2, 2, false)
+#undef TG_RING
+    }
+  }
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major

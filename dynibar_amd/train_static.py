@@ -88,9 +88,19 @@ class _Lin:
     self.W, self.bias, self.col0 = W, bias, col0
     self.n_out, self.k_full = W.shape
     self.K = self.k_full - col0 if K is None else K
+    # The operand of the forward and data-gradient products: the weight slice itself when its rows are 16-byte aligned, else a copy with
+    # the row stride padded to a multiple of four floats (made once per step; the GEMM's ring form takes aligned quads only, and an odd
+    # stride -- ray_dir_fc.0: 103, base_fc.0: 210, rgb_fc.0: 261 ... -- would leave these layers on the slower tile form).
+    if self.k_full % 4 == 0 and col0 % 4 == 0 and W.data_ptr() % 16 == 0:
+      self.Wop, self.op_off, self.op_ld = W, col0, self.k_full
+    else:
+      k4 = (self.K + 3) // 4 * 4
+      self.Wop = torch.zeros((self.n_out, k4), dtype=torch.float32, device=W.device)
+      self.Wop[:, :self.K].copy_(W[:, col0:col0 + self.K])
+      self.op_off, self.op_ld = 0, k4
 
   def fwd(self, st, X, x_off, ldx, Y, y_off, ldy, M, act=NONE, addend=None, ld_add=0, add_div=1, bias=True):
-    _gemm(st, _p(X, x_off), ldx, 1, _p(self.W, self.col0), self.k_full, 1, _p(Y, y_off), ldy, M, self.n_out, self.K,
+    _gemm(st, _p(X, x_off), ldx, 1, _p(self.Wop, self.op_off), self.op_ld, 1, _p(Y, y_off), ldy, M, self.n_out, self.K,
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
           ld_add=ld_add, add_div=add_div, act=act)
 
@@ -107,7 +117,7 @@ class _Lin:
       am = _Scalars.take(dZ.device)
       call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
       dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
-    ks = max(1, min(512, M // 1024))
+    ks = max(1, min(1024, M // 1024))  # reduction chunks of the weight gradient: enough (row tile, chunk) units for every resident workgroup
     _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
           a_absmax=_p(am))
     if dX is not None:
@@ -115,12 +125,12 @@ class _Lin:
       sums = dbias is not None and acc_dx == 0 and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0
       if sums:
         tiles, ctiles = (M + 127) // 128, (self.K + 127) // 128
-        part = torch.empty((tiles, self.K), dtype=torch.float32, device=dX.device)
-        apart = torch.empty(tiles * ctiles, dtype=torch.float32, device=dX.device)
+        part = torch.zeros((tiles, self.K), dtype=torch.float32, device=dX.device)  # zeroed: the kernel's row tile is 128 or 256 rows
+        apart = torch.zeros(tiles * ctiles, dtype=torch.float32, device=dX.device)
         fy.update(colsum_part=_p(part), ld_part=self.K, amax_part=_p(apart))
       if acc_dx != 0:
         _untag(dX)
-      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.W, self.col0), 1, self.k_full, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
+      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
             a_absmax=_p(am), **fy)
       if sums:
         am2 = _Scalars.take(dX.device)

@@ -300,13 +300,18 @@ typedef struct {
                           * (mlp_network.py:342-397, 587-603).  NULL to skip; needs accumulate = 0 */
   long ld_y;
   int act_y_kind;        /* 1 ELU, 2 ReLU */
-  float* colsum_part;    /* [ceil(M / 128), ld_part]: every workgroup leaves the column sums of its result tile here (the partial sums of the NEXT
+  float* colsum_part;    /* [ceil(M / 128), ld_part], ZEROED by the caller: a workgroup leaves the column sums of its result tile (128 or 256 rows:
+                          * the kernel form's choice, so not every row is written) in row (tile index) -- the partial sums of the NEXT
                           * bias gradient: autograd of nn.Linear's bias, mlp_network.py:342-397) -- NULL to skip; needs accumulate = 0 and
                           * 16-byte-aligned result rows (N, ldc multiples of 4) */
   long ld_part;
-  float* amax_part;      /* [ceil(M / 128) * ceil(N / 128)]: largest |result| per workgroup (required with colsum_part) */
+  float* amax_part;      /* [ceil(M / 128) * ceil(N / 128)], zeroed by the caller: largest |result| per workgroup (required with colsum_part) */
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
+/* Developer / test knob: which kernel form dyn_train_gemm uses -- 0 automatic (default; the environment variable DYNIBAR_TRAIN_GEMM =
+ * auto | tile | ring sets the initial value: the ring form for the backward products, the tile kernel for the forward ones), 1 the tile
+ * kernel only, 2 the ring form wherever the operands allow it.  Results do not depend on it beyond the summation order. */
+int dyn_train_gemm_mode(int mode);
 /* second stage of colsum_part / amax_part: dbias[n] += sum over the tiles (dbias may be NULL), *absmax = max(*absmax, all of amax_part) */
 int dyn_train_colsum_reduce(const float* colsum_part, long tiles, int N, long ld_part, float* dbias, const float* amax_part, long n_amax,
                             float* absmax, void* stream);

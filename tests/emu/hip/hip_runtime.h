@@ -60,6 +60,8 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; int clockRate; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 7; p->clockRate = 1000000; return hipSuccess; }
 static inline hipError_t hipStreamGetDevice(hipStream_t, int* d) { *d = 0; return hipSuccess; }
+template <class F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }  // 7 "CUs" x 1: persistent kernels walk several tiles per workgroup
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 
 namespace emu {

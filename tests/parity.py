@@ -1252,6 +1252,53 @@ def check_train_gemm(device):
   dW = torch.zeros_like(W)
   TS._Lin(W).bwd(TS.stream_of(X), dZ, 0, 1, X, 0, 64, dW, M)
   assert_close(dW, dZ.double().cpu().T @ X.double().cpu(), 2e-4, 2e-6, 'train gemm split weight gradient')
+  check_train_gemm_many_tiles(device)
+  from dynibar_amd._lib import call
+  try:  # the same with every product on the ring form, and with every product on the tile kernel
+    for mode, M in ((2, None), (1, 1100)):
+      call('dyn_train_gemm_mode', mode)
+      check_train_gemm_many_tiles(device, M)
+  finally:
+    call('dyn_train_gemm_mode', 0)
+
+
+def check_train_gemm_many_tiles(device, M=None):
+  """The ring form's persistent walk: more tiles than resident workgroups (512 on an MI355X; 7 in the emulator), so that a workgroup passes
+  from one tile to the next with the next tile's first operand tiles already requested -- forward with bias, per-point addend and ELU
+  over two column tiles and a k range that is not a multiple of the step (72: 3 steps, the last one half empty), data gradient with the
+  activation derivative and the column sums, weight gradient over many reduction chunks; weight slices with an odd row stride (the
+  padded operand copy)."""
+  from dynibar_amd import train_static as TS
+  g = torch.Generator().manual_seed(11)
+  if M is None:
+    M = 70003 if str(device).startswith('cuda') else 1100
+  V, K, N, col0, kfull = 7, 70, 200, 140, 211
+  P = (M + V - 1) // V
+  X = torch.randn(M, 72, generator=g).to(device)
+  Wfull = (torch.randn(N, kfull, generator=g) * 0.3).to(device)
+  b = torch.randn(N, generator=g).to(device)
+  Pp = torch.randn(P, N, generator=g).to(device)
+  Y = torch.full((M, N), float('nan'), device=device)
+  lin = TS._Lin(Wfull, b, col0, K)
+  st = TS.stream_of(X)
+  lin.fwd(st, X, 0, 72, Y, 0, N, M, TS.ELU, addend=Pp, ld_add=N, add_div=V)
+  Wd = Wfull[:, col0:col0 + K].double().cpu()
+  ref = torch.nn.functional.elu(X[:, :K].double().cpu() @ Wd.T + b.double().cpu() + Pp.double().cpu().repeat_interleave(V, 0)[:M])
+  assert_close(Y, ref, 1e-5, 4e-6, 'train gemm (many tiles) forward')
+  dZ = (torch.randn(M, N, generator=g) * 1e-4).to(device)
+  dW = torch.zeros_like(Wfull)
+  dX = torch.full((M, 72), float('nan'), device=device)
+  Ysaved = torch.where(X > 0, X, torch.expm1(X))  # the saved output of the layer that produced X (its first K = 70 columns matter; 72 are read)
+  db = torch.zeros(K, device=device)
+  lin.bwd(st, dZ, 0, N, Ysaved, 0, 72, dW, M, dX, 0, 72, act_y=(Ysaved, 0, 72, TS.ELU), dbias=db)
+  y = Ysaved[:, :K].double().cpu()
+  der = torch.where(y > 0, torch.ones_like(y), y + 1.0)
+  big = float(dZ.abs().max())
+  refx = (dZ.double().cpu() @ Wd) * der
+  assert_close(dX[:, :K], refx, 3e-6 * big * 4, 4e-6, 'train gemm (many tiles) data gradient x ELU\'')
+  refw = dZ.double().cpu().T @ Ysaved[:, :K].double().cpu()
+  assert_close(dW[:, col0:col0 + K], refw, 2e-6 * float(refw.abs().max()), 4e-6, 'train gemm (many tiles) weight gradient')
+  assert float(dW[:, :col0].abs().max()) == 0.0 and float(dW[:, col0 + K:].abs().max()) == 0.0, 'weight gradient outside the slice'
 
 
 def oracle_bootstrap_step(kid, w, jitter_seed=None):
