@@ -1795,6 +1795,153 @@ __global__ void __launch_bounds__(256) k_train_vis_split_bwd(const float* __rest
     dxv[row * ld_dxv + 128] = dvis0[row] * mask[row] * sg * (1.0f - sg);
   }
 }
+// ---- two passes in one: the row-scale / visibility-split backward followed by the activation derivative of the layer whose output the
+// gradient has now been collected for (round 3; before: `..._bwd` wrote dX and dyn_train_act_bwd read and rewrote it -- three passes over
+// the row matrix saved per call, and for the 129-column vis_fc.2 the scalar form of that kernel).  128 columns as 32 float4 lanes per
+// row; a block's eight lane groups own consecutive spans of rows, four rows per trip (every load of a trip in flight before the first use);
+// bias gradient: the groups' partial column sums meet in LDS, one atomic per column and block; largest |result| -> *absmax. ----
+#define TR_FUSE_SPAN 256  // rows per lane group: 2048 rows per block (same-address atomics per column: see k_train_act_bwd)
+__device__ __forceinline__ float tr_dact(float y, int act) { return y > 0.f ? 1.0f : (act == 1 ? y + 1.0f : 0.f); }
+
+// dx = (dx + dy * s[row]) * act'(x)   (x: the saved OUTPUT of the activation, which is also what s multiplied in the forward pass),
+// ds[row] (=|+=) <dy[row], x[row]>
+__global__ void __launch_bounds__(256) k_train_rowscale_act_bwd4(const float4* __restrict__ dy, long ld_dy4, const float4* __restrict__ x, long ldx4,
+                                                                 const float* __restrict__ s, long s_stride, long N, float4* __restrict__ dx,
+                                                                 long ld_dx4, float* __restrict__ ds, long ds_stride, int ds_accumulate, int act,
+                                                                 float* __restrict__ dbias, float* __restrict__ absmax) {
+  float4* part = dyn_smem;  // [8][32] partial column sums
+  const int g = threadIdx.x >> 5, q = threadIdx.x & 31;
+  const long ra = ((long)blockIdx.x * 8 + g) * TR_FUSE_SPAN;
+  const long rb = ra + TR_FUSE_SPAN < N ? ra + TR_FUSE_SPAN : N;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amax = 0.f;
+  // the trip count is the same for the two lane groups of a wave (its shuffles need every lane): rows beyond a group's span are clamped
+  // (loaded again, never stored)
+  const long ra_even = ((long)blockIdx.x * 8 + (g & ~1)) * TR_FUSE_SPAN;
+  for (int t = 0; t < TR_FUSE_SPAN && ra_even + t < N; t += 4) {
+    const long r = ra + t;
+    float4 d[4], xv[4], o[4];
+    float sv[4], dsv[4];
+    long rr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rr[u] = r + u < N ? r + u : N - 1;
+      d[u] = dy[rr[u] * ld_dy4 + q];
+      xv[u] = x[rr[u] * ldx4 + q];
+      o[u] = dx[rr[u] * ld_dx4 + q];
+      sv[u] = s[rr[u] * s_stride];
+      dsv[u] = ds_accumulate ? ds[rr[u] * ds_stride] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float dot = (d[u].x * xv[u].x + d[u].y * xv[u].y) + (d[u].z * xv[u].z + d[u].w * xv[u].w);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+      float4 v = make_float4(o[u].x + d[u].x * sv[u], o[u].y + d[u].y * sv[u], o[u].z + d[u].z * sv[u], o[u].w + d[u].w * sv[u]);
+      if (act != 0) {
+        v.x *= tr_dact(xv[u].x, act); v.y *= tr_dact(xv[u].y, act); v.z *= tr_dact(xv[u].z, act); v.w *= tr_dact(xv[u].w, act);
+      }
+      if (r + u < rb) {
+        dx[rr[u] * ld_dx4 + q] = v;
+        if (q == 0) ds[rr[u] * ds_stride] = dsv[u] + dot;
+        colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+  }
+  part[g * 32 + q] = colsum;
+  __syncthreads();
+  if (dbias != nullptr && threadIdx.x < 128) {
+    const float* pf = reinterpret_cast<const float*>(part);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += pf[k * 128 + threadIdx.x];
+    atomicAdd(dbias + threadIdx.x, t);
+  }
+  if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
+}
+extern "C" int dyn_train_rowscale_act_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, float* dx,
+                                          long ld_dx, float* ds, long ds_stride, int ds_accumulate, int act, float* dbias, float* absmax,
+                                          void* stream) {
+  DYN_REQUIRE(dy && x && s && dx && ds && N > 0, "dyn_train_rowscale_act_bwd: bad arguments");
+  DYN_REQUIRE(act >= 0 && act <= 2, "dyn_train_rowscale_act_bwd: act %d (0 none, 1 ELU, 2 ReLU)", act);
+  DYN_REQUIRE(((ld_dy | ldx | ld_dx) & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0,
+              "dyn_train_rowscale_act_bwd: 128 columns in 16-byte-aligned rows (leading dimensions multiples of 4 floats)");
+  const long blocks = (N + 8L * TR_FUSE_SPAN - 1) / (8L * TR_FUSE_SPAN);
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowscale_act_bwd", k_train_rowscale_act_bwd4, dim3((unsigned)blocks), dim3(256), 257 * sizeof(float4),
+             (hipStream_t)stream, reinterpret_cast<const float4*>(dy), ld_dy / 4, reinterpret_cast<const float4*>(x), ldx / 4, s, s_stride, N,
+             reinterpret_cast<float4*>(dx), ld_dx / 4, ds, ds_stride, ds_accumulate, act, dbias, absmax);
+  return 0;
+}
+
+// dxv[:, 0:128] = dx2 * ELU'(xv[:, 0:128]),  dxv[:, 128] = dvis0 * mask * sigmoid'(xv[:, 128]) * ELU'(xv[:, 128]): the split's backward
+// and the ELU of vis_fc.2 (129 outputs) in one pass; dbias[129] += column sums
+__global__ void __launch_bounds__(256) k_train_vis_split_act_bwd4(const float4* __restrict__ dx2, long ld_dx24, const float* __restrict__ dvis0,
+                                                                  const float* __restrict__ xv, long ldv, const float* __restrict__ mask, long N,
+                                                                  float* __restrict__ dxv, long ld_dxv, float* __restrict__ dbias,
+                                                                  float* __restrict__ absmax) {
+  float4* part = dyn_smem;                                        // [8][32] partial column sums
+  float* part_v = reinterpret_cast<float*>(dyn_smem + 256) + 8;   // [8] partial sums of column 128 (behind tr_block_absmax's four floats)
+  const int g = threadIdx.x >> 5, q = threadIdx.x & 31;
+  const long ra = ((long)blockIdx.x * 8 + g) * TR_FUSE_SPAN;
+  const long rb = ra + TR_FUSE_SPAN < N ? ra + TR_FUSE_SPAN : N;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float vsum = 0.f, amax = 0.f;
+  for (long r = ra; r < rb; r += 4) {
+    float4 d[4], y[4];
+    float yv[4], dv[4], mk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + u < rb ? r + u : rb - 1;
+      d[u] = dx2[rr * ld_dx24 + q];
+      y[u] = *reinterpret_cast<const float4*>(xv + rr * ldv + 4 * q);
+      if (q == 0) { yv[u] = xv[rr * ldv + 128]; dv[u] = dvis0[rr]; mk[u] = mask[rr]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u >= rb) continue;
+      const float4 v = make_float4(d[u].x * tr_dact(y[u].x, 1), d[u].y * tr_dact(y[u].y, 1), d[u].z * tr_dact(y[u].z, 1), d[u].w * tr_dact(y[u].w, 1));
+      *reinterpret_cast<float4*>(dxv + (r + u) * ld_dxv + 4 * q) = v;
+      colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      if (q == 0) {
+        const float sg = tr_sigmoid(yv[u]);
+        const float w = dv[u] * mk[u] * sg * (1.0f - sg) * tr_dact(yv[u], 1);
+        dxv[(r + u) * ld_dxv + 128] = w;
+        vsum += w;
+        amax = fmaxf(amax, fabsf(w));
+      }
+    }
+  }
+  part[g * 32 + q] = colsum;
+  if (q == 0) part_v[g] = vsum;
+  __syncthreads();
+  if (dbias != nullptr && threadIdx.x < 128) {
+    const float* pf = reinterpret_cast<const float*>(part);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += pf[k * 128 + threadIdx.x];
+    atomicAdd(dbias + threadIdx.x, t);
+  }
+  if (dbias != nullptr && threadIdx.x == 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part_v[k];
+    atomicAdd(dbias + 128, t);
+  }
+  if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
+}
+extern "C" int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
+                                           float* dxv, long ld_dxv, float* dbias, float* absmax, void* stream) {
+  DYN_REQUIRE(dx2 && dvis0 && xv && mask && dxv && N > 0, "dyn_train_vis_split_act_bwd: bad arguments");
+  DYN_REQUIRE(((ld_dx2 | ldv | ld_dxv) & 3) == 0 && ldv >= 129 && ld_dxv >= 129 && (((uintptr_t)dx2 | (uintptr_t)xv | (uintptr_t)dxv) & 15) == 0,
+              "dyn_train_vis_split_act_bwd: rows must be 16-byte aligned (leading dimensions multiples of 4 floats, >= 129 for xv / dxv)");
+  const long blocks = (N + 8L * TR_FUSE_SPAN - 1) / (8L * TR_FUSE_SPAN);
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split_act_bwd", k_train_vis_split_act_bwd4, dim3((unsigned)blocks), dim3(256), 260 * sizeof(float4),
+             (hipStream_t)stream, reinterpret_cast<const float4*>(dx2), ld_dx2 / 4, dvis0, xv, ldv, mask, N, dxv, ld_dxv, dbias, absmax);
+  return 0;
+}
+
 extern "C" int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, const float* mask, const float* ray_diff, long N, float* x2,
                                    long ld2, float* vis0, void* stream) {
   DYN_REQUIRE(x1 && xv && mask && x2 && vis0 && N > 0, "dyn_train_vis_split: bad arguments");

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
-from .train_static import ELU, NONE, _Lin, _act_bwd, _p, _untag, zero_grads
+from .train_static import ELU, NONE, _Lin, _act_bwd, _p, _rowscale_act_bwd, _split_act_bwd, _untag, zero_grads
 
 PARAM_NAMES = ops.DYNAMIC_TENSORS
 
@@ -196,16 +196,14 @@ def _backward(s, draw):
   _untag(dX)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
   dXV, dH3, dXW, scratch = new(N, 132), new(N, 128), new(N, 128), new(N)
-  call('dyn_train_vis_split_bwd', _p(dX), 128, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
-  _act_bwd(st, dXV, 0, 132, s.XV, 0, 132, N, 129, ELU, g['vis_fc.2.bias'])
+  _split_act_bwd(st, dX, 128, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
-  _untag(dX)
-  call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dX), 128, 1, _p(scratch), 1, 0, st)  # w1 = mask / sum: no parameter behind it
+  # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass (w1 = mask / sum: no parameter behind it)
+  _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dX, 128, scratch, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 36), new(P, 72)
-  _act_bwd(st, dX, 0, 128, s.X1, 0, 128, N, 128, ELU, g['base_fc.2.bias'])
   L['b2'].bwd(st, dX, 0, 128, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 36, g['base_fc.0.weight'], N, dF, 0, 36)

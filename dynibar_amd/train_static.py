@@ -147,6 +147,21 @@ def _act_bwd(st, dY, dy_off, ld_dy, Y, y_off, ld_y, rows, cols, act, dbias=None,
   dY._dyn_absmax = ((dy_off, ld_dy, rows, cols), am)  # largest |dZ|: the scale of the backward GEMMs that consume this tensor
 
 
+def _rowscale_act_bwd(st, dY, ld_dy, X, ldx, s_row, rows, dX, ld_dx, ds, ds_accumulate, act, dbias):
+  """dX[:, :128] = (dX[:, :128] + dY * s_row[:, None]) * act'(X); ds (=|+=) <dY, X> per row; dbias += column sums; dX tagged with its scale."""
+  am = _Scalars.take(dX.device)
+  call('dyn_train_rowscale_act_bwd', _p(dY), ld_dy, _p(X), ldx, _p(s_row), 1, rows, _p(dX), ld_dx, _p(ds), 1, ds_accumulate, act,
+       _p(dbias) if dbias is not None else None, _p(am), st)
+  dX._dyn_absmax = ((0, ld_dx, rows, 128), am)
+
+
+def _split_act_bwd(st, dX2, ld_dx2, dvis0, XV, mask_eff, rows, dXV, dbias):
+  """dXV [rows, 132] (129 used) = backward of vis_split through vis_fc.2's ELU (saved output XV [rows, 132]); dbias[129] += column sums."""
+  am = _Scalars.take(dXV.device)
+  call('dyn_train_vis_split_act_bwd', _p(dX2), ld_dx2, _p(dvis0), _p(XV), 132, _p(mask_eff), rows, _p(dXV), 132, _p(dbias), _p(am), st)
+  dXV._dyn_absmax = ((0, 132, rows, 129), am)
+
+
 PARAM_NAMES = tuple(n for n in ops.STATIC_TENSORS)  # state-dict order; 's' (last) only exists with anti_alias_pooling
 
 
@@ -332,17 +347,15 @@ def _backward(s, draw):
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
   # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
   dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
-  call('dyn_train_vis_split_bwd', _p(dRIN), 136, _p(dvis0), _p(s.XV), 132, _p(s.M), N, _p(dXV), 132, st)
-  _act_bwd(st, dXV, 0, 132, s.XV, 0, 132, N, 129, ELU, g['vis_fc.2.bias'])
+  _split_act_bwd(st, dRIN, 136, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
   dw1 = new(N)
-  _untag(dRIN)
-  call('dyn_train_rowscale_bwd', _p(dXW), 128, _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(dRIN), 136, 1, _p(dw1), 1, 0, st)
+  # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass
+  _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dRIN, 136, dw1, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 72), new(P, 140)
-  _act_bwd(st, dRIN, 0, 136, s.X1, 0, 128, N, 128, ELU, g['base_fc.2.bias'])
   L['b2'].bwd(st, dRIN, 0, 136, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 72, g['base_fc.0.weight'], N, dF, 0, 72)

@@ -363,6 +363,16 @@ int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, co
                         long ld2, float* vis0, void* stream);
 int dyn_train_vis_split_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N, float* dxv,
                             long ld_dxv, void* stream);
+/* The two calls above followed by dyn_train_act_bwd in ONE pass over the rows (128 columns, 16-byte-aligned rows):
+ *  dyn_train_rowscale_act_bwd: dx = (dx + dy * s[row]) * act'(x), ds[row] (=|+=) <dy[row], x[row]> -- x is both what s multiplied in the
+ *    forward pass and the saved output of the activation in front of it (mlp_network.py:466-470: x = base_fc(...); vis_fc(x * weight));
+ *  dyn_train_vis_split_act_bwd: dxv[:, 0:128] = dx2 * ELU'(xv[:, 0:128]), dxv[:, 128] = dvis0 * mask * sigmoid'(xv[:, 128]) * ELU'(xv[:, 128])
+ *    (mlp_network.py:470-473: vis_fc ends in an ELU over its 129 outputs).
+ * dbias (may be NULL) += the column sums of the result (128 / 129 entries), absmax (may be NULL) = max(absmax, largest |result|). */
+int dyn_train_rowscale_act_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, float* dx,
+                               long ld_dx, float* ds, long ds_stride, int ds_accumulate, int act, float* dbias, float* absmax, void* stream);
+int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
+                                float* dxv, long ld_dxv, float* dbias, float* absmax, void* stream);
 
 /* ScaledDotProductAttention (mlp_network.py:13-31) for 4 heads of 32: qkv [P,384] = q | k | v, nvalid [P] = views that see the point
  * (query rows with nvalid <= 1 are masked, :24 and :486-488), out [P,128], prob [R,4,S,S] saved for the backward;
