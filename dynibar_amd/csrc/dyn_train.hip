@@ -191,6 +191,7 @@ struct TrGemmArgs {
   float* colsum_part;    // [row tiles, ld_part] per-workgroup column sums of the result (the bias gradient's partial sums), or null (needs c_vec)
   long ld_part;
   float* amax_part;      // [row tiles * column tiles] per-workgroup largest |result| (with colsum_part)
+  const float* rowscale; // [M] or null: row m of the product is multiplied by rowscale[m] (before addend, bias, activation)
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -348,6 +349,17 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
           acc[i][1][r] = yB > 0.f ? acc[i][1][r] : (elu ? acc[i][1][r] * (yB + 1.0f) : 0.f);
         }
     }
+  }
+  if (g.rowscale != nullptr) {  // Y = act(diag(s) (X W^T) + b): the forward of a Linear on x * s[row] without materialising x * s
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const float f = g.rowscale[m < g.M ? m : g.M - 1];
+        acc[i][0][r] *= f;
+        acc[i][1][r] *= f;
+      }
   }
   if (g.addend != nullptr) {
 #pragma unroll
@@ -666,6 +678,10 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
       for (int j = 0; j < ITEMS; ++j) {
         const int row = (tid >> 5) + (THREADS / 32) * j;
         tr_f32x4 v = *reinterpret_cast<const tr_f32x4*>(Ct + row * TG_BN + 4 * c4);
+        if (g.rowscale != nullptr) {
+          const int m = m0 + pass * 64 + row;
+          v *= g.rowscale[m < g.M ? m : g.M - 1];
+        }
         if (side == 1) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = sv[j][c] > 0.f ? v[c] : (elu_y ? v[c] * (sv[j][c] + 1.0f) : 0.f);
@@ -740,6 +756,11 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
           const float yA = yrow[nAc], yB = yrow[nBc];
           vA = yA > 0.f ? vA : (elu_y ? vA * (yA + 1.0f) : 0.f);
           vB = yB > 0.f ? vB : (elu_y ? vB * (yB + 1.0f) : 0.f);
+        }
+        if (g.rowscale != nullptr) {
+          const float f = g.rowscale[mc];
+          vA *= f;
+          vB *= f;
         }
         if (g.addend != nullptr) {
           const float* add = g.addend + (long)(mc / g.add_div) * g.ld_add;
@@ -893,6 +914,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   DYN_REQUIRE(p->k_split >= 1 && (p->k_split == 1 || (p->accumulate == 2 && p->act == 0 && p->addend == nullptr)),
               "dyn_train_gemm: a split reduction needs accumulate = 2 (atomic) and a linear epilogue");
   DYN_REQUIRE(p->addend == nullptr || p->add_div >= 1, "dyn_train_gemm: add_div must be >= 1");
+  DYN_REQUIRE(p->rowscale == nullptr || p->k_split == 1, "dyn_train_gemm: rowscale needs k_split = 1");
   TrGemmArgs g;
   g.a.p = p->A; g.a.rs = p->a_rs; g.a.ks = p->a_ks; g.a.nrows = p->M; g.a.aligned = ((uintptr_t)p->A & 15) == 0;
   g.b.p = p->B; g.b.rs = p->b_rs; g.b.ks = p->b_ks; g.b.nrows = p->N; g.b.aligned = ((uintptr_t)p->B & 15) == 0;
@@ -910,6 +932,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   DYN_REQUIRE(p->colsum_part == nullptr || (g.c_vec && p->amax_part != nullptr && p->ld_part >= p->N),
               "dyn_train_gemm: colsum_part needs plain 16-byte-aligned stores (accumulate 0, N and ldc multiples of 4), amax_part and ld_part >= N");
   g.colsum_part = p->colsum_part; g.ld_part = p->ld_part; g.amax_part = p->amax_part;
+  g.rowscale = p->rowscale;
   g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
   g.mt = dyn_cdiv(p->M, TG_BM); g.nt = dyn_cdiv(p->N, TG_BN); g.nz = nz;
   {

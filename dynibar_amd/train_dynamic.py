@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
-from .train_static import ELU, NONE, _Lin, _act_bwd, _p, _rowscale_act_bwd, _split_act_bwd, _untag, zero_grads
+from .train_static import ELU, NONE, _Lin, _Step, _act_bwd, _p, _rowscale_act_bwd, _split_act_bwd, _untag, zero_grads
 
 PARAM_NAMES = ops.DYNAMIC_TENSORS
 
@@ -35,10 +35,6 @@ def _time_pe(time, dev):
   t = time.reshape(-1)[:1].to(dev).float()
   f = 2.0 ** torch.arange(10, device=dev, dtype=torch.float32)
   return torch.cat([t, torch.cos(f * t), torch.sin(f * t), torch.zeros(3, device=dev)]).reshape(1, 24).contiguous()
-
-
-class _Step:
-  pass
 
 
 def _forward(w, shift, pos_table, ray_d, pts, rgb_feat, mask, time):
@@ -89,15 +85,13 @@ def _forward(w, shift, pos_table, ray_d, pts, rgb_feat, mask, time):
   L['b0g'].fwd(st, s.G1, 0, 72, s.PP1, 0, 256, P)
   L['b0f'].fwd(st, s.F, 0, 36, s.H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
   L['b2'].fwd(st, s.H2, 0, 256, s.X1, 0, 128, N, ELU)
-  s.XW, s.H3, s.XV = new(N, 128), new(N, 128), new(N, 132)
-  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(s.XW), 128, st)
-  L['v0'].fwd(st, s.XW, 0, 128, s.H3, 0, 128, N, ELU)
+  s.H3, s.XV = new(N, 128), new(N, 132)
+  L['v0'].fwd(st, s.X1, 0, 128, s.H3, 0, 128, N, ELU, rowscale=s.w1)  # vis_fc.0 on x * weight: the scale rides in the epilogue
   L['v2'].fwd(st, s.H3, 0, 128, s.XV, 0, 132, N, ELU)
   s.X2, s.vis0 = new(N, 128), new(N)
   call('dyn_train_vis_split', _p(s.X1), 128, _p(s.XV), 132, _p(s.M), None, N, _p(s.X2), 128, _p(s.vis0), st)
-  s.XS, s.H4, s.VL = new(N, 128), new(N, 128), new(N)
-  call('dyn_train_rowscale', _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(s.XS), 128, st)
-  L['w0'].fwd(st, s.XS, 0, 128, s.H4, 0, 128, N, ELU)
+  s.H4, s.VL = new(N, 128), new(N)
+  L['w0'].fwd(st, s.X2, 0, 128, s.H4, 0, 128, N, ELU, rowscale=s.vis0)  # vis_fc2.0 on x * vis
   L['w2'].fwd(st, s.H4, 0, 128, s.VL, 0, 1, N)
   s.w2, s.VIS, s.G0, s.nvalid = new(N), new(N), new(P, 260), new(P)
   call('dyn_train_view_weights', 1, _p(s.VL), 1, _p(s.M), None, P, V, _p(s.w2), _p(s.VIS), 1, _p(s.G0, 256), 260, _p(s.nvalid), st)
@@ -192,21 +186,35 @@ def _backward(s, draw):
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
-  L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  s.drop('H4')
+  XS = new(N, 128)  # x * vis again, for the weight gradient only (not kept from the forward pass)
+  call('dyn_train_rowscale', _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(XS), 128, st)
+  L['w0'].bwd(st, dH4, 0, 128, XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  del dH4, XS
   _untag(dX)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
+  del dXS
+  s.drop('X2')
   dXV, dH3, dXW, scratch = new(N, 132), new(N, 128), new(N, 128), new(N)
   _split_act_bwd(st, dX, 128, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
-  L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
+  del dXV
+  s.drop('XV', 'H3')
+  XW = new(N, 128)  # x * weight again, for the weight gradient only
+  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(XW), 128, st)
+  L['v0'].bwd(st, dH3, 0, 128, XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
+  del dH3, XW
   # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass (w1 = mask / sum: no parameter behind it)
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dX, 128, scratch, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 36), new(P, 72)
   L['b2'].bwd(st, dX, 0, 128, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
+  del dX, dXW
+  s.drop('H2', 'X1')
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 36, g['base_fc.0.weight'], N, dF, 0, 36)
+  del dH2
   L['b0g'].bwd(st, dPP1, 0, 256, s.G1, 0, 72, g['base_fc.0.weight'], P, dG1, 0, 72)
   _untag(dF)
   call('dyn_train_meanvar_bwd', _p(s.F), 36, _p(s.w1), P, V, 35, _p(s.G1), _p(dG1), _p(dG1, 35), 72, _p(dF), 36, 1, _p(scratch), 0, st)

@@ -62,14 +62,14 @@ GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} 
 
 
 def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
-          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0, colsum_part=None, ld_part=0, amax_part=None):
+          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0, colsum_part=None, ld_part=0, amax_part=None, rowscale=None):
   if GEMM_STATS is not None:  # algorithmic: every operand element read once, every result element written once
     GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N + (M * N if act_y is not None else 0))
     GEMM_STATS['flops'] += 2 * M * N * K
     GEMM_STATS['calls'] += 1
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
              ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax, act_y=act_y, ld_y=ld_y,
-             act_y_kind=act_y_kind, colsum_part=colsum_part, ld_part=ld_part, amax_part=amax_part)
+             act_y_kind=act_y_kind, colsum_part=colsum_part, ld_part=ld_part, amax_part=amax_part, rowscale=rowscale)
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
@@ -99,10 +99,11 @@ class _Lin:
       self.Wop[:, :self.K].copy_(W[:, col0:col0 + self.K])
       self.op_off, self.op_ld = 0, k4
 
-  def fwd(self, st, X, x_off, ldx, Y, y_off, ldy, M, act=NONE, addend=None, ld_add=0, add_div=1, bias=True):
+  def fwd(self, st, X, x_off, ldx, Y, y_off, ldy, M, act=NONE, addend=None, ld_add=0, add_div=1, bias=True, rowscale=None):
+    """Y = act((X * rowscale[:, None]) W^T + b + addend[row // add_div]); the row scale is applied to the product, X * rowscale is not formed."""
     _gemm(st, _p(X, x_off), ldx, 1, _p(self.Wop, self.op_off), self.op_ld, 1, _p(Y, y_off), ldy, M, self.n_out, self.K,
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
-          ld_add=ld_add, add_div=add_div, act=act)
+          ld_add=ld_add, add_div=add_div, act=act, rowscale=_p(rowscale) if rowscale is not None else None)
 
   def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None, dbias=None):
     # act_y = (Y, y_off, ld_y, kind): X is the output Y of an ELU / ReLU layer and dX comes out already multiplied by act'(Y).
@@ -190,7 +191,12 @@ def wants_grad(net, featmaps):
 
 class _Step:
   """One forward pass with everything the backward pass needs (buffers named as in the module docstring)."""
-  pass
+
+  def drop(self, *names):
+    """release saved activations whose last reader has been launched (the allocator hands the memory to the backward pass's own
+    buffers: stream-ordered, so the kernels in flight are safe) -- a step's peak is its forward total, not forward + backward"""
+    for n in names:
+      setattr(self, n, None)
 
 
 def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask):
@@ -247,16 +253,14 @@ def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask
   L['b0f'].fwd(st, s.F, 0, 72, s.H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
   L['b2'].fwd(st, s.H2, 0, 256, s.X1, 0, 128, N, ELU)
   # vis_fc on x * weight, residual, first visibility (:470-473)
-  s.XW, s.H3, s.XV = new(N, 128), new(N, 128), new(N, 132)
-  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(s.XW), 128, st)
-  L['v0'].fwd(st, s.XW, 0, 128, s.H3, 0, 128, N, ELU)
+  s.H3, s.XV = new(N, 128), new(N, 132)
+  L['v0'].fwd(st, s.X1, 0, 128, s.H3, 0, 128, N, ELU, rowscale=s.w1)  # vis_fc.0 on x * weight: the scale rides in the epilogue
   L['v2'].fwd(st, s.H3, 0, 128, s.XV, 0, 132, N, ELU)
   s.RIN, s.vis0 = new(N, 136), new(N)   # RIN = [x2 128 | vis 1 | ray_diff 4 | 0 0 0]: rgb_fc.0's per-view input
   call('dyn_train_vis_split', _p(s.X1), 128, _p(s.XV), 132, _p(s.M), _p(ray_diff), N, _p(s.RIN), 136, _p(s.vis0), st)
   # vis_fc2 on x * vis, second visibility, pooled statistics (:474-481)
-  s.XS, s.H4, s.VL = new(N, 128), new(N, 128), new(N)
-  call('dyn_train_rowscale', _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(s.XS), 128, st)
-  L['w0'].fwd(st, s.XS, 0, 128, s.H4, 0, 128, N, ELU)
+  s.H4, s.VL = new(N, 128), new(N)
+  L['w0'].fwd(st, s.RIN, 0, 136, s.H4, 0, 128, N, ELU, rowscale=s.vis0)  # vis_fc2.0 on x * vis
   L['w2'].fwd(st, s.H4, 0, 128, s.VL, 0, 1, N)
   s.w2, s.G0, s.nvalid = new(N), new(P, 260), new(P)
   call('dyn_train_view_weights', 1, _p(s.VL), 1, _p(s.M), None, P, V, _p(s.w2), _p(s.RIN, 128), 136, _p(s.G0, 256), 260, _p(s.nvalid), st)
@@ -298,16 +302,21 @@ def _backward(s, draw):
   # blending softmax / density fill
   dRL, dSIG = new(N), new(P)
   call('dyn_train_blend_bwd', _p(draw), _p(s.BW), _p(s.M), _p(s.rgb_feat), _p(s.nvalid), P, V, _p(dRL), 1, _p(dSIG), 1, st)
+  s.drop('BW', 'RL')
   # rgb_fc.4 / .2 / .0
   dR2, dR1 = new(N, 64), new(N, 128)
   _act_bwd(st, dRL, 0, 1, None, 0, 1, N, 1, NONE, g['rgb_fc.4.bias'])
   if not L['r4'].bwd(st, dRL, 0, 1, s.R2, 0, 64, g['rgb_fc.4.weight'], N, dR2, 0, 64, act_y=(s.R2, 0, 64, ELU), dbias=g['rgb_fc.2.bias']):  # dR2 arrives times ELU'(R2)
     _act_bwd(st, dR2, 0, 64, None, 0, 64, N, 64, NONE, g['rgb_fc.2.bias'])
+  del dRL
   L['r2'].bwd(st, dR2, 0, 64, s.R1, 0, 128, g['rgb_fc.2.weight'], N, dR1, 0, 128, act_y=(s.R1, 0, 128, ELU))
+  del dR2
+  s.drop('R2', 'R1')
   dPP2 = new(P, 128)
   _act_bwd(st, dR1, 0, 128, None, 0, 128, N, 128, NONE, g['rgb_fc.0.bias'], V, dPP2, 128)
   dRIN = new(N, 136)  # gradient of [x2 | vis | ray_diff]; its first 128 columns go on to collect every gradient of x2, then of x1
   L['r0x'].bwd(st, dR1, 0, 128, s.RIN, 0, 136, g['rgb_fc.0.weight'], N, dRIN, 0, 136)
+  del dR1
   dG3 = new(P, 128)
   L['r0g'].bwd(st, dPP2, 0, 128, s.G3, 0, 128, g['rgb_fc.0.weight'], P, dG3, 0, 128)
   # out_geometry_fc
@@ -342,23 +351,37 @@ def _backward(s, draw):
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
-  L['w0'].bwd(st, dH4, 0, 128, s.XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  s.drop('H4')
+  XS = new(N, 128)  # x * vis again, for the weight gradient only (not kept from the forward pass: 0.5 KB per row and net)
+  call('dyn_train_rowscale', _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(XS), 128, st)
+  L['w0'].bwd(st, dH4, 0, 128, XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
+  del dH4, XS
   _untag(dRIN)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
+  del dXS
+  s.drop('RIN')
   # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
   dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
   _split_act_bwd(st, dRIN, 136, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
-  L['v0'].bwd(st, dH3, 0, 128, s.XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
+  del dXV
+  s.drop('XV', 'H3')
+  XW = new(N, 128)  # x * weight again, for the weight gradient only
+  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(XW), 128, st)
+  L['v0'].bwd(st, dH3, 0, 128, XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
+  del dH3, XW
   dw1 = new(N)
   # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dRIN, 136, dw1, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 72), new(P, 140)
   L['b2'].bwd(st, dRIN, 0, 136, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
+  del dRIN, dXW
+  s.drop('H2', 'X1')
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 72, g['base_fc.0.weight'], N, dF, 0, 72)
+  del dH2
   L['b0g'].bwd(st, dPP1, 0, 256, s.G1, 0, 140, g['base_fc.0.weight'], P, dG1, 0, 140)
   _untag(dF)
   call('dyn_train_meanvar_bwd', _p(s.F), 72, _p(s.w1), P, V, 70, _p(s.G1), _p(dG1), _p(dG1, 70), 140, _p(dF), 72, 1, _p(dw1), 1, st)
@@ -373,6 +396,8 @@ def _backward(s, draw):
   _act_bwd(st, dSRCF, 0, 36, None, 0, 36, N, 35, NONE, g['ray_dir_fc.2.bias'])
   if not L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(s.H1, 0, 256, ELU), dbias=g['ray_dir_fc.0.bias']):
     _act_bwd(st, dH1, 0, 256, None, 0, 256, N, 256, NONE, g['ray_dir_fc.0.bias'])
+  del dSRCF
+  s.drop('H1', 'F', 'SRCF')
   L['rd0'].bwd(st, dH1, 0, 256, s.A0, 0, 104, g['ray_dir_fc.0.weight'], N)
   return g, dF  # dF[:, 0:35] = d rgb_feat (the gather's backward, train_motion.GatherFunction, carries it on into the maps)
 

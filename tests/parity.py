@@ -1285,6 +1285,11 @@ def check_train_gemm_many_tiles(device, M=None):
   Wd = Wfull[:, col0:col0 + K].double().cpu()
   ref = torch.nn.functional.elu(X[:, :K].double().cpu() @ Wd.T + b.double().cpu() + Pp.double().cpu().repeat_interleave(V, 0)[:M])
   assert_close(Y, ref, 1e-5, 4e-6, 'train gemm (many tiles) forward')
+  rs = (torch.rand(M, generator=g) * 2.0).to(device)  # a Linear on x * s[row]: the scale applied to the product (vis_fc.0 on x * weight)
+  Y.fill_(float('nan'))
+  lin.fwd(st, X, 0, 72, Y, 0, N, M, TS.ELU, rowscale=rs)
+  ref = torch.nn.functional.elu(rs.double().cpu()[:, None] * (X[:, :K].double().cpu() @ Wd.T) + b.double().cpu())
+  assert_close(Y, ref, 1e-5, 4e-6, 'train gemm (many tiles) forward with a row scale')
   dZ = (torch.randn(M, N, generator=g) * 1e-4).to(device)
   dW = torch.zeros_like(Wfull)
   dX = torch.full((M, 72), float('nan'), device=device)
