@@ -14,6 +14,7 @@ import torch
 
 from . import ops
 from ._lib import call, stream_of
+from . import train_static as TS
 from .train_static import ELU, NONE, _Lin, _Step, _act_bwd, _p, _rowscale_act_bwd, _split_act_bwd, _untag, zero_grads
 
 PARAM_NAMES = ops.DYNAMIC_TENSORS
@@ -85,6 +86,8 @@ def _forward(w, shift, pos_table, ray_d, pts, rgb_feat, mask, time):
   L['b0g'].fwd(st, s.G1, 0, 72, s.PP1, 0, 256, P)
   L['b0f'].fwd(st, s.F, 0, 36, s.H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
   L['b2'].fwd(st, s.H2, 0, 256, s.X1, 0, 128, N, ELU)
+  if TS.RECOMPUTE_HIDDEN:
+    s.drop('H2')  # recomputed from f (36 wide) and the per-point part in the backward pass (train_static.RECOMPUTE_HIDDEN)
   s.H3, s.XV = new(N, 128), new(N, 132)
   L['v0'].fwd(st, s.X1, 0, 128, s.H3, 0, 128, N, ELU, rowscale=s.w1)  # vis_fc.0 on x * weight: the scale rides in the epilogue
   L['v2'].fwd(st, s.H3, 0, 128, s.XV, 0, 132, N, ELU)
@@ -209,9 +212,13 @@ def _backward(s, draw):
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dX, 128, scratch, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 36), new(P, 72)
-  L['b2'].bwd(st, dX, 0, 128, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
-  del dX, dXW
-  s.drop('H2', 'X1')
+  H2 = s.H2
+  if H2 is None:  # RECOMPUTE_HIDDEN: the hidden layer of base_fc again (the same launch as in the forward pass: bit-identical)
+    H2 = new(N, 256)
+    L['b0f'].fwd(st, s.F, 0, 36, H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
+  L['b2'].bwd(st, dX, 0, 128, H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(H2, 0, 256, ELU))
+  del dX, dXW, H2
+  s.drop('X1', 'H2')
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 36, g['base_fc.0.weight'], N, dF, 0, 36)
   del dH2

@@ -18,6 +18,7 @@ P = R*S rows; the buffers and their widths are listed in ``_forward``.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -25,6 +26,11 @@ from . import _lib, ops
 from ._lib import call, params, stream_of
 
 ELU, NONE = 1, 0
+
+# Memory for time: with RECOMPUTE_HIDDEN the 256-wide hidden layers of ray_dir_fc / base_fc (1 KB per row each) are not kept from the forward
+# pass but recomputed from their narrow inputs right before the backward pass needs them (the same launches: bit-identical results).
+# Measured at 3072 rays (MI355X): peak 46.4 -> 37.0 GB, iteration 107.2 -> 112.6 ms; off by default (a 288 GB device has the room).
+RECOMPUTE_HIDDEN = os.environ.get('DYNIBAR_TRAIN_RECOMPUTE', '0') == '1'
 
 
 def _p(t, off=0):
@@ -241,6 +247,8 @@ def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask
   s.H1, s.SRCF, s.REFF = new(N, 256), new(N, 36), new(R, 36)
   L['rd0'].fwd(st, s.A0, 0, 104, s.H1, 0, 256, N, ELU)
   L['rd2'].fwd(st, s.H1, 0, 256, s.SRCF, 0, 36, N)
+  if RECOMPUTE_HIDDEN:
+    s.drop('H1')  # recomputed from the 104-wide input in the backward pass
   L['ref'].fwd(st, s.REFPE, 0, 68, s.REFF, 0, 36, R)
   # f = [rgb_feat | src_feat * ref_feat], pooling weights, mean / variance (:450-462)
   s.F, s.w1, s.G1 = new(N, 72), new(N), new(P, 140)
@@ -252,6 +260,8 @@ def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask
   L['b0g'].fwd(st, s.G1, 0, 140, s.PP1, 0, 256, P)
   L['b0f'].fwd(st, s.F, 0, 72, s.H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
   L['b2'].fwd(st, s.H2, 0, 256, s.X1, 0, 128, N, ELU)
+  if RECOMPUTE_HIDDEN:
+    s.drop('H2')  # recomputed from f (72 wide) and the per-point part
   # vis_fc on x * weight, residual, first visibility (:470-473)
   s.H3, s.XV = new(N, 128), new(N, 132)
   L['v0'].fwd(st, s.X1, 0, 128, s.H3, 0, 128, N, ELU, rowscale=s.w1)  # vis_fc.0 on x * weight: the scale rides in the epilogue
@@ -376,9 +386,13 @@ def _backward(s, draw):
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dRIN, 136, dw1, 0, ELU, g['base_fc.2.bias'])
   # base_fc
   dH2, dPP1, dF, dG1 = new(N, 256), new(P, 256), new(N, 72), new(P, 140)
-  L['b2'].bwd(st, dRIN, 0, 136, s.H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(s.H2, 0, 256, ELU))
-  del dRIN, dXW
-  s.drop('H2', 'X1')
+  H2 = s.H2
+  if H2 is None:  # RECOMPUTE_HIDDEN: the hidden layer of base_fc again (the same launch as in the forward pass: bit-identical)
+    H2 = new(N, 256)
+    L['b0f'].fwd(st, s.F, 0, 72, H2, 0, 256, N, ELU, addend=s.PP1, ld_add=256, add_div=V)
+  L['b2'].bwd(st, dRIN, 0, 136, H2, 0, 256, g['base_fc.2.weight'], N, dH2, 0, 256, act_y=(H2, 0, 256, ELU))
+  del dRIN, dXW, H2
+  s.drop('X1', 'H2')
   _act_bwd(st, dH2, 0, 256, None, 0, 256, N, 256, NONE, g['base_fc.0.bias'], V, dPP1, 256)
   L['b0f'].bwd(st, dH2, 0, 256, s.F, 0, 72, g['base_fc.0.weight'], N, dF, 0, 72)
   del dH2
@@ -394,10 +408,14 @@ def _backward(s, draw):
   _act_bwd(st, dREFF, 0, 36, None, 0, 36, R, 35, NONE, g['ref_feature_fc.0.bias'])
   L['ref'].bwd(st, dREFF, 0, 36, s.REFPE, 0, 68, g['ref_feature_fc.0.weight'], R)
   _act_bwd(st, dSRCF, 0, 36, None, 0, 36, N, 35, NONE, g['ray_dir_fc.2.bias'])
-  if not L['rd2'].bwd(st, dSRCF, 0, 36, s.H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(s.H1, 0, 256, ELU), dbias=g['ray_dir_fc.0.bias']):
+  H1 = s.H1
+  if H1 is None:  # RECOMPUTE_HIDDEN: the hidden layer of ray_dir_fc again
+    H1 = new(N, 256)
+    L['rd0'].fwd(st, s.A0, 0, 104, H1, 0, 256, N, ELU)
+  if not L['rd2'].bwd(st, dSRCF, 0, 36, H1, 0, 256, g['ray_dir_fc.2.weight'], N, dH1, 0, 256, act_y=(H1, 0, 256, ELU), dbias=g['ray_dir_fc.0.bias']):
     _act_bwd(st, dH1, 0, 256, None, 0, 256, N, 256, NONE, g['ray_dir_fc.0.bias'])
-  del dSRCF
-  s.drop('H1', 'F', 'SRCF')
+  del dSRCF, H1
+  s.drop('F', 'SRCF', 'H1')
   L['rd0'].bwd(st, dH1, 0, 256, s.A0, 0, 104, g['ray_dir_fc.0.weight'], N)
   return g, dF  # dF[:, 0:35] = d rgb_feat (the gather's backward, train_motion.GatherFunction, carries it on into the maps)
 

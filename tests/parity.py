@@ -1174,6 +1174,34 @@ def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=Fal
   return worst
 
 
+def check_train_recompute(device, name='small', S=16):
+  """train_static.RECOMPUTE_HIDDEN (the 256-wide hidden layers recomputed in the backward pass instead of kept): the static step's values
+  and gradients are BIT-identical with and without it (the recomputation is the forward launch again), and the dual-branch step -- which
+  runs the dynamic net's variant -- still meets its parity limits."""
+  from dynibar_amd import train_static as TS
+  args = (name, S, None, True, False, 'init', 0)
+  scene, o, d, sd, _, cot, _, _ = train_static_reference(*args)
+  was = TS.RECOMPUTE_HIDDEN
+  try:
+    res = []
+    for flag in (False, True):
+      TS.RECOMPUTE_HIDDEN = flag
+      out, raw, g = run_train_static(device, scene, o, d, sd, S, True, False, cot)
+      res.append((cpu(raw), {k: cpu(v) for k, v in g.items() if v is not None}))
+    assert torch.equal(res[0][0], res[1][0]), 'raw differs with recomputed hidden layers'
+    for k, v in res[0][1].items():
+      if k in ('featmaps',):  # scattered with atomics: the order of the sums differs from run to run
+        assert_close(res[1][1][k], v, 1e-6 * float(v.abs().max()), 1e-5, f'recompute grad {k}')
+      else:
+        same = torch.equal(res[1][1][k], v)
+        # weight gradients are atomic sums too (split reductions): equal to the last bits, not necessarily bit-identical
+        assert same or float((res[1][1][k] - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-12, f'recompute grad {k}'
+    TS.RECOMPUTE_HIDDEN = True
+    check_train_dual(device, name, S=S)
+  finally:
+    TS.RECOMPUTE_HIDDEN = was
+
+
 def check_train_gemm(device):
   """dyn_train_gemm in its three roles (forward with bias / per-point addend / ELU, data gradient, split weight gradient) vs fp64 matmul,
   on shapes that are not multiples of the tile, at gradient-like magnitudes as well (the bf16 split keeps fp32's exponent range)."""

@@ -249,3 +249,9 @@ def test_projector_helper_methods(dev):
   """Projector.inbound / normalize / compute_projections / compute_angle (projection.py:13-101): the reference's helper surface, kernel-backed"""
   parity.check_projector_helpers(dev, 'small')
   parity.check_projector_helpers(dev, 'harsh')
+
+
+@pytest.mark.gpu
+def test_training_with_recomputed_hidden_layers(dev):
+  """DYNIBAR_TRAIN_RECOMPUTE=1 / train_static.RECOMPUTE_HIDDEN: memory for time, same numbers."""
+  parity.check_train_recompute(dev)
