@@ -1965,6 +1965,69 @@ extern "C" int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const 
   return 0;
 }
 
+// dX[row, :] = dz[row] * w[:] * act'(Y[row, :]): the data gradient of a Linear with ONE output (vis_fc2.2, rgb_fc.4 of the static net,
+// out_geometry_fc.2: a rank-one product -- as a GEMM it ran a 128-column tile for one useful column, 4.7 ms per iteration) through the
+// activation of the layer in front of it, with that layer's bias gradient (column sums) and the scale of dX.  C = 4 L columns (L a power
+// of two, 4 .. 64 lanes per row); a block's 256 / L lane groups own consecutive spans of rows, four rows per trip.
+__global__ void __launch_bounds__(256) k_train_outer_act_bwd4(const float* __restrict__ dz, long dz_stride, const float4* __restrict__ w,
+                                                              const float4* __restrict__ y, long ld_y4, long N, int sh, int act,
+                                                              float4* __restrict__ dx, long ld_dx4, float* __restrict__ dbias,
+                                                              float* __restrict__ absmax) {
+  float4* part = dyn_smem;  // [G][L] partial column sums
+  const int L = 1 << sh, G = 256 >> sh, g = threadIdx.x >> sh, q = threadIdx.x & (L - 1);
+  const long ra = ((long)blockIdx.x * G + g) * TR_FUSE_SPAN;
+  const long rb = ra + TR_FUSE_SPAN < N ? ra + TR_FUSE_SPAN : N;
+  const float4 wq = w[q];
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float amax = 0.f;
+  for (long r = ra; r < rb; r += 4) {
+    float4 yv[4];
+    float d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + u < rb ? r + u : rb - 1;
+      d[u] = dz[rr * dz_stride];
+      if (act != 0) yv[u] = y[rr * ld_y4 + q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u >= rb) continue;
+      float4 v = make_float4(d[u] * wq.x, d[u] * wq.y, d[u] * wq.z, d[u] * wq.w);
+      if (act != 0) {
+        v.x *= tr_dact(yv[u].x, act); v.y *= tr_dact(yv[u].y, act); v.z *= tr_dact(yv[u].z, act); v.w *= tr_dact(yv[u].w, act);
+      }
+      dx[(r + u) * ld_dx4 + q] = v;
+      colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
+  part[g * L + q] = colsum;
+  __syncthreads();
+  if (dbias != nullptr && threadIdx.x < 4 * L) {
+    const float* pf = reinterpret_cast<const float*>(part);
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += pf[k * 4 * L + threadIdx.x];
+    atomicAdd(dbias + threadIdx.x, t);
+  }
+  if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
+}
+extern "C" int dyn_train_outer_act_bwd(const float* dz, long dz_stride, const float* w, const float* Y, long ld_y, long N, int C, int act,
+                                       float* dX, long ld_dx, float* dbias, float* absmax, void* stream) {
+  DYN_REQUIRE(dz && w && dX && N > 0 && C > 0, "dyn_train_outer_act_bwd: bad arguments");
+  DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_outer_act_bwd: ELU / ReLU backward needs the saved output");
+  const int c4 = C / 4;
+  DYN_REQUIRE((C & 3) == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0, "dyn_train_outer_act_bwd: %d columns (4, 8, 16, ... 256)", C);
+  DYN_REQUIRE((ld_dx & 3) == 0 && (act == 0 || (ld_y & 3) == 0) && (((uintptr_t)w | (uintptr_t)dX | (act ? (uintptr_t)Y : 0)) & 15) == 0,
+              "dyn_train_outer_act_bwd: rows must be 16-byte aligned (leading dimensions multiples of 4 floats)");
+  int sh = 0;
+  while ((1 << sh) < c4) ++sh;
+  const long per_block = (long)(256 >> sh) * TR_FUSE_SPAN;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_outer_act_bwd", k_train_outer_act_bwd4, dim3((unsigned)((N + per_block - 1) / per_block)), dim3(256),
+             257 * sizeof(float4), (hipStream_t)stream, dz, dz_stride, reinterpret_cast<const float4*>(w),
+             reinterpret_cast<const float4*>(act != 0 ? Y : nullptr), ld_y / 4, N, sh, act, reinterpret_cast<float4*>(dX), ld_dx / 4, dbias, absmax);
+  return 0;
+}
+
 extern "C" int dyn_train_vis_split(const float* x1, long ld1, const float* xv, long ldv, const float* mask, const float* ray_diff, long N, float* x2,
                                    long ld2, float* vis0, void* stream) {
   DYN_REQUIRE(x1 && xv && mask && x2 && vis0 && N > 0, "dyn_train_vis_split: bad arguments");

@@ -127,6 +127,15 @@ class _Lin:
     ks = max(1, min(1024, M // 1024))  # reduction chunks of the weight gradient: enough (row tile, chunk) units for every resident workgroup
     _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
           a_absmax=_p(am))
+    if (dX is not None and self.n_out == 1 and acc_dx == 0 and dx_off == 0 and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
+        (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0))):
+      # one output: the data gradient is a rank-one product -- a row kernel, not a GEMM
+      am2 = _Scalars.take(dX.device)
+      call('dyn_train_outer_act_bwd', _p(dZ, dz_off), ld_dz, _p(self.W), _p(act_y[0]) if act_y is not None else None,
+           act_y[2] if act_y is not None else 0, M, self.K, act_y[3] if act_y is not None else NONE, _p(dX), ld_dx,
+           _p(dbias) if dbias is not None else None, _p(am2), st)
+      dX._dyn_absmax = ((0, ld_dx, M, self.K), am2)
+      return dbias is not None
     if dX is not None:
       fy = {} if act_y is None else dict(act_y=_p(act_y[0], act_y[1]), ld_y=act_y[2], act_y_kind=act_y[3])
       sums = dbias is not None and acc_dx == 0 and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0
