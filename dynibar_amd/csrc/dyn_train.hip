@@ -192,6 +192,7 @@ struct TrGemmArgs {
   long ld_part;
   float* amax_part;      // [row tiles * column tiles] per-workgroup largest |result| (with colsum_part)
   const float* rowscale; // [M] or null: row m of the product is multiplied by rowscale[m] (before addend, bias, activation)
+  const float* kscale;   // [K] or null (ring form only): operand b's element (n, k) is multiplied by kscale[k]
 };
 
 // Workgroup barrier that publishes this wave's LDS accesses but leaves its global loads in flight: __syncthreads() carries a
@@ -816,6 +817,24 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
         float va[8], vb[8];
         tr_ring_fragment<A_MODE>(At, wm * 64 + i * 32 + (lane & 31), k16, h, va);
         tr_ring_fragment<B_MODE>(Bt, wn * 64 + i * 32 + (lane & 31), k16, h, vb);
+        if (g.kscale != nullptr) {
+          // dW = dZ^T (diag(s) X): the scale of the reduction index on operand b.  Wave-uniform addresses (both halves' values, then a
+          // select on h): scalar loads, which the vector-memory counter of the ring does not see
+          // (constant address space: what makes the compiler pick s_load for a uniform address; the data was written by earlier kernels)
+#if defined(__AMDGCN__)
+          typedef const __attribute__((address_space(4))) float* tr_kptr;
+          tr_kptr ksc = (tr_kptr)(uintptr_t)g.kscale;
+#else
+          const float* ksc = g.kscale;
+#endif
+          const int kb = cur.k0 + 16 * k16;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int klo = kb + e < g.K ? kb + e : g.K - 1, khi = kb + 8 + e < g.K ? kb + 8 + e : g.K - 1;
+            const float flo = ksc[klo], fhi = ksc[khi];
+            vb[e] *= h ? fhi : flo;
+          }
+        }
         if (k_edge) {  // the k tail of a tile (its last step only): both operands, a zero times a stray NaN is a NaN
           const int kb = cur.k0 + 16 * k16 + 8 * h;
 #pragma unroll
@@ -932,7 +951,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
   DYN_REQUIRE(p->colsum_part == nullptr || (g.c_vec && p->amax_part != nullptr && p->ld_part >= p->N),
               "dyn_train_gemm: colsum_part needs plain 16-byte-aligned stores (accumulate 0, N and ldc multiples of 4), amax_part and ld_part >= N");
   g.colsum_part = p->colsum_part; g.ld_part = p->ld_part; g.amax_part = p->amax_part;
-  g.rowscale = p->rowscale;
+  g.rowscale = p->rowscale; g.kscale = p->kscale;
   g.act_y_vec = p->act_y != nullptr && (p->N & 3) == 0 && (p->ld_y & 3) == 0 && ((uintptr_t)p->act_y & 15) == 0;
   g.mt = dyn_cdiv(p->M, TG_BM); g.nt = dyn_cdiv(p->N, TG_BN); g.nz = nz;
   {
@@ -948,7 +967,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     const bool fast = g.c_vec && (p->bias == nullptr || ((uintptr_t)p->bias & 15) == 0) && (p->act_y == nullptr || g.act_y_vec) && add_vec &&
                       !(p->act_y != nullptr && p->addend != nullptr);
     const int mode = tr_gemm_mode();
-    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)))) {
+    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)) || (mode != 1 && p->kscale != nullptr))) {
       const long units = (long)g.mt * g.nz;
 #define TG_RING(A, B, F)                                                                                                                   \
   if (ra == A && rb == B && fast == F) {                                                                                                   \
@@ -962,6 +981,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
 #undef TG_RING
     }
   }
+  DYN_REQUIRE(p->kscale == nullptr, "dyn_train_gemm: kscale needs the ring form (operands k-minor with aligned quads or k-major with 16-byte-aligned rows; dyn_train_gemm_mode 0 or 2)");
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major

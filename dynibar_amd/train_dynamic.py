@@ -190,10 +190,8 @@ def _backward(s, draw):
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   s.drop('H4')
-  XS = new(N, 128)  # x * vis again, for the weight gradient only (not kept from the forward pass)
-  call('dyn_train_rowscale', _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(XS), 128, st)
-  L['w0'].bwd(st, dH4, 0, 128, XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
-  del dH4, XS
+  L['w0'].bwd(st, dH4, 0, 128, s.X2, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128, x_scale=s.vis0)  # the layer ran on x * vis
+  del dH4
   _untag(dX)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
   del dXS
@@ -204,10 +202,8 @@ def _backward(s, draw):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   del dXV
   s.drop('XV', 'H3')
-  XW = new(N, 128)  # x * weight again, for the weight gradient only
-  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(XW), 128, st)
-  L['v0'].bwd(st, dH3, 0, 128, XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
-  del dH3, XW
+  L['v0'].bwd(st, dH3, 0, 128, s.X1, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128, x_scale=s.w1)  # the layer ran on x * weight
+  del dH3
   # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass (w1 = mask / sum: no parameter behind it)
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dX, 128, scratch, 0, ELU, g['base_fc.2.bias'])
   # base_fc

@@ -68,14 +68,14 @@ GEMM_STATS = None  # bench.py sets this to {'bytes': 0, 'flops': 0, 'calls': 0} 
 
 
 def _gemm(st, A, a_rs, a_ks, B, b_rs, b_ks, C, ldc, M, N, K, bias=None, addend=None, ld_add=0, add_div=1, act=NONE, accumulate=0, k_split=1,
-          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0, colsum_part=None, ld_part=0, amax_part=None, rowscale=None):
+          a_absmax=None, act_y=None, ld_y=0, act_y_kind=0, colsum_part=None, ld_part=0, amax_part=None, rowscale=None, kscale=None):
   if GEMM_STATS is not None:  # algorithmic: every operand element read once, every result element written once
     GEMM_STATS['bytes'] += 4 * (M * K + N * K + M * N + (M * N if act_y is not None else 0))
     GEMM_STATS['flops'] += 2 * M * N * K
     GEMM_STATS['calls'] += 1
   p = params('DynTrainGemmParams', A=A, a_rs=a_rs, a_ks=a_ks, B=B, b_rs=b_rs, b_ks=b_ks, C=C, ldc=ldc, M=M, N=N, K=K, bias=bias, addend=addend,
              ld_add=ld_add, add_div=add_div, act=act, accumulate=accumulate, k_split=k_split, a_absmax=a_absmax, act_y=act_y, ld_y=ld_y,
-             act_y_kind=act_y_kind, colsum_part=colsum_part, ld_part=ld_part, amax_part=amax_part, rowscale=rowscale)
+             act_y_kind=act_y_kind, colsum_part=colsum_part, ld_part=ld_part, amax_part=amax_part, rowscale=rowscale, kscale=kscale)
   call('dyn_train_gemm', ctypes.byref(p), st)
 
 
@@ -111,7 +111,7 @@ class _Lin:
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
           ld_add=ld_add, add_div=add_div, act=act, rowscale=_p(rowscale) if rowscale is not None else None)
 
-  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None, dbias=None):
+  def bwd(self, st, dZ, dz_off, ld_dz, X, x_off, ldx, dW, M, dX=None, dx_off=0, ld_dx=0, acc_dx=0, act_y=None, dbias=None, x_scale=None):
     # act_y = (Y, y_off, ld_y, kind): X is the output Y of an ELU / ReLU layer and dX comes out already multiplied by act'(Y).
     # dbias: the bias gradient of THAT layer (column sums of dX) and the scale of dX are taken from the result tiles on their way out;
     # returns True when that happened (16-byte-aligned dX rows), False when the caller still has to run _act_bwd for them.
@@ -125,8 +125,9 @@ class _Lin:
       call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
       dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
     ks = max(1, min(1024, M // 1024))  # reduction chunks of the weight gradient: enough (row tile, chunk) units for every resident workgroup
+    # x_scale [M]: the layer ran on X * x_scale[:, None] (fwd's rowscale); its weight gradient takes the scale on the reduction index
     _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
-          a_absmax=_p(am))
+          a_absmax=_p(am), kscale=_p(x_scale) if x_scale is not None else None)
     if (dX is not None and self.n_out == 1 and acc_dx == 0 and dx_off == 0 and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
         (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0))):
       # one output: the data gradient is a rank-one product -- a row kernel, not a GEMM
@@ -371,10 +372,8 @@ def _backward(s, draw):
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   s.drop('H4')
-  XS = new(N, 128)  # x * vis again, for the weight gradient only (not kept from the forward pass: 0.5 KB per row and net)
-  call('dyn_train_rowscale', _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(XS), 128, st)
-  L['w0'].bwd(st, dH4, 0, 128, XS, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128)
-  del dH4, XS
+  L['w0'].bwd(st, dH4, 0, 128, s.RIN, 0, 136, g['vis_fc2.0.weight'], N, dXS, 0, 128, x_scale=s.vis0)  # the layer ran on x * vis
+  del dH4
   _untag(dRIN)
   call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
   del dXS
@@ -386,10 +385,8 @@ def _backward(s, draw):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   del dXV
   s.drop('XV', 'H3')
-  XW = new(N, 128)  # x * weight again, for the weight gradient only
-  call('dyn_train_rowscale', _p(s.X1), 128, _p(s.w1), 1, N, 128, _p(XW), 128, st)
-  L['v0'].bwd(st, dH3, 0, 128, XW, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128)
-  del dH3, XW
+  L['v0'].bwd(st, dH3, 0, 128, s.X1, 0, 128, g['vis_fc.0.weight'], N, dXW, 0, 128, x_scale=s.w1)  # the layer ran on x * weight
+  del dH3
   dw1 = new(N)
   # d x1 is complete with this term: its row-scale backward and base_fc.2's ELU in one pass
   _rowscale_act_bwd(st, dXW, 128, s.X1, 128, s.w1, N, dRIN, 136, dw1, 0, ELU, g['base_fc.2.bias'])

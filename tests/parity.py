@@ -1285,9 +1285,18 @@ def check_train_gemm(device):
   try:  # the same with every product on the ring form, and with every product on the tile kernel
     for mode, M in ((2, None), (1, 1100)):
       call('dyn_train_gemm_mode', mode)
+      _GEMM_MODE[0] = mode
       check_train_gemm_many_tiles(device, M)
   finally:
     call('dyn_train_gemm_mode', 0)
+    _GEMM_MODE[0] = 0
+
+
+_GEMM_MODE = [0]
+
+
+def mode_has_ring():
+  return _GEMM_MODE[0] != 1
 
 
 def check_train_gemm_many_tiles(device, M=None):
@@ -1332,6 +1341,12 @@ def check_train_gemm_many_tiles(device, M=None):
   refw = dZ.double().cpu().T @ Ysaved[:, :K].double().cpu()
   assert_close(dW[:, col0:col0 + K], refw, 2e-6 * float(refw.abs().max()), 4e-6, 'train gemm (many tiles) weight gradient')
   assert float(dW[:, :col0].abs().max()) == 0.0 and float(dW[:, col0 + K:].abs().max()) == 0.0, 'weight gradient outside the slice'
+  if mode_has_ring():
+    # the weight gradient of a Linear that ran on x * s[row]: dW = dZ^T (diag(s) X) from the unscaled X
+    dW2 = torch.zeros_like(Wfull)
+    lin.bwd(st, dZ, 0, N, Ysaved, 0, 72, dW2, M, x_scale=rs)
+    refw2 = dZ.double().cpu().T @ (rs.double().cpu()[:, None] * Ysaved[:, :K].double().cpu())
+    assert_close(dW2[:, col0:col0 + K], refw2, 2e-6 * float(refw2.abs().max()), 4e-6, 'train gemm (many tiles) weight gradient with a scaled reduction index')
 
 
 def oracle_bootstrap_step(kid, w, jitter_seed=None):
