@@ -612,7 +612,9 @@ __device__ __forceinline__ float tr_act(float v, int act) {
 
 // A workgroup walks units blockIdx.x, blockIdx.x + gridDim.x, ... (a unit = (reduction chunk z, row tile) with its column tiles back to
 // back, so that the second column tile finds the row tile's operand in this CU's caches); grid = the resident workgroups of the device.
-template <int A_MODE, int B_MODE, bool FAST>
+// KSCALE: operand b carries a scale on the reduction index (kscale) -- its own instantiation: as a run-time branch in the fragment loop
+// it cost every weight gradient 10 %
+template <int A_MODE, int B_MODE, bool FAST, bool KSCALE>
 __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
   constexpr int THREADS = 256, PASSES = 2, ITEMS = 8;  // epilogue: 64 rows per pass, quads per thread and pass
   float* ring = reinterpret_cast<float*>(dyn_smem);
@@ -817,7 +819,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
         float va[8], vb[8];
         tr_ring_fragment<A_MODE>(At, wm * 64 + i * 32 + (lane & 31), k16, h, va);
         tr_ring_fragment<B_MODE>(Bt, wn * 64 + i * 32 + (lane & 31), k16, h, vb);
-        if (g.kscale != nullptr) {
+        if constexpr (KSCALE) {
           // dW = dZ^T (diag(s) X): the scale of the reduction index on operand b.  Wave-uniform addresses (both halves' values, then a
           // select on h): scalar loads, which the vector-memory counter of the ring does not see
           // (constant address space: what makes the compiler pick s_load for a uniform address; the data was written by earlier kernels)
@@ -893,7 +895,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
 }
 
 // resident workgroups of k_train_gemm_ring<A, B, F> per device: the persistent kernel's grid (queried once per instantiation and device)
-template <int A_MODE, int B_MODE, bool FAST>
+template <int A_MODE, int B_MODE, bool FAST, bool KSCALE>
 static int tr_ring_slots() {
   static int slots[DYN_MAX_DEVICES] = {0};
   int dev = 0;
@@ -902,7 +904,7 @@ static int tr_ring_slots() {
   if (slots[d] == 0) {
     int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_gemm_ring<A_MODE, B_MODE, FAST>, 256, TR_RING_BYTES) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_gemm_ring<A_MODE, B_MODE, FAST, KSCALE>, 256, TR_RING_BYTES) != hipSuccess || per_cu < 1) per_cu = 2;
     const int n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     slots[d] = per_cu * n_cu;
   }
@@ -969,19 +971,21 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     const int mode = tr_gemm_mode();
     if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)) || (mode != 1 && p->kscale != nullptr))) {
       const long units = (long)g.mt * g.nz;
-#define TG_RING(A, B, F)                                                                                                                   \
-  if (ra == A && rb == B && fast == F) {                                                                                                   \
-    const long slots = tr_ring_slots<A, B, F>();                                                                                           \
+#define TG_RING(A, B, F, S)                                                                                                                \
+  if (ra == A && rb == B && fast == F && (p->kscale != nullptr) == S) {                                                                    \
+    const long slots = tr_ring_slots<A, B, F, S>();                                                                                        \
     const dim3 rgrid((unsigned)(units < slots ? units : slots));                                                                           \
-    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm_ring<A, B, F>), rgrid, dim3(256), TR_RING_BYTES, (hipStream_t)stream, g);  \
+    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm_ring<A, B, F, S>), rgrid, dim3(256), TR_RING_BYTES, (hipStream_t)stream,   \
+               g);                                                                                                                         \
     return 0;                                                                                                                              \
   }
-      TG_RING(0, 0, true) TG_RING(0, 0, false) TG_RING(0, 2, true) TG_RING(0, 2, false)
-      TG_RING(2, 0, true) TG_RING(2, 0, false) TG_RING(2, 2, true) TG_RING(2, 2, false)
+      TG_RING(0, 0, true, false) TG_RING(0, 0, false, false) TG_RING(0, 2, true, false) TG_RING(0, 2, false, false)
+      TG_RING(2, 0, true, false) TG_RING(2, 0, false, false) TG_RING(2, 2, true, false) TG_RING(2, 2, false, false)
+      TG_RING(2, 2, false, true)  // the weight gradient of a Linear on x * s[row]
 #undef TG_RING
     }
   }
-  DYN_REQUIRE(p->kscale == nullptr, "dyn_train_gemm: kscale needs the ring form (operands k-minor with aligned quads or k-major with 16-byte-aligned rows; dyn_train_gemm_mode 0 or 2)");
+  DYN_REQUIRE(p->kscale == nullptr, "dyn_train_gemm: kscale is for the weight-gradient shape on the ring form (both operands k-major with 16-byte-aligned rows, accumulation into C; dyn_train_gemm_mode 0 or 2)");
   const dim3 grid(dyn_cdiv(p->M, TG_BM), dyn_cdiv(p->N, TG_BN), nz);
   // loader mode per operand: 0 = k-minor dwordx4 (aligned base, row stride a multiple of 4 floats and >= round_up4(K)), 1 = k-minor
   // dword, 2 = k-major

@@ -309,7 +309,7 @@ typedef struct {
   const float* rowscale; /* [M] or NULL: C = act(diag(rowscale) (A . B) + addend + bias) -- the forward of a Linear applied to x * s[row] (x * weight,
                           * x * vis: mlp_network.py:470, 474) without materialising the scaled input; not with a split reduction */
   const float* kscale;   /* [K] or NULL: B's element (n, k) is multiplied by kscale[k] -- the weight gradient dW = dZ^T (diag(s) X) of such a Linear
-                          * from the unscaled X (ring form only: an error where the operands force the tile kernel) */
+                          * from the unscaled X (the weight-gradient shape on the ring form only: both operands k-major with 16-byte-aligned rows, accumulate != 0) */
 } DynTrainGemmParams;
 int dyn_train_gemm(const DynTrainGemmParams* p, void* stream);
 /* Developer / test knob: which kernel form dyn_train_gemm uses -- 0 automatic (default; the environment variable DYNIBAR_TRAIN_GEMM =

@@ -154,7 +154,7 @@ int main() {
   hipMemset(src, 0, wgs * per_wg * 4);
   const double gb = (double)wgs * per_wg * 4 / 1e9;
   printf("%d workgroups x %d steps x 32 KiB = %.2f GB\n", wgs, steps, gb);
-#define ROW(L, M, V, D, what) { float us = run<L, M, V, D>(src, per_wg, out, steps, wgs); printf("%-62s %8.1f us  %5.2f TB/s\n", what, us, (L) ? gb / us * 1e-3 * 1e3 / 1e3 * 1e3 : 0.0); }
+#define ROW(L, M, V, D, what) { float us = run<L, M, V, D>(src, per_wg, out, steps, wgs); if (L) printf("%-62s %8.1f us  %5.2f TB/s\n", what, us, gb / us * 1e-3); else printf("%-62s %8.1f us\n", what, us); }
   ROW(1, 0, 0, 0, "LDS-DMA only")
   ROW(2, 0, 0, 0, "register loads only")
   ROW(0, 24, 0, 0, "24 MFMA per step, no loads")
