@@ -26,7 +26,7 @@ __device__ __forceinline__ void barrier_lds() {
 // ---- second experiment: what keeps the stream fast?  QH quads per thread and step from the workgroup's own HBM stream, QS quads from a
 // small region every workgroup shares (a weight tile: L2 hits), NSLOT ring slots (request distance NSLOT - 1), compute as above ----
 template <int QH, int QS, int NSLOT, int NM, int NV, int NL>
-__global__ void __launch_bounds__(256, 2) k2(const float* __restrict__ src, long floats_per_wg, const float* __restrict__ shared_src, float* out, int steps) {
+__global__ void __launch_bounds__(256) k2(const float* __restrict__ src, long floats_per_wg, const float* __restrict__ shared_src, float* out, int steps) {
   const int tid = threadIdx.x, wave = tid >> 6;
   constexpr int SLOT = (QH + QS) * 1024;  // floats
   const float* base = src + (long)blockIdx.x * floats_per_wg;
@@ -182,5 +182,12 @@ int main() {
   run2<4, 2, 3, 24, 48, 16>(src, sh, out, total, 512, "4 HBM + 2 shared quads / step, 3 slots (72 KiB: two workgroups)");
   run2<2, 2, 4, 12, 24, 8>(src, sh, out, total, 512, "2 HBM + 2 shared quads / step, 4 slots, half the compute per step (BK = 16)");
   run2<2, 2, 5, 12, 24, 8>(src, sh, out, total, 512, "2 HBM + 2 shared quads / step, 5 slots, half the compute per step (BK = 16)");
+  run2<4, 4, 2, 24, 24, 16>(src, sh, out, total, 512, "4 HBM + 4 shared quads / step, 2 slots, HALF the fma work (24 MFMA + 96 fma + 16 ds_read)");
+  run2<4, 4, 2, 24, 0, 16>(src, sh, out, total, 512, "4 HBM + 4 shared quads / step, 2 slots, NO fma work (24 MFMA + 16 ds_read)");
+  run2<4, 4, 2, 0, 48, 16>(src, sh, out, total, 512, "4 HBM + 4 shared quads / step, 2 slots, NO MFMA (192 fma + 16 ds_read)");
+  run2<2, 2, 2, 12, 24, 8>(src, sh, out, total, 768, "2 HBM + 2 shared quads / step, 2 slots, BK = 16, THREE workgroups per CU");
+  run2<2, 2, 2, 12, 24, 8>(src, sh, out, total, 1024, "2 HBM + 2 shared quads / step, 2 slots, BK = 16, FOUR workgroups per CU");
+  run2<2, 2, 3, 12, 24, 8>(src, sh, out, total, 768, "2 HBM + 2 shared quads / step, 3 slots, BK = 16, THREE workgroups per CU");
+  run2<4, 4, 2, 24, 48, 16>(src, sh, out, total, 768, "4 HBM + 4 shared quads / step, 2 slots, BK = 32, three workgroups requested (LDS allows two)");
   return 0;
 }
