@@ -2148,7 +2148,10 @@ __global__ void k_train_attn_bwd(const float* __restrict__ qkv, const float* __r
     dsr[j] = ds;
     for (int d = 0; d < 32; ++d) dq[d] += ds * ks[j * 33 + d];
   }
-  for (int d = 0; d < 32; ++d) dqkv[p * 384 + head * 32 + d] = dq[d] / 5.656854249492381f;
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4)
+    reinterpret_cast<float4*>(dqkv + p * 384 + head * 32)[d4] = make_float4(dq[4 * d4] / 5.656854249492381f, dq[4 * d4 + 1] / 5.656854249492381f,
+                                                                            dq[4 * d4 + 2] / 5.656854249492381f, dq[4 * d4 + 3] / 5.656854249492381f);
   __syncthreads();  // every thread is done with K and V
   for (int d = 0; d < 32; ++d) {
     ks[i * 33 + d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;  // Q / sqrt(d)
@@ -2177,16 +2180,24 @@ __global__ void k_train_attn_bwd(const float* __restrict__ qkv, const float* __r
 // HBM traffic per launch for 0.6 GB of algorithmic bytes.  Here the probabilities leave once, as coalesced rows, and come back once.
 __global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, float* __restrict__ out,
                                  float* __restrict__ prob) {
-  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]
-  float* vs = ks + S * 33;                         // [S][33]
-  float* ps = vs + S * 33;                         // [S][S + 1]
+  // K and V rows at a 36-float stride: 16-byte aligned, so that the inner products below read them (every lane the same address: a broadcast)
+  // four values per LDS instruction -- with one value per instruction the kernel was bound by the LDS instruction count
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][36]
+  float* vs = ks + S * 36;                         // [S][36]
+  float* ps = vs + S * 36;                         // [S][S + 1]
   const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
   const long p = (long)ray * S + i;
   float q[32];
-  for (int d = 0; d < 32; ++d) {
-    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
-    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
-    q[d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;
+  {  // the thread's rows of Q, K, V: 128 contiguous bytes each, as 16-byte loads (the 4-byte form cost 4x the instructions for the same lines)
+    const float4* row = reinterpret_cast<const float4*>(qkv + p * 384 + head * 32);
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 qv = row[d4], kv = row[32 + d4], vv = row[64 + d4];
+      q[4 * d4] = qv.x / 5.656854249492381f; q[4 * d4 + 1] = qv.y / 5.656854249492381f;
+      q[4 * d4 + 2] = qv.z / 5.656854249492381f; q[4 * d4 + 3] = qv.w / 5.656854249492381f;
+      *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = kv;
+      *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = vv;
+    }
   }
   __syncthreads();
   const bool live = nvalid[p] > 1.0f;
@@ -2194,7 +2205,11 @@ __global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __r
   float mx = -INFINITY;
   for (int j = 0; j < S; ++j) {
     float sc = 0.f;
-    for (int d = 0; d < 32; ++d) sc += q[d] * ks[j * 33 + d];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 k4 = *reinterpret_cast<const float4*>(ks + j * 36 + 4 * d4);
+      sc += (q[4 * d4] * k4.x + q[4 * d4 + 1] * k4.y) + (q[4 * d4 + 2] * k4.z + q[4 * d4 + 3] * k4.w);
+    }
     if (!live) sc = -1e9f;
     pr[j] = sc;
     mx = fmaxf(mx, sc);
@@ -2210,27 +2225,40 @@ __global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __r
   for (int j = 0; j < S; ++j) {
     const float a = pr[j] / den;
     pr[j] = a;
-    for (int d = 0; d < 32; ++d) o[d] += a * vs[j * 33 + d];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vs + j * 36 + 4 * d4);
+      o[4 * d4] += a * v4.x; o[4 * d4 + 1] += a * v4.y; o[4 * d4 + 2] += a * v4.z; o[4 * d4 + 3] += a * v4.w;
+    }
   }
-  for (int d = 0; d < 32; ++d) out[p * 128 + head * 32 + d] = o[d];
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4)
+    reinterpret_cast<float4*>(out + p * 128 + head * 32)[d4] = make_float4(o[4 * d4], o[4 * d4 + 1], o[4 * d4 + 2], o[4 * d4 + 3]);
   __syncthreads();
   float* g = prob + (long)blockIdx.x * S * S;
   for (int r = 0; r < S; ++r) g[(long)r * S + i] = ps[r * SP + i];  // coalesced rows
 }
 __global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, const float* __restrict__ prob,
                                      const float* __restrict__ dout, float* __restrict__ dqkv) {
-  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][33]: K, later Q / sqrt(d)
-  float* vs = ks + S * 33;                         // [S][33]: V, later dO
-  float* ps = vs + S * 33;                         // [S][S + 1]: probabilities
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][36]: K, later Q / sqrt(d)   (36: see k_train_attn_lds)
+  float* vs = ks + S * 36;                         // [S][36]: V, later dO
+  float* ps = vs + S * 36;                         // [S][S + 1]: probabilities
   float* db = ps + S * (S + 1);                    // [S][S + 1]: score gradients
   const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
   const long p = (long)ray * S + i;
   float dO[32], q[32];
-  for (int d = 0; d < 32; ++d) {
-    ks[i * 33 + d] = qkv[p * 384 + 128 + head * 32 + d];
-    vs[i * 33 + d] = qkv[p * 384 + 256 + head * 32 + d];
-    dO[d] = dout[p * 128 + head * 32 + d];
-    q[d] = qkv[p * 384 + head * 32 + d] / 5.656854249492381f;
+  {  // 16-byte loads of the thread's rows (see k_train_attn_lds)
+    const float4* row = reinterpret_cast<const float4*>(qkv + p * 384 + head * 32);
+    const float4* drow = reinterpret_cast<const float4*>(dout + p * 128 + head * 32);
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 qv = row[d4], kv = row[32 + d4], vv = row[64 + d4], dv4 = drow[d4];
+      q[4 * d4] = qv.x / 5.656854249492381f; q[4 * d4 + 1] = qv.y / 5.656854249492381f;
+      q[4 * d4 + 2] = qv.z / 5.656854249492381f; q[4 * d4 + 3] = qv.w / 5.656854249492381f;
+      dO[4 * d4] = dv4.x; dO[4 * d4 + 1] = dv4.y; dO[4 * d4 + 2] = dv4.z; dO[4 * d4 + 3] = dv4.w;
+      *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = kv;
+      *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = vv;
+    }
   }
   const float* g = prob + (long)blockIdx.x * S * S;
   for (int r = 0; r < S; ++r) ps[r * SP + i] = g[(long)r * S + i];
@@ -2239,7 +2267,11 @@ __global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float*
   float dot = 0.f;
   for (int j = 0; j < S; ++j) {
     float dp = 0.f;
-    for (int d = 0; d < 32; ++d) dp += dO[d] * vs[j * 33 + d];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vs + j * 36 + 4 * d4);
+      dp += (dO[4 * d4] * v4.x + dO[4 * d4 + 1] * v4.y) + (dO[4 * d4 + 2] * v4.z + dO[4 * d4 + 3] * v4.w);
+    }
     db[i * SP + j] = dp;
     dot += dp * ps[i * SP + j];
   }
@@ -2248,35 +2280,43 @@ __global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float*
   for (int j = 0; j < S; ++j) {
     const float ds = live ? ps[i * SP + j] * (db[i * SP + j] - dot) : 0.f;
     db[i * SP + j] = ds;
-    for (int d = 0; d < 32; ++d) dq[d] += ds * ks[j * 33 + d];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 k4 = *reinterpret_cast<const float4*>(ks + j * 36 + 4 * d4);
+      dq[4 * d4] += ds * k4.x; dq[4 * d4 + 1] += ds * k4.y; dq[4 * d4 + 2] += ds * k4.z; dq[4 * d4 + 3] += ds * k4.w;
+    }
   }
   for (int d = 0; d < 32; ++d) dqkv[p * 384 + head * 32 + d] = dq[d] / 5.656854249492381f;
   __syncthreads();  // every thread is done with K and V
-  for (int d = 0; d < 32; ++d) {
-    ks[i * 33 + d] = q[d];
-    vs[i * 33 + d] = dO[d];
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4) {
+    *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = make_float4(q[4 * d4], q[4 * d4 + 1], q[4 * d4 + 2], q[4 * d4 + 3]);
+    *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = make_float4(dO[4 * d4], dO[4 * d4 + 1], dO[4 * d4 + 2], dO[4 * d4 + 3]);
   }
   __syncthreads();
   float dk[32], dv[32];
   for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
   for (int qi = 0; qi < S; ++qi) {
     const float a = ps[qi * SP + i], ds = db[qi * SP + i];
-    for (int d = 0; d < 32; ++d) {
-      dk[d] += ds * ks[qi * 33 + d];
-      dv[d] += a * vs[qi * 33 + d];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const float4 q4 = *reinterpret_cast<const float4*>(ks + qi * 36 + 4 * d4), o4 = *reinterpret_cast<const float4*>(vs + qi * 36 + 4 * d4);
+      dk[4 * d4] += ds * q4.x; dk[4 * d4 + 1] += ds * q4.y; dk[4 * d4 + 2] += ds * q4.z; dk[4 * d4 + 3] += ds * q4.w;
+      dv[4 * d4] += a * o4.x; dv[4 * d4 + 1] += a * o4.y; dv[4 * d4 + 2] += a * o4.z; dv[4 * d4 + 3] += a * o4.w;
     }
   }
-  for (int d = 0; d < 32; ++d) {
-    dqkv[p * 384 + 128 + head * 32 + d] = dk[d];
-    dqkv[p * 384 + 256 + head * 32 + d] = dv[d];
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4) {
+    reinterpret_cast<float4*>(dqkv + p * 384 + 128 + head * 32)[d4] = make_float4(dk[4 * d4], dk[4 * d4 + 1], dk[4 * d4 + 2], dk[4 * d4 + 3]);
+    reinterpret_cast<float4*>(dqkv + p * 384 + 256 + head * 32)[d4] = make_float4(dv[4 * d4], dv[4 * d4 + 1], dv[4 * d4 + 2], dv[4 * d4 + 3]);
   }
 }
 #define TR_ATTN_LDS_MAX_S 112
 
 extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int S, float* out, float* prob, void* stream) {
   DYN_REQUIRE(qkv && nvalid && out && prob && R > 0 && S > 0 && S <= 256, "dyn_train_attn: bad arguments (S <= 256)");
-  if (S <= TR_ATTN_LDS_MAX_S) {
-    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 66 + S * (S + 1)) * 4, (hipStream_t)stream,
+  if (S <= TR_ATTN_LDS_MAX_S && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0) {  // (16-byte row accesses)
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 72 + S * (S + 1)) * 4, (hipStream_t)stream,
                qkv, nvalid, S, out, prob);
     return 0;
   }
@@ -2287,8 +2327,8 @@ extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int 
 extern "C" int dyn_train_attn_bwd(const float* qkv, const float* nvalid, int R, int S, const float* prob, const float* dout, float* dscore,
                                   float* dqkv, void* stream) {
   DYN_REQUIRE(qkv && nvalid && prob && dout && dscore && dqkv && R > 0 && S > 0 && S <= 256, "dyn_train_attn_bwd: bad arguments (S <= 256)");
-  if (S <= TR_ATTN_LDS_MAX_S) {
-    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 66 + 2 * S * (S + 1)) * 4,
+  if (S <= TR_ATTN_LDS_MAX_S && (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0) {
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 72 + 2 * S * (S + 1)) * 4,
                (hipStream_t)stream, qkv, nvalid, S, prob, dout, dqkv);
     return 0;
   }
