@@ -1989,6 +1989,41 @@ extern "C" int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const 
   return 0;
 }
 
+// y[row] = <x[row, 0:C], w> + b: the forward of a Linear with ONE output (vis_fc2.2, rgb_fc.4 of the static net, out_geometry_fc.2) as a
+// row kernel -- as a GEMM it ran a 128-column tile for one useful column.  C = 4 L columns (L a power of two lanes per row), four rows
+// per lane group and trip, the row's dot product by a shuffle reduction inside its lane group.
+__global__ void __launch_bounds__(256) k_train_rowdot4(const float4* __restrict__ x, long ldx4, const float4* __restrict__ w, const float* __restrict__ bias,
+                                                       long N, int sh, float* __restrict__ y, long y_stride) {
+  const int L = 1 << sh, G = 256 >> sh, g = threadIdx.x >> sh, q = threadIdx.x & (L - 1);
+  const float4 wq = w[q];
+  const float b = bias != nullptr ? bias[0] : 0.f;
+  const long r0 = ((long)blockIdx.x * G + g) * 4;
+  float4 xv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long rr = r0 + u < N ? r0 + u : N - 1;  // every lane takes part in the shuffles
+    xv[u] = x[rr * ldx4 + q];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float dot = (xv[u].x * wq.x + xv[u].y * wq.y) + (xv[u].z * wq.z + xv[u].w * wq.w);
+    for (int off = L >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if (q == 0 && r0 + u < N) y[(r0 + u) * y_stride] = dot + b;
+  }
+}
+extern "C" int dyn_train_rowdot(const float* X, long ldx, const float* w, const float* bias, long N, int C, float* y, long y_stride, void* stream) {
+  DYN_REQUIRE(X && w && y && N > 0 && C > 0, "dyn_train_rowdot: bad arguments");
+  const int c4 = C / 4;
+  DYN_REQUIRE((C & 3) == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0, "dyn_train_rowdot: %d columns (4, 8, 16, ... 256)", C);
+  DYN_REQUIRE((ldx & 3) == 0 && (((uintptr_t)X | (uintptr_t)w) & 15) == 0, "dyn_train_rowdot: rows must be 16-byte aligned");
+  int sh = 0;
+  while ((1 << sh) < c4) ++sh;
+  const long per_block = (long)(256 >> sh) * 4;
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_rowdot", k_train_rowdot4, dim3((unsigned)((N + per_block - 1) / per_block)), dim3(256), 0, (hipStream_t)stream,
+             reinterpret_cast<const float4*>(X), ldx / 4, reinterpret_cast<const float4*>(w), bias, N, sh, y, y_stride);
+  return 0;
+}
+
 // dX[row, :] = dz[row] * w[:] * act'(Y[row, :]): the data gradient of a Linear with ONE output (vis_fc2.2, rgb_fc.4 of the static net,
 // out_geometry_fc.2: a rank-one product -- as a GEMM it ran a 128-column tile for one useful column, 4.7 ms per iteration) through the
 // activation of the layer in front of it, with that layer's bias gradient (column sums) and the scale of dX.  C = 4 L columns (L a power

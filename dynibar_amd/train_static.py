@@ -107,6 +107,12 @@ class _Lin:
 
   def fwd(self, st, X, x_off, ldx, Y, y_off, ldy, M, act=NONE, addend=None, ld_add=0, add_div=1, bias=True, rowscale=None):
     """Y = act((X * rowscale[:, None]) W^T + b + addend[row // add_div]); the row scale is applied to the product, X * rowscale is not formed."""
+    if (self.n_out == 1 and act == NONE and addend is None and rowscale is None and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
+        (self.K // 4) & (self.K // 4 - 1) == 0 and ldx % 4 == 0 and x_off % 4 == 0 and self.W.data_ptr() % 16 == 0):
+      # one output: a dot product per row -- a row kernel, not a GEMM tile with one useful column
+      call('dyn_train_rowdot', _p(X, x_off), ldx, _p(self.W), _p(self.bias) if (bias and self.bias is not None) else None, M, self.K,
+           _p(Y, y_off), ldy, st)
+      return
     _gemm(st, _p(X, x_off), ldx, 1, _p(self.Wop, self.op_off), self.op_ld, 1, _p(Y, y_off), ldy, M, self.n_out, self.K,
           bias=_p(self.bias) if (bias and self.bias is not None) else None, addend=_p(addend) if addend is not None else None,
           ld_add=ld_add, add_div=add_div, act=act, rowscale=_p(rowscale) if rowscale is not None else None)

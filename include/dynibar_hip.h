@@ -377,6 +377,9 @@ int dyn_train_rowscale_act_bwd(const float* dy, long ld_dy, const float* x, long
                                long ld_dx, float* ds, long ds_stride, int ds_accumulate, int act, float* dbias, float* absmax, void* stream);
 int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
                                 float* dxv, long ld_dxv, float* dbias, float* absmax, void* stream);
+/* Forward of a Linear with ONE output (mlp_network.py:474-476, 487-493, 505-507): y[row * y_stride] = <X[row, 0:C], w> + bias[0] (bias may be
+ * NULL) for C = 4 * 2^k <= 256 columns in 16-byte-aligned rows; fp32 products and sums. */
+int dyn_train_rowdot(const float* X, long ldx, const float* w, const float* bias, long N, int C, float* y, long y_stride, void* stream);
 /* Data gradient of a Linear with ONE output through the activation in front of it (autograd of vis_fc2.2 / rgb_fc.4 / out_geometry_fc.2 and
  * of the ELU before them, mlp_network.py:474-476, 487-493, 505-507): dX[row, c] = dz[row] * w[c] * act'(Y[row, c]) for C = 4 * 2^k <= 256 columns
  * in 16-byte-aligned rows; dbias (may be NULL) += column sums, absmax (may be NULL) = max(absmax, largest |dX|). */
