@@ -4,12 +4,14 @@
 //
 // Design, as opposed to the inference kernels of dyn_nets.hip (register-resident chains, nothing saved): a training step needs every
 // layer's output again in the backward pass, so the step is a sequence of
-//   * ONE tiled GEMM kernel on the matrix pipe (k_train_gemm) used for forward (Y = act(X W^T + b + P[row / V])), data gradients
-//     (dX = dZ W) and weight gradients (dW += dZ^T X, split over the rows with fp32 atomics), and
+//   * ONE GEMM entry on the matrix pipe (dyn_train_gemm) used for forward (Y = act(diag(s) X W^T + b + P[row / V])), data gradients
+//     (dX = dZ W) and weight gradients (dW += dZ^T X, split over the rows with fp32 atomics), in two kernel forms: k_train_gemm (tiles
+//     through registers; the forward products) and k_train_gemm_ring (persistent workgroups, operand tiles by LDS-DMA: the backward
+//     products -- see the comment in front of it), and
 //   * small HBM-bound row / per-point kernels for everything between the Linear layers (Fourier features, pooling over views,
 //     sigmoids, softmaxes, ray attention, LayerNorm, compositing) with their hand-derived backward forms,
-// over row-major fp32 activation matrices that stay in HBM between kernels (a step of 2048 rays x 64 samples x 15 views keeps
-// about 12 GB: sized for the 288 GB of an MI355X, nothing is recomputed).
+// over row-major fp32 activation matrices that stay in HBM between kernels (the full iteration at 3072 rays x 64 samples x 10 + 10 + 15
+// views peaks at 46 GB: sized for the 288 GB of an MI355X; the host side can recompute the 256-wide hidden layers instead, 37 GB).
 //
 // Arithmetic of the GEMM: fp32 in, fp32 accumulate; every fp32 operand is split into two IEEE half parts x = hi + mid (22 mantissa
 // bits, like the inference engine) and the three partial products hi.hi + hi.mid + mid.hi run on v_mfma_f32_32x32x16_f16: fp32-class
