@@ -1202,6 +1202,88 @@ def check_train_recompute(device, name='small', S=16):
     TS.RECOMPUTE_HIDDEN = was
 
 
+def check_train_gemm_fuzz(device, n_cases=40, seed=123, max_rows=3000):
+  """Random shapes / epilogues through dyn_train_gemm in both kernel forms against fp64: row counts and widths that are not multiples of
+  the tile or of four, k tails, padded leading dimensions, bias / per-point addend / row scale / ELU / ReLU (forward), activation derivative
+  + column sums (data gradient), split reductions with a scaled reduction index (weight gradient)."""
+  import random
+  from dynibar_amd import train_static as TS
+  from dynibar_amd._lib import call
+  rng = random.Random(seed)
+  g = torch.Generator().manual_seed(seed)
+  try:
+    for case in range(n_cases):
+      mode = (0, 2, 1)[case % 3]
+      call('dyn_train_gemm_mode', mode)
+      _GEMM_MODE[0] = mode
+      M = rng.choice([1, 7, 127, 128, 129, 300, 1000, rng.randint(2, max_rows)])
+      K = rng.choice([1, 3, 4, 31, 32, 33, 64, 70, 104, 128, 136, rng.randint(1, 260)])
+      N = rng.choice([1, 4, 35, 36, 64, 128, 129, 132, 200, 256, rng.randint(1, 300)])
+      ldx = (K + 3) // 4 * 4 + rng.choice([0, 4])
+      ldy = (N + 3) // 4 * 4 + rng.choice([0, 0, 8]) if rng.random() < 0.8 else N
+      col0 = rng.choice([0, 0, 4, 5])
+      kfull = col0 + K + rng.choice([0, 1, 3])
+      V = rng.choice([1, 3, 7])
+      X = torch.randn(M, ldx, generator=g).to(device)
+      Wf = (torch.randn(N, kfull, generator=g) * 0.3).to(device)
+      b = torch.randn(N, generator=g).to(device) if rng.random() < 0.7 else None
+      lin = TS._Lin(Wf, b, col0, K)
+      st = TS.stream_of(X)
+      Wd = Wf[:, col0:col0 + K].double().cpu()
+      tag = f'fuzz {case} (mode {mode}, M {M} N {N} K {K} ldx {ldx} ldy {ldy} col0 {col0})'
+      # forward
+      act = rng.choice([TS.NONE, TS.ELU, 2])
+      use_add = rng.random() < 0.4 and ldy % 4 == 0
+      use_rs = rng.random() < 0.4
+      Pp = torch.randn((M + V - 1) // V, ldy, generator=g).to(device) if use_add else None
+      rs = (torch.rand(M, generator=g) * 2.0).to(device) if use_rs else None
+      Y = torch.full((M, ldy), float('nan'), device=device)
+      TS._gemm(st, TS._p(X), ldx, 1, TS._p(lin.Wop, lin.op_off), lin.op_ld, 1, TS._p(Y), ldy, M, N, K, bias=TS._p(b) if b is not None else None,
+               addend=TS._p(Pp) if use_add else None, ld_add=ldy, add_div=V, act=act, rowscale=TS._p(rs) if use_rs else None)
+      ref = X[:, :K].double().cpu() @ Wd.T
+      if use_rs:
+        ref = ref * rs.double().cpu()[:, None]
+      if use_add:
+        ref = ref + Pp.double().cpu().repeat_interleave(V, 0)[:M, :N]
+      if b is not None:
+        ref = ref + b.double().cpu()
+      ref = torch.nn.functional.elu(ref) if act == TS.ELU else (torch.relu(ref) if act == 2 else ref)
+      assert_close(Y[:, :N], ref, 2e-5, 6e-6, tag + ' forward')
+      if ldy > N:
+        assert bool(torch.isnan(Y[:, N:]).all()), tag + ': forward wrote beyond its columns'
+      # backward through _Lin.bwd: weight gradient (+ scaled reduction index where the ring form takes it), data gradient (+ act', column sums)
+      dZ = (torch.randn(M, ldy, generator=g) * rng.choice([1.0, 1e-5])).to(device)
+      Ys = torch.where(X > 0, X, torch.expm1(X))
+      kind = rng.choice([None, TS.ELU, 2])
+      dW = torch.zeros_like(Wf)
+      dX = torch.full((M, ldx), float('nan'), device=device)
+      db = torch.zeros(K, device=device)
+      xs = (torch.rand(M, generator=g) * 2.0).to(device) if (mode != 1 and rng.random() < 0.4 and ldx % 4 == 0 and ldy % 4 == 0 and ldy >= (N + 3) // 4 * 4) else None
+      try:
+        summed = lin.bwd(st, dZ, 0, ldy, Ys, 0, ldx, dW, M, dX, 0, ldx, act_y=(Ys, 0, ldx, kind) if kind else None, dbias=db, x_scale=xs)
+      except RuntimeError as e:  # a scaled reduction index where the operands force the tile kernel: refused, not computed wrongly
+        assert xs is not None and 'kscale' in str(e), (tag, str(e))
+        xs = None
+        dW.zero_()
+        summed = lin.bwd(st, dZ, 0, ldy, Ys, 0, ldx, dW, M, dX, 0, ldx, act_y=(Ys, 0, ldx, kind) if kind else None, dbias=db)
+      big = float(dZ[:, :N].abs().max())
+      refx = dZ[:, :N].double().cpu() @ Wd
+      if kind:
+        y = Ys[:, :K].double().cpu()
+        refx = refx * torch.where(y > 0, torch.ones_like(y), (y + 1.0) if kind == TS.ELU else torch.zeros_like(y))
+      assert_close(dX[:, :K], refx, 4e-6 * big * max(1.0, N ** 0.5), 6e-6, tag + ' data gradient')
+      if summed:
+        assert_close(db, refx.sum(0), 4e-6 * big * max(1.0, (N * M) ** 0.5), 1e-5, tag + ' column sums')
+      xk = Ys[:, :K].double().cpu() * (xs.double().cpu()[:, None] if xs is not None else 1.0)
+      refw = dZ[:, :N].double().cpu().T @ xk
+      assert_close(dW[:, col0:col0 + K], refw, 4e-6 * float(refw.abs().max()) + 1e-30, 6e-6, tag + ' weight gradient')
+      if col0 > 0:
+        assert float(dW[:, :col0].abs().max()) == 0.0, tag + ': weight gradient outside the slice'
+  finally:
+    call('dyn_train_gemm_mode', 0)
+    _GEMM_MODE[0] = 0
+
+
 def check_train_gemm(device):
   """dyn_train_gemm in its three roles (forward with bias / per-point addend / ELU, data gradient, split weight gradient) vs fp64 matmul,
   on shapes that are not multiples of the tile, at gradient-like magnitudes as well (the bf16 split keeps fp32's exponent range)."""

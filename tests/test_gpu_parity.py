@@ -252,6 +252,13 @@ def test_projector_helper_methods(dev):
 
 
 @pytest.mark.gpu
+def test_train_gemm_random_shapes(dev):
+  """both kernel forms of dyn_train_gemm on 90 random shapes / epilogues vs fp64 (+ two large ones: more tiles than resident workgroups)"""
+  parity.check_train_gemm_fuzz(dev, n_cases=90)
+  parity.check_train_gemm_fuzz(dev, n_cases=3, seed=7, max_rows=90000)
+
+
+@pytest.mark.gpu
 def test_training_with_recomputed_hidden_layers(dev):
   """DYNIBAR_TRAIN_RECOMPUTE=1 / train_static.RECOMPUTE_HIDDEN: memory for time, same numbers."""
   parity.check_train_recompute(dev)
