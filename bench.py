@@ -396,6 +396,35 @@ def main():
           extra['feature_encoder']['max_abs_diff_vs_pytorch_eager'] = float((xc - rc).abs().max())
         except Exception as e:
           extra['feature_encoder']['pytorch_eager_same_gpu_ms'] = 'failed: ' + str(e)[:120]
+        try:  # training form (forward with saved activations + backward: train.py:272-281 optimises feature_net) and the same through PyTorch eager
+          from dynibar_amd import train_encoder
+          pt = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in ew.items() if k in train_encoder.PARAMS}
+          cot = torch.randn(n_img, 32, H // 4, W // 4, device=dev)
+
+          def train_pass(fn):
+            for q in pt.values():
+              q.grad = None
+            c, f = fn()
+            ((c * cot).sum() + (f * cot).sum()).backward()
+
+          ours = lambda: train_encoder.encoder_forward(pt, x)
+          train_pass(ours); fence()
+          t0 = time.perf_counter()
+          for _ in range(3):
+            train_pass(ours)
+          fence()
+          tdt = (time.perf_counter() - t0) / 3
+          extra['feature_encoder']['training_form'] = {'what': 'forward with saved activations + backward to all 26 parameter tensors (im2col + dyn_train_gemm + InstanceNorm row kernels), 18 images',
+                                                       'ms_forward_backward': tdt * 1e3}
+          eager = lambda: O.resnet_encoder(pt, x.contiguous())
+          train_pass(eager); fence()
+          t0 = time.perf_counter()
+          for _ in range(3):
+            train_pass(eager)
+          fence()
+          extra['feature_encoder']['training_form']['pytorch_eager_same_gpu_ms'] = (time.perf_counter() - t0) / 3 * 1e3
+        except Exception as e:
+          extra['feature_encoder']['training_form'] = {'error': str(e)[:200]}
         del imgs, enc, x
       except Exception as e:
         extra['feature_encoder'] = {'error': str(e)[:300]}

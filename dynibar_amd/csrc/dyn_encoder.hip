@@ -480,3 +480,254 @@ extern "C" int dyn_encoder_forward(const DynEncoderParams* q, void* stream_) {
   if ((rc = launch_conv<1, 1, 1, 64, LOAD_NORM_ADD_RELU>(DYN_K_ENC_CONV1, "k_enc_out_conv", a, stream))) return rc;
   return 0;
 }
+
+// ===================================================================================================================
+// Training form (SURVEY 8f-3 / train.py:272-281: the reference optimises feature_net too).  The inference kernels above keep nothing;
+// the backward pass needs every convolution's input and output again, so the training form is built like the networks' (dyn_train.hip):
+// every convolution is an explicit im2col (channels-last patches, K = (ky, kx, ic)) + dyn_train_gemm in its three roles, and small row
+// kernels do what sits between -- InstanceNorm (+ affine, + residual, + ReLU) forward and backward with per-(image, channel) statistics
+// in fp64 tables, the scatter of patch gradients back onto the input map.  Host side: dynibar_amd/train_encoder.py.
+// ===================================================================================================================
+struct EncGeom {
+  int N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout;
+};
+// col[row, tap * C + c] = in[n, reflect(oy * stride - pad + ky), reflect(ox * stride - pad + kx), c]; row = (n * Hout + oy) * Wout + ox
+__global__ void __launch_bounds__(256) k_enc_im2col(EncGeom q, const float* __restrict__ in, float* __restrict__ col, long ldc) {
+  const int cq = q.C >= 4 && (q.C & 3) == 0 ? q.C / 4 : 1;  // float4 pieces per tap (C % 4 == 0), else one thread per tap
+  const long total = (long)q.N * q.Hout * q.Wout * q.KH * q.KW * cq;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int piece = (int)(idx % cq);
+  const long rt = idx / cq;
+  const int tap = (int)(rt % (q.KH * q.KW));
+  const long row = rt / (q.KH * q.KW);
+  const int ox = (int)(row % q.Wout), oy = (int)((row / q.Wout) % q.Hout), n = (int)(row / ((long)q.Wout * q.Hout));
+  const int iy = reflect_idx(oy * q.stride - q.pad + tap / q.KW, q.Hin), ix = reflect_idx(ox * q.stride - q.pad + tap % q.KW, q.Win);
+  const float* src = in + (((long)n * q.Hin + iy) * q.Win + ix) * q.C;
+  float* dst = col + row * ldc + (long)tap * q.C;
+  if (cq > 1 || q.C == 4) {
+    reinterpret_cast<float4*>(dst)[piece] = reinterpret_cast<const float4*>(src)[piece];
+  } else {
+    for (int c = 0; c < q.C; ++c) dst[c] = src[c];
+  }
+}
+// the adjoint: din[n, iy, ix, c] += dcol[row, tap * C + c] (atomics: border pixels are read by several taps of one row under reflection)
+__global__ void __launch_bounds__(256) k_enc_col2im(EncGeom q, const float* __restrict__ dcol, long ldc, float* __restrict__ din) {
+  const int cq = q.C / 4;
+  const long total = (long)q.N * q.Hout * q.Wout * q.KH * q.KW * cq;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int piece = (int)(idx % cq);
+  const long rt = idx / cq;
+  const int tap = (int)(rt % (q.KH * q.KW));
+  const long row = rt / (q.KH * q.KW);
+  const int ox = (int)(row % q.Wout), oy = (int)((row / q.Wout) % q.Hout), n = (int)(row / ((long)q.Wout * q.Hout));
+  const int iy = reflect_idx(oy * q.stride - q.pad + tap / q.KW, q.Hin), ix = reflect_idx(ox * q.stride - q.pad + tap % q.KW, q.Win);
+  const float4 v = reinterpret_cast<const float4*>(dcol + row * ldc + (long)tap * q.C)[piece];
+  float* dst = din + (((long)n * q.Hin + iy) * q.Win + ix) * q.C + 4 * piece;
+  atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+}
+static int enc_geom_check(const EncGeom& q, const char* who) {
+  DYN_REQUIRE(q.N > 0 && q.Hin > 0 && q.Win > 0 && q.C > 0 && q.KH > 0 && q.KW > 0 && q.stride > 0 && q.pad >= 0 && q.pad < q.Hin && q.pad < q.Win,
+              "%s: bad geometry", who);
+  DYN_REQUIRE(q.Hout == (q.Hin + 2 * q.pad - q.KH) / q.stride + 1 && q.Wout == (q.Win + 2 * q.pad - q.KW) / q.stride + 1, "%s: output size %d x %d does not match", who,
+              q.Hout, q.Wout);
+  return 0;
+}
+extern "C" int dyn_enc_im2col(const float* in, int N, int Hin, int Win, int C, int KH, int KW, int stride, int pad, int Hout, int Wout, float* col,
+                              long ldc, void* stream) {
+  DYN_REQUIRE(in && col && ldc >= (long)KH * KW * C, "dyn_enc_im2col: bad arguments");
+  const EncGeom q{N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout};
+  if (int rc = enc_geom_check(q, "dyn_enc_im2col")) return rc;
+  DYN_REQUIRE((C & 3) != 0 || ((ldc & 3) == 0 && (((uintptr_t)in | (uintptr_t)col) & 15) == 0), "dyn_enc_im2col: 16-byte alignment (C a multiple of 4)");
+  const int cq = C >= 4 && (C & 3) == 0 ? C / 4 : 1;
+  const long total = (long)N * Hout * Wout * KH * KW * cq;
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_im2col", k_enc_im2col, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, in, col, ldc);
+  return 0;
+}
+extern "C" int dyn_enc_col2im(const float* dcol, long ldc, int N, int Hin, int Win, int C, int KH, int KW, int stride, int pad, int Hout, int Wout,
+                              float* din, void* stream) {
+  DYN_REQUIRE(dcol && din && ldc >= (long)KH * KW * C && (C & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)dcol & 15) == 0, "dyn_enc_col2im: bad arguments (C, ldc multiples of 4, aligned)");
+  const EncGeom q{N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout};
+  if (int rc = enc_geom_check(q, "dyn_enc_col2im")) return rc;
+  const long total = (long)N * Hout * Wout * KH * KW * (C / 4);
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_col2im", k_enc_col2im, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, dcol, ldc, din);
+  return 0;
+}
+
+// ---- InstanceNorm over [N, HW, 64] maps.  grid (chunks of ENC_IN_CHUNK pixels, N), 256 threads = 16 float4 channel groups x 16 pixel lanes ----
+#define ENC_IN_CHUNK 1024
+// stats[n][c] = {sum x, sum x^2} (fp64, zeroed by the caller)
+__global__ void __launch_bounds__(256) k_enc_in_stats(const float4* __restrict__ x, long HW, double* __restrict__ stats) {
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [16 pixel lanes][64 ch][2]
+  const int n = blockIdx.y, g = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const long p0 = (long)blockIdx.x * ENC_IN_CHUNK, p1 = p0 + ENC_IN_CHUNK < HW ? p0 + ENC_IN_CHUNK : HW;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+  for (long p = p0 + pl; p < p1; p += 16) {
+    const float4 v = x[((long)n * HW + p) * 16 + g];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+  }
+  float* r = red + (pl * 64 + 4 * g) * 2;
+  r[0] = s.x; r[1] = s2.x; r[2] = s.y; r[3] = s2.y; r[4] = s.z; r[5] = s2.z; r[6] = s.w; r[7] = s2.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+    double t = 0.0;
+    for (int l = 0; l < 16; ++l) t += (double)red[(l * 64 + c) * 2 + k];
+    atomicAdd(stats + ((long)n * 64 + c) * 2 + k, t);
+  }
+}
+// per-block table of the (image, channel) normalisation: mean, rstd (and gamma * rstd, beta - mean * gamma * rstd) from the fp64 sums
+__device__ __forceinline__ void enc_in_table(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int n,
+                                             long HW, float* tab) {  // tab [4][64]: mean, rstd, sc, sh
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    const double inv = 1.0 / (double)HW, mean = stats[((long)n * 64 + c) * 2] * inv;
+    double var = stats[((long)n * 64 + c) * 2 + 1] * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + ENC_EPS);
+    tab[c] = (float)mean;
+    tab[64 + c] = (float)rstd;
+    tab[128 + c] = (float)(rstd * (double)gamma[c]);
+    tab[192 + c] = (float)((double)beta[c] - mean * rstd * (double)gamma[c]);
+  }
+  __syncthreads();
+}
+// y = relu?(IN(x) * gamma + beta (+ res))
+__global__ void __launch_bounds__(256) k_enc_in_apply(const float4* __restrict__ x, const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float4* __restrict__ res, int relu, long HW,
+                                                      float4* __restrict__ y) {
+  float* tab = reinterpret_cast<float*>(dyn_smem);
+  const int n = blockIdx.y, g = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  enc_in_table(stats, gamma, beta, n, HW, tab);
+  const float4 sc = *reinterpret_cast<const float4*>(tab + 128 + 4 * g), sh = *reinterpret_cast<const float4*>(tab + 192 + 4 * g);
+  const long p0 = (long)blockIdx.x * ENC_IN_CHUNK, p1 = p0 + ENC_IN_CHUNK < HW ? p0 + ENC_IN_CHUNK : HW;
+  for (long p = p0 + pl; p < p1; p += 16) {
+    const long i = ((long)n * HW + p) * 16 + g;
+    const float4 v = x[i];
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (res != nullptr) {
+      const float4 r = res[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    y[i] = o;
+  }
+}
+// backward, first pass: sums2[n][c] = {sum dyr, sum dyr * xhat} with dyr = relu ? dy * (y > 0) : dy, xhat = (x - mean) * rstd
+__global__ void __launch_bounds__(256) k_enc_in_bwd_stats(const float4* __restrict__ dy, const float4* __restrict__ y, int relu,
+                                                          const float4* __restrict__ x, const double* __restrict__ stats, long HW,
+                                                          double* __restrict__ sums2) {
+  float* tab = reinterpret_cast<float*>(dyn_smem);  // [256] table, then [16][64][2] partial sums
+  float* red = tab + 256;
+  const int n = blockIdx.y, g = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    const double inv = 1.0 / (double)HW, mean = stats[((long)n * 64 + c) * 2] * inv;
+    double var = stats[((long)n * 64 + c) * 2 + 1] * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    tab[c] = (float)mean;
+    tab[64 + c] = (float)(1.0 / sqrt(var + ENC_EPS));
+  }
+  __syncthreads();
+  const float4 mean = *reinterpret_cast<const float4*>(tab + 4 * g), rstd = *reinterpret_cast<const float4*>(tab + 64 + 4 * g);
+  const long p0 = (long)blockIdx.x * ENC_IN_CHUNK, p1 = p0 + ENC_IN_CHUNK < HW ? p0 + ENC_IN_CHUNK : HW;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+  for (long p = p0 + pl; p < p1; p += 16) {
+    const long i = ((long)n * HW + p) * 16 + g;
+    float4 d = dy[i];
+    if (relu) {
+      const float4 o = y[i];
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+    const float4 v = x[i];
+    s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    s2.x += d.x * (v.x - mean.x) * rstd.x; s2.y += d.y * (v.y - mean.y) * rstd.y;
+    s2.z += d.z * (v.z - mean.z) * rstd.z; s2.w += d.w * (v.w - mean.w) * rstd.w;
+  }
+  float* r = red + (pl * 64 + 4 * g) * 2;
+  r[0] = s.x; r[1] = s2.x; r[2] = s.y; r[3] = s2.y; r[4] = s.z; r[5] = s2.z; r[6] = s.w; r[7] = s2.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+    double t = 0.0;
+    for (int l = 0; l < 16; ++l) t += (double)red[(l * 64 + c) * 2 + k];
+    atomicAdd(sums2 + ((long)n * 64 + c) * 2 + k, t);
+  }
+}
+// backward, second pass: dx = gamma * rstd * (dyr - S0 / HW - xhat * S1 / HW); dres (may be NULL) = dyr; the first block of an image adds
+// its sums to dgamma (S1) and dbeta (S0)
+__global__ void __launch_bounds__(256) k_enc_in_bwd_apply(const float4* __restrict__ dy, const float4* __restrict__ y, int relu,
+                                                          const float4* __restrict__ x, const double* __restrict__ stats,
+                                                          const double* __restrict__ sums2, const float* __restrict__ gamma, long HW,
+                                                          float4* __restrict__ dx, float4* __restrict__ dres, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  float* tab = reinterpret_cast<float*>(dyn_smem);  // [5][64]: mean, rstd, gamma * rstd, S0 / HW, S1 / HW
+  const int n = blockIdx.y, g = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    const double inv = 1.0 / (double)HW, mean = stats[((long)n * 64 + c) * 2] * inv;
+    double var = stats[((long)n * 64 + c) * 2 + 1] * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + ENC_EPS);
+    const double S0 = sums2[((long)n * 64 + c) * 2], S1 = sums2[((long)n * 64 + c) * 2 + 1];
+    tab[c] = (float)mean;
+    tab[64 + c] = (float)rstd;
+    tab[128 + c] = (float)(rstd * (double)gamma[c]);
+    tab[192 + c] = (float)(S0 * inv);
+    tab[256 + c] = (float)(S1 * inv);
+    if (blockIdx.x == 0) {
+      atomicAdd(dgamma + c, (float)S1);
+      atomicAdd(dbeta + c, (float)S0);
+    }
+  }
+  __syncthreads();
+  const float4 mean = *reinterpret_cast<const float4*>(tab + 4 * g), rstd = *reinterpret_cast<const float4*>(tab + 64 + 4 * g);
+  const float4 gs = *reinterpret_cast<const float4*>(tab + 128 + 4 * g), m0 = *reinterpret_cast<const float4*>(tab + 192 + 4 * g);
+  const float4 m1 = *reinterpret_cast<const float4*>(tab + 256 + 4 * g);
+  const long p0 = (long)blockIdx.x * ENC_IN_CHUNK, p1 = p0 + ENC_IN_CHUNK < HW ? p0 + ENC_IN_CHUNK : HW;
+  for (long p = p0 + pl; p < p1; p += 16) {
+    const long i = ((long)n * HW + p) * 16 + g;
+    float4 d = dy[i];
+    if (relu) {
+      const float4 o = y[i];
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+    if (dres != nullptr) dres[i] = d;
+    const float4 v = x[i];
+    dx[i] = make_float4(gs.x * (d.x - m0.x - (v.x - mean.x) * rstd.x * m1.x), gs.y * (d.y - m0.y - (v.y - mean.y) * rstd.y * m1.y),
+                        gs.z * (d.z - m0.z - (v.z - mean.z) * rstd.z * m1.z), gs.w * (d.w - m0.w - (v.w - mean.w) * rstd.w * m1.w));
+  }
+}
+static bool enc_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+extern "C" int dyn_enc_in_stats(const float* x, int N, long HW, double* stats, void* stream) {
+  DYN_REQUIRE(x && stats && N > 0 && HW > 0 && enc_al16(x), "dyn_enc_in_stats: bad arguments");
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_in_stats", k_enc_in_stats, dim3((unsigned)((HW + ENC_IN_CHUNK - 1) / ENC_IN_CHUNK), N), dim3(256), 16 * 64 * 2 * 4,
+             (hipStream_t)stream, reinterpret_cast<const float4*>(x), HW, stats);
+  return 0;
+}
+extern "C" int dyn_enc_in_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* res, int relu, int N, long HW,
+                                float* y, void* stream) {
+  DYN_REQUIRE(x && stats && gamma && beta && y && N > 0 && HW > 0 && enc_al16(x) && enc_al16(y) && (res == nullptr || enc_al16(res)), "dyn_enc_in_apply: bad arguments");
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_in_apply", k_enc_in_apply, dim3((unsigned)((HW + ENC_IN_CHUNK - 1) / ENC_IN_CHUNK), N), dim3(256), 256 * 4,
+             (hipStream_t)stream, reinterpret_cast<const float4*>(x), stats, gamma, beta, reinterpret_cast<const float4*>(res), relu, HW,
+             reinterpret_cast<float4*>(y));
+  return 0;
+}
+extern "C" int dyn_enc_in_bwd(const float* dy, const float* y, int relu, const float* x, const double* stats, const float* gamma, int N, long HW,
+                              double* sums2, float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+  DYN_REQUIRE(dy && x && stats && gamma && sums2 && dx && dgamma && dbeta && N > 0 && HW > 0 && (!relu || y != nullptr), "dyn_enc_in_bwd: bad arguments");
+  DYN_REQUIRE(enc_al16(dy) && enc_al16(x) && enc_al16(dx) && (y == nullptr || enc_al16(y)) && (dres == nullptr || enc_al16(dres)), "dyn_enc_in_bwd: 16-byte alignment");
+  const dim3 grid((unsigned)((HW + ENC_IN_CHUNK - 1) / ENC_IN_CHUNK), N);
+  if (hipMemsetAsync(sums2, 0, (size_t)N * 64 * 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) {
+    dyn_set_error("dyn_enc_in_bwd: hipMemsetAsync failed");
+    return DYN_E_LAUNCH;
+  }
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_in_bwd", k_enc_in_bwd_stats, grid, dim3(256), (256 + 16 * 64 * 2) * 4, (hipStream_t)stream,
+             reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), relu, reinterpret_cast<const float4*>(x), stats, HW, sums2);
+  DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_in_bwd", k_enc_in_bwd_apply, grid, dim3(256), 320 * 4, (hipStream_t)stream, reinterpret_cast<const float4*>(dy),
+             reinterpret_cast<const float4*>(y), relu, reinterpret_cast<const float4*>(x), stats, sums2, gamma, HW, reinterpret_cast<float4*>(dx),
+             reinterpret_cast<float4*>(dres), dgamma, dbeta);
+  return 0;
+}

@@ -2,7 +2,8 @@
 feature_network.py:179-311), executed by the HIP convolution kernels of csrc/dyn_encoder.hip.
 
 Only the part of ``ResNet.forward`` the reference executes exists here (conv1 -> bn1 -> relu -> layer1 -> out_conv; the decoder
-layers the reference constructs are never run, :302-311).  Forward only: the returned maps carry no autograd graph.
+layers the reference constructs are never run, :302-311).  Under grad mode with trainable parameters the call runs the training
+form of the encoder (train_encoder.py) and the maps carry the graph into its parameters; otherwise the forward-only kernels.
 
 Layout: the reference's callers pass ``src_rgbs.squeeze(0).permute(0, 3, 1, 2)`` (eval_nvidia.py:335-358), i.e. an NCHW *view* of
 channels-last memory; the kernels read that memory as it is.  The returned ``x_coarse`` / ``x_fine`` are NCHW views ([N,32,Hf,Wf],
@@ -78,15 +79,12 @@ class ResNet(object):
   def cuda(self, device=None):
     return self.to('cuda' if device is None else device)
 
-  def _refuse_training(self):
-    """The HIP encoder is forward-only: its maps carry no autograd graph.  Left in place of `model.feature_net` during training the
-    encoder would silently stop learning (the reference trains it, train.py:272-281), so a forward under grad mode over a module that
-    still has trainable parameters is refused."""
+  def _trains(self):
+    """True when this call must carry an autograd graph into the encoder: grad mode on and a wrapped module with trainable parameters (the
+    reference trains feature_net, train.py:272-281).  Such a call runs the training form (train_encoder.py: saved activations, backward
+    kernels); everything else the forward-only kernels."""
     src = _unwrap(self._source)
-    if torch.is_grad_enabled() and hasattr(src, 'parameters') and any(p.requires_grad for p in src.parameters()):
-      raise RuntimeError('dynibar_amd.feature_network.ResNet is forward-only: called under grad mode on an encoder with trainable parameters. '
-                         'Keep the reference nn.Module as model.feature_net while training (its maps carry the graph our feature-map gradients '
-                         'flow into), or call under torch.no_grad() / freeze the encoder for evaluation.')
+    return torch.is_grad_enabled() and hasattr(src, 'parameters') and any(p.requires_grad for p in src.parameters())
 
   def _state(self):
     src = _unwrap(self._source)
@@ -109,7 +107,9 @@ class ResNet(object):
   def forward(self, x):
     """x [N,3,H,W] -> (x_coarse [N,32,Hf,Wf], x_fine [N,32,Hf,Wf])."""
     assert x.dim() == 4 and x.shape[1] == 3
-    self._refuse_training()
+    if self._trains():
+      from . import train_encoder
+      return train_encoder.encoder_forward(_unwrap(self._source), x)
     img = x.permute(0, 2, 3, 1)
     if img.dtype != torch.float32 or not img.is_contiguous():
       img = img.float().contiguous()

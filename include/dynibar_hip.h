@@ -246,6 +246,25 @@ typedef struct {
 } DynEncoderParams;
 int dyn_encoder_forward(const DynEncoderParams* p, void* stream);
 
+/* ---- training form of the encoder (autograd of ibrnet/feature_network.py:179-311; train.py:272-281 optimises feature_net): explicit
+ * im2col + dyn_train_gemm for the convolutions, row kernels for what sits between; channels-last fp32 maps [N, H, W, C]. ----
+ * dyn_enc_im2col: col[row, (ky * KW + kx) * C + c] = in[n, reflect(oy * stride - pad + ky), reflect(ox * stride - pad + kx), c],
+ *   row = (n * Hout + oy) * Wout + ox (padding_mode='reflect' as conv3x3 / conv1 of the reference; pad 0 for the 1x1 convolutions);
+ * dyn_enc_col2im: the adjoint, din += (atomics; din holds whatever gradient the map already has);
+ * dyn_enc_in_stats: stats[n][c] = {sum, sum of squares} over the HW pixels of image n (fp64, ZEROED by the caller), 64 channels;
+ * dyn_enc_in_apply: y = [relu](InstanceNorm(x) * gamma + beta [+ res])  (nn.InstanceNorm2d(affine=True, eps=1e-5), BasicBlock.forward);
+ * dyn_enc_in_bwd: its backward -- dyr = relu ? dy * (y > 0) : dy; dx = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat));
+ *   dres (may be NULL) = dyr (the residual branch); dgamma += sum dyr * xhat, dbeta += sum dyr; sums2 [N][64][2] doubles of workspace. */
+int dyn_enc_im2col(const float* in, int N, int Hin, int Win, int C, int KH, int KW, int stride, int pad, int Hout, int Wout, float* col, long ldc,
+                   void* stream);
+int dyn_enc_col2im(const float* dcol, long ldc, int N, int Hin, int Win, int C, int KH, int KW, int stride, int pad, int Hout, int Wout, float* din,
+                   void* stream);
+int dyn_enc_in_stats(const float* x, int N, long HW, double* stats, void* stream);
+int dyn_enc_in_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* res, int relu, int N, long HW, float* y,
+                     void* stream);
+int dyn_enc_in_bwd(const float* dy, const float* y, int relu, const float* x, const double* stats, const float* gamma, int N, long HW, double* sums2,
+                   float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
+
 /* ---- how the network kernels of this build multiply (csrc/dyn_mlp.h): split terms = partial products kept per fp32 product (3 or 6;
  * 0 = native fp32 MFMA engine); split kind = what the operand parts are: 0 none (fp32 MFMA), 1 bf16 (3 terms: 16 mantissa bits per
  * operand; 6 terms: fp32-class), 2 IEEE half (3 terms: 22 mantissa bits per operand, fp32-class; the shipped engine) --------------- */

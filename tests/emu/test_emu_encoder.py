@@ -11,3 +11,8 @@ pytestmark = pytest.mark.emu
 
 def test_encoder(emu, golden_dir):
   parity.check_encoder(emu, dict(np.load(os.path.join(golden_dir, 'encoder.npz'))), 'small')
+
+
+def test_encoder_training_form(emu):
+  """forward with saved activations + backward (im2col + training GEMM + InstanceNorm kernels) vs autograd through the oracle"""
+  parity.check_encoder_training(emu, 'small')

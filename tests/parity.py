@@ -672,6 +672,102 @@ def check_encoder(device, golden, name='small', atol=1e-4):
   return float((cpu(xc) - torch.from_numpy(golden[f'{name}/coarse'])).abs().max())
 
 
+def encoder_graph_with_masks(p, x, masks=None):
+  """The executed part of ResNet.forward exactly as oracle/ibr_oracle.py:resnet_encoder states it (feature_network.py:302-311), with the
+  ReLUs optionally replaced by GIVEN 0/1 masks -> (coarse, fine, pre-activations of the four kinds of ReLU in order).  With masks=None it
+  is the oracle's function (asserted by the caller); with the product's own masks it is the smooth function whose gradient the product
+  must reproduce -- a ReLU whose argument is within rounding of zero is not determined by the reference's fp32 arithmetic either."""
+  pre_acts, it = [], iter(masks) if masks is not None else None
+
+  def relu(v):
+    pre_acts.append(v)
+    return F.relu(v) if it is None else v * next(it)
+
+  x = relu(O._inorm(p, 'bn1', O._conv_reflect(x, p['conv1.weight'], 2, 3)))
+  for b in range(3):
+    pre = 'layer1.%d.' % b
+    identity = x
+    out = relu(O._inorm(p, pre + 'bn1', O._conv_reflect(x, p[pre + 'conv1.weight'], 2 if b == 0 else 1, 1)))
+    out = O._inorm(p, pre + 'bn2', O._conv_reflect(out, p[pre + 'conv2.weight'], 1, 1))
+    if b == 0:
+      identity = O._inorm(p, pre + 'downsample.1', O._conv_reflect(x, p[pre + 'downsample.0.weight'], 2, 0))
+    x = relu(out + identity)
+  x_out = F.conv2d(x, p['out_conv.weight'], p['out_conv.bias'])
+  return x_out[:, :32], x_out[:, -32:], pre_acts
+
+
+def check_encoder_training(device, name='small'):
+  """Training form of the feature encoder (dynibar_amd.train_encoder) against autograd through the oracle's restatement of the reference's
+  ResNet (pinned to the reference's own outputs by the encoder golden): the maps, and the gradient of a seeded linear functional of both
+  maps w.r.t. every parameter the executed part of ResNet.forward has (feature_network.py:179-311).  ReLU arguments within rounding of zero
+  (one or two of 10^5 on a GPU, none under the emulator) make the gradient jump: the reference gradient is taken with the product's own
+  ReLU decisions, after checking that they differ from the oracle's only where the oracle's argument is |v| < 1e-5 of the map's scale.
+  Also: a ResNet wrapper around a module with trainable parameters takes this path under grad mode and the forward-only kernels under
+  no_grad, with the same values."""
+  from dynibar_amd import feature_network, train_encoder
+  imgs, sd = cases.encoder_case(name)
+  g = torch.Generator().manual_seed(3)
+  x64 = imgs.permute(0, 3, 1, 2).double()
+  ref_p = {k: v.clone().double().requires_grad_(True) for k, v in O.tdict(sd).items() if k in train_encoder.PARAMS}
+  with torch.no_grad():
+    oc0, of0 = O.resnet_encoder(ref_p, x64)
+    oc1, of1, pre_oracle = encoder_graph_with_masks(ref_p, x64)
+  assert torch.equal(oc0, oc1) and torch.equal(of0, of1), 'the masked restatement must BE the oracle function when no masks are given'
+  # the product: forward with its saved state (for the ReLU decisions), then the public entry for the gradients
+  w = {k: torch.from_numpy(np.asarray(sd[k])).float().to(device) for k in train_encoder.PARAMS}
+  _, _, state = train_encoder._forward(w, imgs.to(device).contiguous())
+  stem_x = state['stem'][3]
+  relu_outs = [stem_x] + [t for blk in state['blocks'] for t in (blk[4], blk[9])]  # x0, then per block h1 and the block output
+  masks = [(cpu(t).permute(0, 3, 1, 2) > 0).double() for t in relu_outs]
+  flips = 0
+  for m, v in zip(masks, pre_oracle):
+    diff = (m > 0) != (v > 0)
+    flips += int(diff.sum())
+    if bool(diff.any()):
+      assert float(v[diff].abs().max()) < 1e-5 * float(v.abs().max()), 'a ReLU decision differs from the oracle away from zero'
+  assert flips <= 8, f'{flips} ReLU decisions differ from the oracle'
+  oc, of, _ = encoder_graph_with_masks(ref_p, x64, masks)
+  cot_c, cot_f = torch.randn(oc.shape, generator=g).double(), torch.randn(of.shape, generator=g).double()
+  ((oc * cot_c).sum() + (of * cot_f).sum()).backward()
+  dev_p = {k: w[k].clone().requires_grad_(True) for k in train_encoder.PARAMS}
+  xc, xf = train_encoder.encoder_forward(dev_p, imgs.to(device).permute(0, 3, 1, 2))
+  assert ops._channels_last_view(xc) is not None and ops._channels_last_view(xf) is not None, 'training encoder outputs must be channels-last in memory'
+  assert_close(xc, oc0, 1e-4, 1e-4, f'training encoder {name} coarse (|ref| up to {float(oc0.abs().max()):.1f})')
+  assert_close(xf, of0, 1e-4, 1e-4, f'training encoder {name} fine')
+  ((xc * cot_c.float().to(device)).sum() + (xf * cot_f.float().to(device)).sum()).backward()
+  worst = 0.0
+  for k in train_encoder.PARAMS:
+    ref = ref_p[k].grad
+    got = dev_p[k].grad
+    assert got is not None, f'training encoder: no gradient for {k}'
+    scale = float(ref.abs().max())
+    # fp32-class products, fp32 sums in another order (atomics, split reductions): 3e-5 of the tensor's largest gradient + 1e-4 relative
+    assert_close(got, ref, 3e-5 * scale + 1e-7, 1e-4, f'training encoder {name} grad {k} (max |g| {scale:.2e})')
+    worst = max(worst, float((cpu(got).double() - ref).abs().max()) / max(scale, 1e-30))
+  print(f'  training encoder {name}: {flips} ReLU decision(s) at arguments within rounding of zero differ from the oracle; worst gradient error {worst:.1e} of the tensor maximum')
+  # the wrapper: training form under grad mode, forward-only kernels under no_grad, same maps
+  class Holder(torch.nn.Module):
+    def __init__(self):
+      super().__init__()
+      self.p = torch.nn.ParameterDict({k.replace('.', '__'): torch.nn.Parameter(v.detach().clone()) for k, v in dev_p.items()})
+
+    def named_parameters(self, *a, **kw):
+      return [(k.replace('__', '.'), v) for k, v in self.p.items()]
+
+    def state_dict(self, *a, **kw):
+      return {k.replace('__', '.'): v.detach() for k, v in self.p.items()}
+
+  net = feature_network.ResNet.from_module(Holder())
+  x = imgs.to(device).permute(0, 3, 1, 2)
+  tc, _ = net(x)
+  assert tc.requires_grad, 'wrapper under grad mode with trainable parameters must return maps with a graph'
+  with torch.no_grad():
+    ic, _ = net(x)
+  assert not ic.requires_grad
+  assert_close(tc.detach(), ic, 5e-5, 1e-4, f'training encoder {name} vs forward-only kernels')
+  return worst
+
+
 def check_encoder_feeds_gather(device):
   """Maps produced by the HIP encoder are tapped in place (no repack): the gather on them equals the gather on an NCHW copy."""
   from dynibar_amd import feature_network

@@ -252,6 +252,13 @@ def test_projector_helper_methods(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['small', 'odd'])
+def test_feature_encoder_training_form(dev, name):
+  """forward with saved activations + backward of the encoder (train.py:272-281 optimises feature_net) vs autograd through the oracle"""
+  parity.check_encoder_training(dev, name)
+
+
+@pytest.mark.gpu
 def test_train_gemm_random_shapes(dev):
   """both kernel forms of dyn_train_gemm on 90 random shapes / epilogues vs fp64 (+ two large ones: more tiles than resident workgroups)"""
   parity.check_train_gemm_fuzz(dev, n_cases=90)
