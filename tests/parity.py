@@ -759,8 +759,11 @@ def check_encoder_training(device, name='small'):
 
   net = feature_network.ResNet.from_module(Holder())
   x = imgs.to(device).permute(0, 3, 1, 2)
-  tc, _ = net(x)
+  tc, tf = net(x)
   assert tc.requires_grad, 'wrapper under grad mode with trainable parameters must return maps with a graph'
+  (tc.square().mean() + tf.mean()).backward()  # what the renderer's feature-map gradient does: into the wrapped module's parameters
+  for k, v in net._source.named_parameters():
+    assert v.grad is not None and bool(torch.isfinite(v.grad).all()) and float(v.grad.abs().max()) > 0.0, f'wrapper: no gradient reached {k}'
   with torch.no_grad():
     ic, _ = net(x)
   assert not ic.requires_grad
@@ -784,6 +787,44 @@ def check_encoder_feeds_gather(device):
   ra = ops.project_gather(va, o.shape[0], 16, ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
   rb = ops.project_gather(vb, o.shape[0], 16, ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
   assert_bitexact(ra[0], rb[0], 'gather on in-place channels-last maps')
+
+
+def check_encoder_trains_through_gather(device):
+  """The renderer's feature-map gradient reaches the encoder's parameters: maps from the ResNet wrapper under grad mode (training form) are
+  tapped by the differentiable gather, and a loss on the gathered features fills the wrapped module's .grad with the same values as feeding
+  the gather's map gradient to the encoder's backward by hand (two autograd Functions composed by torch)."""
+  from dynibar_amd import feature_network, train_encoder, train_motion
+  scene, o, d, uv, _ = cases.scene_case('small')
+  sd = to_dev(scene, device)
+  params = {k: torch.from_numpy(np.asarray(v)).float().to(device).requires_grad_(True) for k, v in syn_encoder().items() if k in train_encoder.PARAMS}
+  imgs = sd['static_src_rgbs'][0]
+  R, S = o.shape[0], 16
+  pts_r, z_r, _ = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  kw = dict(ray_o=o.to(device), ray_d=d.to(device), z_vals=z_r.to(device))
+  g = torch.Generator().manual_seed(9)
+
+  def loss_of(fine):
+    views = ops.SourceViews(sd['camera'], sd['static_src_rgbs'], sd['static_src_cameras'], fine.detach())
+    rgb_feat = train_motion.gather(views, fine, R, S, **kw)[0]
+    return rgb_feat
+
+  _, fine = train_encoder.encoder_forward(params, imgs.permute(0, 3, 1, 2))
+  rf = loss_of(fine)
+  cot = torch.randn(rf.shape, generator=g).to(device)
+  (rf * cot).sum().backward()
+  got = {k: v.grad.clone() for k, v in params.items()}
+  assert all(bool(torch.isfinite(v).all()) for v in got.values()) and float(got['conv1.weight'].abs().max()) > 0.0
+  # by hand: the gather's gradient w.r.t. a leaf copy of the maps, pushed through the encoder separately
+  for v in params.values():
+    v.grad = None
+  _, fine2 = train_encoder.encoder_forward(params, imgs.permute(0, 3, 1, 2))
+  leaf = fine2.detach().clone().requires_grad_(True)
+  (loss_of(leaf) * cot).sum().backward()
+  fine2.backward(leaf.grad)
+  for k, v in params.items():
+    if k == 'out_conv.weight' or k == 'out_conv.bias':
+      continue  # (rows of the coarse half get exact zeros in both)
+    assert_close(v.grad, got[k], 2e-5 * float(got[k].abs().max()) + 1e-12, 1e-5, f'encoder through gather: grad {k}')
 
 
 def syn_encoder():

@@ -259,6 +259,11 @@ def test_feature_encoder_training_form(dev, name):
 
 
 @pytest.mark.gpu
+def test_feature_encoder_trains_through_the_gather(dev):
+  parity.check_encoder_trains_through_gather(dev)
+
+
+@pytest.mark.gpu
 def test_train_gemm_random_shapes(dev):
   """both kernel forms of dyn_train_gemm on 90 random shapes / epilogues vs fp64 (+ two large ones: more tiles than resident workgroups)"""
   parity.check_train_gemm_fuzz(dev, n_cases=90)
