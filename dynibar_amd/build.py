@@ -16,7 +16,7 @@ OUT_X6 = os.path.join(CSRC, 'libdynibar_hip_x6.so')
 UNITS = [
     ('dyn_geometry.hip', ['-ffp-contract=off', '-munsafe-fp-atomics']),
     ('dyn_nets.hip', []),
-    ('dyn_encoder.hip', []),
+    ('dyn_encoder.hip', ['-munsafe-fp-atomics']),  # (the training form's col2im adds with hardware fp32 atomics, not CAS loops)
     ('dyn_train.hip', ['-munsafe-fp-atomics']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

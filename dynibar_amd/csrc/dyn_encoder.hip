@@ -492,8 +492,32 @@ struct EncGeom {
   int N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout;
 };
 // col[row, tap * C + c] = in[n, reflect(oy * stride - pad + ky), reflect(ox * stride - pad + kx), c]; row = (n * Hout + oy) * Wout + ox
+// C not a multiple of four (the images' three channels): one thread per four consecutive elements of a patch row (a 16-byte store; the
+// image is small and cached, the patch matrix is what costs) -- ldc a multiple of four, the tail beyond KH * KW * C written as zeros
+__global__ void __launch_bounds__(256) k_enc_im2col_any(EncGeom q, const float* __restrict__ in, float* __restrict__ col, long ldc) {
+  const int q4 = (int)(ldc / 4), K = q.KH * q.KW * q.C;
+  const long total = (long)q.N * q.Hout * q.Wout * q4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int piece = (int)(idx % q4);
+  const long row = idx / q4;
+  const int ox = (int)(row % q.Wout), oy = (int)((row / q.Wout) % q.Hout), n = (int)(row / ((long)q.Wout * q.Hout));
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * piece + e;
+    if (j < K) {
+      const int tap = j / q.C, c = j - tap * q.C;
+      const int iy = reflect_idx(oy * q.stride - q.pad + tap / q.KW, q.Hin), ix = reflect_idx(ox * q.stride - q.pad + tap % q.KW, q.Win);
+      v[e] = in[(((long)n * q.Hin + iy) * q.Win + ix) * q.C + c];
+    } else {
+      v[e] = 0.f;
+    }
+  }
+  reinterpret_cast<float4*>(col + row * ldc)[piece] = make_float4(v[0], v[1], v[2], v[3]);
+}
 __global__ void __launch_bounds__(256) k_enc_im2col(EncGeom q, const float* __restrict__ in, float* __restrict__ col, long ldc) {
-  const int cq = q.C >= 4 && (q.C & 3) == 0 ? q.C / 4 : 1;  // float4 pieces per tap (C % 4 == 0), else one thread per tap
+  const int cq = q.C / 4;  // float4 pieces per tap (C % 4 == 0; k_enc_im2col_any otherwise)
   const long total = (long)q.N * q.Hout * q.Wout * q.KH * q.KW * cq;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -505,27 +529,48 @@ __global__ void __launch_bounds__(256) k_enc_im2col(EncGeom q, const float* __re
   const int iy = reflect_idx(oy * q.stride - q.pad + tap / q.KW, q.Hin), ix = reflect_idx(ox * q.stride - q.pad + tap % q.KW, q.Win);
   const float* src = in + (((long)n * q.Hin + iy) * q.Win + ix) * q.C;
   float* dst = col + row * ldc + (long)tap * q.C;
-  if (cq > 1 || q.C == 4) {
-    reinterpret_cast<float4*>(dst)[piece] = reinterpret_cast<const float4*>(src)[piece];
-  } else {
-    for (int c = 0; c < q.C; ++c) dst[c] = src[c];
-  }
+  reinterpret_cast<float4*>(dst)[piece] = reinterpret_cast<const float4*>(src)[piece];
 }
-// the adjoint: din[n, iy, ix, c] += dcol[row, tap * C + c] (atomics: border pixels are read by several taps of one row under reflection)
+// the adjoint: din[n, iy, ix, c] += sum over the (row, tap) pairs whose patch element is this pixel.  Gather form, one thread per (input
+// pixel, four channels): a tap (ky, kx) reads row index v = oy * stride - pad + ky, mirrored into the map by reflect_idx, so pixel iy is
+// read through v = iy, through v = -iy (top border, 1 <= iy <= pad) and through v = 2 (H - 1) - iy (bottom border) -- at most three
+// candidates per axis, each valid when (v + pad - ky) is a multiple of the stride inside the output.  (A scatter with fp32 atomics, the
+// first version, took 1.15 ms per 3x3 convolution of 18 quarter-resolution maps: 95 M atomics; this one reads the patch gradients once.)
+__device__ __forceinline__ int enc_mirror_candidates(int i, int n, int pad, int (&v)[3]) {
+  int c = 0;
+  v[c++] = i;
+  if (i >= 1 && i <= pad) v[c++] = -i;
+  if (i <= n - 2 && i >= n - 1 - pad) v[c++] = 2 * (n - 1) - i;
+  return c;
+}
 __global__ void __launch_bounds__(256) k_enc_col2im(EncGeom q, const float* __restrict__ dcol, long ldc, float* __restrict__ din) {
   const int cq = q.C / 4;
-  const long total = (long)q.N * q.Hout * q.Wout * q.KH * q.KW * cq;
+  const long total = (long)q.N * q.Hin * q.Win * cq;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int piece = (int)(idx % cq);
-  const long rt = idx / cq;
-  const int tap = (int)(rt % (q.KH * q.KW));
-  const long row = rt / (q.KH * q.KW);
-  const int ox = (int)(row % q.Wout), oy = (int)((row / q.Wout) % q.Hout), n = (int)(row / ((long)q.Wout * q.Hout));
-  const int iy = reflect_idx(oy * q.stride - q.pad + tap / q.KW, q.Hin), ix = reflect_idx(ox * q.stride - q.pad + tap % q.KW, q.Win);
-  const float4 v = reinterpret_cast<const float4*>(dcol + row * ldc + (long)tap * q.C)[piece];
-  float* dst = din + (((long)n * q.Hin + iy) * q.Win + ix) * q.C + 4 * piece;
-  atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+  const long pix = idx / cq;
+  const int ix = (int)(pix % q.Win), iy = (int)((pix / q.Win) % q.Hin), n = (int)(pix / ((long)q.Win * q.Hin));
+  int vy[3], vx[3];
+  const int ny = enc_mirror_candidates(iy, q.Hin, q.pad, vy), nx = enc_mirror_candidates(ix, q.Win, q.pad, vx);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ky = 0; ky < q.KH; ++ky)
+    for (int a = 0; a < ny; ++a) {
+      const int ty = vy[a] + q.pad - ky;
+      if (ty < 0 || ty % q.stride != 0 || ty / q.stride >= q.Hout) continue;
+      const int oy = ty / q.stride;
+      for (int kx = 0; kx < q.KW; ++kx)
+        for (int b = 0; b < nx; ++b) {
+          const int tx = vx[b] + q.pad - kx;
+          if (tx < 0 || tx % q.stride != 0 || tx / q.stride >= q.Wout) continue;
+          const long row = ((long)n * q.Hout + oy) * q.Wout + tx / q.stride;
+          const float4 v = reinterpret_cast<const float4*>(dcol + row * ldc + (long)(ky * q.KW + kx) * q.C)[piece];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+  float4* dst = reinterpret_cast<float4*>(din + pix * q.C) + piece;
+  const float4 o = *dst;
+  *dst = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
 }
 static int enc_geom_check(const EncGeom& q, const char* who) {
   DYN_REQUIRE(q.N > 0 && q.Hin > 0 && q.Win > 0 && q.C > 0 && q.KH > 0 && q.KW > 0 && q.stride > 0 && q.pad >= 0 && q.pad < q.Hin && q.pad < q.Win,
@@ -539,24 +584,29 @@ extern "C" int dyn_enc_im2col(const float* in, int N, int Hin, int Win, int C, i
   DYN_REQUIRE(in && col && ldc >= (long)KH * KW * C, "dyn_enc_im2col: bad arguments");
   const EncGeom q{N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout};
   if (int rc = enc_geom_check(q, "dyn_enc_im2col")) return rc;
-  DYN_REQUIRE((C & 3) != 0 || ((ldc & 3) == 0 && (((uintptr_t)in | (uintptr_t)col) & 15) == 0), "dyn_enc_im2col: 16-byte alignment (C a multiple of 4)");
-  const int cq = C >= 4 && (C & 3) == 0 ? C / 4 : 1;
-  const long total = (long)N * Hout * Wout * KH * KW * cq;
+  DYN_REQUIRE((ldc & 3) == 0 && ((uintptr_t)col & 15) == 0 && ((C & 3) != 0 || ((uintptr_t)in & 15) == 0),
+              "dyn_enc_im2col: ldc a multiple of 4 floats, 16-byte-aligned patch matrix (and map, when C is a multiple of 4)");
+  if ((C & 3) != 0) {
+    const long total4 = (long)N * Hout * Wout * (ldc / 4);
+    DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_im2col", k_enc_im2col_any, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, in, col, ldc);
+    return 0;
+  }
+  const long total = (long)N * Hout * Wout * KH * KW * (C / 4);
   DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_im2col", k_enc_im2col, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, in, col, ldc);
   return 0;
 }
 extern "C" int dyn_enc_col2im(const float* dcol, long ldc, int N, int Hin, int Win, int C, int KH, int KW, int stride, int pad, int Hout, int Wout,
                               float* din, void* stream) {
-  DYN_REQUIRE(dcol && din && ldc >= (long)KH * KW * C && (C & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)dcol & 15) == 0, "dyn_enc_col2im: bad arguments (C, ldc multiples of 4, aligned)");
+  DYN_REQUIRE(dcol && din && ldc >= (long)KH * KW * C && (C & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)dcol | (uintptr_t)din) & 15) == 0, "dyn_enc_col2im: bad arguments (C, ldc multiples of 4, aligned)");
   const EncGeom q{N, Hin, Win, C, KH, KW, stride, pad, Hout, Wout};
   if (int rc = enc_geom_check(q, "dyn_enc_col2im")) return rc;
-  const long total = (long)N * Hout * Wout * KH * KW * (C / 4);
+  const long total = (long)N * Hin * Win * (C / 4);
   DYN_LAUNCH(DYN_K_ENC_BLOCK, "dyn_enc_col2im", k_enc_col2im, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, dcol, ldc, din);
   return 0;
 }
 
 // ---- InstanceNorm over [N, HW, 64] maps.  grid (chunks of ENC_IN_CHUNK pixels, N), 256 threads = 16 float4 channel groups x 16 pixel lanes ----
-#define ENC_IN_CHUNK 1024
+#define ENC_IN_CHUNK 256  // pixels per block: 18 quarter-resolution maps give 648 blocks (1024 left a third of the CUs idle)
 // stats[n][c] = {sum x, sum x^2} (fp64, zeroed by the caller)
 __global__ void __launch_bounds__(256) k_enc_in_stats(const float4* __restrict__ x, long HW, double* __restrict__ stats) {
   float* red = reinterpret_cast<float*>(dyn_smem);  // [16 pixel lanes][64 ch][2]

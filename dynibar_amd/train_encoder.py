@@ -51,9 +51,7 @@ class _Conv:
     Ho, Wo = _out_hw(H, W, self.k, self.stride, self.pad)
     if self.k == 1 and self.stride == 1:
       return x.reshape(N * H * W, C), Ho, Wo
-    col = torch.empty((N * Ho * Wo, self.ldc), dtype=torch.float32, device=x.device)
-    if self.ldc != self.K:
-      col[:, self.K:].zero_()
+    col = torch.empty((N * Ho * Wo, self.ldc), dtype=torch.float32, device=x.device)  # (dyn_enc_im2col writes the padding columns as zeros)
     call('dyn_enc_im2col', _p(x), N, H, W, C, self.k, self.k, self.stride, self.pad, Ho, Wo, _p(col), self.ldc, st)
     return col, Ho, Wo
 

@@ -249,8 +249,9 @@ int dyn_encoder_forward(const DynEncoderParams* p, void* stream);
 /* ---- training form of the encoder (autograd of ibrnet/feature_network.py:179-311; train.py:272-281 optimises feature_net): explicit
  * im2col + dyn_train_gemm for the convolutions, row kernels for what sits between; channels-last fp32 maps [N, H, W, C]. ----
  * dyn_enc_im2col: col[row, (ky * KW + kx) * C + c] = in[n, reflect(oy * stride - pad + ky), reflect(ox * stride - pad + kx), c],
- *   row = (n * Hout + oy) * Wout + ox (padding_mode='reflect' as conv3x3 / conv1 of the reference; pad 0 for the 1x1 convolutions);
- * dyn_enc_col2im: the adjoint, din += (atomics; din holds whatever gradient the map already has);
+ *   row = (n * Hout + oy) * Wout + ox (padding_mode='reflect' as conv3x3 / conv1 of the reference; pad 0 for the 1x1 convolutions); ldc a
+ *   multiple of 4, columns KH * KW * C .. ldc - 1 are written as zeros;
+ * dyn_enc_col2im: the adjoint, din += (a gather over the patches that contain a pixel; din holds whatever gradient the map already has);
  * dyn_enc_in_stats: stats[n][c] = {sum, sum of squares} over the HW pixels of image n (fp64, ZEROED by the caller), 64 channels;
  * dyn_enc_in_apply: y = [relu](InstanceNorm(x) * gamma + beta [+ res])  (nn.InstanceNorm2d(affine=True, eps=1e-5), BasicBlock.forward);
  * dyn_enc_in_bwd: its backward -- dyr = relu ? dy * (y > 0) : dy; dx = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat));

@@ -93,7 +93,8 @@ def anchor_case(scene, num_vv=2, anchor_shift=1):
 
 def encoder_case(name='small'):
   """Seeded image batch [N,H,W,3] in [0,1] for the feature encoder (the data loaders' source images) and the encoder weights."""
-  cfg = {'small': dict(seed=11, N=2, H=40, W=56), 'odd': dict(seed=12, N=3, H=37, W=50), 'wide': dict(seed=13, N=1, H=64, W=160)}[name]
+  cfg = {'small': dict(seed=11, N=2, H=40, W=56), 'odd': dict(seed=12, N=3, H=37, W=50), 'wide': dict(seed=13, N=1, H=64, W=160),
+         'tiny': dict(seed=14, N=2, H=21, W=30)}[name]  # tiny: the emulator's training-form case (no golden)
   rng = np.random.default_rng([cfg['seed'], 5])
   yy, xx = np.meshgrid(np.linspace(0, 1, cfg['H']), np.linspace(0, 1, cfg['W']), indexing='ij')
   imgs = []

@@ -15,4 +15,4 @@ def test_encoder(emu, golden_dir):
 
 def test_encoder_training_form(emu):
   """forward with saved activations + backward (im2col + training GEMM + InstanceNorm kernels) vs autograd through the oracle"""
-  parity.check_encoder_training(emu, 'small')
+  parity.check_encoder_training(emu, 'tiny')

@@ -12,7 +12,7 @@ for a in rest:
   elif a == '--nets': cur = nets
   else: cur.append(a)
 objs = []
-for src, base, extra in (('dyn_geometry.hip', ['-ffp-contract=off', '-munsafe-fp-atomics'], geom), ('dyn_nets.hip', [], nets), ('dyn_encoder.hip', [], []),
+for src, base, extra in (('dyn_geometry.hip', ['-ffp-contract=off', '-munsafe-fp-atomics'], geom), ('dyn_nets.hip', [], nets), ('dyn_encoder.hip', ['-munsafe-fp-atomics'], []),
                          ('dyn_train.hip', ['-munsafe-fp-atomics'], [])):
   obj = os.path.join(CSRC, src.replace('.hip', '.o'))
   if extra:
