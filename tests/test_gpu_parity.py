@@ -223,6 +223,18 @@ def test_training_loop_reduces_the_loss(dev):
   assert h['main'][-1] < 0.97 * h['main'][0], h
 
 
+@pytest.mark.gpu
+def test_training_loop_with_the_feature_encoders(dev):
+  """the same loop with feature_net / feature_net_st in it (train.py:264-281): maps recomputed from the source images every iteration by the
+  encoder's training form, its parameters in the optimizer -- the loss must go down and the encoders' parameters must move"""
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  import train_loop
+  h = train_loop.run(dev, iters=20, R=256, S=32, log_every=19, quiet=True, encoders=True)
+  assert h['bootstrap'][-1] < 0.97 * h['bootstrap'][0], h
+  assert h['main'][-1] < 0.97 * h['main'][0], h
+
+
 def test_checkpoint_files_to_rendered_frame(dev, golden_dir, tmp_path):
   """Section 8f-4: torch.save files in the reference's two checkpoint formats -> checkpoint.load_model -> HIP encoders (vs the encoder golden) and
   render_single_image_nvi with the loaded model (vs the real reference's frame)."""

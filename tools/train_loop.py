@@ -34,7 +34,9 @@ def main_loss(ret, batch):
   return loss + 0.05 * torch.mean(torch.abs(anc['sf_seq']))
 
 
-def run(dev='cuda:0', iters=40, R=1024, S=64, log_every=10, quiet=False):
+def run(dev='cuda:0', iters=40, R=1024, S=64, log_every=10, quiet=False, encoders=False):
+  """encoders: also train feature_net / feature_net_st (train.py:272-281: the maps are recomputed from the source images every iteration by
+  the encoder's training form, the gradients of the maps flow on into its parameters, which sit in the optimizer with lrate_feature)."""
   tc = TrainCase(dev, R=R, S=S)
   g = torch.Generator().manual_seed(9)
   batch = dict(tc.batch)
@@ -43,13 +45,26 @@ def run(dev='cuda:0', iters=40, R=1024, S=64, log_every=10, quiet=False):
                motion_mask=(torch.rand(R, generator=g) < 0.5).float().to(dev), static_mask=(torch.rand(R, generator=g) < 0.3).float().to(dev))
   m = tc.model
   params = [p for n in ('net_coarse_st', 'net_coarse_dy', 'motion_mlp') for p in getattr(m, n).values()] + [m.trajectory_basis]
-  opt = torch.optim.Adam(params, lr=4e-4)  # lrate_mlp of the config (model.py:339-378)
+  groups = [{'params': params, 'lr': 4e-4}]  # lrate_mlp of the config (model.py:339-378)
+  enc = None
+  if encoders:
+    from dynibar_amd import synthetic as syn, train_encoder
+    enc = [{k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in syn.make_encoder_weights(sd).items() if k in train_encoder.PARAMS} for sd in (0, 1)]
+    groups.append({'params': [p for e in enc for p in e.values()], 'lr': 1e-3})  # lrate_feature
+  opt = torch.optim.Adam(groups)
   hist = {'bootstrap': [], 'main': []}
   for stage in ('bootstrap', 'main'):
     t0 = time.perf_counter()
     for it in range(iters):
       opt.zero_grad()
-      ret = render_ray.render_rays_mono(tc.fidx, tc.temb, tc.toff, batch, m, tc.feat, tc.proj, S, tc.args, inv_uniform=True, det=True,
+      feat = tc.feat
+      if enc is not None:  # train.py:264-281
+        nd = batch['src_rgbs'].shape[1]
+        cb = torch.cat([batch['src_rgbs'].squeeze(0).permute(0, 3, 1, 2), batch['anchor_src_rgbs'].squeeze(0).permute(0, 3, 1, 2)], 0)
+        cb_maps, _ = train_encoder.encoder_forward(enc[0], cb)
+        st_maps, _ = train_encoder.encoder_forward(enc[1], batch['static_src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+        feat = (cb_maps[:nd], cb_maps[nd:], st_maps)
+      ret = render_ray.render_rays_mono(tc.fidx, tc.temb, tc.toff, batch, m, feat, tc.proj, S, tc.args, inv_uniform=True, det=True,
                                         is_train=(stage == 'main'), num_vv=tc.num_vv)
       if stage == 'bootstrap':   # train.py:180-190
         w = (1.0 - batch['static_mask']) * ret['outputs_coarse_ref']['mask'].float()
@@ -70,4 +85,4 @@ def run(dev='cuda:0', iters=40, R=1024, S=64, log_every=10, quiet=False):
 if __name__ == '__main__':
   it = int(sys.argv[1]) if len(sys.argv) > 1 else 40
   R = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-  print(json.dumps(run(iters=it, R=R)))
+  print(json.dumps(run(iters=it, R=R, encoders='--encoders' in sys.argv)))
