@@ -562,6 +562,33 @@ def main():
                 'algorithmic_bytes_per_iteration': gst['bytes'] / 3, 'ms_per_iteration': gms, 'algorithmic_tflops': gst['flops'] / 3 / gms / 1e9,
                 'frac_of_split3_mfma_peak': gst['flops'] / 3 / gms / 1e9 / (2500.0 / 3),
                 'note': 'activations round-trip through HBM between layers (about 40 FLOP per byte): HBM-bound by design; launch time from HIP events on the launch stream'}
+          if Rt == 3072:
+            try:  # the part of the reference's iteration in front of render_rays_mono: both feature nets on the source views, trained (train.py:264-281)
+              from dynibar_amd import synthetic as _syn, train_encoder
+              encs = [{k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in _syn.make_encoder_weights(sd).items() if k in train_encoder.PARAMS} for sd in (0, 1)]
+              cb = torch.cat([tc.batch['src_rgbs'].squeeze(0), tc.batch['anchor_src_rgbs'].squeeze(0)], 0).permute(0, 3, 1, 2)
+              stx = tc.batch['static_src_rgbs'].squeeze(0).permute(0, 3, 1, 2)
+
+              def enc_step():
+                for e_ in encs:
+                  for q_ in e_.values():
+                    q_.grad = None
+                a_, _ = train_encoder.encoder_forward(encs[0], cb)
+                b_, _ = train_encoder.encoder_forward(encs[1], stx)
+                (a_.square().mean() + b_.square().mean()).backward()
+
+              enc_step(); fence()
+              t0 = time.perf_counter()
+              for _ in range(3):
+                enc_step()
+              fence()
+              leg['rays_3072']['feature_nets_ms'] = (time.perf_counter() - t0) / 3 * 1e3
+              leg['rays_3072']['feature_nets_what'] = ('feature_net on %d + feature_net_st on %d source images %dx%d, training form: forward + backward to their parameters '
+                                                       '(train.py:264-281; in front of the iteration timed above, which takes the maps as given)' %
+                                                       (cb.shape[0], stx.shape[0], cb.shape[2], cb.shape[3]))
+              del encs, cb, stx
+            except Exception as e:
+              leg['rays_3072']['feature_nets_ms'] = 'failed: ' + str(e)[:160]
           if Rt == 1024:
             try:  # the reference's own route on this GPU: the same iteration as PyTorch eager ops + autograd (the oracle's restatement on the device)
               from oracle import ibr_oracle as O
