@@ -1924,38 +1924,59 @@ extern "C" int dyn_train_rowscale_act_bwd(const float* dy, long ld_dy, const flo
 }
 
 // dxv[:, 0:128] = dx2 * ELU'(xv[:, 0:128]),  dxv[:, 128] = dvis0 * mask * sigmoid'(xv[:, 128]) * ELU'(xv[:, 128]): the split's backward
-// and the ELU of vis_fc.2 (129 outputs) in one pass; dbias[129] += column sums
-__global__ void __launch_bounds__(256) k_train_vis_split_act_bwd4(const float4* __restrict__ dx2, long ld_dx24, const float* __restrict__ dvis0,
+// and the ELU of vis_fc.2 (129 outputs) in one pass; dbias[129] += column sums.  With dxs != NULL the row-scale backward in front of it
+// (x * vis, mlp_network.py:474) rides along as well: dx2 += dxs * vis0[row] first (written back: dx2 goes on collecting the gradient of x),
+// and dvis0[row] = <dxs[row], x2[row]> is formed in the pass instead of read.
+__global__ void __launch_bounds__(256) k_train_vis_split_act_bwd4(float4* __restrict__ dx2, long ld_dx24, const float* __restrict__ dvis0,
                                                                   const float* __restrict__ xv, long ldv, const float* __restrict__ mask, long N,
                                                                   float* __restrict__ dxv, long ld_dxv, float* __restrict__ dbias,
-                                                                  float* __restrict__ absmax) {
+                                                                  float* __restrict__ absmax, const float4* __restrict__ dxs, long ld_dxs4,
+                                                                  const float4* __restrict__ x2, long ldx24, const float* __restrict__ vis0) {
   float4* part = dyn_smem;                                        // [8][32] partial column sums
   float* part_v = reinterpret_cast<float*>(dyn_smem + 256) + 8;   // [8] partial sums of column 128 (behind tr_block_absmax's four floats)
   const int g = threadIdx.x >> 5, q = threadIdx.x & 31;
   const long ra = ((long)blockIdx.x * 8 + g) * TR_FUSE_SPAN;
   const long rb = ra + TR_FUSE_SPAN < N ? ra + TR_FUSE_SPAN : N;
+  const long ra_even = ((long)blockIdx.x * 8 + (g & ~1)) * TR_FUSE_SPAN;  // (the same trip count for the two lane groups of a wave: shuffles)
+  const bool fused = dxs != nullptr;
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
   float vsum = 0.f, amax = 0.f;
-  for (long r = ra; r < rb; r += 4) {
-    float4 d[4], y[4];
-    float yv[4], dv[4], mk[4];
+  for (int t = 0; t < TR_FUSE_SPAN && ra_even + t < N; t += 4) {
+    const long r = ra + t;
+    float4 d[4], y[4], ds[4], xx[4];
+    float yv[4], dv[4], mk[4], vs[4];
+    long rr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long rr = r + u < rb ? r + u : rb - 1;
-      d[u] = dx2[rr * ld_dx24 + q];
-      y[u] = *reinterpret_cast<const float4*>(xv + rr * ldv + 4 * q);
-      if (q == 0) { yv[u] = xv[rr * ldv + 128]; dv[u] = dvis0[rr]; mk[u] = mask[rr]; }
+      rr[u] = r + u < N ? r + u : N - 1;
+      d[u] = dx2[rr[u] * ld_dx24 + q];
+      y[u] = *reinterpret_cast<const float4*>(xv + rr[u] * ldv + 4 * q);
+      if (fused) {
+        ds[u] = dxs[rr[u] * ld_dxs4 + q];
+        xx[u] = x2[rr[u] * ldx24 + q];
+        vs[u] = vis0[rr[u]];
+      }
+      if (q == 0) { yv[u] = xv[rr[u] * ldv + 128]; mk[u] = mask[rr[u]]; dv[u] = fused ? 0.f : dvis0[rr[u]]; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (r + u >= rb) continue;
+      const bool live = r + u < rb;
+      float dot = 0.f;
+      if (fused) {
+        dot = (ds[u].x * xx[u].x + ds[u].y * xx[u].y) + (ds[u].z * xx[u].z + ds[u].w * xx[u].w);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        d[u].x += ds[u].x * vs[u]; d[u].y += ds[u].y * vs[u]; d[u].z += ds[u].z * vs[u]; d[u].w += ds[u].w * vs[u];
+        if (live) dx2[rr[u] * ld_dx24 + q] = d[u];
+      }
+      if (!live) continue;
       const float4 v = make_float4(d[u].x * tr_dact(y[u].x, 1), d[u].y * tr_dact(y[u].y, 1), d[u].z * tr_dact(y[u].z, 1), d[u].w * tr_dact(y[u].w, 1));
       *reinterpret_cast<float4*>(dxv + (r + u) * ld_dxv + 4 * q) = v;
       colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
       if (q == 0) {
         const float sg = tr_sigmoid(yv[u]);
-        const float w = dv[u] * mk[u] * sg * (1.0f - sg) * tr_dact(yv[u], 1);
+        const float w = (fused ? dot : dv[u]) * mk[u] * sg * (1.0f - sg) * tr_dact(yv[u], 1);
         dxv[(r + u) * ld_dxv + 128] = w;
         vsum += w;
         amax = fmaxf(amax, fabsf(w));
@@ -1980,14 +2001,18 @@ __global__ void __launch_bounds__(256) k_train_vis_split_act_bwd4(const float4* 
   }
   if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
 }
-extern "C" int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
-                                           float* dxv, long ld_dxv, float* dbias, float* absmax, void* stream) {
-  DYN_REQUIRE(dx2 && dvis0 && xv && mask && dxv && N > 0, "dyn_train_vis_split_act_bwd: bad arguments");
+extern "C" int dyn_train_vis_split_act_bwd(float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
+                                           float* dxv, long ld_dxv, float* dbias, float* absmax, const float* dxs, long ld_dxs, const float* x2,
+                                           long ldx2, const float* vis0, void* stream) {
+  DYN_REQUIRE(dx2 && xv && mask && dxv && N > 0 && (dvis0 != nullptr || dxs != nullptr), "dyn_train_vis_split_act_bwd: bad arguments");
   DYN_REQUIRE(((ld_dx2 | ldv | ld_dxv) & 3) == 0 && ldv >= 129 && ld_dxv >= 129 && (((uintptr_t)dx2 | (uintptr_t)xv | (uintptr_t)dxv) & 15) == 0,
               "dyn_train_vis_split_act_bwd: rows must be 16-byte aligned (leading dimensions multiples of 4 floats, >= 129 for xv / dxv)");
+  DYN_REQUIRE(dxs == nullptr || (x2 && vis0 && ((ld_dxs | ldx2) & 3) == 0 && (((uintptr_t)dxs | (uintptr_t)x2) & 15) == 0),
+              "dyn_train_vis_split_act_bwd: the row-scale part needs dxs, x2 (16-byte-aligned rows) and vis0");
   const long blocks = (N + 8L * TR_FUSE_SPAN - 1) / (8L * TR_FUSE_SPAN);
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_vis_split_act_bwd", k_train_vis_split_act_bwd4, dim3((unsigned)blocks), dim3(256), 260 * sizeof(float4),
-             (hipStream_t)stream, reinterpret_cast<const float4*>(dx2), ld_dx2 / 4, dvis0, xv, ldv, mask, N, dxv, ld_dxv, dbias, absmax);
+             (hipStream_t)stream, reinterpret_cast<float4*>(dx2), ld_dx2 / 4, dvis0, xv, ldv, mask, N, dxv, ld_dxv, dbias, absmax,
+             reinterpret_cast<const float4*>(dxs), ld_dxs / 4, reinterpret_cast<const float4*>(x2), ldx2 / 4, vis0);
   return 0;
 }
 

@@ -185,19 +185,19 @@ def _backward(s, draw):
   call('dyn_train_meanvar_bwd', _p(s.X2), 128, _p(s.w2), P, V, 128, _p(s.G0), _p(dG0), _p(dG0, 128), 260, _p(dX), 128, 0, _p(dw2), 0, st)
   call('dyn_train_view_weights_bwd', 1, _p(s.VL), 1, _p(s.M), None, P, V, _p(s.w2), _p(dw2), None, 0, _p(s.VIS), 1, _p(dG0, 256), 260,
        _p(dVL), 1, None, st)
-  dH4, dXS, dvis0 = new(N, 128), new(N, 128), new(N)
+  dH4, dXS = new(N, 128), new(N, 128)
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   s.drop('H4')
   L['w0'].bwd(st, dH4, 0, 128, s.X2, 0, 128, g['vis_fc2.0.weight'], N, dXS, 0, 128, x_scale=s.vis0)  # the layer ran on x * vis
   del dH4
-  _untag(dX)
-  call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.X2), 128, _p(s.vis0), 1, N, 128, _p(dX), 128, 1, _p(dvis0), 1, 0, st)
+  dXV, scratch = new(N, 132), new(N)
+  # the row-scale backward of x * vis, the split's backward and vis_fc.2's ELU in one pass
+  _split_act_bwd(st, dX, 128, None, s.XV, s.M, N, dXV, g['vis_fc.2.bias'], dXS=dXS, X2=s.X2, ldx2=128, vis0=s.vis0)
   del dXS
   s.drop('X2')
-  dXV, dH3, dXW, scratch = new(N, 132), new(N, 128), new(N, 128), new(N)
-  _split_act_bwd(st, dX, 128, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
+  dH3, dXW = new(N, 128), new(N, 128)
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   del dXV

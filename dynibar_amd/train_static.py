@@ -178,10 +178,15 @@ def _rowscale_act_bwd(st, dY, ld_dy, X, ldx, s_row, rows, dX, ld_dx, ds, ds_accu
   dX._dyn_absmax = ((0, ld_dx, rows, 128), am)
 
 
-def _split_act_bwd(st, dX2, ld_dx2, dvis0, XV, mask_eff, rows, dXV, dbias):
-  """dXV [rows, 132] (129 used) = backward of vis_split through vis_fc.2's ELU (saved output XV [rows, 132]); dbias[129] += column sums."""
+def _split_act_bwd(st, dX2, ld_dx2, dvis0, XV, mask_eff, rows, dXV, dbias, dXS=None, X2=None, ldx2=0, vis0=None):
+  """dXV [rows, 132] (129 used) = backward of vis_split through vis_fc.2's ELU (saved output XV [rows, 132]); dbias[129] += column sums.
+  With dXS (the gradient of x * vis, vis_fc2.0's input): dX2[:, :128] += dXS * vis0[:, None] and dvis0 = <dXS, X2> first, in the same pass."""
   am = _Scalars.take(dXV.device)
-  call('dyn_train_vis_split_act_bwd', _p(dX2), ld_dx2, _p(dvis0), _p(XV), 132, _p(mask_eff), rows, _p(dXV), 132, _p(dbias), _p(am), st)
+  if dXS is not None:
+    _untag(dX2)
+  call('dyn_train_vis_split_act_bwd', _p(dX2), ld_dx2, _p(dvis0) if dvis0 is not None else None, _p(XV), 132, _p(mask_eff), rows, _p(dXV), 132,
+       _p(dbias), _p(am), _p(dXS) if dXS is not None else None, 128, _p(X2) if X2 is not None else None, ldx2,
+       _p(vis0) if vis0 is not None else None, st)
   dXV._dyn_absmax = ((0, 132, rows, 129), am)
 
 
@@ -373,20 +378,20 @@ def _backward(s, draw):
   call('dyn_train_view_weights_bwd', 1, _p(s.VL), 1, _p(s.M), None, P, V, _p(s.w2), _p(dw2), _p(dRIN, 128), 136, _p(s.RIN, 128), 136,
        _p(dG0, 256), 260, _p(dVL), 1, None, st)
   # vis_fc2
-  dH4, dXS, dvis0 = new(N, 128), new(N, 128), new(N)
+  dH4, dXS = new(N, 128), new(N, 128)
   _act_bwd(st, dVL, 0, 1, None, 0, 1, N, 1, NONE, g['vis_fc2.2.bias'])
   if not L['w2'].bwd(st, dVL, 0, 1, s.H4, 0, 128, g['vis_fc2.2.weight'], N, dH4, 0, 128, act_y=(s.H4, 0, 128, ELU), dbias=g['vis_fc2.0.bias']):
     _act_bwd(st, dH4, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc2.0.bias'])
   s.drop('H4')
   L['w0'].bwd(st, dH4, 0, 128, s.RIN, 0, 136, g['vis_fc2.0.weight'], N, dXS, 0, 128, x_scale=s.vis0)  # the layer ran on x * vis
   del dH4
-  _untag(dRIN)
-  call('dyn_train_rowscale_bwd', _p(dXS), 128, _p(s.RIN), 136, _p(s.vis0), 1, N, 128, _p(dRIN), 136, 1, _p(dvis0), 1, 0, st)
+  # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
+  dXV = new(N, 132)
+  # the row-scale backward of x * vis, the split's backward and vis_fc.2's ELU in one pass
+  _split_act_bwd(st, dRIN, 136, None, s.XV, s.M, N, dXV, g['vis_fc.2.bias'], dXS=dXS, X2=s.RIN, ldx2=136, vis0=s.vis0)
   del dXS
   s.drop('RIN')
-  # x2 = x1 + x_res, vis0 = sigmoid(.) mask: dRIN[:, :128] is now d x2 = d x1 (so far) = d x_res
-  dXV, dH3, dXW = new(N, 132), new(N, 128), new(N, 128)
-  _split_act_bwd(st, dRIN, 136, dvis0, s.XV, s.M, N, dXV, g['vis_fc.2.bias'])  # the split's backward and vis_fc.2's ELU in one pass
+  dH3, dXW = new(N, 128), new(N, 128)
   if not L['v2'].bwd(st, dXV, 0, 132, s.H3, 0, 128, g['vis_fc.2.weight'], N, dH3, 0, 128, act_y=(s.H3, 0, 128, ELU), dbias=g['vis_fc.0.bias']):
     _act_bwd(st, dH3, 0, 128, None, 0, 128, N, 128, NONE, g['vis_fc.0.bias'])
   del dXV

@@ -391,12 +391,14 @@ int dyn_train_vis_split_bwd(const float* dx2, long ld_dx2, const float* dvis0, c
  *  dyn_train_rowscale_act_bwd: dx = (dx + dy * s[row]) * act'(x), ds[row] (=|+=) <dy[row], x[row]> -- x is both what s multiplied in the
  *    forward pass and the saved output of the activation in front of it (mlp_network.py:466-470: x = base_fc(...); vis_fc(x * weight));
  *  dyn_train_vis_split_act_bwd: dxv[:, 0:128] = dx2 * ELU'(xv[:, 0:128]), dxv[:, 128] = dvis0 * mask * sigmoid'(xv[:, 128]) * ELU'(xv[:, 128])
- *    (mlp_network.py:470-473: vis_fc ends in an ELU over its 129 outputs).
+ *    (mlp_network.py:470-473: vis_fc ends in an ELU over its 129 outputs); with dxs != NULL (then dvis0 may be NULL) the backward of
+ *    vis_fc2's input x * vis (:474) comes first in the same pass: dx2 += dxs * vis0[row] (written back), dvis0[row] = <dxs[row], x2[row]>.
  * dbias (may be NULL) += the column sums of the result (128 / 129 entries), absmax (may be NULL) = max(absmax, largest |result|). */
 int dyn_train_rowscale_act_bwd(const float* dy, long ld_dy, const float* x, long ldx, const float* s, long s_stride, long N, float* dx,
                                long ld_dx, float* ds, long ds_stride, int ds_accumulate, int act, float* dbias, float* absmax, void* stream);
-int dyn_train_vis_split_act_bwd(const float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N,
-                                float* dxv, long ld_dxv, float* dbias, float* absmax, void* stream);
+int dyn_train_vis_split_act_bwd(float* dx2, long ld_dx2, const float* dvis0, const float* xv, long ldv, const float* mask, long N, float* dxv,
+                                long ld_dxv, float* dbias, float* absmax, const float* dxs, long ld_dxs, const float* x2, long ldx2,
+                                const float* vis0, void* stream);
 /* Forward of a Linear with ONE output (mlp_network.py:474-476, 487-493, 505-507): y[row * y_stride] = <X[row, 0:C], w> + bias[0] (bias may be
  * NULL) for C = 4 * 2^k <= 256 columns in 16-byte-aligned rows; fp32 products and sums. */
 int dyn_train_rowdot(const float* X, long ldx, const float* w, const float* bias, long N, int C, float* y, long y_stride, void* stream);
