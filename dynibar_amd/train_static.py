@@ -153,7 +153,13 @@ class _Lin:
         fy.update(colsum_part=_p(part), ld_part=self.K, amax_part=_p(apart))
       if acc_dx != 0:
         _untag(dX)
-      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, self.K, self.n_out, accumulate=acc_dx,
+      # a slice whose width is not a multiple of four (rgb_fc.0: 133, base_fc.0: 70 / 35 ...) is computed over the padded operand copy's
+      # full width: the extra columns are exact zeros landing in dX's padding columns, and the product gets 16-byte result rows (the
+      # epilogue's fast form) instead of 4-byte stores
+      Nd = self.K
+      if self.K % 4 != 0 and self.Wop is not self.W and acc_dx == 0 and act_y is None and ld_dx >= self.op_ld and ld_dx % 4 == 0 and dx_off % 4 == 0:
+        Nd = self.op_ld
+      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, Nd, self.n_out, accumulate=acc_dx,
             a_absmax=_p(am), **fy)
       if sums:
         am2 = _Scalars.take(dX.device)
