@@ -2058,13 +2058,13 @@ extern "C" int dyn_train_rowdot(const float* X, long ldx, const float* w, const 
 __global__ void __launch_bounds__(256) k_train_outer_act_bwd4(const float* __restrict__ dz, long dz_stride, const float4* __restrict__ w,
                                                               const float4* __restrict__ y, long ld_y4, long N, int sh, int act,
                                                               float4* __restrict__ dx, long ld_dx4, float* __restrict__ dbias,
-                                                              float* __restrict__ absmax) {
+                                                              float* __restrict__ absmax, float* __restrict__ dw) {
   float4* part = dyn_smem;  // [G][L] partial column sums
   const int L = 1 << sh, G = 256 >> sh, g = threadIdx.x >> sh, q = threadIdx.x & (L - 1);
   const long ra = ((long)blockIdx.x * G + g) * TR_FUSE_SPAN;
   const long rb = ra + TR_FUSE_SPAN < N ? ra + TR_FUSE_SPAN : N;
   const float4 wq = w[q];
-  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f), wsum = make_float4(0.f, 0.f, 0.f, 0.f);
   float amax = 0.f;
   for (long r = ra; r < rb; r += 4) {
     float4 yv[4];
@@ -2080,6 +2080,8 @@ __global__ void __launch_bounds__(256) k_train_outer_act_bwd4(const float* __res
       if (r + u >= rb) continue;
       float4 v = make_float4(d[u] * wq.x, d[u] * wq.y, d[u] * wq.z, d[u] * wq.w);
       if (act != 0) {
+        // the weight gradient of the one-output layer rides along: its input IS the saved output Y of the layer in front
+        wsum.x = fmaf(d[u], yv[u].x, wsum.x); wsum.y = fmaf(d[u], yv[u].y, wsum.y); wsum.z = fmaf(d[u], yv[u].z, wsum.z); wsum.w = fmaf(d[u], yv[u].w, wsum.w);
         v.x *= tr_dact(yv[u].x, act); v.y *= tr_dact(yv[u].y, act); v.z *= tr_dact(yv[u].z, act); v.w *= tr_dact(yv[u].w, act);
       }
       dx[(r + u) * ld_dx4 + q] = v;
@@ -2096,11 +2098,23 @@ __global__ void __launch_bounds__(256) k_train_outer_act_bwd4(const float* __res
     atomicAdd(dbias + threadIdx.x, t);
   }
   if (absmax != nullptr) tr_block_absmax(amax, reinterpret_cast<float*>(dyn_smem + 256), absmax);
+  if (dw != nullptr) {  // uniform over the block
+    __syncthreads();
+    part[g * L + q] = wsum;
+    __syncthreads();
+    if (threadIdx.x < 4 * L) {
+      const float* pf = reinterpret_cast<const float*>(part);
+      float t = 0.f;
+      for (int k = 0; k < G; ++k) t += pf[k * 4 * L + threadIdx.x];
+      atomicAdd(dw + threadIdx.x, t);
+    }
+  }
 }
 extern "C" int dyn_train_outer_act_bwd(const float* dz, long dz_stride, const float* w, const float* Y, long ld_y, long N, int C, int act,
-                                       float* dX, long ld_dx, float* dbias, float* absmax, void* stream) {
+                                       float* dX, long ld_dx, float* dbias, float* absmax, float* dW, void* stream) {
   DYN_REQUIRE(dz && w && dX && N > 0 && C > 0, "dyn_train_outer_act_bwd: bad arguments");
   DYN_REQUIRE(act == 0 || Y != nullptr, "dyn_train_outer_act_bwd: ELU / ReLU backward needs the saved output");
+  DYN_REQUIRE(dW == nullptr || act != 0, "dyn_train_outer_act_bwd: the weight gradient is taken against Y (the layer's input), which needs act != 0");
   const int c4 = C / 4;
   DYN_REQUIRE((C & 3) == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0, "dyn_train_outer_act_bwd: %d columns (4, 8, 16, ... 256)", C);
   DYN_REQUIRE((ld_dx & 3) == 0 && (act == 0 || (ld_y & 3) == 0) && (((uintptr_t)w | (uintptr_t)dX | (act ? (uintptr_t)Y : 0)) & 15) == 0,
@@ -2110,7 +2124,7 @@ extern "C" int dyn_train_outer_act_bwd(const float* dz, long dz_stride, const fl
   const long per_block = (long)(256 >> sh) * TR_FUSE_SPAN;
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_outer_act_bwd", k_train_outer_act_bwd4, dim3((unsigned)((N + per_block - 1) / per_block)), dim3(256),
              257 * sizeof(float4), (hipStream_t)stream, dz, dz_stride, reinterpret_cast<const float4*>(w),
-             reinterpret_cast<const float4*>(act != 0 ? Y : nullptr), ld_y / 4, N, sh, act, reinterpret_cast<float4*>(dX), ld_dx / 4, dbias, absmax);
+             reinterpret_cast<const float4*>(act != 0 ? Y : nullptr), ld_y / 4, N, sh, act, reinterpret_cast<float4*>(dX), ld_dx / 4, dbias, absmax, dW);
   return 0;
 }
 

@@ -123,24 +123,30 @@ class _Lin:
     # returns True when that happened (16-byte-aligned dX rows), False when the caller still has to run _act_bwd for them.
     """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K].  dZ is the GEMMs' scaled operand:
     its largest magnitude comes from the activation-derivative pass that made it (_act_bwd leaves it on the tensor) or is measured here."""
-    tag = getattr(dZ, '_dyn_absmax', None)
-    if tag is not None and tag[0] == (dz_off, ld_dz, M, self.n_out):
-      am = tag[1]
-    else:
-      am = _Scalars.take(dZ.device)
-      call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
-      dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
-    ks = max(1, min(1024, M // 1024))  # reduction chunks of the weight gradient: enough (row tile, chunk) units for every resident workgroup
-    # x_scale [M]: the layer ran on X * x_scale[:, None] (fwd's rowscale); its weight gradient takes the scale on the reduction index
-    _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
-          a_absmax=_p(am), kscale=_p(x_scale) if x_scale is not None else None)
-    if (dX is not None and self.n_out == 1 and acc_dx == 0 and dx_off == 0 and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
-        (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0))):
+    one_out = (dX is not None and self.n_out == 1 and acc_dx == 0 and dx_off == 0 and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
+               (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0)))
+    # one output whose input is the saved activation the data gradient goes back through: the weight gradient is a weighted column sum
+    # of the rows that pass already reads (as a GEMM it was a 128-row tile with one useful row)
+    fused_w = (one_out and act_y is not None and x_scale is None and self.k_full == self.K and x_off == 0 and act_y[2] == ldx and
+               act_y[0].data_ptr() == X.data_ptr())
+    if not fused_w:
+      tag = getattr(dZ, '_dyn_absmax', None)
+      if tag is not None and tag[0] == (dz_off, ld_dz, M, self.n_out):
+        am = tag[1]
+      else:
+        am = _Scalars.take(dZ.device)
+        call('dyn_train_absmax', _p(dZ, dz_off), M, self.n_out, ld_dz, _p(am), st)
+        dZ._dyn_absmax = ((dz_off, ld_dz, M, self.n_out), am)
+      ks = max(1, min(1024, M // 1024))  # reduction chunks of the weight gradient: enough (row tile, chunk) units for every resident workgroup
+      # x_scale [M]: the layer ran on X * x_scale[:, None] (fwd's rowscale); its weight gradient takes the scale on the reduction index
+      _gemm(st, _p(dZ, dz_off), 1, ld_dz, _p(X, x_off), 1, ldx, _p(dW, self.col0), self.k_full, self.n_out, self.K, M, accumulate=2, k_split=ks,
+            a_absmax=_p(am), kscale=_p(x_scale) if x_scale is not None else None)
+    if one_out:
       # one output: the data gradient is a rank-one product -- a row kernel, not a GEMM
       am2 = _Scalars.take(dX.device)
       call('dyn_train_outer_act_bwd', _p(dZ, dz_off), ld_dz, _p(self.W), _p(act_y[0]) if act_y is not None else None,
            act_y[2] if act_y is not None else 0, M, self.K, act_y[3] if act_y is not None else NONE, _p(dX), ld_dx,
-           _p(dbias) if dbias is not None else None, _p(am2), st)
+           _p(dbias) if dbias is not None else None, _p(am2), _p(dW) if fused_w else None, st)
       dX._dyn_absmax = ((0, ld_dx, M, self.K), am2)
       return dbias is not None
     if dX is not None:

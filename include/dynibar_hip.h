@@ -404,9 +404,10 @@ int dyn_train_vis_split_act_bwd(float* dx2, long ld_dx2, const float* dvis0, con
 int dyn_train_rowdot(const float* X, long ldx, const float* w, const float* bias, long N, int C, float* y, long y_stride, void* stream);
 /* Data gradient of a Linear with ONE output through the activation in front of it (autograd of vis_fc2.2 / rgb_fc.4 / out_geometry_fc.2 and
  * of the ELU before them, mlp_network.py:474-476, 487-493, 505-507): dX[row, c] = dz[row] * w[c] * act'(Y[row, c]) for C = 4 * 2^k <= 256 columns
- * in 16-byte-aligned rows; dbias (may be NULL) += column sums, absmax (may be NULL) = max(absmax, largest |dX|). */
+ * in 16-byte-aligned rows; dbias (may be NULL) += column sums, absmax (may be NULL) = max(absmax, largest |dX|); dW (may be NULL; needs
+ * act != 0) [C] += sum over the rows of dz[row] * Y[row, :], the layer's own weight gradient (its input is Y), in the same pass. */
 int dyn_train_outer_act_bwd(const float* dz, long dz_stride, const float* w, const float* Y, long ld_y, long N, int C, int act, float* dX,
-                            long ld_dx, float* dbias, float* absmax, void* stream);
+                            long ld_dx, float* dbias, float* absmax, float* dW, void* stream);
 
 /* ScaledDotProductAttention (mlp_network.py:13-31) for 4 heads of 32: qkv [P,384] = q | k | v, nvalid [P] = views that see the point
  * (query rows with nvalid <= 1 are masked, :24 and :486-488), out [P,128], prob [R,4,S,S] saved for the backward;
