@@ -612,12 +612,26 @@ __device__ __forceinline__ float tr_act(float v, int act) {
   return v;
 }
 
+// the same ELU as straight-line code: both branches computed, the exponential pinned in front of the selects (left to itself the
+// compiler turns the selects into a branch per element around v_exp_f32 -- 64 branches per result tile and wave)
+__device__ __forceinline__ float tr_elu_flat(float v) {
+  float e = __expf(v) - 1.0f;
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(e));
+#endif
+  const float q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
+  return v > 0.f ? v : (v > -0.01f ? q : e);
+}
+
 // A workgroup walks units blockIdx.x, blockIdx.x + gridDim.x, ... (a unit = (reduction chunk z, row tile) with its column tiles back to
 // back, so that the second column tile finds the row tile's operand in this CU's caches); grid = the resident workgroups of the device.
 // KSCALE: operand b carries a scale on the reduction index (kscale) -- its own instantiation: as a run-time branch in the fragment loop
 // it cost every weight gradient 10 %
-template <int A_MODE, int B_MODE, bool FAST, bool KSCALE>
+// EPI: the epilogue -- -1 general form; fast form: 0 bias / activation only, 1 the saved output's activation derivative (act_y), 2 a per-point
+// addend, 3 a row scale.  Compile-time so that the fast form's global loads are unconditional straight-line code (below).
+template <int A_MODE, int B_MODE, int EPI, bool KSCALE>
 __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
+  constexpr bool FAST = EPI >= 0;
   constexpr int THREADS = 256, PASSES = 2, ITEMS = 8;  // epilogue: 64 rows per pass, quads per thread and pass
   float* ring = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -647,26 +661,34 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
   int newer_stores = 0;  // vector stores the epilogue just before certainly issued: they are newer than the request the next step waits for
 
   // ---- epilogue, fast form; Ct = the ring slot the tile's last step consumed ----
+  // Loads and stores of a wave retire through ONE in-order counter on gfx9 (vmcnt), and the compiler waits with vmcnt(0) wherever a load
+  // MAY be pending at a control-flow merge.  A load issued after a pass's stores therefore waits for the stores' acknowledgements, and a
+  // load inside a run-time branch drains everything (measured: 6-12 us per tile, more than the tile's k-steps).  So: every global load of
+  // the epilogue is issued HERE in one unconditional batch (what is loaded is a compile-time choice, EPI), consumed once -- the empty asm
+  // statements below are where the compiler's wait lands, behind the first LDS pass -- and nothing but stores follows.
   auto epilogue_fast = [&](const TrCursor& t, float* Ct) __attribute__((always_inline)) {
     const int m0 = t.m0, n0 = t.n0;
     const int n4lim = g.N >> 2, c4 = tid & 31, n4 = (n0 >> 2) + c4, n4c = n4 < n4lim ? n4 : n4lim - 1;
-    const int side = g.act_y != nullptr ? 1 : (g.addend != nullptr ? 2 : 0);
     const bool elu_y = g.act_y_kind == 1;
+    constexpr bool BIAS = EPI != 1;  // (a product that goes back through an activation derivative has no bias: checked by the host wrapper)
+    const bool has_bias = BIAS && g.bias != nullptr && t.z == 0;
     tr_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias != nullptr && t.z == 0) bias4 = *reinterpret_cast<const tr_f32x4*>(g.bias + 4 * n4c);
-    tr_f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    float cmax = 0.f;
-    for (int pass = 0; pass < PASSES; ++pass) {
-      // the side tile's quads of this pass, requested before the accumulators move: their latency hides behind the LDS round trip
-      tr_f32x4 sv[ITEMS];
-      if (side != 0) {
+    if constexpr (BIAS) bias4 = *reinterpret_cast<const tr_f32x4*>(has_bias ? g.bias + 4 * n4c : g.a.p);  // (a valid 16-byte-aligned stand-in)
+    tr_f32x4 sv[EPI == 1 || EPI == 2 ? PASSES * ITEMS : 1];
+    float rsc[EPI == 3 ? PASSES * ITEMS : 1];
+    if constexpr (EPI != 0) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-          const int row = (tid >> 5) + (THREADS / 32) * j;
-          const int m = m0 + pass * 64 + row, mc = m < g.M ? m : g.M - 1;
-          sv[j] = *reinterpret_cast<const tr_f32x4*>(side == 1 ? g.act_y + (long)mc * g.ld_y + 4 * n4c : g.addend + (long)(mc / g.add_div) * g.ld_add + 4 * n4c);
-        }
+      for (int j = 0; j < PASSES * ITEMS; ++j) {
+        const int m = m0 + (j / ITEMS) * 64 + (tid >> 5) + (THREADS / 32) * (j % ITEMS), mc = m < g.M ? m : g.M - 1;
+        if constexpr (EPI == 1) sv[j] = *reinterpret_cast<const tr_f32x4*>(g.act_y + (long)mc * g.ld_y + 4 * n4c);
+        if constexpr (EPI == 2) sv[j] = *reinterpret_cast<const tr_f32x4*>(g.addend + (long)(mc / g.add_div) * g.ld_add + 4 * n4c);
+        if constexpr (EPI == 3) rsc[j] = g.rowscale[mc];
       }
+    }
+    // the accumulators -> row-major quads through the slot, 64 rows per pass; a thread ends up with 16 quads of its four columns
+    tr_f32x4 res[PASSES * ITEMS];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
       if (wm == pass) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -678,42 +700,62 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
           }
       }
       tr_barrier_lds();
-      tr_f32x4 res[ITEMS];
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        const int row = (tid >> 5) + (THREADS / 32) * j;
-        tr_f32x4 v = *reinterpret_cast<const tr_f32x4*>(Ct + row * TG_BN + 4 * c4);
-        if (g.rowscale != nullptr) {
-          const int m = m0 + pass * 64 + row;
-          v *= g.rowscale[m < g.M ? m : g.M - 1];
-        }
-        if (side == 1) {
+      for (int j = 0; j < ITEMS; ++j) res[pass * ITEMS + j] = *reinterpret_cast<const tr_f32x4*>(Ct + ((tid >> 5) + (THREADS / 32) * j) * TG_BN + 4 * c4);
+      tr_barrier_lds();  // the slot takes the second pass, then the column sums or the next request
+    }
+    // the batch of loads has had both LDS passes to land: consumed here, all of it (see above)
+#if defined(__AMDGCN__)
+    if constexpr (BIAS) asm volatile("" : "+v"(bias4));
+    if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = sv[j][c] > 0.f ? v[c] : (elu_y ? v[c] * (sv[j][c] + 1.0f) : 0.f);
-        } else if (side == 2) {
-          v += sv[j];
-        }
-        res[j] = v + bias4;
+      for (int j = 0; j < PASSES * ITEMS; ++j) asm volatile("" : "+v"(sv[j]));
+    }
+    if constexpr (EPI == 3) {
+#pragma unroll
+      for (int j = 0; j < PASSES * ITEMS; ++j) asm volatile("" : "+v"(rsc[j]));
+    }
+#endif
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bias4[c] = has_bias ? bias4[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PASSES * ITEMS; ++j) {
+      tr_f32x4 v = res[j];
+      if constexpr (EPI == 3) v *= rsc[j];
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = sv[j][c] > 0.f ? v[c] : (elu_y ? v[c] * (sv[j][c] + 1.0f) : 0.f);
       }
-      if (g.act != 0) {  // one uniform branch per pass, not per element
+      if constexpr (EPI == 2) v += sv[j];
+      if constexpr (BIAS) v += bias4;
+      res[j] = v;
+    }
+    if (g.act == 1) {  // uniform branches around the whole tile, straight-line code inside
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
+      for (int j = 0; j < PASSES * ITEMS; ++j)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) res[j][c] = tr_act(res[j][c], g.act);
-      }
+        for (int c = 0; c < 4; ++c) res[j][c] = tr_elu_flat(res[j][c]);
+    } else if (g.act == 2) {
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        const int m = m0 + pass * 64 + (tid >> 5) + (THREADS / 32) * j;
-        if (m < g.M && n4 < n4lim) {
-          const tr_f32x4 v = res[j];
-          if (!(TR_RX & 1) || v[0] == 1.2345f) *reinterpret_cast<tr_f32x4*>(g.c + (long)m * g.ldc + 4 * n4) = v;
-          if (g.colsum_part != nullptr) {
-            csum += v;  // a thread keeps its four columns (c4 = tid & 31) over all its rows
-            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-          }
+      for (int j = 0; j < PASSES * ITEMS; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) res[j][c] = fmaxf(res[j][c], 0.f);
+    }
+    tr_f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    float cmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < PASSES * ITEMS; ++j) {
+      const int m = m0 + (j / ITEMS) * 64 + (tid >> 5) + (THREADS / 32) * (j % ITEMS);
+      if (m < g.M && n4 < n4lim) {
+        const tr_f32x4 v = res[j];
+        if (!(TR_RX & 1) || v[0] == 1.2345f) *reinterpret_cast<tr_f32x4*>(g.c + (long)m * g.ldc + 4 * n4) = v;
+        if (EPI <= 1 && g.colsum_part != nullptr) {  // (the bias gradient of the layer in front; the host wrapper keeps it off EPI 2 / 3)
+          csum += v;  // a thread keeps its four columns (c4 = tid & 31) over all its rows
+          cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
       }
-      tr_barrier_lds();
     }
     if (g.colsum_part != nullptr) {
       // the bias gradient's share of this tile and the largest |dZ| (the next GEMMs' scale): the eight row groups meet in LDS and the workgroup
@@ -896,8 +938,8 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm_ring(TrGemmArgs g) {
   tr_wait_vm<0>();  // the request past the end of the sequence must land before the workgroup's LDS is released
 }
 
-// resident workgroups of k_train_gemm_ring<A, B, F> per device: the persistent kernel's grid (queried once per instantiation and device)
-template <int A_MODE, int B_MODE, bool FAST, bool KSCALE>
+// resident workgroups of k_train_gemm_ring<A, B, E, S> per device: the persistent kernel's grid (queried once per instantiation and device)
+template <int A_MODE, int B_MODE, int EPI, bool KSCALE>
 static int tr_ring_slots() {
   static int slots[DYN_MAX_DEVICES] = {0};
   int dev = 0;
@@ -906,15 +948,15 @@ static int tr_ring_slots() {
   if (slots[d] == 0) {
     int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_gemm_ring<A_MODE, B_MODE, FAST, KSCALE>, 256, TR_RING_BYTES) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_gemm_ring<A_MODE, B_MODE, EPI, KSCALE>, 256, TR_RING_BYTES) != hipSuccess || per_cu < 1) per_cu = 2;
     const int n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     slots[d] = per_cu * n_cu;
   }
   return slots[d];
 }
 // which form takes a product: 0 automatic -- the ring form for the backward products (weight gradient: both operands stream from HBM,
-// +25-35 % measured; data gradient: +0-10 %), the tile kernel for the forward ones (ring: -8 %; four workgroups per CU hide its long
-// epilogue better than the ring's two) --, 1 tile kernel only, 2 ring form wherever the operands allow it.  DYNIBAR_TRAIN_GEMM = auto | tile |
+// +25-35 % measured; data gradient: +0-10 %), the tile kernel for the forward ones (ring: level to -4 % since its epilogue is straight-line
+// code with one batch of loads; -8 % to -30 % before) --, 1 tile kernel only, 2 ring form wherever the operands allow it.  DYNIBAR_TRAIN_GEMM = auto | tile |
 // ring sets the initial value; dyn_train_gemm_mode() changes it (A/B timing, tests).
 static int g_tr_gemm_mode = -1;
 static int tr_gemm_mode() {
@@ -968,22 +1010,33 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     };
     const int ra = ring_mode(g.a), rb = ring_mode(g.b);
     const bool add_vec = p->addend == nullptr || ((p->ld_add & 3) == 0 && ((uintptr_t)p->addend & 15) == 0);
-    const bool fast = g.c_vec && (p->bias == nullptr || ((uintptr_t)p->bias & 15) == 0) && (p->act_y == nullptr || g.act_y_vec) && add_vec &&
-                      !(p->act_y != nullptr && p->addend != nullptr);
+    const int sides = (p->act_y != nullptr) + (p->addend != nullptr) + (p->rowscale != nullptr);
+    const bool fast = g.c_vec && (p->bias == nullptr || ((uintptr_t)p->bias & 15) == 0) && (p->act_y == nullptr || g.act_y_vec) && add_vec && sides <= 1;
     const int mode = tr_gemm_mode();
     if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)) || (mode != 1 && p->kscale != nullptr))) {
       const long units = (long)g.mt * g.nz;
-#define TG_RING(A, B, F, S)                                                                                                                \
-  if (ra == A && rb == B && fast == F && (p->kscale != nullptr) == S) {                                                                    \
-    const long slots = tr_ring_slots<A, B, F, S>();                                                                                        \
+      // the epilogue (EPI of k_train_gemm_ring): the fast forms that are instantiated -- forward shape (both operands k-minor): plain, addend,
+      // row scale; data-gradient shape (b k-major): plain, act_y --, else the general form
+      int epi = -1;
+      if (fast && ra == 0) {
+        const int want = p->act_y != nullptr ? 1 : (p->addend != nullptr ? 2 : (p->rowscale != nullptr ? 3 : 0));
+        if (rb == 0 && want != 1) epi = want;
+        if (rb == 2 && want <= 1) epi = want;
+        if (epi == 1 && p->bias != nullptr) epi = -1;  // the act_y form carries no bias
+      }
+      const bool ring_sums = p->colsum_part == nullptr || epi == 0 || epi == 1;  // else: the tile kernel
+#define TG_RING(A, B, E, S)                                                                                                                \
+  if (ring_sums && ra == A && rb == B && epi == E && (p->kscale != nullptr) == S) {                                                                  \
+    const long slots = tr_ring_slots<A, B, E, S>();                                                                                        \
     const dim3 rgrid((unsigned)(units < slots ? units : slots));                                                                           \
-    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm_ring<A, B, F, S>), rgrid, dim3(256), TR_RING_BYTES, (hipStream_t)stream,   \
+    DYN_LAUNCH(DYN_K_TRAIN_GEMM, "dyn_train_gemm", (k_train_gemm_ring<A, B, E, S>), rgrid, dim3(256), TR_RING_BYTES, (hipStream_t)stream,   \
                g);                                                                                                                         \
     return 0;                                                                                                                              \
   }
-      TG_RING(0, 0, true, false) TG_RING(0, 0, false, false) TG_RING(0, 2, true, false) TG_RING(0, 2, false, false)
-      TG_RING(2, 0, true, false) TG_RING(2, 0, false, false) TG_RING(2, 2, true, false) TG_RING(2, 2, false, false)
-      TG_RING(2, 2, false, true)  // the weight gradient of a Linear on x * s[row]
+      TG_RING(0, 0, 0, false) TG_RING(0, 0, 2, false) TG_RING(0, 0, 3, false) TG_RING(0, 0, -1, false)
+      TG_RING(0, 2, 0, false) TG_RING(0, 2, 1, false) TG_RING(0, 2, -1, false)
+      TG_RING(2, 0, -1, false) TG_RING(2, 2, -1, false)
+      TG_RING(2, 2, -1, true)  // the weight gradient of a Linear on x * s[row]
 #undef TG_RING
     }
   }
