@@ -207,12 +207,29 @@ __device__ __forceinline__ void tr_barrier_lds() {
   asm volatile("" ::: "memory");
 }
 
+// ELU as straight-line code: exp(v) - 1 (6e-8 absolute error) away from zero, the cubic Taylor polynomial (4e-8 relative) for -0.01 < v <= 0;
+// both computed, the exponential pinned in front of the selects (left to itself the compiler turns the selects into a branch per element
+// around v_exp_f32 -- 64 branches per result tile and wave)
+__device__ __forceinline__ float tr_elu_flat(float v) {
+  float e = __expf(v) - 1.0f;
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(e));
+#endif
+  const float q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
+  return v > 0.f ? v : (v > -0.01f ? q : e);
+}
+
 __device__ __forceinline__ f32x16 tr_mfma(tr_u32x4 a, tr_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tr_f16x8, a), __builtin_bit_cast(tr_f16x8, b), c, 0, 0, 0);
 }
 
+// waves per SIMD the tile kernel is compiled for: 214 registers at 2 (two workgroups per CU -- the registers, not the 40 KiB of LDS, set
+// that); 3 (168 registers, 68 B of spills) measured 14-17 % slower, 4 spills 448 B
+#ifndef TG_TILE_WAVES
+#define TG_TILE_WAVES 2
+#endif
 template <int A_MODE, int B_MODE>
-__global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
+__global__ void __launch_bounds__(256, TG_TILE_WAVES) k_train_gemm(TrGemmArgs g) {
   constexpr bool A_KMINOR = A_MODE != 2, B_KMINOR = B_MODE != 2;
   tr_u16* As = reinterpret_cast<tr_u16*>(dyn_smem);
   tr_u16* Bs = As + 2 * TG_PART;
@@ -391,12 +408,7 @@ __global__ void __launch_bounds__(256, 2) k_train_gemm(TrGemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // ELU: exp(v) - 1 (6e-8 absolute error) away from zero, the cubic Taylor polynomial (4e-8 relative) for -0.01 < v <= 0
-          const float v = acc[i][j][r];
-          const float e = __expf(v) - 1.0f, q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
-          acc[i][j][r] = v > 0.f ? v : (v > -0.01f ? q : e);
-        }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = tr_elu_flat(acc[i][j][r]);
   }
   if (g.act == 2) {  // ReLU (MotionMLP)
 #pragma unroll
@@ -610,17 +622,6 @@ __device__ __forceinline__ float tr_act(float v, int act) {
   }
   if (act == 2) return fmaxf(v, 0.f);  // ReLU (MotionMLP)
   return v;
-}
-
-// the same ELU as straight-line code: both branches computed, the exponential pinned in front of the selects (left to itself the
-// compiler turns the selects into a branch per element around v_exp_f32 -- 64 branches per result tile and wave)
-__device__ __forceinline__ float tr_elu_flat(float v) {
-  float e = __expf(v) - 1.0f;
-#if defined(__AMDGCN__)
-  asm volatile("" : "+v"(e));
-#endif
-  const float q = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f)));
-  return v > 0.f ? v : (v > -0.01f ? q : e);
 }
 
 // A workgroup walks units blockIdx.x, blockIdx.x + gridDim.x, ... (a unit = (reduction chunk z, row tile) with its column tiles back to
