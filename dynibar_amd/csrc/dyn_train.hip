@@ -2305,35 +2305,49 @@ __global__ void k_train_attn_bwd(const float* __restrict__ qkv, const float* __r
     dqkv[p * 384 + 256 + head * 32 + d] = dv[d];
   }
 }
+#define TR_ATTN_LDS_MAX_S 112
 // The same two kernels with the S x S score / probability tiles of a (ray, head) kept in LDS (rays of up to 112 samples): the kernels
 // above use the global `prob` / `dscore` arrays as per-thread scratch rows -- 4-byte accesses at a stride of S floats, measured at 6-8 GB of
 // HBM traffic per launch for 0.6 GB of algorithmic bytes.  Here the probabilities leave once, as coalesced rows, and come back once.
-__global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, float* __restrict__ out,
+// FOUR lanes per row (a block = 4 S threads): with one thread per row a (ray, head) was ONE wavefront holding 36-52 KiB of LDS -- three
+// waves per CU, latency bound (0.4 / 0.9 ms per launch).  Lane c of row i takes the keys (later: the queries) j = c, c + 4, ...; the four
+// partial sums meet by two butterfly steps inside the wave.  K, V rows at a 36-float stride (16-byte aligned: an inner product reads four
+// values per LDS instruction, and the four rows a wave touches at once sit in disjoint banks); score rows at S + 4.
+// (DPP quad_perm lane selects on the VALU: [1,0,3,2] and [2,3,0,1]; no LDS traffic)
+__device__ __forceinline__ float tr_quad_get1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float tr_quad_get2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float tr_quad_sum(float v) {
+  v += tr_quad_get1(v);
+  v += tr_quad_get2(v);
+  return v;
+}
+__global__ void __launch_bounds__(4 * TR_ATTN_LDS_MAX_S) k_train_attn_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, float* __restrict__ out,
                                  float* __restrict__ prob) {
-  // K and V rows at a 36-float stride: 16-byte aligned, so that the inner products below read them (every lane the same address: a broadcast)
-  // four values per LDS instruction -- with one value per instruction the kernel was bound by the LDS instruction count
   float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][36]
   float* vs = ks + S * 36;                         // [S][36]
-  float* ps = vs + S * 36;                         // [S][S + 1]
-  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
+  float* ps = vs + S * 36;                         // [S][S + 4]
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x >> 2, c = threadIdx.x & 3, SP = S + 4;
   const long p = (long)ray * S + i;
   float q[32];
-  {  // the thread's rows of Q, K, V: 128 contiguous bytes each, as 16-byte loads (the 4-byte form cost 4x the instructions for the same lines)
+  {  // the row's Q (every lane of the row: the same 128 bytes, one L1 line) and this lane's quarter of its K and V
     const float4* row = reinterpret_cast<const float4*>(qkv + p * 384 + head * 32);
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
-      const float4 qv = row[d4], kv = row[32 + d4], vv = row[64 + d4];
+      const float4 qv = row[d4];
       q[4 * d4] = qv.x / 5.656854249492381f; q[4 * d4 + 1] = qv.y / 5.656854249492381f;
       q[4 * d4 + 2] = qv.z / 5.656854249492381f; q[4 * d4 + 3] = qv.w / 5.656854249492381f;
-      *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = kv;
-      *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = vv;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<float4*>(ks + i * 36 + 4 * (2 * c + u)) = row[32 + 2 * c + u];
+      *reinterpret_cast<float4*>(vs + i * 36 + 4 * (2 * c + u)) = row[64 + 2 * c + u];
     }
   }
   __syncthreads();
   const bool live = nvalid[p] > 1.0f;
   float* pr = ps + i * SP;
   float mx = -INFINITY;
-  for (int j = 0; j < S; ++j) {
+  for (int j = c; j < S; j += 4) {
     float sc = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
@@ -2344,15 +2358,18 @@ __global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __r
     pr[j] = sc;
     mx = fmaxf(mx, sc);
   }
+  mx = fmaxf(mx, tr_quad_get1(mx));
+  mx = fmaxf(mx, tr_quad_get2(mx));
   float den = 0.f;
-  for (int j = 0; j < S; ++j) {
+  for (int j = c; j < S; j += 4) {
     const float e = expf(pr[j] - mx);
     pr[j] = e;
     den += e;
   }
+  den = tr_quad_sum(den);
   float o[32];
   for (int d = 0; d < 32; ++d) o[d] = 0.f;
-  for (int j = 0; j < S; ++j) {
+  for (int j = c; j < S; j += 4) {
     const float a = pr[j] / den;
     pr[j] = a;
 #pragma unroll
@@ -2362,40 +2379,46 @@ __global__ void k_train_attn_lds(const float* __restrict__ qkv, const float* __r
     }
   }
 #pragma unroll
+  for (int d = 0; d < 32; ++d) o[d] = tr_quad_sum(o[d]);
+#pragma unroll
   for (int d4 = 0; d4 < 8; ++d4)
-    reinterpret_cast<float4*>(out + p * 128 + head * 32)[d4] = make_float4(o[4 * d4], o[4 * d4 + 1], o[4 * d4 + 2], o[4 * d4 + 3]);
+    if ((d4 >> 1) == c) reinterpret_cast<float4*>(out + p * 128 + head * 32)[d4] = make_float4(o[4 * d4], o[4 * d4 + 1], o[4 * d4 + 2], o[4 * d4 + 3]);
   __syncthreads();
   float* g = prob + (long)blockIdx.x * S * S;
-  for (int r = 0; r < S; ++r) g[(long)r * S + i] = ps[r * SP + i];  // coalesced rows
+  for (int idx = threadIdx.x; idx < S * S; idx += 4 * S) g[idx] = ps[(idx / S) * SP + (idx % S)];  // coalesced rows
 }
-__global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, const float* __restrict__ prob,
+__global__ void __launch_bounds__(4 * TR_ATTN_LDS_MAX_S) k_train_attn_bwd_lds(const float* __restrict__ qkv, const float* __restrict__ nvalid, int S, const float* __restrict__ prob,
                                      const float* __restrict__ dout, float* __restrict__ dqkv) {
-  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][36]: K, later Q / sqrt(d)   (36: see k_train_attn_lds)
+  float* ks = reinterpret_cast<float*>(dyn_smem);  // [S][36]: K, later Q / sqrt(d)
   float* vs = ks + S * 36;                         // [S][36]: V, later dO
-  float* ps = vs + S * 36;                         // [S][S + 1]: probabilities
-  float* db = ps + S * (S + 1);                    // [S][S + 1]: score gradients
-  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x, SP = S + 1;
+  float* ps = vs + S * 36;                         // [S][S + 4]: probabilities
+  float* db = ps + S * (S + 4);                    // [S][S + 4]: score gradients
+  const int ray = blockIdx.x >> 2, head = blockIdx.x & 3, i = threadIdx.x >> 2, c = threadIdx.x & 3, SP = S + 4;
   const long p = (long)ray * S + i;
   float dO[32], q[32];
-  {  // 16-byte loads of the thread's rows (see k_train_attn_lds)
+  {
     const float4* row = reinterpret_cast<const float4*>(qkv + p * 384 + head * 32);
     const float4* drow = reinterpret_cast<const float4*>(dout + p * 128 + head * 32);
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
-      const float4 qv = row[d4], kv = row[32 + d4], vv = row[64 + d4], dv4 = drow[d4];
+      const float4 qv = row[d4], dv4 = drow[d4];
       q[4 * d4] = qv.x / 5.656854249492381f; q[4 * d4 + 1] = qv.y / 5.656854249492381f;
       q[4 * d4 + 2] = qv.z / 5.656854249492381f; q[4 * d4 + 3] = qv.w / 5.656854249492381f;
       dO[4 * d4] = dv4.x; dO[4 * d4 + 1] = dv4.y; dO[4 * d4 + 2] = dv4.z; dO[4 * d4 + 3] = dv4.w;
-      *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = kv;
-      *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = vv;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<float4*>(ks + i * 36 + 4 * (2 * c + u)) = row[32 + 2 * c + u];
+      *reinterpret_cast<float4*>(vs + i * 36 + 4 * (2 * c + u)) = row[64 + 2 * c + u];
     }
   }
   const float* g = prob + (long)blockIdx.x * S * S;
-  for (int r = 0; r < S; ++r) ps[r * SP + i] = g[(long)r * S + i];
+  for (int idx = threadIdx.x; idx < S * S; idx += 4 * S) ps[(idx / S) * SP + (idx % S)] = g[idx];
   __syncthreads();
+  // as query row i: dP_ij = dO_i . V_j, dS = P (dP - sum_j P dP), dQ_i = sum_j dS_ij K_j / sqrt(d)
   const bool live = nvalid[p] > 1.0f;
   float dot = 0.f;
-  for (int j = 0; j < S; ++j) {
+  for (int j = c; j < S; j += 4) {
     float dp = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
@@ -2405,28 +2428,35 @@ __global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float*
     db[i * SP + j] = dp;
     dot += dp * ps[i * SP + j];
   }
-  float dq[32];
-  for (int d = 0; d < 32; ++d) dq[d] = 0.f;
-  for (int j = 0; j < S; ++j) {
+  dot = tr_quad_sum(dot);
+  float acc[32];
+  for (int d = 0; d < 32; ++d) acc[d] = 0.f;
+  for (int j = c; j < S; j += 4) {
     const float ds = live ? ps[i * SP + j] * (db[i * SP + j] - dot) : 0.f;
     db[i * SP + j] = ds;
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
       const float4 k4 = *reinterpret_cast<const float4*>(ks + j * 36 + 4 * d4);
-      dq[4 * d4] += ds * k4.x; dq[4 * d4 + 1] += ds * k4.y; dq[4 * d4 + 2] += ds * k4.z; dq[4 * d4 + 3] += ds * k4.w;
+      acc[4 * d4] += ds * k4.x; acc[4 * d4 + 1] += ds * k4.y; acc[4 * d4 + 2] += ds * k4.z; acc[4 * d4 + 3] += ds * k4.w;
     }
   }
-  for (int d = 0; d < 32; ++d) dqkv[p * 384 + head * 32 + d] = dq[d] / 5.656854249492381f;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) acc[d] = tr_quad_sum(acc[d]) / 5.656854249492381f;
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4)
+    if ((d4 >> 1) == c) reinterpret_cast<float4*>(dqkv + p * 384 + head * 32)[d4] = make_float4(acc[4 * d4], acc[4 * d4 + 1], acc[4 * d4 + 2], acc[4 * d4 + 3]);
   __syncthreads();  // every thread is done with K and V
 #pragma unroll
-  for (int d4 = 0; d4 < 8; ++d4) {
-    *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = make_float4(q[4 * d4], q[4 * d4 + 1], q[4 * d4 + 2], q[4 * d4 + 3]);
-    *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = make_float4(dO[4 * d4], dO[4 * d4 + 1], dO[4 * d4 + 2], dO[4 * d4 + 3]);
-  }
+  for (int d4 = 0; d4 < 8; ++d4)
+    if ((d4 >> 1) == c) {
+      *reinterpret_cast<float4*>(ks + i * 36 + 4 * d4) = make_float4(q[4 * d4], q[4 * d4 + 1], q[4 * d4 + 2], q[4 * d4 + 3]);
+      *reinterpret_cast<float4*>(vs + i * 36 + 4 * d4) = make_float4(dO[4 * d4], dO[4 * d4 + 1], dO[4 * d4 + 2], dO[4 * d4 + 3]);
+    }
   __syncthreads();
+  // as key row i: dK_i = sum_q dS_qi Q_q / sqrt(d), dV_i = sum_q P_qi dO_q
   float dk[32], dv[32];
   for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-  for (int qi = 0; qi < S; ++qi) {
+  for (int qi = c; qi < S; qi += 4) {
     const float a = ps[qi * SP + i], ds = db[qi * SP + i];
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
@@ -2436,17 +2466,19 @@ __global__ void k_train_attn_bwd_lds(const float* __restrict__ qkv, const float*
     }
   }
 #pragma unroll
-  for (int d4 = 0; d4 < 8; ++d4) {
-    reinterpret_cast<float4*>(dqkv + p * 384 + 128 + head * 32)[d4] = make_float4(dk[4 * d4], dk[4 * d4 + 1], dk[4 * d4 + 2], dk[4 * d4 + 3]);
-    reinterpret_cast<float4*>(dqkv + p * 384 + 256 + head * 32)[d4] = make_float4(dv[4 * d4], dv[4 * d4 + 1], dv[4 * d4 + 2], dv[4 * d4 + 3]);
-  }
+  for (int d = 0; d < 32; ++d) { dk[d] = tr_quad_sum(dk[d]); dv[d] = tr_quad_sum(dv[d]); }
+#pragma unroll
+  for (int d4 = 0; d4 < 8; ++d4)
+    if ((d4 >> 1) == c) {
+      reinterpret_cast<float4*>(dqkv + p * 384 + 128 + head * 32)[d4] = make_float4(dk[4 * d4], dk[4 * d4 + 1], dk[4 * d4 + 2], dk[4 * d4 + 3]);
+      reinterpret_cast<float4*>(dqkv + p * 384 + 256 + head * 32)[d4] = make_float4(dv[4 * d4], dv[4 * d4 + 1], dv[4 * d4 + 2], dv[4 * d4 + 3]);
+    }
 }
-#define TR_ATTN_LDS_MAX_S 112
 
 extern "C" int dyn_train_attn(const float* qkv, const float* nvalid, int R, int S, float* out, float* prob, void* stream) {
   DYN_REQUIRE(qkv && nvalid && out && prob && R > 0 && S > 0 && S <= 256, "dyn_train_attn: bad arguments (S <= 256)");
   if (S <= TR_ATTN_LDS_MAX_S && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0) {  // (16-byte row accesses)
-    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 72 + S * (S + 1)) * 4, (hipStream_t)stream,
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn", k_train_attn_lds, dim3((unsigned)R * 4), dim3(4 * S), (size_t)(S * 72 + S * (S + 4)) * 4, (hipStream_t)stream,
                qkv, nvalid, S, out, prob);
     return 0;
   }
@@ -2458,7 +2490,7 @@ extern "C" int dyn_train_attn_bwd(const float* qkv, const float* nvalid, int R, 
                                   float* dqkv, void* stream) {
   DYN_REQUIRE(qkv && nvalid && prob && dout && dscore && dqkv && R > 0 && S > 0 && S <= 256, "dyn_train_attn_bwd: bad arguments (S <= 256)");
   if (S <= TR_ATTN_LDS_MAX_S && (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0) {
-    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd_lds, dim3((unsigned)R * 4), dim3(S), (size_t)(S * 72 + 2 * S * (S + 1)) * 4,
+    DYN_LAUNCH(DYN_K_TRAIN_ATTN, "dyn_train_attn_bwd", k_train_attn_bwd_lds, dim3((unsigned)R * 4), dim3(4 * S), (size_t)(S * 72 + 2 * S * (S + 4)) * 4,
                (hipStream_t)stream, qkv, nvalid, S, prob, dout, dqkv);
     return 0;
   }
