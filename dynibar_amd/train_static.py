@@ -31,6 +31,9 @@ ELU, NONE = 1, 0
 # pass but recomputed from their narrow inputs right before the backward pass needs them (the same launches: bit-identical results).
 # Measured at 3072 rays (MI355X): peak 46.4 -> 37.0 GB, iteration 107.2 -> 112.6 ms; off by default (a 288 GB device has the room).
 RECOMPUTE_HIDDEN = os.environ.get('DYNIBAR_TRAIN_RECOMPUTE', '0') == '1'
+# Tests set this: buffers a kernel is documented to write completely (the GEMM's partial column sums) start as NaN instead of uninitialised
+# memory, so an entry a launch skipped fails a gradient check every time rather than by luck.
+POISON_SCRATCH = os.environ.get('DYNIBAR_TRAIN_POISON', '0') == '1'
 
 
 def _p(t, off=0):
@@ -154,8 +157,10 @@ class _Lin:
       sums = dbias is not None and acc_dx == 0 and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0
       if sums:
         tiles, ctiles = (M + 127) // 128, (self.K + 127) // 128
-        part = torch.zeros((tiles, self.K), dtype=torch.float32, device=dX.device)  # zeroed: the kernel's row tile is 128 or 256 rows
-        apart = torch.zeros(tiles * ctiles, dtype=torch.float32, device=dX.device)
+        part = torch.empty((tiles, self.K), dtype=torch.float32, device=dX.device)  # every (128-row tile, column) entry is written by the product
+        apart = torch.empty(tiles * ctiles, dtype=torch.float32, device=dX.device)
+        if POISON_SCRATCH:
+          part.fill_(float('nan')); apart.fill_(float('inf'))  # (the reduction takes fmaxf, which drops a NaN)
         fy.update(colsum_part=_p(part), ld_part=self.K, amax_part=_p(apart))
       if acc_dx != 0:
         _untag(dX)

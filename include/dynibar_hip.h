@@ -320,12 +320,12 @@ typedef struct {
                           * (mlp_network.py:342-397, 587-603).  NULL to skip; needs accumulate = 0 */
   long ld_y;
   int act_y_kind;        /* 1 ELU, 2 ReLU */
-  float* colsum_part;    /* [ceil(M / 128), ld_part], ZEROED by the caller: a workgroup leaves the column sums of its result tile (128 or 256 rows:
-                          * the kernel form's choice, so not every row is written) in row (tile index) -- the partial sums of the NEXT
+  float* colsum_part;    /* [ceil(M / 128), ld_part]: a workgroup leaves the column sums of its 128-row result tile in row (tile index); every
+                          * entry [tile, 0:N) is written, no initialisation needed -- the partial sums of the NEXT
                           * bias gradient: autograd of nn.Linear's bias, mlp_network.py:342-397) -- NULL to skip; needs accumulate = 0 and
                           * 16-byte-aligned result rows (N, ldc multiples of 4) */
   long ld_part;
-  float* amax_part;      /* [ceil(M / 128) * ceil(N / 128)], zeroed by the caller: largest |result| per workgroup (required with colsum_part) */
+  float* amax_part;      /* [ceil(M / 128) * ceil(N / 128)], all written: largest |result| per workgroup (required with colsum_part) */
   const float* rowscale; /* [M] or NULL: C = act(diag(rowscale) (A . B) + addend + bias) -- the forward of a Linear applied to x * s[row] (x * weight,
                           * x * vis: mlp_network.py:470, 474) without materialising the scaled input; not with a split reduction */
   const float* kscale;   /* [K] or NULL: B's element (n, k) is multiplied by kscale[k] -- the weight gradient dW = dZ^T (diag(s) X) of such a Linear

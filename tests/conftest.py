@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('DYNIBAR_TRAIN_POISON', '1')  # (dynibar_amd/train_static.py: scratch the kernels must fill starts as NaN under test)
 for p in (ROOT, os.path.join(ROOT, 'tests')):
   if p not in sys.path:
     sys.path.insert(0, p)
