@@ -1339,6 +1339,40 @@ def check_train_recompute(device, name='small', S=16):
     TS.RECOMPUTE_HIDDEN = was
 
 
+def check_train_attention(device, lengths=(5, 16, 37, 64, 112, 120), R=3, seed=11):
+  """dyn_train_attn / dyn_train_attn_bwd alone (ScaledDotProductAttention of the ray transformer, mlp_network.py:13-31, and its autograd)
+  against fp64 torch on ray lengths that are not multiples of four, at the LDS form's limit (112) and beyond it (the global-scratch form);
+  some query rows masked (nvalid <= 1: their scores are filled with -1e9, so they attend uniformly and pass no gradient to q / k)."""
+  from dynibar_amd import train_static as TS
+  from dynibar_amd._lib import call
+  g = torch.Generator().manual_seed(seed)
+  for S in lengths:
+    P = R * S
+    qkv = torch.randn(P, 384, generator=g) * 1.5
+    nvalid = torch.randint(0, 5, (P,), generator=g).float()
+    dout = torch.randn(P, 128, generator=g)
+    # reference (fp64): [R, 4, S, 32] heads
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, 128 * t:128 * (t + 1)].view(R, S, 4, 32).transpose(1, 2) for t in range(3))
+    att = torch.matmul(q / 32 ** 0.5, k.transpose(2, 3))
+    att = att.masked_fill((nvalid.view(R, 1, S, 1) > 1) == 0, -1e9)
+    prob_ref = F.softmax(att, dim=-1)
+    out_ref = torch.matmul(prob_ref, v).transpose(1, 2).reshape(P, 128)
+    out_ref.backward(dout.double())
+    # product
+    d = lambda t: t.to(device).contiguous()
+    qkv_d, nv_d, dout_d = d(qkv), d(nvalid), d(dout)
+    out = torch.empty(P, 128, device=device); prob = torch.empty(R * 4, S, S, device=device)
+    dqkv = torch.empty(P, 384, device=device); dsc = torch.empty(R * 4, S, S, device=device)
+    st = TS.stream_of(qkv_d)
+    call('dyn_train_attn', TS._p(qkv_d), TS._p(nv_d), R, S, TS._p(out), TS._p(prob), st)
+    call('dyn_train_attn_bwd', TS._p(qkv_d), TS._p(nv_d), R, S, TS._p(prob), TS._p(dout_d), TS._p(dsc), TS._p(dqkv), st)
+    assert_close(prob.view(R, 4, S, S), prob_ref, 2e-6, 1e-5, f'train attention S={S} probabilities')
+    assert_close(out, out_ref, 1e-5, 1e-5, f'train attention S={S} output')
+    gref = x.grad
+    assert_close(dqkv, gref, 2e-6 * float(gref.abs().max()) + 1e-7, 2e-5, f'train attention S={S} d(q|k|v)')
+
+
 def check_train_gemm_fuzz(device, n_cases=40, seed=123, max_rows=3000):
   """Random shapes / epilogues through dyn_train_gemm in both kernel forms against fp64: row counts and widths that are not multiples of
   the tile or of four, k tails, padded leading dimensions, bias / per-point addend / row scale / ELU / ReLU (forward), activation derivative

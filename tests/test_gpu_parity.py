@@ -276,6 +276,12 @@ def test_feature_encoder_trains_through_the_gather(dev):
 
 
 @pytest.mark.gpu
+def test_train_attention_lengths(dev):
+  """the ray attention's training kernels alone vs fp64 torch: ray lengths 5 ... 112 (LDS form, four lanes per row) and 120 / 200 (global-scratch form)"""
+  parity.check_train_attention(dev, lengths=(5, 16, 37, 64, 112, 120, 200), R=5)
+
+
+@pytest.mark.gpu
 def test_train_gemm_random_shapes(dev):
   """both kernel forms of dyn_train_gemm on 90 random shapes / epilogues vs fp64 (+ two large ones: more tiles than resident workgroups)"""
   parity.check_train_gemm_fuzz(dev, n_cases=90)
