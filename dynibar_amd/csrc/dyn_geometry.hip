@@ -851,6 +851,61 @@ __global__ void __launch_bounds__(256) k_gather_bwd32(PGShape q, const float* __
     if (wts[k] != 0.f) atomicAdd(base + (long)offs[k] * 32, wts[k] * d);
 }
 
+// The same scatter walked along the ray: a thread owns (ray, view, channel) and visits the S samples in order.  Neighbouring samples of a
+// ray land in the same bilinear cell of a source map again and again (an epipolar line of a 72 x 128 map is a few dozen cells long for 64
+// samples), and every atomic on one 128-byte pixel record serialises in L2 behind the others on it -- so contributions to an unchanged cell
+// are summed in registers and leave as ONE set of four atomics when the cell changes.  Next sample's point and gradient are requested before
+// the current one is used.
+__global__ void __launch_bounds__(256) k_gather_bwd32_ray(PGShape q, const float* __restrict__ pts_st, const float* __restrict__ xyz,
+                                                          const float4* __restrict__ proj4, const float* __restrict__ drgb_feat, long ld_d, int col0,
+                                                          float* __restrict__ dfeat) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long rv = idx >> 5;
+  const int c = (int)(idx & 31);
+  if (rv >= (long)q.R * q.V) return;
+  const long r = rv / q.V;
+  const int v = (int)(rv - r * q.V);
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
+  float* base = dfeat + (long)v * q.Hf * q.Wf * 32 + c;
+  const long rs0 = r * q.S;
+  const float* pt0 = xyz != nullptr ? xyz + ((long)v * q.R * q.S + rs0) * 3 : pts_st + rs0 * 3;
+  const float* d0 = drgb_feat + (rs0 * q.V + v) * ld_d + col0 + c;
+  const long d_step = (long)q.V * ld_d;
+  int cur[4] = {-1, -1, -1, -1};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float x = pt0[0], y = pt0[1], z3 = pt0[2], d = d0[0];
+  for (int s = 0; s < q.S; ++s) {
+    const int sn = s + 1 < q.S ? s + 1 : s;
+    const float xn = pt0[sn * 3], yn = pt0[sn * 3 + 1], zn = pt0[sn * 3 + 2], dn = d0[sn * d_step];
+    const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+    const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+    const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+    const float zc = fmaxf(hz, 1e-8f);
+    float px = hx / zc, py = hy / zc;  // the forward pass's arithmetic (k_gather_bwd32 above)
+    px = fminf(fmaxf(px, -1e6f), 1e6f);
+    py = fminf(fmaxf(py, -1e6f), 1e6f);
+    const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;
+    const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
+    const Taps t = make_taps(nx, ny, q.Wf, q.Hf);
+    const int offs[4] = {t.y0 * q.Wf + t.x0, t.y0 * q.Wf + t.x1, t.y1 * q.Wf + t.x0, t.y1 * q.Wf + t.x1};
+    const float wts[4] = {t.w_nw, t.w_ne, t.w_sw, t.w_se};
+    if (offs[0] != cur[0] || offs[1] != cur[1] || offs[2] != cur[2] || offs[3] != cur[3]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (acc[k] != 0.f) atomicAdd(base + (long)cur[k] * 32, acc[k]);
+        cur[k] = offs[k];
+        acc[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = fmaf(wts[k], d, acc[k]);
+    x = xn; y = yn; z3 = zn; d = dn;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (acc[k] != 0.f) atomicAdd(base + (long)cur[k] * 32, acc[k]);
+}
+
 extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float* proj, int R, int S, int V, int Hf, int Wf, int F, float img_h, float img_w,
                               const float* drgb_feat, long ld_d, int col0, float* dfeat_cl, void* stream) {
   DYN_REQUIRE((pts_st || xyz) && proj && drgb_feat && dfeat_cl, "dyn_gather_bwd: null pointer");
@@ -862,6 +917,11 @@ extern "C" int dyn_gather_bwd(const float* pts_st, const float* xyz, const float
   q.N = (long)R * S * V;
   q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
   if (F == 32) {
+    if (S >= 8) {  // along the rays, contributions to an unchanged bilinear cell merged in registers
+      DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd32_ray, dim3((unsigned)(((long)R * V * 32 + 255) / 256)), dim3(256), 0,
+                 (hipStream_t)stream, q, pts_st, xyz, reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);
+      return 0;
+    }
     DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd", k_gather_bwd32, dim3((unsigned)((q.N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q,
                pts_st, xyz, reinterpret_cast<const float4*>(proj), drgb_feat, ld_d, col0, dfeat_cl);
     return 0;
