@@ -997,6 +997,68 @@ __global__ void __launch_bounds__(256) k_gather_bwd_pts(PGShape q, const float* 
   o[2] = P0.z * ghx + P1.z * ghy + P2.z * ghz;
 }
 
+// The same for 32-channel maps with one lane per channel (32 lanes per (point, view) row): the four pixel records of a tap and the row's
+// gradient are each ONE coalesced 128-byte read instead of 32 four-byte reads per thread (lanes 0..2 also take the colour taps), and the
+// per-channel products meet by a 32-lane butterfly; lane 0 applies the chain rule.
+__device__ __forceinline__ void tap_grad_lane(const float* __restrict__ map, int Wm, int Hm, int C, float nx, float ny, float dc, int c, float& gnx,
+                                              float& gny) {
+  const float ix = safe_floor_coord((nx + 1.0f) * ((float)(Wm - 1) / 2.0f), (float)Wm);
+  const float iy = safe_floor_coord((ny + 1.0f) * ((float)(Hm - 1) / 2.0f), (float)Hm);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float fx = ix - fx0, fy = iy - fy0;
+  const bool x0ok = (x0 >= 0) && (x0 < Wm), x1ok = (x0 + 1 >= 0) && (x0 + 1 < Wm);
+  const bool y0ok = (y0 >= 0) && (y0 < Hm), y1ok = (y0 + 1 >= 0) && (y0 + 1 < Hm);
+  const float a = (x0ok && y0ok) ? map[((long)iclamp(y0, Hm - 1) * Wm + iclamp(x0, Wm - 1)) * C + c] : 0.f;
+  const float b = (x1ok && y0ok) ? map[((long)iclamp(y0, Hm - 1) * Wm + iclamp(x0 + 1, Wm - 1)) * C + c] : 0.f;
+  const float e = (x0ok && y1ok) ? map[((long)iclamp(y0 + 1, Hm - 1) * Wm + iclamp(x0, Wm - 1)) * C + c] : 0.f;
+  const float f = (x1ok && y1ok) ? map[((long)iclamp(y0 + 1, Hm - 1) * Wm + iclamp(x0 + 1, Wm - 1)) * C + c] : 0.f;
+  gnx += dc * ((1.0f - fy) * (b - a) + fy * (f - e)) * ((float)(Wm - 1) / 2.0f);
+  gny += dc * ((1.0f - fx) * (e - a) + fx * (f - b)) * ((float)(Hm - 1) / 2.0f);
+}
+__global__ void __launch_bounds__(256) k_gather_bwd_pts32(PGShape q, const float* __restrict__ pts_st, const float* __restrict__ xyz,
+                                                          const float4* __restrict__ proj4, const float* __restrict__ src_rgb,
+                                                          const float* __restrict__ feat_cl, const float* __restrict__ drgb_feat, long ld_d,
+                                                          float* __restrict__ dxyz) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row_raw = idx >> 5;
+  const int c = (int)(idx & 31);
+  const bool live = row_raw < q.N;
+  const long row = live ? row_raw : q.N - 1;  // (every lane stays for the butterfly)
+  const long rs = row / q.V;
+  const int v = (int)(row - rs * q.V);
+  const float* pt = xyz != nullptr ? xyz + ((long)v * q.R * q.S + rs) * 3 : pts_st + rs * 3;
+  const float x = pt[0], y = pt[1], z3 = pt[2];
+  const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2];
+  const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
+  const float hy = fmaf(P1.w, 1.0f, fmaf(P1.z, z3, fmaf(P1.y, y, P1.x * x)));
+  const float hz = fmaf(P2.w, 1.0f, fmaf(P2.z, z3, fmaf(P2.y, y, P2.x * x)));
+  const float zc = fmaxf(hz, 1e-8f);
+  const float izc = 1.0f / zc;
+  const float pxu = hx / zc, pyu = hy / zc;  // the forward's pixel (same taps); izc only scales the gradient
+  const float px = fminf(fmaxf(pxu, -1e6f), 1e6f), py = fminf(fmaxf(pyu, -1e6f), 1e6f);
+  const float nx = 2.0f * px / (q.img_w - 1.0f) - 1.0f;
+  const float ny = 2.0f * py / (q.img_h - 1.0f) - 1.0f;
+  const float* d = drgb_feat + row * ld_d;
+  float gnx = 0.f, gny = 0.f;
+  if (c < 3) tap_grad_lane(src_rgb + (long)v * q.H * q.W * 3, q.W, q.H, 3, nx, ny, d[c], c, gnx, gny);
+  tap_grad_lane(feat_cl + (long)v * q.Hf * q.Wf * 32, q.Wf, q.Hf, 32, nx, ny, d[3 + c], c, gnx, gny);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) {
+    gnx += __shfl_xor(gnx, o);
+    gny += __shfl_xor(gny, o);
+  }
+  if (c != 0 || !live) return;
+  const float gpx = (pxu >= -1e6f && pxu <= 1e6f) ? gnx * 2.0f * q.inv_wm1 : 0.f;
+  const float gpy = (pyu >= -1e6f && pyu <= 1e6f) ? gny * 2.0f * q.inv_hm1 : 0.f;
+  const float ghx = gpx * izc, ghy = gpy * izc;
+  const float ghz = hz > 1e-8f ? -(gpx * hx + gpy * hy) * izc * izc : 0.f;
+  float* o = dxyz + ((long)v * q.R * q.S + rs) * 3;
+  o[0] = P0.x * ghx + P1.x * ghy + P2.x * ghz;
+  o[1] = P0.y * ghx + P1.y * ghy + P2.y * ghz;
+  o[2] = P0.z * ghx + P1.z * ghy + P2.z * ghz;
+}
+
 extern "C" int dyn_gather_bwd_pts(const float* pts_st, const float* xyz, const float* proj, const float* src_rgb, const float* feat_cl, int R, int S,
                                   int V, int H, int W, int Hf, int Wf, int F, float img_h, float img_w, const float* drgb_feat, long ld_d,
                                   float* dxyz, void* stream) {
@@ -1008,6 +1070,11 @@ extern "C" int dyn_gather_bwd_pts(const float* pts_st, const float* xyz, const f
   q.inv_wm1 = 1.0f / (img_w - 1.0f); q.inv_hm1 = 1.0f / (img_h - 1.0f);
   q.N = (long)R * S * V;
   q.mV = q.mS = 0; q.ntask = 0; q.tasks_per_xcd = 0;
+  if (F == 32) {
+    DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd_pts", k_gather_bwd_pts32, dim3((unsigned)((q.N * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+               q, pts_st, xyz, reinterpret_cast<const float4*>(proj), src_rgb, feat_cl, drgb_feat, ld_d, dxyz);
+    return 0;
+  }
   DYN_LAUNCH(DYN_K_TRAIN_GATHER_BWD, "dyn_gather_bwd_pts", k_gather_bwd_pts, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q,
              pts_st, xyz, reinterpret_cast<const float4*>(proj), src_rgb, feat_cl, drgb_feat, ld_d, dxyz);
   return 0;
