@@ -1017,12 +1017,12 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)) || (mode != 1 && p->kscale != nullptr))) {
       const long units = (long)g.mt * g.nz;
       // the epilogue (EPI of k_train_gemm_ring): the fast forms that are instantiated -- forward shape (both operands k-minor): plain, addend,
-      // row scale; data-gradient shape (b k-major): plain, act_y --, else the general form
+      // row scale; data-gradient shape (b k-major): plain, act_y, addend --, else the general form
       int epi = -1;
       if (fast && ra == 0) {
         const int want = p->act_y != nullptr ? 1 : (p->addend != nullptr ? 2 : (p->rowscale != nullptr ? 3 : 0));
         if (rb == 0 && want != 1) epi = want;
-        if (rb == 2 && want <= 1) epi = want;
+        if (rb == 2 && want <= 2) epi = want;  // (addend on the data-gradient shape: dX += ..., the addend being C itself)
         if (epi == 1 && p->bias != nullptr) epi = -1;  // the act_y form carries no bias
       }
       const bool ring_sums = p->colsum_part == nullptr || epi == 0 || epi == 1;  // else: the tile kernel
@@ -1035,7 +1035,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     return 0;                                                                                                                              \
   }
       TG_RING(0, 0, 0, false) TG_RING(0, 0, 2, false) TG_RING(0, 0, 3, false) TG_RING(0, 0, -1, false)
-      TG_RING(0, 2, 0, false) TG_RING(0, 2, 1, false) TG_RING(0, 2, -1, false)
+      TG_RING(0, 2, 0, false) TG_RING(0, 2, 1, false) TG_RING(0, 2, 2, false) TG_RING(0, 2, -1, false)
       TG_RING(2, 0, -1, false) TG_RING(2, 2, -1, false)
       TG_RING(2, 2, -1, true)  // the weight gradient of a Linear on x * s[row]
 #undef TG_RING

@@ -170,8 +170,14 @@ class _Lin:
       Nd = self.K
       if self.K % 4 != 0 and self.Wop is not self.W and acc_dx == 0 and act_y is None and ld_dx >= self.op_ld and ld_dx % 4 == 0 and dx_off % 4 == 0:
         Nd = self.op_ld
-      _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, Nd, self.n_out, accumulate=acc_dx,
-            a_absmax=_p(am), **fy)
+      if acc_dx == 1 and act_y is None and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0:
+        # dX += dZ W as "dX = dZ W + addend" with the addend dX itself: every element is read and written by the one thread that owns it, and the
+        # product keeps the epilogue's 16-byte form (the accumulate flag takes the 4-byte atomic form)
+        _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, Nd, self.n_out, accumulate=0,
+              a_absmax=_p(am), addend=_p(dX, dx_off), ld_add=ld_dx, add_div=1)
+      else:
+        _gemm(st, _p(dZ, dz_off), ld_dz, 1, _p(self.Wop, self.op_off), 1, self.op_ld, _p(dX, dx_off), ld_dx, M, Nd, self.n_out, accumulate=acc_dx,
+              a_absmax=_p(am), **fy)
       if sums:
         am2 = _Scalars.take(dX.device)
         call('dyn_train_colsum_reduce', _p(part), tiles, self.K, self.K, _p(dbias), _p(apart), tiles * ctiles, _p(am2), st)

@@ -295,7 +295,8 @@ int dyn_profile_read(float* total_ms, int* launches);
  * each).  Forward of nn.Linear: A = X (a_ks = 1), B = W[N,K] (b_rs = ldw, b_ks = 1).  Data gradient dX = dZ W: A = dZ, B rows = input
  * features (b_rs = 1, b_ks = ldw).  Weight gradient dW = dZ^T X: A rows = output features (a_rs = 1, a_ks = ld_dz), B rows = input
  * features (b_rs = 1, b_ks = ldx), K = number of rows, k_split > 1 with accumulate = 2.
- * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip), act (0 none, 1 ELU, 2 ReLU); accumulate 0 store, 1 or 2: += by fp32 atomics
+ * epilogue: + bias[n] + addend[(m / add_div) ld_add + n] (NULL to skip; with add_div = 1 the addend may be C itself -- C += A . B with plain
+ * 16-byte stores, every element read and written by one thread), act (0 none, 1 ELU, 2 ReLU); accumulate 0 store, 1 or 2: += by fp32 atomics
  * (2 is required with k_split > 1).
  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x16_f16: every operand split into two half parts (22 mantissa bits), 3 partial products; the
  * gradient operand A is first multiplied by the power of two that brings a_absmax to 2^14 (undone in the epilogue). */
