@@ -1422,20 +1422,27 @@ extern "C" int dyn_train_static_embed(const float* pts, const float* ray_o, cons
 __global__ void __launch_bounds__(256) k_train_build_f(const float* __restrict__ rgb_feat, const float* __restrict__ src_feat, long ld_src,
                                                        const float* __restrict__ ref_feat, long ld_ref, long N, int rows_per_ray,
                                                        float* __restrict__ f) {
+  // a thread writes one 16-byte quad of a 72-float row (18 quads): a quarter of the store instructions of the one-element form, which ran at
+  // 2.4 TB/s; the 35-float input rows have no 16-byte alignment and are read by element (the lines are shared by the row's threads)
   long row, ray;
-  int c;
-  if (N * 72 < (1L << 32)) {  // 32-bit index arithmetic (a 64-bit division costs ~100 instructions; this kernel had two per element)
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x, r = idx / 72u;
-    row = r; c = (int)(idx - r * 72u); ray = r / (unsigned)rows_per_ray;
+  int q;
+  if (N * 18 < (1L << 32)) {  // 32-bit index arithmetic (a 64-bit division costs ~100 instructions)
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x, r = idx / 18u;
+    row = r; q = (int)(idx - r * 18u); ray = r / (unsigned)rows_per_ray;
   } else {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    row = idx / 72; c = (int)(idx - row * 72); ray = row / rows_per_ray;
+    row = idx / 18; q = (int)(idx - row * 18); ray = row / rows_per_ray;
   }
   if (row >= N) return;
-  float v = 0.f;
-  if (c < 35) v = rgb_feat[row * 35 + c];
-  else if (c < 70) v = src_feat[row * ld_src + c - 35] * ref_feat[ray * ld_ref + c - 35];
-  f[row * 72 + c] = v;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    v[e] = 0.f;
+    if (c < 35) v[e] = rgb_feat[row * 35 + c];
+    else if (c < 70) v[e] = src_feat[row * ld_src + c - 35] * ref_feat[ray * ld_ref + c - 35];
+  }
+  *reinterpret_cast<float4*>(f + row * 72 + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __global__ void __launch_bounds__(256) k_train_build_f_bwd(const float* __restrict__ df, long ld_df, const float* __restrict__ src_feat, long ld_src,
                                                            const float* __restrict__ ref_feat, long ld_ref, int rows_per_ray,
@@ -1464,7 +1471,8 @@ __global__ void __launch_bounds__(256) k_train_build_f_bwd(const float* __restri
 extern "C" int dyn_train_build_f(const float* rgb_feat, const float* src_feat, long ld_src, const float* ref_feat, long ld_ref, long N,
                                  int rows_per_ray, float* f, void* stream) {
   DYN_REQUIRE(rgb_feat && src_feat && ref_feat && f && N > 0 && rows_per_ray > 0, "dyn_train_build_f: bad arguments");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_build_f", k_train_build_f, dim3((unsigned)((N * 72 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  DYN_REQUIRE(((uintptr_t)f & 15) == 0, "dyn_train_build_f: f must be 16-byte aligned");
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_build_f", k_train_build_f, dim3((unsigned)((N * 18 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
              rgb_feat, src_feat, ld_src, ref_feat, ld_ref, N, rows_per_ray, f);
   return 0;
 }
@@ -2630,48 +2638,76 @@ extern "C" int dyn_train_blend_bwd(const float* draw, const float* blend, const 
 // weights_i = alpha_i T_i, T_i = prod_{j<i} (1 - alpha_j + 1e-10); rgb = sum w_i c_i; depth = sum w_i z_i.
 // dw_i = drgb . c_i + ddepth z_i + dweights_i;  dalpha_i = dw_i T_i - (sum_{j>i} dw_j w_j) / (1 - alpha_i + 1e-10);
 // alpha = 1 - exp(-softplus(sigma) dist), dist = 1 (last sample 1e10): dsigma = dalpha exp(-sp dist) dist sigmoid(sigma).
-__global__ void __launch_bounds__(64) k_train_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
-                                                            const float* __restrict__ alpha, const float* __restrict__ weights,
-                                                            const float* __restrict__ drgb, const float* __restrict__ ddepth,
-                                                            const float* __restrict__ dweights, int R, int S, float* __restrict__ draw) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+// One WAVEFRONT per ray, a lane per sample (chunks of 64 samples with carried transmittance / prefix): the one-thread-per-ray form ran 3072
+// rays on 48 wavefronts and took 0.07-0.17 ms per launch for 16 MB.  Prefix products / sums by log-step shuffles; 16-byte stores.
+__device__ __forceinline__ float tr_scan_sum(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float tr_scan_prod(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(256) k_train_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                             const float* __restrict__ alpha, const float* __restrict__ weights,
+                                                             const float* __restrict__ drgb, const float* __restrict__ ddepth,
+                                                             const float* __restrict__ dweights, int R, int S, float* __restrict__ draw) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;  // (whole wavefronts)
   const float g0 = drgb ? drgb[r * 3] : 0.f, g1 = drgb ? drgb[r * 3 + 1] : 0.f, g2 = drgb ? drgb[r * 3 + 2] : 0.f;
   const float gd = ddepth ? ddepth[r] : 0.f;
-  // pass 1: colour gradients, dw_i stashed in the density slot, total = sum_j dw_j w_j
+  // pass 1: total = sum_j dw_j w_j
   float total = 0.f;
-  for (int i = 0; i < S; ++i) {
-    const long o = (long)r * S + i;
-    const float w = weights[o];
-    const float* c = raw + o * 4;
-    const float dw = g0 * c[0] + g1 * c[1] + g2 * c[2] + gd * z_vals[o] + (dweights ? dweights[o] : 0.f);
-    draw[o * 4] = g0 * w; draw[o * 4 + 1] = g1 * w; draw[o * 4 + 2] = g2 * w;
-    draw[o * 4 + 3] = dw;
-    total += dw * w;
+  for (int i0 = 0; i0 < S; i0 += 64) {
+    const int i = i0 + lane;
+    float term = 0.f;
+    if (i < S) {
+      const long o = (long)r * S + i;
+      const float4 c = *reinterpret_cast<const float4*>(raw + o * 4);
+      const float dw = g0 * c.x + g1 * c.y + g2 * c.z + gd * z_vals[o] + (dweights ? dweights[o] : 0.f);
+      term = dw * weights[o];
+    }
+    total += wave_sum(term);
   }
-  // pass 2: running transmittance, suffix sums as total - prefix
-  float T = 1.0f;
-  float prefix = 0.f;
-  for (int i = 0; i < S; ++i) {
-    const long o = (long)r * S + i;
-    const float a = alpha[o], dw = draw[o * 4 + 3];
-    prefix += dw * weights[o];
-    const float suf = total - prefix;
-    const float one_m = 1.0f - a + 1e-10f;
-    const float dalpha = dw * T - suf / one_m;
-    const float sg = raw[o * 4 + 3];
-    const float sp = sg > 20.0f ? sg : log1pf(expf(sg));
-    const float dist = (i == S - 1) ? 1e10f : 1.0f;
-    const float ex = expf(-sp * dist);
-    const float dsp = dalpha * ex * dist;
-    draw[o * 4 + 3] = sg > 20.0f ? dsp : dsp * tr_sigmoid(sg);
-    T *= one_m;
+  // pass 2: transmittance as a prefix product, suffix sums as total - prefix
+  float T_in = 1.0f, prefix_in = 0.f;
+  for (int i0 = 0; i0 < S; i0 += 64) {
+    const int i = i0 + lane;
+    const bool ok = i < S;
+    const long o = (long)r * S + (ok ? i : S - 1);
+    const float4 c = *reinterpret_cast<const float4*>(raw + o * 4);
+    const float w = ok ? weights[o] : 0.f, a = ok ? alpha[o] : 0.f;
+    const float dw = g0 * c.x + g1 * c.y + g2 * c.z + gd * z_vals[o] + (dweights ? dweights[o] : 0.f);
+    const float one_m = ok ? 1.0f - a + 1e-10f : 1.0f;
+    const float incl = tr_scan_prod(one_m, lane);
+    float T = __shfl_up(incl, 1);
+    T = (lane == 0 ? 1.0f : T) * T_in;
+    const float prefix = prefix_in + tr_scan_sum(ok ? dw * w : 0.f, lane);
+    if (ok) {
+      const float dalpha = dw * T - (total - prefix) / one_m;
+      const float sg = c.w;
+      const float sp = sg > 20.0f ? sg : log1pf(expf(sg));
+      const float dist = (i == S - 1) ? 1e10f : 1.0f;
+      const float dsp = dalpha * expf(-sp * dist) * dist;
+      *reinterpret_cast<float4*>(draw + o * 4) = make_float4(g0 * w, g1 * w, g2 * w, sg > 20.0f ? dsp : dsp * tr_sigmoid(sg));
+    }
+    T_in *= __shfl(incl, 63);
+    prefix_in = __shfl(prefix, 63);
   }
 }
 extern "C" int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
                                        const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream) {
   DYN_REQUIRE(raw && z_vals && alpha && weights && draw && R > 0 && S > 0, "dyn_train_composite_bwd: bad arguments");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite_bwd", k_train_composite_bwd, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite_bwd", k_train_composite_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw,
              z_vals, alpha, weights, drgb, ddepth, dweights, R, S, draw);
   return 0;
 }
@@ -2786,13 +2822,15 @@ __device__ __forceinline__ float tr_alpha(float sg, bool last, float& dalpha_dsi
   dalpha_dsigma = ex * dist * (sg > 20.0f ? 1.0f : tr_sigmoid(sg));
   return 1.0f - ex;
 }
-__global__ void __launch_bounds__(64) k_train_composite2_bwd(const float* __restrict__ raw_dy, const float* __restrict__ raw_st,
-                                                             const float* __restrict__ z_vals, const float* __restrict__ g_rgb,
-                                                             const float* __restrict__ g_rgb_st, const float* __restrict__ g_rgb_dy,
-                                                             const float* __restrict__ g_depth, const float* __restrict__ g_wd,
-                                                             const float* __restrict__ g_ws, const float* __restrict__ g_w, int R, int S,
-                                                             float* __restrict__ draw_dy, float* __restrict__ draw_st) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_train_composite2_bwd(const float* __restrict__ raw_dy, const float* __restrict__ raw_st,
+                                                              const float* __restrict__ z_vals, const float* __restrict__ g_rgb,
+                                                              const float* __restrict__ g_rgb_st, const float* __restrict__ g_rgb_dy,
+                                                              const float* __restrict__ g_depth, const float* __restrict__ g_wd,
+                                                              const float* __restrict__ g_ws, const float* __restrict__ g_w, int R, int S,
+                                                              float* __restrict__ draw_dy, float* __restrict__ draw_st) {
+  // one wavefront per ray, a lane per sample (see k_train_composite_bwd)
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   float gd[3], gs[3];
   for (int c = 0; c < 3; ++c) {
@@ -2801,49 +2839,47 @@ __global__ void __launch_bounds__(64) k_train_composite2_bwd(const float* __rest
     gs[c] = g + (g_rgb_st ? g_rgb_st[r * 3 + c] : 0.f);
   }
   const float gz = g_depth ? g_depth[r] : 0.f;
-  // pass 1: total = sum_i Q_i T_i
-  float T = 1.0f, total = 0.f;
-  for (int i = 0; i < S; ++i) {
-    const long o = (long)r * S + i;
-    float dd, ds;
-    const float ad = tr_alpha(raw_dy[o * 4 + 3], i == S - 1, dd), as = tr_alpha(raw_st[o * 4 + 3], i == S - 1, ds);
-    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
-    const float Wd = gd[0] * raw_dy[o * 4] + gd[1] * raw_dy[o * 4 + 1] + gd[2] * raw_dy[o * 4 + 2] + (g_wd ? g_wd[o] : 0.f);
-    const float Ws = gs[0] * raw_st[o * 4] + gs[1] * raw_st[o * 4 + 1] + gs[2] * raw_st[o * 4 + 2] + (g_ws ? g_ws[o] : 0.f);
-    const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
-    total += (Wd * ad + Ws * as + Ww * A) * T;
-    T *= 1.0f - A + 1e-10f;
-  }
-  // pass 2
-  T = 1.0f;
-  float prefix = 0.f;
-  for (int i = 0; i < S; ++i) {
-    const long o = (long)r * S + i;
-    float dd, ds;
-    const float ad = tr_alpha(raw_dy[o * 4 + 3], i == S - 1, dd), as = tr_alpha(raw_st[o * 4 + 3], i == S - 1, ds);
-    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
-    const float Wd = gd[0] * raw_dy[o * 4] + gd[1] * raw_dy[o * 4 + 1] + gd[2] * raw_dy[o * 4 + 2] + (g_wd ? g_wd[o] : 0.f);
-    const float Ws = gs[0] * raw_st[o * 4] + gs[1] * raw_st[o * 4 + 1] + gs[2] * raw_st[o * 4 + 2] + (g_ws ? g_ws[o] : 0.f);
-    const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
-    prefix += (Wd * ad + Ws * as + Ww * A) * T;
-    const float one_m = 1.0f - A + 1e-10f;
-    const float dA = Ww * T - (total - prefix) / one_m;
-    const float dad = Wd * T + dA * (1.0f - as), das = Ws * T + dA * (1.0f - ad);
-    const float wd = ad * T, ws = as * T;
-    for (int c = 0; c < 3; ++c) {
-      draw_dy[o * 4 + c] = gd[c] * wd;
-      draw_st[o * 4 + c] = gs[c] * ws;
+  float total = 0.f, T_in = 1.0f, prefix_in = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: total = sum_i Q_i T_i; pass 1: the gradients
+    T_in = 1.0f;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+      const int i = i0 + lane;
+      const bool ok = i < S;
+      const long o = (long)r * S + (ok ? i : S - 1);
+      const float4 cd = *reinterpret_cast<const float4*>(raw_dy + o * 4), cs = *reinterpret_cast<const float4*>(raw_st + o * 4);
+      float dd, ds;
+      const float ad = tr_alpha(cd.w, i == S - 1, dd), as = tr_alpha(cs.w, i == S - 1, ds);
+      const float A = 1.0f - (1.0f - as) * (1.0f - ad);
+      const float Wd = gd[0] * cd.x + gd[1] * cd.y + gd[2] * cd.z + (g_wd ? g_wd[o] : 0.f);
+      const float Ws = gs[0] * cs.x + gs[1] * cs.y + gs[2] * cs.z + (g_ws ? g_ws[o] : 0.f);
+      const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
+      const float one_m = ok ? 1.0f - A + 1e-10f : 1.0f;
+      const float incl = tr_scan_prod(one_m, lane);
+      float T = __shfl_up(incl, 1);
+      T = (lane == 0 ? 1.0f : T) * T_in;
+      const float term = ok ? (Wd * ad + Ws * as + Ww * A) * T : 0.f;
+      if (pass == 0) {
+        total += wave_sum(term);
+      } else {
+        const float prefix = prefix_in + tr_scan_sum(term, lane);
+        if (ok) {
+          const float dA = Ww * T - (total - prefix) / one_m;
+          const float dad = Wd * T + dA * (1.0f - as), das = Ws * T + dA * (1.0f - ad);
+          const float wd = ad * T, ws = as * T;
+          *reinterpret_cast<float4*>(draw_dy + o * 4) = make_float4(gd[0] * wd, gd[1] * wd, gd[2] * wd, dad * dd);
+          *reinterpret_cast<float4*>(draw_st + o * 4) = make_float4(gs[0] * ws, gs[1] * ws, gs[2] * ws, das * ds);
+        }
+        prefix_in = __shfl(prefix, 63);
+      }
+      T_in *= __shfl(incl, 63);
     }
-    draw_dy[o * 4 + 3] = dad * dd;
-    draw_st[o * 4 + 3] = das * ds;
-    T *= one_m;
   }
 }
 extern "C" int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
                                         const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R,
                                         int S, float* draw_dy, float* draw_st, void* stream) {
   DYN_REQUIRE(raw_dy && raw_st && z_vals && draw_dy && draw_st && R > 0 && S > 0, "dyn_train_composite2_bwd: bad arguments");
-  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw_dy,
+  DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw_dy,
              raw_st, z_vals, g_rgb, g_rgb_st, g_rgb_dy, g_depth, g_wd, g_ws, g_w, R, S, draw_dy, draw_st);
   return 0;
 }
