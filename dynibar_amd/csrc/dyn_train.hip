@@ -1911,7 +1911,9 @@ __global__ void __launch_bounds__(256) k_train_vis_split_bwd(const float* __rest
 // the row matrix saved per call, and for the 129-column vis_fc.2 the scalar form of that kernel).  128 columns as 32 float4 lanes per
 // row; a block's eight lane groups own consecutive spans of rows, four rows per trip (every load of a trip in flight before the first use);
 // bias gradient: the groups' partial column sums meet in LDS, one atomic per column and block; largest |result| -> *absmax. ----
+#ifndef TR_FUSE_SPAN
 #define TR_FUSE_SPAN 256  // rows per lane group: 2048 rows per block (same-address atomics per column: see k_train_act_bwd)
+#endif
 __device__ __forceinline__ float tr_dact(float y, int act) { return y > 0.f ? 1.0f : (act == 1 ? y + 1.0f : 0.f); }
 
 // dx = (dx + dy * s[row]) * act'(x)   (x: the saved OUTPUT of the activation, which is also what s multiplied in the forward pass),
