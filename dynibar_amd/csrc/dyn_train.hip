@@ -1014,7 +1014,13 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
     const int sides = (p->act_y != nullptr) + (p->addend != nullptr) + (p->rowscale != nullptr);
     const bool fast = g.c_vec && (p->bias == nullptr || ((uintptr_t)p->bias & 15) == 0) && (p->act_y == nullptr || g.act_y_vec) && add_vec && sides <= 1;
     const int mode = tr_gemm_mode();
-    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2)) || (mode != 1 && p->kscale != nullptr))) {
+    // (forward products with an addend / row scale on the ring form -- the tile kernel reads those by 4-byte accumulator-layout loads -- measured:
+    // GEMM time -0.2 ms per iteration, not worth a second arithmetic order in the forward pass; -DTR_AUTO_SIDE_RING=1 to try)
+#ifndef TR_AUTO_SIDE_RING
+#define TR_AUTO_SIDE_RING 0
+#endif
+    const bool side_fwd = TR_AUTO_SIDE_RING && fast && (p->addend != nullptr || p->rowscale != nullptr);
+    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2 || side_fwd)) || (mode != 1 && p->kscale != nullptr))) {
       const long units = (long)g.mt * g.nz;
       // the epilogue (EPI of k_train_gemm_ring): the fast forms that are instantiated -- forward shape (both operands k-minor): plain, addend,
       // row scale; data-gradient shape (b k-major): plain, act_y, addend --, else the general form
