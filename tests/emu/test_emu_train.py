@@ -18,6 +18,10 @@ def test_train_gemm_random_shapes(emu):
   parity.check_train_gemm_fuzz(emu, n_cases=9, max_rows=400)
 
 
+def test_train_composite(emu):
+  parity.check_train_composite(emu, lengths=(5, 64, 100), R=3)
+
+
 def test_train_attention(emu):
   parity.check_train_attention(emu, lengths=(5, 16, 37, 120), R=2)
 

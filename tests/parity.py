@@ -1339,6 +1339,42 @@ def check_train_recompute(device, name='small', S=16):
     TS.RECOMPUTE_HIDDEN = was
 
 
+def check_train_composite(device, lengths=(5, 64, 100, 150), R=7, seed=5):
+  """The compositing autograd nodes alone (train_static.composite_vanilla / train_dynamic.composite_dual: raw2outputs_vanilla / raw2outputs,
+  render_ray.py:134-330) against fp64 autograd through the oracle's functions: ray lengths below, at and above one wavefront of samples
+  (the backward kernels walk a ray in chunks of 64 with carried transmittance / prefix sums), every differentiable output weighted."""
+  from dynibar_amd import train_static as TS, train_dynamic as TD
+  g = torch.Generator().manual_seed(seed)
+  for S in lengths:
+    raw_dy = torch.cat([torch.rand(R, S, 3, generator=g), torch.randn(R, S, 1, generator=g) * 2.0 - 1.0], dim=2)
+    raw_st = torch.cat([torch.rand(R, S, 3, generator=g), torch.randn(R, S, 1, generator=g) * 2.0 - 1.0], dim=2)
+    z = torch.sort(torch.rand(R, S, generator=g) * 4.0 + 1.0, dim=1).values
+    pm = torch.ones(R, S)
+    cots = {k: torch.randn(*shape, generator=g) for k, shape in (('rgb', (R, 3)), ('depth', (R,)), ('weights', (R, S)), ('rgb_static', (R, 3)),
+                                                                  ('rgb_dy', (R, 3)), ('weights_dy', (R, S)), ('weights_st', (R, S)))}
+    d = lambda t: t.detach().clone().to(device).contiguous()
+    # one branch
+    x = raw_st.double().requires_grad_(True)
+    ref = O.raw2outputs_vanilla(x, z.double(), pm.double())
+    sum((ref[k] * cots[k].double()).sum() for k in ('rgb', 'depth', 'weights')).backward()
+    xd = d(raw_st).requires_grad_(True)
+    out = TS.composite_vanilla(xd, d(z), d(pm))
+    sum((out[k] * d(cots[k])).sum() for k in ('rgb', 'depth', 'weights')).backward()
+    gmax = float(x.grad.abs().max())
+    assert_close(xd.grad, x.grad, 2e-6 * gmax + 1e-7, 2e-5, f'train composite (vanilla) S={S} d raw')
+    # two branches
+    a, b = raw_dy.double().requires_grad_(True), raw_st.double().requires_grad_(True)
+    ref = O.raw2outputs(a, b, z.double(), pm.double(), pm.double())
+    keys = ('rgb', 'rgb_static', 'rgb_dy', 'depth', 'weights_dy', 'weights_st', 'weights')
+    sum((ref[k] * cots[k].double()).sum() for k in keys).backward()
+    ad, bd = d(raw_dy).requires_grad_(True), d(raw_st).requires_grad_(True)
+    out = TD.composite_dual(ad, bd, d(z), d(pm), d(pm))
+    sum((out[k] * d(cots[k])).sum() for k in keys).backward()
+    for name, got, want in (('dy', ad.grad, a.grad), ('st', bd.grad, b.grad)):
+      gmax = float(want.abs().max())
+      assert_close(got, want, 2e-6 * gmax + 1e-7, 2e-5, f'train composite (two branches) S={S} d raw_{name}')
+
+
 def check_train_attention(device, lengths=(5, 16, 37, 64, 112, 120), R=3, seed=11):
   """dyn_train_attn / dyn_train_attn_bwd alone (ScaledDotProductAttention of the ray transformer, mlp_network.py:13-31, and its autograd)
   against fp64 torch on ray lengths that are not multiples of four, at the LDS form's limit (112) and beyond it (the global-scratch form);
@@ -1360,7 +1396,7 @@ def check_train_attention(device, lengths=(5, 16, 37, 64, 112, 120), R=3, seed=1
     out_ref = torch.matmul(prob_ref, v).transpose(1, 2).reshape(P, 128)
     out_ref.backward(dout.double())
     # product
-    d = lambda t: t.to(device).contiguous()
+    d = lambda t: t.detach().clone().to(device).contiguous()
     qkv_d, nv_d, dout_d = d(qkv), d(nvalid), d(dout)
     out = torch.empty(P, 128, device=device); prob = torch.empty(R * 4, S, S, device=device)
     dqkv = torch.empty(P, 384, device=device); dsc = torch.empty(R * 4, S, S, device=device)

@@ -276,6 +276,12 @@ def test_feature_encoder_trains_through_the_gather(dev):
 
 
 @pytest.mark.gpu
+def test_train_composite_lengths(dev):
+  """the compositing autograd nodes alone vs fp64 autograd through the oracle: rays of 5 ... 200 samples (the backward walks a ray in chunks of 64)"""
+  parity.check_train_composite(dev, lengths=(5, 64, 100, 150, 200), R=70)
+
+
+@pytest.mark.gpu
 def test_train_attention_lengths(dev):
   """the ray attention's training kernels alone vs fp64 torch: ray lengths 5 ... 112 (LDS form, four lanes per row) and 120 / 200 (global-scratch form)"""
   parity.check_train_attention(dev, lengths=(5, 16, 37, 64, 112, 120, 200), R=5)
