@@ -1504,7 +1504,6 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
   const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
   const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
-  const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
 
   const float msk = valid ? p.mask[pv] : 0.f;
