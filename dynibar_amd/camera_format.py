@@ -79,7 +79,7 @@ def load_poses_bounds(poses_arr, image_hw, bd_factor=0.75, recenter=True):
   """``poses_bounds*.npy`` ([N,17]) + the size of the images on disk -> (poses [N,3,5] float32, bds [N,2] float32, scale), as
   ``load_llff_data`` prepares them (llff_data_utils.py:58-62 layout, :107-109 image size into the hwf column, :246-263 axis order,
   rescale by 1 / (min bound * bd_factor), recentre)."""
-  poses_arr = np.asarray(poses_arr)
+  poses_arr = np.array(poses_arr, copy=True)  # the image size is written into the hwf column below: never through a view of the caller's array
   poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
   bds = poses_arr[:, -2:].transpose([1, 0])
   poses[:2, 4, :] = np.array(image_hw[:2]).reshape([2, 1])

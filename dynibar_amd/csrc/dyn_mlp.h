@@ -20,6 +20,8 @@
 //  * the first one (kept for A/B builds, -DDYN_ENGINE_B6=0; first half of this file): native fp32 MFMA (v_mfma_f32_32x32x2_f32),
 //    16 KiB chunks (DYN_CHUNK) in a 2-deep ring, bias folded into K as one extra k-step.
 #pragma once
+#include <utility>
+
 #include "dyn_device.h"
 
 #define DYN_CHUNK 4096        // floats per weight chunk (16 KiB)
@@ -633,6 +635,294 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
       }
     }
   }
+}
+
+// =====================================================================================================================
+// Round 4: the layer loop of the kernels that run ONE wave per SIMD (k_motion_mlp, k_net_points; > 256 registers per lane).
+// With a second wave on the SIMD every bubble of mlp_layer_b6 is filled by the partner; alone, the wave shows what the loop costs
+// (k_motion_mlp, a plain 256-wide ReLU chain with ~2.5 VALU per MFMA triple, had the matrix pipe 0.51 busy):
+//  * the three partial products of a pair went to ONE accumulator back to back, and hipcc put the next pair's two ds_read_b128 between the
+//    first and the second of them: an instruction between two MFMAs on the same accumulator costs ~43 cycles (the result is forwarded
+//    only to an MFMA that issues right behind), and a dependent MFMA cannot issue before its predecessor has finished anyway;
+//  * the A fragments were requested ONE pair ahead (~64 cycles before their `s_waitcnt lgkmcnt(0)`), less than the LDS latency under
+//    four waves' traffic;
+//  * the twelve 1 KiB LDS-DMA pieces of the next chunk were issued as one burst right behind the chunk barrier (~60 issue cycles each,
+//    nothing to hide them under), and the barrier itself sat in front of the chunk's first LDS reads.
+// mlp_layer_b6_duo issues the products of TWO output tiles interleaved (M1 t0, M1 t1, M2 t0, M2 t1, M3 t0, M3 t1: consecutive MFMAs
+// never share an accumulator), keeps B6D_AHEAD pairs of A fragments in flight, also across chunk boundaries, gives every gap between
+// two MFMAs a few instructions (two LDS reads, one third of a pair's split, one DMA piece), pinned with scheduling barriers, and
+// runs on a THREE-slot ring whose only barrier sits in the MIDDLE of a chunk:
+//     middle of chunk c:  s_waitcnt vmcnt(0)  (the wave's pieces of chunk c + 1, requested during the second half of chunk c - 1)
+//                         s_barrier           (=> chunk c + 1 has landed for everybody; everybody has left chunk c - 1)
+//     second half of c :  one piece of chunk c + 2 per unit, into the slot chunk c - 1 occupied
+// so no wave waits for memory or for LDS behind a barrier; the barrier only costs the skew of four waves doing identical work.
+// =====================================================================================================================
+#ifndef B6D_AHEAD
+#define B6D_AHEAD 4  // pairs of A fragments in flight from LDS (even)
+#endif
+#define B6D_SLOTS 3
+// timing-only decomposition builds (tools/motionbench.py; results are garbage with any of them): B6D_NO_DMA = no pieces after the first two
+// chunks, B6D_NO_BARRIER = no chunk barrier, B6D_NO_LDS = A fragments loaded once per layer, B6D_DMA_BURST = all pieces right behind the barrier
+#ifndef B6D_NO_DMA
+#define B6D_NO_DMA 0
+#endif
+#ifndef B6D_NO_BARRIER
+#define B6D_NO_BARRIER 0
+#endif
+#ifndef B6D_NO_LDS
+#define B6D_NO_LDS 0
+#endif
+#ifndef B6D_DMA_BURST
+#define B6D_DMA_BURST 0
+#endif
+#ifndef B6D_DMA_SADDR
+#define B6D_DMA_SADDR 0  /* 1: the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction) */
+#endif
+struct WeightRing3 {
+  const float* gbase;  // the packed stream (uniform)
+  const float* glane;  // this lane's source of the wave's slice of chunk 0 (+ 512 floats: the middle of a six-piece group, see ring6_issue)
+  float* buf;          // LDS: B6D_SLOTS chunks
+  unsigned lds_wave;   // LDS byte address of the wave's slice of slot 0 (+ 512 floats), wave-uniform (an SGPR)
+  unsigned lane_off;   // byte offset of glane from gbase
+  int next, total;     // chunk being consumed / chunks in the stream
+  int waves;           // waves of the workgroup (compile-time at every call site)
+  int fill, issued;    // chunk being requested (-1: none) and how many of this wave's pieces of it have been issued
+#ifdef DYN_PHASE_TIMING
+  int kid;
+#endif
+};
+// One 1 KiB piece global -> LDS (16 bytes per lane; the LDS side is M0 + offset + 16 lane).  Inline asm: hipcc counts the builtin as an
+// access to both memories ("flat"), and while one is pending every LDS wait becomes lgkmcnt(0) -- which would drain the A-fragment
+// look-ahead at every unit.  The ring waits for its pieces itself (ring3_barrier).
+template <int OFF>
+__device__ __forceinline__ void ring3_dma(const float* g, float* l_emu, unsigned l, const float* g_uniform, unsigned lane_off) {
+#if defined(__AMDGCN__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#if B6D_DMA_SADDR
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
+#else
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(g), "s"(l), "n"(OFF) : "m0", "memory");
+#endif
+#pragma clang diagnostic pop
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l_emu, 16, OFF, 0);
+#endif
+}
+__device__ __forceinline__ int ring3_pieces(const WeightRing3& R) { return B6_CHUNK / (R.waves * 256); }  // 1 KiB pieces per wave and chunk
+// piece k of this wave's slice of `chunk` (the slice is contiguous; six pieces share one address pair through the immediate offset, as in ring6_issue)
+__device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int k) {
+  const int per_wave = B6_CHUNK / R.waves;
+  const int grp = k / 6, i = k % 6;
+  const float* g = R.glane + (long)chunk * B6_CHUNK + grp * 1536;
+  const float* gu = R.gbase + (long)chunk * B6_CHUNK + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
+  const unsigned l = R.lds_wave + (unsigned)(((chunk % B6D_SLOTS) * B6_CHUNK + grp * 1536) * sizeof(float));
+  float* le = R.buf + (chunk % B6D_SLOTS) * B6_CHUNK + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
+  if (i == 0) ring3_dma<-2048>(g, le, l, gu, R.lane_off);
+  if (i == 1) ring3_dma<-1024>(g, le, l, gu, R.lane_off);
+  if (i == 2) ring3_dma<0>(g, le, l, gu, R.lane_off);
+  if (i == 3) ring3_dma<1024>(g, le, l, gu, R.lane_off);
+  if (i == 4) ring3_dma<2048>(g, le, l, gu, R.lane_off);
+  if (i == 5) ring3_dma<3072>(g, le, l, gu, R.lane_off);
+}
+__device__ __forceinline__ void ring3_barrier() {
+#if B6D_NO_BARRIER
+  return;
+#endif
+#if defined(__AMDGCN__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed (LDS reads in flight stay in flight)
+  __builtin_amdgcn_s_barrier();
+#else
+  __syncthreads();
+#endif
+}
+__device__ __forceinline__ void ring3_init(WeightRing3& R, const float* stream, int total, float* lds, int threads) {
+  R.gbase = stream;
+  R.buf = lds;
+  R.next = 0;
+  R.total = total;
+  R.waves = threads / 64;
+  {
+    const int per_wave = B6_CHUNK / R.waves;
+#if defined(__AMDGCN__)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    R.lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + wave * per_wave + 512);
+#else
+    const int wave = threadIdx.x >> 6;
+    R.lds_wave = 0;
+#endif
+    R.glane = stream + wave * per_wave + 512 + (threadIdx.x & 63) * 4;
+    R.lane_off = (unsigned)((wave * per_wave + 512 + (threadIdx.x & 63) * 4) * sizeof(float));
+  }
+  R.fill = -1;
+  R.issued = 0;
+  DYN_PHASE_RING_KID(R, 0);
+  for (int c = 0; c < 2 && c < total; ++c)
+    for (int k = 0; k < ring3_pieces(R); ++k) ring3_piece(R, c, k);
+}
+// first read of chunk R.next: chunk 0 is waited for here, every later chunk was published by the barrier in the middle of its predecessor
+__device__ __forceinline__ void ring3_enter(WeightRing3& R) {
+  if (R.next == 0) ring3_barrier();
+}
+__device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chunk) { return R.buf + (chunk % B6D_SLOTS) * B6_CHUNK; }
+// request pieces of the chunk being filled until `num / den` of them are out
+__device__ __forceinline__ void ring3_feed(WeightRing3& R, int num, int den) {
+  if (R.fill < 0 || B6D_NO_DMA) return;
+  const int want = B6D_DMA_BURST ? ring3_pieces(R) : (ring3_pieces(R) * num + den - 1) / den;
+  for (; R.issued < want; ++R.issued) ring3_piece(R, R.fill, R.issued);
+}
+// the middle of chunk R.next (once per chunk)
+__device__ __forceinline__ void ring3_mid(WeightRing3& R) {
+  DYN_PHASE_T0
+  if (R.next + 1 < R.total) ring3_barrier();
+  DYN_PHASE_WAIT(R, R.next);
+  R.fill = R.next + 2 < R.total ? R.next + 2 : -1;
+  R.issued = 0;
+  if (B6D_DMA_BURST) ring3_feed(R, 1, 1);
+}
+__device__ __forceinline__ void ring3_leave(WeightRing3& R) {
+  ring3_feed(R, 1, 1);
+  R.fill = -1;
+  ++R.next;
+}
+
+__device__ __forceinline__ float relu1(float v) {
+#if defined(__AMDGCN__)
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));  // fmaxf() canonicalises its operand first (a second v_max_f32)
+  return r;
+#else
+  return v > 0.f ? v : 0.f;
+#endif
+}
+
+// One Linear layer, interleaved form.  NT output tiles (NT = 1: plain triples, everything else in front of them), NSLOTS input slots,
+// feed(s) as in mlp_layer_b6 (called exactly once per slot, in slot order).  Units of U = 2 pairs (tiles t, t + 1 of one k-group):
+//   gap 0: A fragments of pair P + AHEAD          M1(t0)
+//   gap 1: A fragments of pair P + AHEAD + 1      M1(t1)
+//   gap 2 .. 5: the unit's share of the next k-group's operand, in thirds of a pair (feed, feed, split); gap 5 also one DMA piece
+//               M2(t0) | M2(t1) | M3(t0) | M3(t1)
+// (The unit loop is a compile-time expansion, dyn_static_for: left to `#pragma unroll`, a 100-unit layer exceeds the unroller's size limit,
+// stays a loop, and the accumulators it then indexes at run time move to scratch memory.)
+template <class F, int... Is>
+__device__ __forceinline__ void dyn_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void dyn_static_for(F&& f) {
+  dyn_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+#define DYN_INLINE_LAMBDA __attribute__((always_inline))
+
+// An MFMA pinned to its place in the instruction stream.  The intrinsic has no side effects, so nothing ties it to the scheduling barriers
+// around it (hipcc moved the products of half a chunk behind the chunk's barrier and issued them as one block); two empty volatile asm
+// statements do: the first redefines the B operand (the MFMA cannot rise above it), the second redefines the result (it cannot sink below),
+// and volatile statements keep their order among themselves and against loads, stores, barriers and the scheduling barriers.
+__device__ __forceinline__ f32x16 mfma_pinned(const u32x4v& a, u32x4v& b, f32x16 c) {
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(b));  // (the B operand: redefined in place, one chain per k-group -- touching the A fragment instead makes hipcc copy it for its second use)
+  f32x16 d = mfma_bf16(a, b, c);
+  asm volatile("" : "+a"(d));
+  return d;
+#else
+  return mfma_bf16(a, b, c);
+#endif
+}
+
+template <int NT, int NSLOTS, int AHEAD = B6D_AHEAD, class Feed>
+__device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[NT], Feed&& feed) {
+  constexpr int NG = (NSLOTS + 7) / 8;
+  constexpr int NP = NG * NT;             // pairs of the layer
+  constexpr int U = NT >= 2 ? 2 : 1;      // pairs per unit
+  constexpr int CP = B6_CHUNK_PAIRS;      // pairs per (full) chunk: a multiple of NT
+  constexpr int QN = AHEAD + U;
+  constexpr int NM = 3 * 4 * U / NT;      // operand micro-steps per unit: 4 pairs of slots per k-group, three steps each (feed, feed, split)
+  static_assert(B6_CHUNK_PAIRS % NT == 0 && (NT == 1 || NT == 2 || NT == 4 || NT == 8), "output tiles per layer");
+  static_assert(AHEAD % 2 == 0 && AHEAD >= 2 && AHEAD <= CP / 2, "the look-ahead must stay inside the published half chunk");
+  const int lane = threadIdx.x & 63;
+  const int c0 = R.next;
+  u32x4v bh, bm, bl, nh, nm, nl;
+  b6_split_pairs<NSLOTS, 0, 4>(feed, 0, bh, bm, bl);
+  nh = bh; nm = bm; nl = bl;
+  float v0 = 0.f, v1 = 0.f;  // the pair of slots being prepared
+  B6A q[QN];
+  auto load = [&](int P) DYN_INLINE_LAMBDA {
+    if (B6D_NO_LDS && P >= AHEAD + U) return q[P % QN];
+    return b6_load_a(ring3_slot(R, c0 + P / CP) + (P % CP) * B6_PAIR_FLOATS, lane);
+  };
+  ring3_enter(R);
+  dyn_static_for<(AHEAD < NP ? AHEAD : NP)>([&](auto I) DYN_INLINE_LAMBDA { q[decltype(I)::value % QN] = load(decltype(I)::value); });
+  __builtin_amdgcn_sched_barrier(0);
+  dyn_static_for<NP / U>([&](auto I) DYN_INLINE_LAMBDA {
+    constexpr int P = decltype(I)::value * U;
+    constexpr int pr = P % CP;                                    // pair inside its chunk
+    constexpr int npc = NP - (P - pr) < CP ? NP - (P - pr) : CP;  // pairs of this chunk
+    constexpr int mid = (npc / 2) / U * U;                        // the chunk's barrier stands in front of this pair
+    constexpr int g = P / NT, t0 = P % NT, t1 = t0 + U - 1;
+    constexpr int um = (P % NT) / U;                              // unit within the k-group
+    if constexpr (pr == mid) ring3_mid(R);
+    // the micro-steps of gap k: thirds of a pair of slots of k-group g + 1
+    auto gap = [&](auto K) DYN_INLINE_LAMBDA {
+      dyn_static_for<NM>([&](auto M) DYN_INLINE_LAMBDA {
+        constexpr int m = decltype(M)::value;
+        constexpr int at = NT == 1 ? 0 : (NM <= 4 ? 2 + m : m * 6 / NM);
+        if constexpr (at == decltype(K)::value && g + 1 < NG) {
+          constexpr int step = um * NM + m, p2 = step / 3, st = step % 3, s0 = (g + 1) * 8 + 2 * p2;
+          if constexpr (st == 0) v0 = s0 < NSLOTS ? feed(s0) : 0.f;
+          if constexpr (st == 1) v1 = s0 + 1 < NSLOTS ? feed(s0 + 1) : 0.f;
+          if constexpr (st == 2) {
+            unsigned h_, m_, l_;
+            split3_pair(v0, v1, h_, m_, l_);
+            nh[p2] = h_; nm[p2] = m_; nl[p2] = l_;
+          }
+        }
+      });
+    };
+    // ---- gap 0
+    if constexpr (P + AHEAD < NP) q[(P + AHEAD) % QN] = load(P + AHEAD);
+    gap(std::integral_constant<int, 0>{});
+    const B6A& a0 = q[P % QN];
+    const B6A& a1 = q[(P + U - 1) % QN];
+#if DYN_SPLIT_TERMS == 6
+    acc[t0] = mfma_pinned(a0.lo, bh, acc[t0]);
+    if constexpr (U == 2) acc[t1] = mfma_pinned(a1.lo, bh, acc[t1]);
+    acc[t0] = mfma_pinned(a0.hi, bl, acc[t0]);
+    if constexpr (U == 2) acc[t1] = mfma_pinned(a1.hi, bl, acc[t1]);
+    acc[t0] = mfma_pinned(a0.mid, bm, acc[t0]);
+    if constexpr (U == 2) acc[t1] = mfma_pinned(a1.mid, bm, acc[t1]);
+#endif
+    acc[t0] = mfma_pinned(a0.mid, bh, acc[t0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (U == 2) {
+      // ---- gap 1
+      if constexpr (P + AHEAD + 1 < NP) q[(P + AHEAD + 1) % QN] = load(P + AHEAD + 1);
+      gap(std::integral_constant<int, 1>{});
+      acc[t1] = mfma_pinned(a1.mid, bh, acc[t1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gap(std::integral_constant<int, 2>{});
+    }
+    acc[t0] = mfma_pinned(a0.hi, bm, acc[t0]);
+    if constexpr (U == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      gap(std::integral_constant<int, 3>{});
+      if constexpr (pr >= mid) ring3_feed(R, pr + 1 - mid, npc - mid);  // the second half of the chunk requests the chunk after next, piece by piece
+      acc[t1] = mfma_pinned(a1.hi, bm, acc[t1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gap(std::integral_constant<int, 4>{});
+    }
+    acc[t0] = mfma_pinned(a0.hi, bh, acc[t0]);
+    if constexpr (U == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      gap(std::integral_constant<int, 5>{});
+      if constexpr (pr >= mid) ring3_feed(R, pr + U - mid, npc - mid);
+      acc[t1] = mfma_pinned(a1.hi, bh, acc[t1]);
+    } else {
+      if constexpr (pr >= mid) ring3_feed(R, pr + U - mid, npc - mid);
+    }
+    if constexpr (t1 == NT - 1) { bh = nh; bm = nm; bl = nl; }
+    if constexpr (pr + U == npc) ring3_leave(R);
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 // The same layer shared out over the waves of a workgroup: all waves stream the chunks of an NT-tile layer, wave w evaluates only

@@ -1874,6 +1874,12 @@ extern "C" int dyn_motion_mlp_pack(const float* const* T, int num_basis, float* 
   return 0;
 }
 
+// sin | cos of an argument beyond the two-constant reduction's reach (|x| > 1e6: never a scene coordinate times a frequency <= 17, but the
+// reference's torch.sin / torch.cos take any float).  By VALUE: the library's sincosf(x, &s, &c) writes through pointers, and with it in the
+// loop the 66-entry embedding lived in scratch memory -- every read of it a scratch load behind `s_waitcnt vmcnt(0)`, which also drained
+// the weight ring's DMA queue (round 4).
+__device__ __attribute__((noinline)) float sin_or_cos_huge(float x, int want_sin) { return want_sin ? sinf(x) : cosf(x); }
+
 __device__ __forceinline__ void motion_embed(const float (&c4)[4], const float* __restrict__ freq, int h, float (&pe)[MO_PE_STEPS]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1882,27 +1888,37 @@ __device__ __forceinline__ void motion_embed(const float (&c4)[4], const float* 
       float sn, cs;
       const float arg = freq[f] * c4[c];
       sincos_small(arg, sn, cs);
-      if (fabsf(arg) > 1.0e6f) sincosf(arg, &sn, &cs);  // beyond the two-constant reduction's reach: the library's full-range path
-      pe[c * 16 + f] = h == 0 ? cs : sn;
+      float v = h == 0 ? cs : sn;
+      if (__builtin_expect(fabsf(arg) > 1.0e6f, 0)) v = sin_or_cos_huge(arg, h);
+      pe[c * 16 + f] = v;
     }
   pe[64] = h == 0 ? c4[0] : c4[1];
   pe[65] = h == 0 ? c4[2] : c4[3];
 }
 
-__device__ __forceinline__ void acc_relu8(f32x16 (&acc)[8]) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-}
+// DYN_MOTION_DUO = 1 (default): the interleaved layer loop on the three-slot ring (dyn_mlp.h, round 4); 0: the round-3 form (A/B builds)
+#ifndef DYN_MOTION_DUO
+#define DYN_MOTION_DUO (DYN_ENGINE_B6 ? 1 : 0)
+#endif
+#if DYN_MOTION_DUO
+typedef WeightRing3 MotionRing;
+#define MOTION_RING_SLOTS B6D_SLOTS
+#define motion_ring_init(R, stream, total, lds) ring3_init(R, stream, total, lds, DYN_NET_THREADS)
+#define motion_layer mlp_layer_b6_duo
+#else
+typedef NetRing MotionRing;
+#define MOTION_RING_SLOTS 2
+#define motion_ring_init(R, stream, total, lds) net_ring_init_t(R, stream, total, lds, DYN_NET_THREADS)
+#define motion_layer net_layer
+#endif
 
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1)
 k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, const float* __restrict__ time, long n_pts, int S, int n_zero_last,
              int n_out, float inv_div, float* __restrict__ coeff) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-  NetRing ring;
-  net_ring_init_t(ring, blob, MO_CHUNKS, lds, DYN_NET_THREADS);
+  MotionRing ring;
+  motion_ring_init(ring, blob, MO_CHUNKS, lds);
   const long point = ((long)blockIdx.x * 4 + wave) * 32 + j;
   const bool valid = point < n_pts;
   float c4[4] = {0.f, 0.f, 0.f, time[0]};
@@ -1913,36 +1929,30 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
   // the embedding feeds layer 0 and the skip layer: evaluated once and kept (one wave per SIMD: 512 registers per lane to spend)
   float pe[MO_PE_STEPS];
   motion_embed(c4, freq, h, pe);
+  // the ReLU of a layer rides in its consumer's feed (two instructions per value in the gaps between MFMAs instead of a 256-instruction
+  // sweep over the accumulators between the layers)
   acc_zero(a);
-  net_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
-  acc_relu8(a);
+  motion_layer<8, MO_PE_STEPS + 1>(ring, a, [&](int s) { return s < MO_PE_STEPS ? pe[s] : one_h0; });
   acc_zero(b);
-  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
-  acc_relu8(b);
+  motion_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? relu1(a[s / 16][s % 16]) : one_h0; });
   acc_zero(a);
-  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
-  acc_relu8(a);
+  motion_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? relu1(b[s / 16][s % 16]) : one_h0; });
   acc_zero(b);
-  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
-  acc_relu8(b);
+  motion_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? relu1(a[s / 16][s % 16]) : one_h0; });
   acc_zero(a);
-  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
-  acc_relu8(a);
+  motion_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? relu1(b[s / 16][s % 16]) : one_h0; });
   acc_zero(b);
-  net_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
+  motion_layer<8, MO_PE_STEPS + 129>(ring, b, [&](int s) {
     if (s < MO_PE_STEPS) return pe[s];
-    return s - MO_PE_STEPS < 128 ? a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16] : one_h0;
+    return s - MO_PE_STEPS < 128 ? relu1(a[(s - MO_PE_STEPS) / 16][(s - MO_PE_STEPS) % 16]) : one_h0;
   });
-  acc_relu8(b);
   acc_zero(a);
-  net_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
-  acc_relu8(a);
+  motion_layer<8, 129>(ring, a, [&](int s) { return s < 128 ? relu1(b[s / 16][s % 16]) : one_h0; });
   acc_zero(b);
-  net_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? a[s / 16][s % 16] : one_h0; });
-  acc_relu8(b);
+  motion_layer<8, 129>(ring, b, [&](int s) { return s < 128 ? relu1(a[s / 16][s % 16]) : one_h0; });
   f32x16 c1[1];
   acc_zero(c1);
-  net_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? b[s / 16][s % 16] : one_h0; });
+  motion_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? relu1(b[s / 16][s % 16]) : one_h0; });
   if (valid) {
     // raw_coeff[:, -n_zero_last:, :] *= 0 (render_ray.py:684): the last samples of every ray carry no motion
     const int smp = (int)(point % S);
@@ -1960,7 +1970,7 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
   DYN_REQUIRE(blob && pts && time && coeff, "dyn_motion_mlp: null pointer");
   DYN_REQUIRE(R > 0 && S > 0 && num_basis >= 1 && 3 * num_basis <= 32 && n_zero_last >= 0 && sf_mag_div != 0.f, "dyn_motion_mlp: bad argument");
   const long n_pts = (long)R * S;
-  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), 2 * NET_CHUNK * sizeof(float),
+  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), MOTION_RING_SLOTS * NET_CHUNK * sizeof(float),
              (hipStream_t)stream, blob, pts, time, n_pts, S, n_zero_last, 3 * num_basis, 1.0f / sf_mag_div, coeff);
   return 0;
 }

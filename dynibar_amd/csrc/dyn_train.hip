@@ -1020,7 +1020,7 @@ extern "C" int dyn_train_gemm(const DynTrainGemmParams* p, void* stream) {
 #define TR_AUTO_SIDE_RING 0
 #endif
     const bool side_fwd = TR_AUTO_SIDE_RING && fast && (p->addend != nullptr || p->rowscale != nullptr);
-    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2 || side_fwd)) || (mode != 1 && p->kscale != nullptr))) {
+    if (ra >= 0 && rb >= 0 && (mode == 2 || (mode == 0 && (ra == 2 || rb == 2 || side_fwd)) || p->kscale != nullptr)) {  // (a scale on the reduction index exists on the ring form only: also under DYNIBAR_TRAIN_GEMM=tile)
       const long units = (long)g.mt * g.nz;
       // the epilogue (EPI of k_train_gemm_ring): the fast forms that are instantiated -- forward shape (both operands k-minor): plain, addend,
       // row scale; data-gradient shape (b k-major): plain, act_y, addend --, else the general form
@@ -2715,6 +2715,7 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(const float* __rest
 extern "C" int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
                                        const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream) {
   DYN_REQUIRE(raw && z_vals && alpha && weights && draw && R > 0 && S > 0, "dyn_train_composite_bwd: bad arguments");
+  DYN_REQUIRE(((size_t)raw | (size_t)draw) % 16 == 0, "dyn_train_composite_bwd: raw / draw must be 16-byte aligned (float4 accesses)");
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite_bwd", k_train_composite_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw,
              z_vals, alpha, weights, drgb, ddepth, dweights, R, S, draw);
   return 0;
@@ -2887,6 +2888,8 @@ extern "C" int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st
                                         const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R,
                                         int S, float* draw_dy, float* draw_st, void* stream) {
   DYN_REQUIRE(raw_dy && raw_st && z_vals && draw_dy && draw_st && R > 0 && S > 0, "dyn_train_composite2_bwd: bad arguments");
+  DYN_REQUIRE(((size_t)raw_dy | (size_t)raw_st | (size_t)draw_dy | (size_t)draw_st) % 16 == 0,
+              "dyn_train_composite2_bwd: raw / draw tensors must be 16-byte aligned (float4 accesses)");
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw_dy,
              raw_st, z_vals, g_rgb, g_rgb_st, g_rgb_dy, g_depth, g_wd, g_ws, g_w, R, S, draw_dy, draw_st);
   return 0;

@@ -80,11 +80,18 @@ class ResNet(object):
     return self.to('cuda' if device is None else device)
 
   def _trains(self):
-    """True when this call must carry an autograd graph into the encoder: grad mode on and a wrapped module with trainable parameters (the
-    reference trains feature_net, train.py:272-281).  Such a call runs the training form (train_encoder.py: saved activations, backward
-    kernels); everything else the forward-only kernels."""
+    """True when this call must carry an autograd graph into the encoder: grad mode on and a source with trainable tensors -- a wrapped module's
+    parameters (the reference trains feature_net, train.py:272-281) or a state dict whose tensors require grad (what
+    train_dist.trainable_parameters and train_encoder.encoder_forward accept).  Such a call runs the training form (train_encoder.py: saved
+    activations, backward kernels); everything else the forward-only kernels."""
+    if not torch.is_grad_enabled():
+      return False
     src = _unwrap(self._source)
-    return torch.is_grad_enabled() and hasattr(src, 'parameters') and any(p.requires_grad for p in src.parameters())
+    if hasattr(src, 'parameters'):
+      return any(p.requires_grad for p in src.parameters())
+    if isinstance(src, dict):
+      return any(torch.is_tensor(v) and v.requires_grad for v in src.values())
+    return False
 
   def _state(self):
     src = _unwrap(self._source)
@@ -93,7 +100,7 @@ class ResNet(object):
     if hasattr(src, 'state_dict'):
       ver = tuple((p.data_ptr(), p._version) for p in src.parameters())
       return src.state_dict(), ver
-    return src, id(src)
+    return src, (id(src),) + tuple((v.data_ptr(), v._version) for v in src.values() if torch.is_tensor(v))
 
   def _encoder(self, device):
     sd, ver = self._state()

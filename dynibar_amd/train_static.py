@@ -127,7 +127,8 @@ class _Lin:
     """dW[:, col0:col0+K] += dZ^T X (split over the rows, atomics); dX (=|+=) dZ W[:, col0:col0+K].  dZ is the GEMMs' scaled operand:
     its largest magnitude comes from the activation-derivative pass that made it (_act_bwd leaves it on the tensor) or is measured here."""
     one_out = (dX is not None and self.n_out == 1 and acc_dx == 0 and dx_off == 0 and self.col0 == 0 and self.K % 4 == 0 and self.K <= 256 and
-               (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0)))
+               (self.K // 4) & (self.K // 4 - 1) == 0 and ld_dx % 4 == 0 and self.W.data_ptr() % 16 == 0 and
+               (act_y is None or (act_y[1] == 0 and act_y[2] % 4 == 0)))
     # one output whose input is the saved activation the data gradient goes back through: the weight gradient is a weighted column sum
     # of the rows that pass already reads (as a GEMM it was a 128-row tile with one useful row)
     fused_w = (one_out and act_y is not None and x_scale is None and self.k_full == self.K and x_off == 0 and act_y[2] == ldx and
@@ -168,7 +169,8 @@ class _Lin:
       # full width: the extra columns are exact zeros landing in dX's padding columns, and the product gets 16-byte result rows (the
       # epilogue's fast form) instead of 4-byte stores
       Nd = self.K
-      if self.K % 4 != 0 and self.Wop is not self.W and acc_dx == 0 and act_y is None and ld_dx >= self.op_ld and ld_dx % 4 == 0 and dx_off % 4 == 0:
+      if (self.K % 4 != 0 and self.Wop is not self.W and acc_dx == 0 and act_y is None and ld_dx % 4 == 0 and dx_off % 4 == 0 and
+          dx_off + self.op_ld <= ld_dx):  # columns [K, op_ld) of the slice must be dX's own padding, never a neighbour's live columns
         Nd = self.op_ld
       if acc_dx == 1 and act_y is None and self.K % 4 == 0 and ld_dx % 4 == 0 and (dX.data_ptr() + 4 * dx_off) % 16 == 0:
         # dX += dZ W as "dX = dZ W + addend" with the addend dX itself: every element is read and written by the one thread that owns it, and the

@@ -1272,6 +1272,24 @@ def run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot):
   return out, raw, grads
 
 
+def add_run_spread(sens, g0, more, tag, factor=4.0):
+  """sens[k] += factor x (per-element max - min of gradient k over the identical steps g0, *more); the largest spread, as a fraction of
+  2e-4 of the tensor's largest gradient, goes into the margin table (informational: the assertion is the caller's assert_close)."""
+  out = dict(sens)
+  worst, worst_k = 0.0, ''
+  for k in sens:
+    if g0.get(k) is None or any(m.get(k) is None for m in more):
+      continue
+    runs = torch.stack([cpu(g0[k]).double().reshape(-1)] + [cpu(m[k]).double().reshape(-1) for m in more])
+    sp = (runs.max(0).values - runs.min(0).values).reshape(sens[k].shape)
+    out[k] = sens[k] + factor * sp
+    scale = float(runs[0].abs().max())
+    if scale > 0 and float(sp.max()) / scale > worst:
+      worst, worst_k = float(sp.max()) / scale, k
+  record_margin(f'{tag} run-to-run spread of three identical steps (largest: {worst_k}), fraction of 2e-4 max|g|', worst, 2e-4)
+  return out
+
+
 def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=False, weights='init', seed=0):
   args = (name, S, R, aa, mask_rgb, weights, seed)
   scene, o, d, sd, v_ref, cot, g_ref, keep = train_static_reference(*args)
@@ -1291,6 +1309,10 @@ def check_train_static(device, name='small', S=16, R=None, aa=True, mask_rgb=Fal
         sens_g[k] = torch.maximum(sens_g[k], 4.0 * (gj[k] - g_ref[k]).abs().double())
   out, raw, g = run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot)
   tag = f'train {name} aa={int(aa)} mask_rgb={int(mask_rgb)}'
+  # (iii) the kernels' own run-to-run spread: weight / bias / feature-map gradients are fp32 atomic sums whose order changes from launch to
+  # launch and from box to box, and a gradient that is a sum of cancelling terms moves by more than its last bits.  Two more identical
+  # steps; 4 x the per-element spread of the three joins the allowance, so that an unlucky order cannot turn a correct kernel red.
+  sens_g = add_run_spread(sens_g, g, [run_train_static(device, scene, o, d, sd, S, aa, mask_rgb, cot)[2] for _ in range(2)], tag)
   assert_close(cpu(raw)[keep][..., :3], v_ref['raw'][keep][..., :3], 1e-4, 0.0, f'{tag} raw rgb', extra=sens_v['raw'][keep][..., :3])
   assert_close(cpu(raw)[keep][..., 3], v_ref['raw'][keep][..., 3], 1e-4, 1e-4, f'{tag} raw sigma', extra=sens_v['raw'][keep][..., 3])
   assert_close(cpu(out['rgb'])[keep], v_ref['rgb'][keep], 1e-4, 0.0, f'{tag} rgb', extra=sens_v['rgb'][keep])
@@ -1783,31 +1805,38 @@ def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5
       sens[k] = sens[k] + 4.0 * (gj[k] - g_ref[k]).abs().double() / 3.0
   scene = di['scene']
   sc = to_dev(scene, device)
-  fm_dy = scene['featmaps'].to(device).requires_grad_(True)
-  fm_st = scene['static_featmaps'].to(device).requires_grad_(True)
-  od, dd, pts, pts_seq, z = (di[k].to(device) for k in ('o', 'd', 'pts', 'pts_seq', 'z'))
-  Rn = od.shape[0]
-  views_dy = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], fm_dy.detach())
-  views_st = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm_st.detach())
   from dynibar_amd import train_motion as TM
-  rf, _, mk, pm_dy = TM.gather(views_dy, fm_dy, Rn, S, xyz=pts_seq, pts_st=pts, pix_mask_thresh=1.0)
-  rfs, rds, mks, pm_st = TM.gather(views_st, fm_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
-  prm_dy = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_dy'].items()}
-  prm_st = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_st'].items()}
-  raw_dy = TD.dynamic_raw(prm_dy, shift, rf, dd, pts, mk, di['temb'].to(device))
-  raw_st = TS.static_raw(prm_st, (True, False), views_st, rfs, od, dd, pts, rds, mks)
-  out = TD.composite_dual(raw_dy, raw_st, z, pm_dy, pm_st)
-  out_dy = TS.composite_vanilla(raw_dy, z, pm_dy)
-  loss = sum((out[k] * cot[k].to(device)).sum() for k in cot if k != 'dy_rgb') + (out_dy['rgb'] * cot['dy_rgb'].to(device)).sum()
-  loss.backward()
+
+  def hip_step():
+    fm_dy = scene['featmaps'].to(device).requires_grad_(True)
+    fm_st = scene['static_featmaps'].to(device).requires_grad_(True)
+    od, dd, pts, pts_seq, z = (di[k].to(device) for k in ('o', 'd', 'pts', 'pts_seq', 'z'))
+    Rn = od.shape[0]
+    views_dy = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], fm_dy.detach())
+    views_st = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], fm_st.detach())
+    rf, _, mk, pm_dy = TM.gather(views_dy, fm_dy, Rn, S, xyz=pts_seq, pts_st=pts, pix_mask_thresh=1.0)
+    rfs, rds, mks, pm_st = TM.gather(views_st, fm_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+    prm_dy = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_dy'].items()}
+    prm_st = {k: v.detach().to(device).requires_grad_(True) for k, v in di['W']['net_coarse_st'].items()}
+    raw_dy = TD.dynamic_raw(prm_dy, shift, rf, dd, pts, mk, di['temb'].to(device))
+    raw_st = TS.static_raw(prm_st, (True, False), views_st, rfs, od, dd, pts, rds, mks)
+    out = TD.composite_dual(raw_dy, raw_st, z, pm_dy, pm_st)
+    out_dy = TS.composite_vanilla(raw_dy, z, pm_dy)
+    loss = sum((out[k] * cot[k].to(device)).sum() for k in cot if k != 'dy_rgb') + (out_dy['rgb'] * cot['dy_rgb'].to(device)).sum()
+    loss.backward()
+    got = {'dy/' + k: v.grad for k, v in prm_dy.items()}
+    got.update({'st/' + k: v.grad for k, v in prm_st.items()})
+    got['featmaps_dy'], got['featmaps_st'] = fm_dy.grad, fm_st.grad
+    return raw_dy, out, got
+
+  raw_dy, out, got = hip_step()
   tag = f'train dual {name}'
   assert_close(cpu(raw_dy)[keep][..., :3], v_ref['raw_dy'][keep][..., :3], 1e-4, 0.0, f'{tag} raw_dy rgb')
   assert_close(cpu(raw_dy)[keep][..., 3], v_ref['raw_dy'][keep][..., 3], 1e-4, 1e-4, f'{tag} raw_dy sigma')
   for k in ('rgb_dy', 'weights_dy'):
     assert_close(cpu(out[k])[keep], v_ref[k][keep], 1e-4, 0.0, f'{tag} {k}')
-  got = {'dy/' + k: v.grad for k, v in prm_dy.items()}
-  got.update({'st/' + k: v.grad for k, v in prm_st.items()})
-  got['featmaps_dy'], got['featmaps_st'] = fm_dy.grad, fm_st.grad
+  # the kernels' own run-to-run spread (fp32 atomic sums in a launch-dependent order) joins the allowance: see check_train_static (iii)
+  sens = add_run_spread(sens, got, [hip_step()[2] for _ in range(2)], tag)
   gmax = max(float(v.abs().max()) for k, v in g_ref.items() if not k.startswith('featmaps'))
   worst = 0.0
   for k, ref in g_ref.items():  # every gradient of BOTH branches, one limit
