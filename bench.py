@@ -223,6 +223,10 @@ def main():
   ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (11 views, full frame)')
   ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc child runs that measure HBM traffic per launch')
   ap.add_argument('--dry-run', action='store_true', help='rehearse the (multi-rank) control flow on CPU ranks over gloo with a stub of the kernel layer; numbers are meaningless')
+  ap.add_argument('--force-dist', action='store_true', help='with ONE rank under torch.distributed.run: initialise the process group (RCCL) anyway and take the '
+                  'multi-rank code path -- per-step pixel all-gather, barrier-bracketed fences, the ray-tiled frame leg -- so that this path runs on a single MI355X')
+  ap.add_argument('--gather', choices=('torch', 'abi'), default=None, help="the frame leg's pixel gather: torch.distributed (default) or the C-ABI's dyn_gather_tiles")
+  ap.add_argument('--frame-only', action='store_true', help='of the extra legs only the full frame (tests)')
   ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
   a = ap.parse_args()
   if a.child:
@@ -242,12 +246,19 @@ def main():
   if not dry:
     torch.cuda.set_device(dev)
   dist = None
-  if world > 1:
+  multi_rank = world > 1 or a.force_dist  # the collective code path is live (also with a process group of one rank under --force-dist)
+  if multi_rank:
     import torch.distributed as dist
+    if 'MASTER_ADDR' not in os.environ:  # --force-dist without torch.distributed.run
+      os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'), RANK='0', WORLD_SIZE='1')
     if dry:
       dist.init_process_group('gloo')
     else:
       dist.init_process_group('nccl', device_id=dev)
+    if a.force_dist:
+      os.environ['DYNIBAR_FORCE_DIST'] = '1'
+  if a.gather:
+    os.environ['DYNIBAR_GATHER'] = a.gather
 
   lib = None
   if not dry:
@@ -257,25 +268,25 @@ def main():
 
   R, S, V = a.rays, a.samples, a.views
   wl = (DryStep if dry else StaticStep)(dev, R, S, V, rank)
-  gathered = torch.empty((world * R, 4), dtype=torch.float32, device=dev) if world > 1 else None
+  gathered = torch.empty((world * R, 4), dtype=torch.float32, device=dev) if multi_rank else None
 
   def pixels(out):
     return torch.cat([out['rgb'], out['depth'][:, None]], dim=1)
 
   def step():
     out = wl.step()
-    if world > 1:
+    if multi_rank:
       dist.all_gather_into_tensor(gathered, pixels(out))
     return out
 
   def fence():
     sync()
-    if world > 1:
+    if multi_rank:
       dist.barrier()
       sync()
 
   def max_over_ranks(x):
-    if world == 1:
+    if not multi_rank:
       return x
     tt = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -283,7 +294,7 @@ def main():
 
   def every_rank(x):
     """x of every rank, in rank order (a list of one on a single GPU)."""
-    if world == 1:
+    if not multi_rank:
       return [float(x)]
     tt = torch.zeros(world, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(tt, torch.tensor([x], dtype=torch.float64, device=dev))
@@ -292,7 +303,7 @@ def main():
   out, dt_own, kernels = timed(lib, step, a.steps, a.warmup, fence)
   dt = max_over_ranks(dt_own)
   multi = None
-  if world > 1:
+  if multi_rank:
     # what the collective alone costs (the same payload, the same stream, nothing to overlap with), and every rank's own clock
     send = pixels(out).contiguous()
     fence()
@@ -333,7 +344,7 @@ def main():
       extra['frame_nvi_288x512'] = {
           'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
                   + ('rays tiled over %d ranks, one packed [rays,5] all-gather: strong scaling' % world if world > 1 else 'one GPU'),
-          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': n_frame_rays / fdt,
+          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': n_frame_rays / fdt, 'gather': render_image.GATHER if multi_rank else None,
           'per_rank': {'tile_rays': [int(v) for v in every_rank(fst.get('tile_rays', 0))],
                        'render_ms': [round(v, 3) for v in every_rank(fst.get('render_ms', 0.0))],
                        'gather_and_copy_ms': [round(v, 3) for v in every_rank(fst.get('gather_ms', 0.0))],
@@ -347,7 +358,7 @@ def main():
       del fc, smp, rb, ret
     except Exception as e:
       extra['frame_nvi_288x512'] = {'error': str(e)[:300]}
-    if world == 1 and not dry:
+    if world == 1 and not dry and not a.frame_only:
       try:
         wl11 = StaticStep(dev, R, S, 11, rank)
         _, dt11, k11 = timed(lib, wl11.step, max(5, a.steps // 2), 2, fence)
@@ -359,7 +370,7 @@ def main():
       except Exception as e:
         extra['views_11'] = {'error': str(e)[:300]}
 
-    if world == 1 and not dry:
+    if world == 1 and not dry and not a.frame_only:
       try:
         # section 8(f)1: the feature encoder on the 18 source images of one Balloon1 target view (7 dynamic + 11 static, eval_nvidia.py:335-358)
         from dynibar_amd import feature_network, synthetic as syn
@@ -471,6 +482,7 @@ def main():
         # activations + backward through the dyn_train_* kernels into DynibarStatic's parameters and the static feature maps
         from dynibar_amd import ops as _ops, synthetic as syn, train_motion as TM, train_static as TS
         Rt, St, Vt = 3072, 64, 15
+        torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()  # peak_mem_gb below is this leg's own peak, not the process's
         sc = syn.make_scene(seed=21, H=H, W=W, V=7, n_static=Vt, smooth=False)
         td = lambda x: torch.from_numpy(x).to(dev)
         fm = td(sc['static_featmaps']).requires_grad_(True)
@@ -535,6 +547,7 @@ def main():
         # section 8(f)3 complete: the reference's whole main-loop iteration (train.py:203-467) at the kid-running training shape:
         # render_rays_mono(is_train=True) under grad mode + backward into the 3 nets, the trajectory basis and the 3 feature-map sets
         from train_case import TrainCase
+        torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()  # (this leg's own peak)
         leg = {}
         for Rt in (3072, 1024):
           tc = TrainCase(dev, R=Rt)
@@ -621,7 +634,7 @@ def main():
         extra['train_full_iteration'] = {'error': str(e)[:300]}
 
   if rank != 0:
-    if world > 1:
+    if multi_rank:
       dist.destroy_process_group()
     return
 
@@ -634,7 +647,7 @@ def main():
                                  'rays_per_step_per_gpu': R, 'samples': S, 'src_views': V},
                       'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': None, 'peak': split_peak(3), 'unit': 'TFLOP/s', 'frac': None, 'traffic': None},
                       'multi_gpu': multi, 'extra': extra}))
-    if world > 1:
+    if multi_rank:
       dist.destroy_process_group()
     return
   terms, kind = int(lib.dyn_mlp_split_terms()), int(lib.dyn_mlp_split_kind())
@@ -732,7 +745,7 @@ def main():
     except Exception as e:  # the extra leg must never cost the main line
       res['bf16x6_engine'] = {'error': str(e)[:200]}
   print(json.dumps(res))
-  if world > 1:
+  if multi_rank:
     dist.destroy_process_group()
 
 

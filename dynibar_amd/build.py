@@ -1,6 +1,6 @@
 """Build libdynibar_hip.so for gfx950 in-tree (dynibar_amd/csrc/).   python -m dynibar_amd.build [--force]
 
-Three translation units: the geometry/compositing kernels are compiled with -ffp-contract=off (bit-exact sample depths,
+Translation units: the geometry/compositing kernels are compiled with -ffp-contract=off (bit-exact sample depths,
 points and indices versus the reference's un-fused fp32 ops), the MFMA network kernels and the feature encoder with default contraction.
 """
 from __future__ import annotations
@@ -18,6 +18,7 @@ UNITS = [
     ('dyn_nets.hip', []),
     ('dyn_encoder.hip', ['-munsafe-fp-atomics']),  # (the training form's col2im adds with hardware fp32 atomics, not CAS loops)
     ('dyn_train.hip', ['-munsafe-fp-atomics']),
+    ('dyn_comm.hip', []),  # the RCCL pixel gather (RCCL itself is resolved at run time: no link dependency)
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -58,7 +59,7 @@ def build(force=False, verbose=True):
       print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
     objs.append(obj)
-  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-ldl', '-o', OUT]
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)
@@ -68,7 +69,7 @@ def build(force=False, verbose=True):
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)
-  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6] + objs[2:] + ['-o', OUT_X6]
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', objs[0], obj6] + objs[2:] + ['-ldl', '-o', OUT_X6]
   subprocess.check_call(cmd)
   if _stamp() == stamp:  # the sources did not change while the compilers ran
     with open(STAMP, 'w') as f:

@@ -513,8 +513,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {  // 
 #endif
 }
 
-__host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS) {
-  return (((NSLOTS + 7) / 8) + (B6_CHUNK_PAIRS / NT) - 1) / (B6_CHUNK_PAIRS / NT);
+__host__ __device__ constexpr int b6_layer_chunks(int NT, int NSLOTS, int CP = B6_CHUNK_PAIRS) {
+  return (((NSLOTS + 7) / 8) + (CP / NT) - 1) / (CP / NT);
 }
 
 // One Linear layer on the B6 engine: NT output tiles, NSLOTS input register slots (one fp32 activation per lane per slot; slot s of
@@ -654,7 +654,7 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
 // runs on a THREE-slot ring whose only barrier sits in the MIDDLE of a chunk:
 //     middle of chunk c:  s_waitcnt vmcnt(0)  (the wave's pieces of chunk c + 1, requested during the second half of chunk c - 1)
 //                         s_barrier           (=> chunk c + 1 has landed for everybody; everybody has left chunk c - 1)
-//     second half of c :  one piece of chunk c + 2 per unit, into the slot chunk c - 1 occupied
+//     from there on    :  the pieces of chunk c + 2, a few per unit, into the slot chunk c - 1 occupied -- until shortly before the next barrier
 // so no wave waits for memory or for LDS behind a barrier; the barrier only costs the skew of four waves doing identical work.
 // =====================================================================================================================
 #ifndef B6D_AHEAD
@@ -675,8 +675,11 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
 #ifndef B6D_DMA_BURST
 #define B6D_DMA_BURST 0
 #endif
+#ifndef B6D_NO_MFMA
+#define B6D_NO_MFMA 0  /* the matrix instructions left out (their operands are still produced and consumed): what everything else costs */
+#endif
 #ifndef B6D_DMA_SADDR
-#define B6D_DMA_SADDR 0  /* 1: the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction) */
+#define B6D_DMA_SADDR 1  /* 1: the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction: -1.5 % of k_motion_mlp) */
 #endif
 struct WeightRing3 {
   const float* gbase;  // the packed stream (uniform)
@@ -686,6 +689,7 @@ struct WeightRing3 {
   unsigned lane_off;   // byte offset of glane from gbase
   int next, total;     // chunk being consumed / chunks in the stream
   int waves;           // waves of the workgroup (compile-time at every call site)
+  int cf;              // floats per chunk: (pairs per chunk) x B6_PAIR_FLOATS -- 48 KiB (24 pairs) by default, 32 KiB for the point kernels' stream
   int fill, issued;    // chunk being requested (-1: none) and how many of this wave's pieces of it have been issued
 #ifdef DYN_PHASE_TIMING
   int kid;
@@ -709,15 +713,15 @@ __device__ __forceinline__ void ring3_dma(const float* g, float* l_emu, unsigned
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l_emu, 16, OFF, 0);
 #endif
 }
-__device__ __forceinline__ int ring3_pieces(const WeightRing3& R) { return B6_CHUNK / (R.waves * 256); }  // 1 KiB pieces per wave and chunk
+__device__ __forceinline__ int ring3_pieces(const WeightRing3& R) { return R.cf / (R.waves * 256); }  // 1 KiB pieces per wave and chunk
 // piece k of this wave's slice of `chunk` (the slice is contiguous; six pieces share one address pair through the immediate offset, as in ring6_issue)
 __device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int k) {
-  const int per_wave = B6_CHUNK / R.waves;
+  const int per_wave = R.cf / R.waves;
   const int grp = k / 6, i = k % 6;
-  const float* g = R.glane + (long)chunk * B6_CHUNK + grp * 1536;
-  const float* gu = R.gbase + (long)chunk * B6_CHUNK + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
-  const unsigned l = R.lds_wave + (unsigned)(((chunk % B6D_SLOTS) * B6_CHUNK + grp * 1536) * sizeof(float));
-  float* le = R.buf + (chunk % B6D_SLOTS) * B6_CHUNK + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
+  const float* g = R.glane + (long)chunk * R.cf + grp * 1536;
+  const float* gu = R.gbase + (long)chunk * R.cf + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
+  const unsigned l = R.lds_wave + (unsigned)(((chunk % B6D_SLOTS) * R.cf + grp * 1536) * sizeof(float));
+  float* le = R.buf + (chunk % B6D_SLOTS) * R.cf + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
   if (i == 0) ring3_dma<-2048>(g, le, l, gu, R.lane_off);
   if (i == 1) ring3_dma<-1024>(g, le, l, gu, R.lane_off);
   if (i == 2) ring3_dma<0>(g, le, l, gu, R.lane_off);
@@ -736,14 +740,15 @@ __device__ __forceinline__ void ring3_barrier() {
   __syncthreads();
 #endif
 }
-__device__ __forceinline__ void ring3_init(WeightRing3& R, const float* stream, int total, float* lds, int threads) {
+__device__ __forceinline__ void ring3_init(WeightRing3& R, const float* stream, int total, float* lds, int threads, int chunk_pairs = B6_CHUNK_PAIRS) {
   R.gbase = stream;
   R.buf = lds;
   R.next = 0;
   R.total = total;
   R.waves = threads / 64;
+  R.cf = chunk_pairs * B6_PAIR_FLOATS;
   {
-    const int per_wave = B6_CHUNK / R.waves;
+    const int per_wave = R.cf / R.waves;
 #if defined(__AMDGCN__)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     R.lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + wave * per_wave + 512);
@@ -764,27 +769,33 @@ __device__ __forceinline__ void ring3_init(WeightRing3& R, const float* stream, 
 __device__ __forceinline__ void ring3_enter(WeightRing3& R) {
   if (R.next == 0) ring3_barrier();
 }
-__device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chunk) { return R.buf + (chunk % B6D_SLOTS) * B6_CHUNK; }
-// request pieces of the chunk being filled until `num / den` of them are out
-__device__ __forceinline__ void ring3_feed(WeightRing3& R, int num, int den) {
+__device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chunk) { return R.buf + (chunk % B6D_SLOTS) * R.cf; }
+// Request pieces of the chunk being filled.  Its window runs from the barrier in the middle of chunk c to B6D_DMA_MARGIN pairs before the barrier
+// in the middle of chunk c + 1 (which waits for them): `half` 0 = the second half of chunk c carries the first half of the pieces, `half` 1 =
+// the first half of chunk c + 1 the rest; num / den = how far through that half the wave is.  A CU's four waves then issue about one piece per
+// 45 cycles -- the rate the L2 -> LDS path takes them at (tools/motionbench.py, `dmaonly`: 48 KiB per 1790 cycles) -- instead of twice that in
+// one half of the time, which backed the queue up and stalled the issuing wave.
+#ifndef B6D_DMA_MARGIN
+#define B6D_DMA_MARGIN 4
+#endif
+__device__ __forceinline__ void ring3_feed(WeightRing3& R, int half, int num, int den) {
   if (R.fill < 0 || B6D_NO_DMA) return;
-  const int want = B6D_DMA_BURST ? ring3_pieces(R) : (ring3_pieces(R) * num + den - 1) / den;
+  const int n = ring3_pieces(R), h0 = n / 2;
+  int want = half == 0 ? (h0 * num + den - 1) / den : h0 + ((n - h0) * num + den - 1) / den;
+  if (B6D_DMA_BURST || want > n) want = n;
   for (; R.issued < want; ++R.issued) ring3_piece(R, R.fill, R.issued);
 }
 // the middle of chunk R.next (once per chunk)
 __device__ __forceinline__ void ring3_mid(WeightRing3& R) {
   DYN_PHASE_T0
+  ring3_feed(R, 1, 1, 1);  // (whatever is left of chunk R.next + 1: normally nothing)
   if (R.next + 1 < R.total) ring3_barrier();
   DYN_PHASE_WAIT(R, R.next);
   R.fill = R.next + 2 < R.total ? R.next + 2 : -1;
   R.issued = 0;
-  if (B6D_DMA_BURST) ring3_feed(R, 1, 1);
+  if (B6D_DMA_BURST) ring3_feed(R, 1, 1, 1);
 }
-__device__ __forceinline__ void ring3_leave(WeightRing3& R) {
-  ring3_feed(R, 1, 1);
-  R.fill = -1;
-  ++R.next;
-}
+__device__ __forceinline__ void ring3_leave(WeightRing3& R) { ++R.next; }
 
 __device__ __forceinline__ float relu1(float v) {
 #if defined(__AMDGCN__)
@@ -821,7 +832,12 @@ __device__ __forceinline__ void dyn_static_for(F&& f) {
 __device__ __forceinline__ f32x16 mfma_pinned(const u32x4v& a, u32x4v& b, f32x16 c) {
 #if defined(__AMDGCN__)
   asm volatile("" : "+v"(b));  // (the B operand: redefined in place, one chain per k-group -- touching the A fragment instead makes hipcc copy it for its second use)
+#if B6D_NO_MFMA
+  asm volatile("" ::"v"(a));
+  f32x16 d = c;
+#else
   f32x16 d = mfma_bf16(a, b, c);
+#endif
   asm volatile("" : "+a"(d));
   return d;
 #else
@@ -829,15 +845,14 @@ __device__ __forceinline__ f32x16 mfma_pinned(const u32x4v& a, u32x4v& b, f32x16
 #endif
 }
 
-template <int NT, int NSLOTS, int AHEAD = B6D_AHEAD, class Feed>
+template <int NT, int NSLOTS, int CP = B6_CHUNK_PAIRS, int AHEAD = B6D_AHEAD, class Feed>
 __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[NT], Feed&& feed) {
   constexpr int NG = (NSLOTS + 7) / 8;
   constexpr int NP = NG * NT;             // pairs of the layer
   constexpr int U = NT >= 2 ? 2 : 1;      // pairs per unit
-  constexpr int CP = B6_CHUNK_PAIRS;      // pairs per (full) chunk: a multiple of NT
   constexpr int QN = AHEAD + U;
   constexpr int NM = 3 * 4 * U / NT;      // operand micro-steps per unit: 4 pairs of slots per k-group, three steps each (feed, feed, split)
-  static_assert(B6_CHUNK_PAIRS % NT == 0 && (NT == 1 || NT == 2 || NT == 4 || NT == 8), "output tiles per layer");
+  static_assert(CP % NT == 0 && (NT == 1 || NT == 2 || NT == 4 || NT == 8), "output tiles per layer; pairs per chunk (CP) a multiple of them");
   static_assert(AHEAD % 2 == 0 && AHEAD >= 2 && AHEAD <= CP / 2, "the look-ahead must stay inside the published half chunk");
   const int lane = threadIdx.x & 63;
   const int c0 = R.next;
@@ -878,6 +893,14 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
         }
       });
     };
+    // the weight stream: this unit's share of the pieces of the chunk being filled (see ring3_feed), after `done` of the unit's U pairs
+    auto dma = [&](auto D) DYN_INLINE_LAMBDA {
+      constexpr int done = decltype(D)::value;
+      constexpr int wend = mid - B6D_DMA_MARGIN;  // (first half of the chunk: the window closes here)
+      if constexpr (pr >= mid) ring3_feed(R, 0, pr + done - mid, npc - mid);
+      else if constexpr (wend <= 0) ring3_feed(R, 1, 1, 1);
+      else ring3_feed(R, 1, pr + done < wend ? pr + done : wend, wend);
+    };
     // ---- gap 0
     if constexpr (P + AHEAD < NP) q[(P + AHEAD) % QN] = load(P + AHEAD);
     gap(std::integral_constant<int, 0>{});
@@ -905,7 +928,7 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
     if constexpr (U == 2) {
       __builtin_amdgcn_sched_barrier(0);
       gap(std::integral_constant<int, 3>{});
-      if constexpr (pr >= mid) ring3_feed(R, pr + 1 - mid, npc - mid);  // the second half of the chunk requests the chunk after next, piece by piece
+      dma(std::integral_constant<int, 1>{});
       acc[t1] = mfma_pinned(a1.hi, bm, acc[t1]);
       __builtin_amdgcn_sched_barrier(0);
       gap(std::integral_constant<int, 4>{});
@@ -914,10 +937,10 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
     if constexpr (U == 2) {
       __builtin_amdgcn_sched_barrier(0);
       gap(std::integral_constant<int, 5>{});
-      if constexpr (pr >= mid) ring3_feed(R, pr + U - mid, npc - mid);
+      dma(std::integral_constant<int, U>{});
       acc[t1] = mfma_pinned(a1.hi, bh, acc[t1]);
     } else {
-      if constexpr (pr >= mid) ring3_feed(R, pr + U - mid, npc - mid);
+      dma(std::integral_constant<int, U>{});
     }
     if constexpr (t1 == NT - 1) { bh = nh; bm = nm; bl = nl; }
     if constexpr (pr + U == npc) ring3_leave(R);

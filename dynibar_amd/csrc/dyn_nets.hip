@@ -44,10 +44,12 @@ void pack_layer(std::vector<float>& out, int NT, int NSTEPS, const SlotFn& fn) {
 }
 
 // B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
+int g_pack_chunk_pairs = B6_CHUNK_PAIRS;  // pairs per chunk of the stream being packed (the point kernels' streams use PTS_CP)
 void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
-  const int NG = (NSLOTS + 7) / 8, GPC = B6_CHUNK_PAIRS / NT, NCH = (NG + GPC - 1) / GPC;
+  const int CPAIRS = g_pack_chunk_pairs, CFLOATS = CPAIRS * B6_PAIR_FLOATS;
+  const int NG = (NSLOTS + 7) / 8, GPC = CPAIRS / NT, NCH = (NG + GPC - 1) / GPC;
   const size_t base = out.size();
-  out.resize(base + (size_t)NCH * B6_CHUNK, 0.f);
+  out.resize(base + (size_t)NCH * CFLOATS, 0.f);
   unsigned short* img = reinterpret_cast<unsigned short*>(out.data() + base);
   for (int c = 0; c < NCH; ++c)
     for (int gi = 0; gi < GPC; ++gi) {
@@ -61,7 +63,7 @@ void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn
             const float w = fn(t, lane & 31, s, lane >> 5);
             unsigned short hi, mid, lo;
             split_weight(w, hi, mid, lo);
-            const size_t pair = (size_t)c * B6_CHUNK * 2 + (size_t)(gi * NT + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
+            const size_t pair = (size_t)c * CFLOATS * 2 + (size_t)(gi * NT + t) * B6_PAIR_FLOATS * 2;  // in 16-bit units
             img[pair + 0 * 512 + lane * 8 + e] = hi;
             img[pair + 1 * 512 + lane * 8 + e] = mid;
             if (DYN_SPLIT_PARTS == 3) img[pair + 2 * 512 + lane * 8 + e] = lo;
@@ -134,7 +136,29 @@ enum {
 #define SA_L5_STEPS 64   /* vis_fc.0 / vis_fc.2 / vis_fc2.0 */
 constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3P_STEPS) + net_layer_chunks(8, SA_L3V_STEPS) +
                           net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
-constexpr int SB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + 2 * net_layer_chunks(4, 65);
+// The point kernels (k_net_points) run one wave per SIMD on the interleaved layer loop with the three-slot ring (dyn_mlp.h, round 4).  Their LDS also
+// holds the ray attention's K / V images (32.5 KiB), so their weight streams are packed in chunks of PTS_CP = 16 pairs (32 KiB; 3 slots = 96 KiB,
+// what the two 48 KiB slots took).  DYN_POINTS_DUO = 0: the round-3 form (A/B builds; the 6-term bf16 build keeps it: its pairs are 3 KiB).
+#ifndef DYN_POINTS_DUO
+#define DYN_POINTS_DUO (DYN_ENGINE_B6 && DYN_SPLIT_TERMS == 3 ? 1 : 0)
+#endif
+#if DYN_POINTS_DUO
+#define PTS_CP 16
+#define PTS_CHUNK (PTS_CP * B6_PAIR_FLOATS)
+#define PTS_RING_SLOTS B6D_SLOTS
+__host__ __device__ constexpr int pts_layer_chunks(int NT, int NSLOTS) { return b6_layer_chunks(NT, NSLOTS, PTS_CP); }
+typedef WeightRing3 PtsRing;
+#define pts_ring_init(R, stream, total, lds) ring3_init(R, stream, total, lds, DYN_NET_THREADS, PTS_CP)
+#define PTS_LAYER(NT, NSLOTS) mlp_layer_b6_duo<NT, NSLOTS, PTS_CP>
+#else
+#define PTS_CHUNK NET_CHUNK
+#define PTS_RING_SLOTS 2
+__host__ __device__ constexpr int pts_layer_chunks(int NT, int NSLOTS) { return net_layer_chunks(NT, NSLOTS); }
+typedef NetRing PtsRing;
+#define pts_ring_init(R, stream, total, lds) net_ring_init_t(R, stream, total, lds, DYN_NET_THREADS)
+#define PTS_LAYER(NT, NSLOTS) net_layer<NT, NSLOTS>
+#endif
+constexpr int SB_CHUNKS = pts_layer_chunks(8, 129) + pts_layer_chunks(4, 129) + 4 * pts_layer_chunks(4, 64) + 2 * pts_layer_chunks(4, 65);
 #define SC_L11_STEPS 67
 constexpr int SC_CHUNKS = net_layer_chunks(4, SC_L11_STEPS) + net_layer_chunks(2, 64);
 // constant tables (floats): A: vis row [2][64] @0, vis_fc2.2 row [2][64] @128, b_vis @256, b_vis2 @257, |s| @258
@@ -145,7 +169,7 @@ constexpr int SC_CHUNKS = net_layer_chunks(4, SC_L11_STEPS) + net_layer_chunks(2
 #define SC_CT 144   /* + bias table of rgb_fc.2 @80 (64) */
 constexpr size_t ST_OFF_A = 0;
 constexpr size_t ST_OFF_B = ST_OFF_A + (size_t)SA_CHUNKS * NET_CHUNK;
-constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * NET_CHUNK;
+constexpr size_t ST_OFF_C = ST_OFF_B + (size_t)SB_CHUNKS * PTS_CHUNK;
 constexpr size_t ST_OFF_CTA = ST_OFF_C + (size_t)SC_CHUNKS * NET_CHUNK;
 constexpr size_t ST_OFF_CTB = ST_OFF_CTA + SA_CT;
 constexpr size_t ST_OFF_CTC = ST_OFF_CTB + SB_CT;
@@ -166,13 +190,13 @@ enum {
 #define DA_L3P_STEPS (2 * DA_NX)
 #define DA_L3V_STEPS (DA_NX + 1)
 constexpr int DA_CHUNKS = net_layer_chunks(8, DA_L3P_STEPS) + net_layer_chunks(8, DA_L3V_STEPS) + net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
-constexpr int DB_CHUNKS = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 4 * net_layer_chunks(4, 64) + net_layer_chunks(8, 81) +
-                          net_layer_chunks(4, 129) + net_layer_chunks(4, 65) + net_layer_chunks(4, 78) + net_layer_chunks(2, 65);
+constexpr int DB_CHUNKS = pts_layer_chunks(8, 129) + pts_layer_chunks(4, 129) + 4 * pts_layer_chunks(4, 64) + pts_layer_chunks(8, 81) +
+                          pts_layer_chunks(4, 129) + pts_layer_chunks(4, 65) + pts_layer_chunks(4, 78) + pts_layer_chunks(2, 65);
 // B table: ln gamma @0, ln beta @128, out_geometry_fc.2 row @256, its bias @384, rgb_fc.4 biases @385..387, rgb_fc.4 rows [3][2][32] @400
 #define DB_CT 592
 constexpr size_t DY_OFF_A = 0;
 constexpr size_t DY_OFF_B = DY_OFF_A + (size_t)DA_CHUNKS * NET_CHUNK;
-constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * NET_CHUNK;
+constexpr size_t DY_OFF_CTA = DY_OFF_B + (size_t)DB_CHUNKS * PTS_CHUNK;
 constexpr size_t DY_OFF_CTB = DY_OFF_CTA + SA_CT;
 constexpr size_t DY_OFF_POSENC = DY_OFF_CTB + DB_CT;                 // [256 positions][2][64]
 constexpr size_t DY_OFF_TIME = DY_OFF_POSENC + 256 * 128;            // ray_dir_fc: W0 [256,21], b0 [256], W2 [35,256], b2 [35]
@@ -242,6 +266,9 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[ST_VISB0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == ST_OFF_B, "static pack: A stream size mismatch");
   // ---- B ----
+#if DYN_POINTS_DUO
+  g_pack_chunk_pairs = PTS_CP;
+#endif
   {
     const float *W = T[ST_GEO0_W], *b = T[ST_GEO0_B];
     pack_net_layer(o, 8, 129, scaled([=](int t, int i, int s, int h) -> float {
@@ -257,6 +284,7 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   pack_net_layer(o, 4, 64, chained(T[ST_FC], nullptr, 128, 128, 128));
   pack_net_layer(o, 4, 65, scaled(chained(T[ST_OG0_W], T[ST_OG0_B], 128, 128, 128), DYN_ELU_PRE));
   pack_net_layer(o, 4, 65, scaled(chained(T[ST_RGB0_W], T[ST_RGB0_B], 128, 128, 261), DYN_ELU_PRE));  // columns 0..127 = globalfeat part
+  g_pack_chunk_pairs = B6_CHUNK_PAIRS;
   DYN_REQUIRE(o.size() == ST_OFF_C, "static pack: B stream size mismatch");
   // ---- C ----
   {
@@ -1008,24 +1036,24 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 // PHASE 0: the whole chain in one launch (rays of <= 128 samples: a ray's tiles sit in one workgroup and K / V never leave the chip).
 // Longer rays run it in two launches: PHASE 1 ends after the Q/K/V projections and stores g, q, k, v per tile; PHASE 2 picks them up,
 // streams the ray's keys through LDS in blocks of 128 with a running softmax, and finishes the chain.
-constexpr int SB_CHUNKS_QKV = net_layer_chunks(8, 129) + net_layer_chunks(4, 129) + 3 * net_layer_chunks(4, 64);
+constexpr int SB_CHUNKS_QKV = pts_layer_chunks(8, 129) + pts_layer_chunks(4, 129) + 3 * pts_layer_chunks(4, 64);
 template <bool DYN, int PHASE>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
   constexpr int PHASE_KID = 1;
   (void)PHASE_KID;
   DYN_PHASE(0);
   float* lds = reinterpret_cast<float*>(dyn_smem);
-  float* ctab = lds + 2 * NET_CHUNK;  // [SB_CT] / [DB_CT]
+  float* ctab = lds + PTS_RING_SLOTS * PTS_CHUNK;  // [SB_CT] / [DB_CT]
   float* Kl = ctab + (DYN ? DB_CT : SB_CT);
   float* Vl = Kl + SB_KL_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   constexpr int CT = DYN ? DB_CT : SB_CT;
   for (int i = tid; i < CT; i += DYN_NET_THREADS) ctab[i] = p.blob[(DYN ? DY_OFF_CTB : ST_OFF_CTB) + i];
-  NetRing ring;
+  PtsRing ring;
   if (PHASE == 2)
-    net_ring_init_t(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * NET_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds, DYN_NET_THREADS);
+    pts_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B) + (size_t)SB_CHUNKS_QKV * PTS_CHUNK, (DYN ? DB_CHUNKS : SB_CHUNKS) - SB_CHUNKS_QKV, lds);
   else
-    net_ring_init_t(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds, DYN_NET_THREADS);
+    pts_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds);
   DYN_PHASE_RING_KID(ring, 1);
 
   const int TPR = p.TPR;
@@ -1064,10 +1092,10 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       }
       gin[128] = valid ? src[32 * 64].x : (h == 1 ? 1.0f : 0.f);
       acc_zero(a9);
-      net_layer<8, 129>(ring, a9, [&](int s) { return gin[s]; });
+      PTS_LAYER(8, 129)(ring, a9, [&](int s) { return gin[s]; });
     }
     acc_zero(g);
-    net_layer<4, 129>(ring, g, [&](int s) { return s < 128 ? elu_s(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
+    PTS_LAYER(4, 129)(ring, g, [&](int s) { return s < 128 ? elu_s(a9[s / 16][s % 16]) : one_h0; });  // ELUs ride in the consumer's feed
     acc_elu(g);
   }
   if (DYN && PHASE != 2) {
@@ -1176,9 +1204,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   } else {
     f32x16 qh[4], kh[4], vh[4];
     acc_zero(qh); acc_zero(kh); acc_zero(vh);
-    net_layer<4, 64>(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
-    net_layer<4, 64>(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
-    net_layer<4, 64>(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
+    PTS_LAYER(4, 64)(ring, qh, [&](int s) { return g[s / 16][s % 16]; });
+    PTS_LAYER(4, 64)(ring, kh, [&](int s) { return g[s / 16][s % 16]; });
+    PTS_LAYER(4, 64)(ring, vh, [&](int s) { return g[s / 16][s % 16]; });
     if (PHASE == 1) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -1370,7 +1398,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     f32x16 o[4];
     acc_zero(o);
     DYN_PHASE(3);  // attention heads done
-    net_layer<4, 64>(ring, o, [&](int s) { return att[s / 16][s % 16]; });
+    PTS_LAYER(4, 64)(ring, o, [&](int s) { return att[s / 16][s % 16]; });
     // residual + LayerNorm(eps = 1e-6) over the 128 features (64 here, 64 in the other half's lane)
     float s1 = 0.f;
 #pragma unroll
@@ -1403,13 +1431,13 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   if (!DYN) {
     f32x16 a[4];
     acc_zero(a);
-    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    PTS_LAYER(4, 65)(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
     acc_elu_s(a);
     float sigma = row_dot<4>(a, ctab + 256) + ctab[384];
     if (nvalid < 1.0f) sigma = -1e9f;
     if (valid && h == 0) p.raw[point * 4 + 3] = sigma;
     acc_zero(a);
-    net_layer<4, 65>(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
+    PTS_LAYER(4, 65)(ring, a, [&](int s) { return s < 64 ? g[s / 16][s % 16] : one_h0; });
     if (valid) {
       float4* dst = reinterpret_cast<float4*>(p.ws + p.o.off_hg) + tile * SB_HG_RECS * 64 + lane;
 #pragma unroll
@@ -1430,13 +1458,13 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       pe[16] = h == 0 ? c3[2] : 1.0f;
       f32x16 a8[8];
       acc_zero(a8);
-      net_layer<8, 81>(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
+      PTS_LAYER(8, 81)(ring, a8, [&](int s) { return s < 64 ? g[s / 16][s % 16] : pe[s - 64]; });
       acc_zero(g2);
-      net_layer<4, 129>(ring, g2, [&](int s) { return s < 128 ? elu_s(a8[s / 16][s % 16]) : one_h0; });
+      PTS_LAYER(4, 129)(ring, g2, [&](int s) { return s < 128 ? elu_s(a8[s / 16][s % 16]) : one_h0; });
     }
     f32x16 a[4];
     acc_zero(a);
-    net_layer<4, 65>(ring, a, [&](int s) {
+    PTS_LAYER(4, 65)(ring, a, [&](int s) {
       if (s >= 64) return one_h0;
       const float r = elu1(g2[s / 16][s % 16]);  // g2 = ELU(out_geometry_fc.2) is kept: rgb_fc reads it again
       g2[s / 16][s % 16] = r;
@@ -1456,10 +1484,10 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       pd[13] = h == 0 ? d3[2] : 1.0f;
     }
     acc_zero(a);
-    net_layer<4, 78>(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
+    PTS_LAYER(4, 78)(ring, a, [&](int s) { return s < 64 ? g2[s / 16][s % 16] : pd[s - 64]; });
     f32x16 b2[2];
     acc_zero(b2);
-    net_layer<2, 65>(ring, b2, [&](int s) { return s < 64 ? elu_s(a[s / 16][s % 16]) : one_h0; });
+    PTS_LAYER(2, 65)(ring, b2, [&](int s) { return s < 64 ? elu_s(a[s / 16][s % 16]) : one_h0; });
     acc_elu_s(b2);
     float rgb[3];
 #pragma unroll
@@ -1576,7 +1604,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
-  const size_t lds_b = (2 * NET_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  const size_t lds_b = (PTS_RING_SLOTS * PTS_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (NET_CHUNK + SC_CT) * sizeof(float);
   const dim3 grid_c(dyn_cdiv(a.n_tiles_a, DYN_BLEND_THREADS / 64)), blk_c(DYN_BLEND_THREADS);
   if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
@@ -1629,6 +1657,9 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
   pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[DT_VIS2_W], nullptr, 128, 128, 128), DYN_ELU_POST));
   pack_net_layer(o, 4, SA_L5_STEPS, scaled(chained(T[DT_VISB0_W], nullptr, 128, 128, 128), DYN_ELU_PRE));
   DYN_REQUIRE(o.size() == DY_OFF_B, "dynamic pack: A stream size mismatch");
+#if DYN_POINTS_DUO
+  g_pack_chunk_pairs = PTS_CP;
+#endif
   {
     const float *W = T[DT_GEO0_W], *b = T[DT_GEO0_B];
     pack_net_layer(o, 8, 129, scaled([=](int t, int i, int s, int h) -> float {
@@ -1665,6 +1696,7 @@ extern "C" int dyn_dynamic_net_pack(const float* const* T, int F, float* blob, s
     }, DYN_ELU_PRE));
   }
   pack_net_layer(o, 2, 65, scaled_wb(chained(T[DT_RGB2_W], T[DT_RGB2_B], 64, 128, 128), 64, DYN_ELU_POST * DYN_ELU_PRE, DYN_ELU_PRE));
+  g_pack_chunk_pairs = B6_CHUNK_PAIRS;
   DYN_REQUIRE(o.size() == DY_OFF_CTA, "dynamic pack: B stream size mismatch");
   pack_rowtab(o, T[DT_VIS2_W] + 128 * 128, 128, DYN_ELU_POST);
   pack_rowtab(o, T[DT_VISB2_W], 128, DYN_ELU_POST);
@@ -1798,7 +1830,7 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
              q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
-  const size_t lds_b = (2 * NET_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
+  const size_t lds_b = (PTS_RING_SLOTS * PTS_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   if (a.o.dense) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
   else if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);

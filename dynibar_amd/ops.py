@@ -280,6 +280,25 @@ def _infer_F(state_dict, key='ray_dir_fc.2.weight'):
   return int(w.shape[0]) - 3
 
 
+_CROSS_WARNED = []
+
+
+def check_cross_axis_quirk(R, S, V):
+  """The reference forms the Pluecker moments with ``torch.cross`` WITHOUT ``dim`` (render_ray.py:375, :392), which crosses over the FIRST axis of
+  size 3: with exactly 3 source views or 3 samples per ray -- or, for a chunk of exactly 3 rays, over the rays -- it does not cross over xyz.  The
+  kernels (and the oracle) always cross over xyz.  No shipped configuration has 3 views or 3 samples, so those shapes are refused instead of silently
+  rendering something the reference would not; a 3-ray chunk can occur as the tail of a frame (H x W mod chunk_size == 3): it is rendered with the
+  intended cross product and a one-time warning says so."""
+  if S == 3 or V == 3:
+    raise ValueError(f'DynibarStatic with S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the '
+                     'first axis of size 3 for this shape, which the kernels do not reproduce (no shipped configuration uses it)')
+  if R == 3 and not _CROSS_WARNED:
+    import warnings
+    _CROSS_WARNED.append(1)
+    warnings.warn('a chunk of exactly 3 rays: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the RAY axis here; '
+                  'dynibar_amd renders the intended xyz cross product', RuntimeWarning, stacklevel=3)
+
+
 class StaticNet:
   """DynibarStatic (mlp_network.py:319-527) as packed MFMA operand tiles on one device.  ``state_dict``: the module's
   state dict (torch tensors or numpy arrays; a DataParallel 'module.' prefix is accepted)."""
@@ -308,6 +327,7 @@ class StaticNet:
     """-> raw [R,S,4]  (k_static_ref_feat, k_static_views, k_static_points, k_static_blend)."""
     k = _Keep()
     R, S, V = rgb_feat.shape[:3]
+    check_cross_axis_quirk(R, S, V)
     dev = rgb_feat.device
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     ws, need = self.workspace(R, S, V, dev)

@@ -32,6 +32,10 @@ _PER_VIEW_KEYS = ('camera', 'anchor_camera', 'render_camera', 'depth_range', 'sr
 FRAME_OUTPUTS = 'lazy'       # 'lazy' | 'all'
 TILE_ACROSS_RANKS = True     # False: every rank renders the whole frame by itself (no collective), e.g. when only one rank calls in
 _EAGER_KEYS = ('rgb', 'depth', 'mask')
+GATHER = os.environ.get('DYNIBAR_GATHER', 'torch')  # the frame's pixel all-gather: 'torch' = torch.distributed.all_gather_into_tensor (RCCL through
+                             # PyTorch's process group), 'abi' = the C-ABI's dyn_gather_tiles on a communicator of this package's own (what a
+                             # host without PyTorch calls; include/dynibar_hip.h)
+FORCE_DIST = os.environ.get('DYNIBAR_FORCE_DIST', '0') == '1'  # take the multi-rank code path (tiles, collective) with a process group of ONE rank too
 FRAME_STATS = None           # bench.py sets this to a dict for ONE frame: per-stage clocks (tile_rays, render_ms, gather_ms, gather_bytes); the device is
                              # synchronised between the stages while it is set, never otherwise
 
@@ -45,9 +49,34 @@ def _clock():
 
 def _dist():
   import torch.distributed as dist
-  if TILE_ACROSS_RANKS and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+  if TILE_ACROSS_RANKS and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_DIST):
     return dist, dist.get_world_size(), dist.get_rank()
   return None, 1, 0
+
+
+_ABI_COMMS = {}
+
+
+def abi_communicator(dist, world, rank, device):
+  """ncclComm_t (a ctypes.c_void_p) of this package's own for dyn_gather_tiles on `device`: rank 0 draws the 128-byte id (dyn_comm_unique_id),
+  torch.distributed carries it to the other ranks, every rank joins (dyn_comm_init_rank).  One per (world, rank, device), kept for the process."""
+  import ctypes
+  from ._lib import call
+  key = (world, rank, device.index)
+  if key not in _ABI_COMMS:
+    idbuf = (ctypes.c_char * 128)()
+    if rank == 0:
+      call('dyn_comm_unique_id', idbuf)
+    if world > 1:
+      on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
+      t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=on)
+      dist.broadcast(t, 0)
+      idbuf = (ctypes.c_char * 128)(*bytes(t.cpu().tolist()))
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(device):
+      call('dyn_comm_init_rank', ctypes.byref(comm), world, idbuf, rank)
+    _ABI_COMMS[key] = comm
+  return _ABI_COMMS[key]
 
 
 def ray_tile(n_rays, world, rank):
@@ -109,13 +138,17 @@ def gather_rows(local, n_rays, dist, world, rank, count=None):
     widths.append(rows.shape[1])
   n_local = packed[0].shape[0] if count is None else count
   buf = packed[0] if len(packed) == 1 else torch.cat(packed, dim=1)
-  if world > 1:
+  if dist is not None:
     lo, hi, tile = ray_tile(n_rays, world, rank)
     assert hi - lo == n_local, 'a rank renders exactly its own tile'
     send = torch.zeros((tile, buf.shape[1]), dtype=torch.float32, device=buf.device)
     send[:n_local] = buf[:n_local]
     recv = torch.empty((world * tile, buf.shape[1]), dtype=torch.float32, device=buf.device)
-    dist.all_gather_into_tensor(recv, send)
+    if GATHER == 'abi' and buf.is_cuda:
+      from ._lib import call, ptr, stream_of
+      call('dyn_gather_tiles', ptr(send), ptr(recv), tile, buf.shape[1], abi_communicator(dist, world, rank, buf.device), stream_of(send))
+    else:
+      dist.all_gather_into_tensor(recv, send)
     spans = [ray_tile(n_rays, world, r) for r in range(world)]
     if all(h - l == tile for l, h, _ in spans):
       buf = recv

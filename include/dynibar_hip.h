@@ -490,6 +490,22 @@ int dyn_render_flows_bwd(const float* dflows, const float* weights, const float*
 int dyn_gather_bwd_pts(const float* pts_st, const float* xyz, const float* proj, const float* src_rgb, const float* feat_cl, int R, int S, int V,
                        int H, int W, int Hf, int Wf, int F, float img_h, float img_w, const float* drgb_feat, long ld_d, float* dxyz, void* stream);
 
+/* ====== multi-GPU pixel gather (the counterpart of nn.DataParallel's gather of the rendered outputs, reference
+ * ibrnet/model.py:134-159, around the chunk loop of render_image.py:60-217) ============================================================
+ * Rays shard across ranks as contiguous tiles with no data-path collective; the one exchange of a frame is an all-gather of every rank's
+ * packed [rows_per_rank, cols] fp32 pixel rows (rgb, depth, mask ...) over RCCL / xGMI.  `comm` is an ncclComm_t: the caller's own, or one made
+ * by dyn_comm_init_rank.  RCCL is taken from the process image at run time (a PyTorch host has loaded its own librccl; a communicator is
+ * only valid in the library instance that made it), else from librccl.so / $DYNIBAR_RCCL_LIB; without it these calls return DYN_E_INVALID. */
+int dyn_comm_available(void);
+/* id128: HOST buffer of 128 bytes (ncclUniqueId).  Rank 0 makes it, the host's own channel hands it to every rank. */
+int dyn_comm_unique_id(void* id128);
+int dyn_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int dyn_comm_size_rank(void* comm, int* nranks, int* rank);
+int dyn_comm_destroy(void* comm);
+/* recv [nranks, rows_per_rank, cols] <- send [rows_per_rank, cols] of every rank, in rank order, on `stream` (one equal-count ncclAllGather;
+ * tiles are padded to the common size by the caller: balanced tiles differ by at most one ray). */
+int dyn_gather_tiles(const float* send, float* recv, long rows_per_rank, int cols, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ cancellation) the allowance added is MEASURED on the oracle per element (project
 a blanket factor.  Every check records the fraction of its limit it used (MARGINS, printed by tests/conftest.py)."""
 import math
 import os
+import sys
 
 import numpy as np
 import torch
@@ -1142,6 +1143,84 @@ def check_full_size_properties(device, R=4096, S=64, V=8, N_importance=64):
   assert_close(cpu(out['rgb'])[idx], ref['rgb'], 1e-4, 0.0, 'full-size rgb vs oracle (48 rays)')
   assert_close(cpu(out['depth'])[idx], ref['depth'], 0.0, 3e-4, 'full-size depth vs oracle (48 rays)')
   return float((cpu(out['rgb'])[idx] - ref['rgb']).abs().max())
+
+
+def _full_frame_subset(ret_group, idx, HW):
+  """pixel entries of a full-frame group ([H,W,...] host tensors) on the strided ray subset idx"""
+  out = {}
+  for k in ('rgb', 'depth', 'mask'):
+    if k in ret_group and ret_group[k] is not None:
+      v = ret_group[k]
+      out[k] = v.reshape((HW,) + tuple(v.shape[2:]))[idx]
+  return out
+
+
+def check_full_frames_vs_oracle(device, stride=563, which=('nvi', 'mono')):
+  """BASELINE configs[2] and configs[3] AT THEIR FULL SIZE (288 x 512 rays, chunk 8192 -- the frames bench.py times): render_single_image_nvi
+  (64 + 64 samples, 7 dynamic + 11 static views) and render_single_image_mono (kid-running arguments: 64 samples, 7 + 3 dynamic and 15 static views,
+  anti_alias_pooling 0, mask_rgb 1) on the HIP path, compared with the oracle on a strided subset of the frame's rays (every `stride`-th ray:
+  262 rays at the default; the oracle needs seconds for them, hours for the frame).  Together with the chunk-invariance property (bit-exact,
+  check_full_size_properties) this holds the frames that are timed to the reference's arithmetic, not only their 12 x 16 twins."""
+  import types
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  from dynibar_amd import synthetic as syn
+  worst = {}
+  W = oracle_models()  # the weights FrameCase / MonoFrame use: syn.make_weights seeds 0 (coarse) and 100 (fine), DCT basis 6 x 24
+  if 'nvi' in which:
+    from frame_case import FrameCase
+    fc = FrameCase(device)
+    smp, rb = fc.sampler()
+    ret = fc.render(smp, rb)
+    HW = fc.H * fc.W
+    idx = torch.arange(0, HW, stride)
+    sc = syn.make_scene(seed=0, H=fc.H, W=fc.W, V=fc.vdy, n_static=fc.vst)
+    fine = syn.make_scene(seed=0, H=fc.H, W=fc.W, V=fc.vdy, n_static=fc.vst, tag=1)
+    scene = {k: cases.t(v) for k, v in sc.items()}
+    scene['featmaps_fine'], scene['static_featmaps_fine'] = cases.t(fine['featmaps']), cases.t(fine['static_featmaps'])
+    o, d, uv = (cpu(rb[k])[idx] for k in ('ray_o', 'ray_d', 'uv_grid'))
+    run = lambda: O.render_rays_mv(W, dict(scene), o, d, uv, fc.fidx, torch.tensor([fc.fidx / 24.0]), fc.toff, 64, 64)
+    ref = run()
+    sens = projection_sensitivity(run)  # the matrices are formed on the device (rocSOLVER) here, by LAPACK in the oracle: the reference's own conditioning
+    for grp in ('outputs_coarse_ref', 'outputs_fine_ref'):
+      got = _full_frame_subset(ret[grp], idx, HW)
+      for k, v in got.items():
+        r = ref[grp][k]
+        if r.dtype == torch.bool:
+          assert_bitexact(v, r, f'full nvi frame {grp}/{k} ({len(idx)} of {HW} rays)')
+        else:
+          tol = _group_tol(k)
+          ex = sens[grp].get(k)
+          assert_close(v.float(), r.float(), tol['atol'], tol['rtol'], f'full nvi frame {grp}/{k} ({len(idx)} of {HW} rays)', extra=None if ex is None else SENS_FACTOR * ex)
+          worst[f'nvi/{grp}/{k}'] = float((v.float() - r.float()).abs().max())
+    del fc, ret, smp, rb
+  if 'mono' in which:
+    from config_cases import MonoFrame
+    mf = MonoFrame(device)
+    ret = mf.render()
+    H, Wd = 288, 512
+    HW = H * Wd
+    idx = torch.arange(0, HW, stride)
+    sc = syn.make_scene(seed=31, H=H, W=Wd, V=10, n_static=15)
+    scene = {k: cases.t(v) for k, v in sc.items()}
+    from dynibar_amd import sample_ray
+    rb = sample_ray.RaySamplerSingleImage(mf.data, device).get_all()
+    o, d, uv = (cpu(rb[k])[idx] for k in ('ray_o', 'ray_d', 'uv_grid'))
+    run = lambda: O.render_rays_mono_eval(W, dict(scene), o, d, uv, mf.fidx, torch.tensor([mf.fidx / 24.0]), mf.toff, 64, anti_alias_pooling=False, mask_rgb=True,
+                                          num_vv=mf.num_vv)
+    ref = run()
+    sens = projection_sensitivity(run)
+    for grp in ('outputs_coarse_ref', 'outputs_coarse_st'):
+      got = _full_frame_subset(ret[grp], idx, HW)
+      for k, v in got.items():
+        r = ref[grp][k]
+        if r.dtype == torch.bool:
+          assert_bitexact(v, r, f'full mono frame {grp}/{k} ({len(idx)} of {HW} rays)')
+        else:
+          tol = _group_tol(k)
+          ex = sens[grp].get(k)
+          assert_close(v.float(), r.float(), tol['atol'], tol['rtol'], f'full mono frame {grp}/{k} ({len(idx)} of {HW} rays)', extra=None if ex is None else SENS_FACTOR * ex)
+          worst[f'mono/{grp}/{k}'] = float((v.float() - r.float()).abs().max())
+  return worst
 
 
 def check_render_rays_mono_vv(device, name='small', S=64, num_vv=2):

@@ -127,6 +127,13 @@ def test_full_size_properties(dev):
   parity.check_full_size_properties(dev)
 
 
+def test_full_frames_against_the_oracle_on_a_strided_ray_subset(dev):
+  """BASELINE configs[2] and configs[3] at the size bench.py times them (288 x 512 rays, chunk 8192): the rendered pixels of every 563rd ray (262 rays)
+  against the oracle -- render_single_image_nvi (64 + 64 samples, 7 + 11 views) and render_single_image_mono (kid-running arguments)."""
+  worst = parity.check_full_frames_vs_oracle(dev)
+  assert len(worst) >= 8
+
+
 def test_full_size_properties_stress(dev):
   """BASELINE configs[4] at full chunk size (8192 rays x 256 samples x 16 views: the two-launch long-ray point chain, 16-lane view
   segments, ~25 GB of workspace): chunk invariance, compositing / resampling invariants, oracle spot check on 48 rays."""

@@ -13,12 +13,12 @@ for a in rest:
   else: cur.append(a)
 objs = []
 for src, base, extra in (('dyn_geometry.hip', ['-ffp-contract=off', '-munsafe-fp-atomics'], geom), ('dyn_nets.hip', [], nets), ('dyn_encoder.hip', ['-munsafe-fp-atomics'], []),
-                         ('dyn_train.hip', ['-munsafe-fp-atomics'], [])):
+                         ('dyn_train.hip', ['-munsafe-fp-atomics'], []), ('dyn_comm.hip', [], [])):
   obj = os.path.join(CSRC, src.replace('.hip', '.o'))
   if extra:
     obj = os.path.join(CSRC, src.replace('.hip', f'_{tag}.o'))
     subprocess.check_call(COMMON + base + extra + ['-c', os.path.join(CSRC, src), '-o', obj])
   objs.append(obj)
 out = os.path.join(CSRC, f'libdynibar_hip_{tag}.so')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-ldl', '-o', out])
 print(out)
