@@ -21,6 +21,7 @@ import argparse
 import ctypes
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
@@ -209,6 +210,51 @@ def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE'), raw=False):
                'children of this command (4 steps each)')
 
 
+def power_sample(step, sync, seconds=4.0):
+  """rocm-smi readings (package power, shader clock, power cap) taken by a side thread while `step` runs back to back for `seconds`."""
+  import re
+  import subprocess
+  import threading
+  smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+  samples = []
+
+  def sampler():
+    time.sleep(1.0)
+    for _ in range(3):
+      try:
+        out = subprocess.run([smi, '--showpower', '--showclocks'], capture_output=True, text=True, timeout=10).stdout
+        w = re.search(r'Package Power \(W\):\s*([0-9.]+)', out)
+        c = re.search(r'sclk clock level:\s*\d+:\s*\((\d+)Mhz\)', out)
+        if w and c:
+          samples.append((float(w.group(1)), int(c.group(1))))
+      except Exception:
+        pass
+      time.sleep(0.3)
+
+  th = threading.Thread(target=sampler)
+  th.start()
+  t0 = time.perf_counter()
+  n = 0
+  while time.perf_counter() - t0 < seconds or th.is_alive():
+    for _ in range(50):
+      step()
+    sync()
+    n += 50
+  dt = time.perf_counter() - t0
+  th.join()
+  cap = None
+  try:
+    out = subprocess.run([smi, '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
+    m = re.search(r'Max Graphics Package Power \(W\):\s*([0-9.]+)', out)
+    cap = float(m.group(1)) if m else None
+  except Exception:
+    pass
+  if not samples:
+    return {'error': 'rocm-smi gave no reading'}
+  return {'what': 'rocm-smi beside %d back-to-back steps (%.2f ms per step)' % (n, dt / n * 1e3), 'package_power_w': [s[0] for s in samples],
+          'shader_clock_mhz': [s[1] for s in samples], 'power_cap_w': cap, 'nominal_clock_mhz': 2400}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -369,6 +415,12 @@ def main():
         del wl11
       except Exception as e:
         extra['views_11'] = {'error': str(e)[:300]}
+      try:
+        # the package power and the shader clock WHILE the step runs back to back (rocm-smi samples beside a 4 s loop of the same step): the 2500 TFLOP/s
+        # peak the roofline is priced against assumes 2.4 GHz, the part clocks down to its power cap under these kernels
+        extra['power_under_step_loop'] = power_sample(wl.step, sync)
+      except Exception as e:
+        extra['power_under_step_loop'] = {'error': str(e)[:300]}
 
     if world == 1 and not dry and not a.frame_only:
       try:

@@ -743,9 +743,11 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
               "dyn_project_gather: R*S*V and the map sizes must stay below 2^31 elements (split the ray batch)");
   static const int legacy = getenv("DYN_PG_ROWS") != nullptr;  // developer A/B: the row-order kernel of round 1
   const int C = 3 + p->F;
-  // points per tile: 64 (one view per wave) while the [P][V][C] tile leaves room for two workgroups per CU, else 32 (two views per wave)
+  // points per tile: 64 (one view per wave) while the [P][V][C] tile leaves room for two workgroups per CU (V <= 8) -- and for 9 ... 11 views, where one
+  // 9- to 11-wave workgroup per CU measured 3-5 % faster than three 6-wave workgroups with an idle view slot (tools/k1sweep.py, round 4: 11 views 172 vs
+  // 177-181 us; at 15 views the two-views-per-wave form wins, 201 vs 221 us) --, else 32 (two views per wave)
   static const int force_p = getenv("DYN_PG_P") ? atoi(getenv("DYN_PG_P")) : 0;  // developer A/B
-  const int P = force_p ? force_p : (((size_t)64 * p->V * C * 4 <= 72 * 1024 && p->V <= 16) ? 64 : 32);
+  const int P = force_p ? force_p : ((((size_t)64 * p->V * C * 4 <= 72 * 1024 && p->V <= 16) || (p->V >= 9 && p->V <= 11 && (size_t)64 * p->V * C * 4 <= 120 * 1024)) ? 64 : 32);
   const int waves = (p->V * P + 63) / 64;
   const size_t lds = (size_t)P * p->V * C * sizeof(float);
   if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);

@@ -362,6 +362,12 @@ extern "C" int dyn_debug_skew_reset(void) { unsigned long long z[32] = {0}; retu
 #define DYN_PHASE_RING_KID(R, k)
 #endif
 
+#ifndef B6_ASM_DMA
+#define B6_ASM_DMA 0  /* the two-slot ring's LDS-DMA pieces as inline asm (see ring6_issue) */
+#endif
+#ifndef B6_PINNED
+#define B6_PINNED 0   /* mlp_layer_b6: the three partial products of a pair pinned back to back, the pair's LDS reads and operand slice in front of them */
+#endif
 struct WeightRing6 {
   const float* gbase;  // the packed stream (uniform)
   float* buf;
@@ -386,6 +392,19 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp)
     if (grp * 1536 < per_wave) {
+#if B6_ASM_DMA && defined(__AMDGCN__)
+      // inline asm: hipcc books the builtin as an access to both memories and, while one is pending, turns every LDS wait into lgkmcnt(0) (round 4,
+      // see mlp_layer_b6_duo) -- with it the A-fragment look-ahead (B6_AHEAD) never had a chance to work.  The ring waits for its pieces itself.
+      const float* gg = g + grp * 1536;
+      const unsigned ll = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(l + grp * 1536));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      asm volatile("s_mov_b32 m0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, off offset:-2048\n\tglobal_load_lds_dwordx4 %0, off offset:-1024\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                   "global_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                   ::"v"(gg), "s"(ll) : "m0", "memory");
+#pragma clang diagnostic pop
+#else
       const auto* gg = (const __attribute__((address_space(1))) void*)(g + grp * 1536);
       auto* ll = (__attribute__((address_space(3))) void*)(l + grp * 1536);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, -2048, 0);
@@ -394,6 +413,7 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 1024, 0);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 2048, 0);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 3072, 0);
+#endif
     }
 }
 // threads: the workgroup size.  Kernels pass their compile-time constant: the piece loop of ring6_issue then unrolls without branches
@@ -626,10 +646,22 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
 #if B6_SPREAD
         __builtin_amdgcn_sched_barrier(0);
 #else
+#if B6_PINNED && defined(__AMDGCN__)
+        // nothing between the three products: an instruction between two MFMAs on one accumulator costs ~43 cycles of the matrix pipe, and hipcc
+        // put the next pair's two ds_read_b128 between the first and the second (the empty asm statements tie the products to their place)
+        asm volatile("" : "+v"(bh), "+v"(bm));
         acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
-#endif
         acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
+        asm volatile("" : "+v"(acc[t]));
+#else
+        acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
+#endif
+#endif
+#if !(B6_PINNED && defined(__AMDGCN__)) || B6_SPREAD
+        acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
+        acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
+#endif
         if (t == NT - 1) { bh = nh; bm = nm; bl = nl; }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -691,6 +723,12 @@ struct WeightRing3 {
   int waves;           // waves of the workgroup (compile-time at every call site)
   int cf;              // floats per chunk: (pairs per chunk) x B6_PAIR_FLOATS -- 48 KiB (24 pairs) by default, 32 KiB for the point kernels' stream
   int fill, issued;    // chunk being requested (-1: none) and how many of this wave's pieces of it have been issued
+  // Persistent workgroups walk the stream once per row tile ("pass"): chunk k of a pass sits in slot[k % 3], the slots rotate by `total` between passes,
+  // and the tail of a pass requests the first two chunks of the next one (wrap = 1, more = another pass follows: the only run-time value here).
+  float* slot[B6D_SLOTS];
+  unsigned lds_slot[B6D_SLOTS];  // lds_wave of each slot (SGPRs)
+  int wrap;
+  bool more;
 #ifdef DYN_PHASE_TIMING
   int kid;
 #endif
@@ -718,10 +756,11 @@ __device__ __forceinline__ int ring3_pieces(const WeightRing3& R) { return R.cf 
 __device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int k) {
   const int per_wave = R.cf / R.waves;
   const int grp = k / 6, i = k % 6;
-  const float* g = R.glane + (long)chunk * R.cf + grp * 1536;
-  const float* gu = R.gbase + (long)chunk * R.cf + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
-  const unsigned l = R.lds_wave + (unsigned)(((chunk % B6D_SLOTS) * R.cf + grp * 1536) * sizeof(float));
-  float* le = R.buf + (chunk % B6D_SLOTS) * R.cf + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
+  const int sc = chunk >= R.total ? chunk - R.total : chunk;  // chunks `total`, `total + 1` of a pass are chunks 0, 1 of the next one
+  const float* g = R.glane + (long)sc * R.cf + grp * 1536;
+  const float* gu = R.gbase + (long)sc * R.cf + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
+  const unsigned l = R.lds_slot[chunk % B6D_SLOTS] + (unsigned)(grp * 1536 * sizeof(float));
+  float* le = R.slot[chunk % B6D_SLOTS] + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
   if (i == 0) ring3_dma<-2048>(g, le, l, gu, R.lane_off);
   if (i == 1) ring3_dma<-1024>(g, le, l, gu, R.lane_off);
   if (i == 2) ring3_dma<0>(g, le, l, gu, R.lane_off);
@@ -729,12 +768,15 @@ __device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int
   if (i == 4) ring3_dma<2048>(g, le, l, gu, R.lane_off);
   if (i == 5) ring3_dma<3072>(g, le, l, gu, R.lane_off);
 }
+// ALLOW: DMA pieces of this wave that may still be in flight behind the barrier (the youngest ones: loads complete in order)
+template <int ALLOW = 0>
 __device__ __forceinline__ void ring3_barrier() {
 #if B6D_NO_BARRIER
   return;
 #endif
 #if defined(__AMDGCN__)
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed (LDS reads in flight stay in flight)
+  static_assert(ALLOW >= 0 && ALLOW < 16, "vmcnt immediate");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ALLOW);  // vmcnt(ALLOW): this wave's older DMA pieces have landed (LDS reads in flight stay in flight)
   __builtin_amdgcn_s_barrier();
 #else
   __syncthreads();
@@ -761,15 +803,29 @@ __device__ __forceinline__ void ring3_init(WeightRing3& R, const float* stream, 
   }
   R.fill = -1;
   R.issued = 0;
+  R.wrap = 0;
+  R.more = false;
+  for (int j = 0; j < B6D_SLOTS; ++j) {
+    R.slot[j] = lds + j * R.cf;
+    R.lds_slot[j] = R.lds_wave + (unsigned)(j * R.cf * sizeof(float));
+  }
   DYN_PHASE_RING_KID(R, 0);
   for (int c = 0; c < 2 && c < total; ++c)
     for (int k = 0; k < ring3_pieces(R); ++k) ring3_piece(R, c, k);
 }
 // first read of chunk R.next: chunk 0 is waited for here, every later chunk was published by the barrier in the middle of its predecessor
 __device__ __forceinline__ void ring3_enter(WeightRing3& R) {
-  if (R.next == 0) ring3_barrier();
+  if (R.next != 0) return;
+  // chunk 1 (requested right behind chunk 0, at ring3_init or in the tail of the previous pass) may still be on its way: the barrier in the middle of
+  // chunk 0 waits for it
+  const int n = R.total > 1 ? ring3_pieces(R) : 0;
+  if (n == 12) ring3_barrier<12>();
+  else if (n == 8) ring3_barrier<8>();
+  else if (n == 6) ring3_barrier<6>();
+  else if (n == 4) ring3_barrier<4>();
+  else ring3_barrier<0>();
 }
-__device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chunk) { return R.buf + (chunk % B6D_SLOTS) * R.cf; }
+__device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chunk) { return R.slot[chunk % B6D_SLOTS]; }
 // Request pieces of the chunk being filled.  Its window runs from the barrier in the middle of chunk c to B6D_DMA_MARGIN pairs before the barrier
 // in the middle of chunk c + 1 (which waits for them): `half` 0 = the second half of chunk c carries the first half of the pieces, `half` 1 =
 // the first half of chunk c + 1 the rest; num / den = how far through that half the wave is.  A CU's four waves then issue about one piece per
@@ -780,6 +836,7 @@ __device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chu
 #endif
 __device__ __forceinline__ void ring3_feed(WeightRing3& R, int half, int num, int den) {
   if (R.fill < 0 || B6D_NO_DMA) return;
+  if (R.fill >= R.total && !R.more) return;  // (the next pass's first chunks: only if there is a next pass)
   const int n = ring3_pieces(R), h0 = n / 2;
   int want = half == 0 ? (h0 * num + den - 1) / den : h0 + ((n - h0) * num + den - 1) / den;
   if (B6D_DMA_BURST || want > n) want = n;
@@ -789,13 +846,27 @@ __device__ __forceinline__ void ring3_feed(WeightRing3& R, int half, int num, in
 __device__ __forceinline__ void ring3_mid(WeightRing3& R) {
   DYN_PHASE_T0
   ring3_feed(R, 1, 1, 1);  // (whatever is left of chunk R.next + 1: normally nothing)
-  if (R.next + 1 < R.total) ring3_barrier();
+  if (R.next + 1 < R.total || R.wrap) ring3_barrier();
   DYN_PHASE_WAIT(R, R.next);
-  R.fill = R.next + 2 < R.total ? R.next + 2 : -1;
+  R.fill = (R.next + 2 < R.total || R.wrap) ? R.next + 2 : -1;
   R.issued = 0;
   if (B6D_DMA_BURST) ring3_feed(R, 1, 1, 1);
 }
-__device__ __forceinline__ void ring3_leave(WeightRing3& R) { ++R.next; }
+__device__ __forceinline__ void ring3_leave(WeightRing3& R) {
+  if (R.wrap && R.next == R.total - 1) ring3_feed(R, 1, 1, 1);  // the window of the next pass's chunk 1 ends with this pass
+  ++R.next;
+}
+// between two passes of a persistent workgroup: the next pass's chunks 0 and 1 have been requested into the slots this pass's chunks `total` and
+// `total + 1` would have taken; the pass starts like a fresh stream (ring3_enter waits for chunk 0 and publishes it)
+__device__ __forceinline__ void ring3_next_pass(WeightRing3& R) {
+  float* s0[B6D_SLOTS];
+  unsigned l0[B6D_SLOTS];
+  for (int j = 0; j < B6D_SLOTS; ++j) { s0[j] = R.slot[j]; l0[j] = R.lds_slot[j]; }
+  for (int j = 0; j < B6D_SLOTS; ++j) { R.slot[j] = s0[(R.total + j) % B6D_SLOTS]; R.lds_slot[j] = l0[(R.total + j) % B6D_SLOTS]; }
+  R.next = 0;
+  R.fill = -1;
+  R.issued = 0;
+}
 
 __device__ __forceinline__ float relu1(float v) {
 #if defined(__AMDGCN__)
@@ -866,6 +937,72 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
     return b6_load_a(ring3_slot(R, c0 + P / CP) + (P % CP) * B6_PAIR_FLOATS, lane);
   };
   ring3_enter(R);
+#if !defined(__AMDGCN__)
+  // Emulator build (tests/emu): the SAME schedule -- ring calls, feed order, order of the products per accumulator -- as a run-time loop; the
+  // compile-time expansion below (up to 100 units per layer, each with its own constants) takes a host compiler tens of minutes.
+  for (int i = 0; i < AHEAD && i < NP; ++i) q[i % QN] = load(i);
+  for (int P = 0; P < NP; P += U) {
+    const int pr = P % CP, npc = NP - (P - pr) < CP ? NP - (P - pr) : CP, mid = (npc / 2) / U * U;
+    const int g = P / NT, t0 = P % NT, t1 = t0 + U - 1, um = (P % NT) / U;
+    if (pr == mid) ring3_mid(R);
+    auto gap = [&](int K) {
+      for (int m = 0; m < NM; ++m) {
+        const int at = NT == 1 ? 0 : (NM <= 4 ? 2 + m : m * 6 / NM);
+        if (at != K || g + 1 >= NG) continue;
+        const int step = um * NM + m, p2 = step / 3, st = step % 3, s0 = (g + 1) * 8 + 2 * p2;
+        if (st == 0) v0 = s0 < NSLOTS ? feed(s0) : 0.f;
+        if (st == 1) v1 = s0 + 1 < NSLOTS ? feed(s0 + 1) : 0.f;
+        if (st == 2) {
+          unsigned h_, m_, l_;
+          split3_pair(v0, v1, h_, m_, l_);
+          nh[p2] = h_; nm[p2] = m_; nl[p2] = l_;
+        }
+      }
+    };
+    auto dma = [&](int done) {
+      const int wend = mid - B6D_DMA_MARGIN;
+      if (pr >= mid) ring3_feed(R, 0, pr + done - mid, npc - mid);
+      else if (wend <= 0) ring3_feed(R, 1, 1, 1);
+      else ring3_feed(R, 1, pr + done < wend ? pr + done : wend, wend);
+    };
+    if (P + AHEAD < NP) q[(P + AHEAD) % QN] = load(P + AHEAD);
+    gap(0);
+    const B6A a0 = q[P % QN], a1 = q[(P + U - 1) % QN];
+#if DYN_SPLIT_TERMS == 6
+    acc[t0] = mfma_bf16(a0.lo, bh, acc[t0]);
+    if (U == 2) acc[t1] = mfma_bf16(a1.lo, bh, acc[t1]);
+    acc[t0] = mfma_bf16(a0.hi, bl, acc[t0]);
+    if (U == 2) acc[t1] = mfma_bf16(a1.hi, bl, acc[t1]);
+    acc[t0] = mfma_bf16(a0.mid, bm, acc[t0]);
+    if (U == 2) acc[t1] = mfma_bf16(a1.mid, bm, acc[t1]);
+#endif
+    acc[t0] = mfma_bf16(a0.mid, bh, acc[t0]);
+    if (U == 2) {
+      if (P + AHEAD + 1 < NP) q[(P + AHEAD + 1) % QN] = load(P + AHEAD + 1);
+      gap(1);
+      acc[t1] = mfma_bf16(a1.mid, bh, acc[t1]);
+      gap(2);
+    }
+    acc[t0] = mfma_bf16(a0.hi, bm, acc[t0]);
+    if (U == 2) {
+      gap(3);
+      dma(1);
+      acc[t1] = mfma_bf16(a1.hi, bm, acc[t1]);
+      gap(4);
+    }
+    acc[t0] = mfma_bf16(a0.hi, bh, acc[t0]);
+    if (U == 2) {
+      gap(5);
+      dma(U);
+      acc[t1] = mfma_bf16(a1.hi, bh, acc[t1]);
+    } else {
+      dma(U);
+    }
+    if (t1 == NT - 1) { bh = nh; bm = nm; bl = nl; }
+    if (pr + U == npc) ring3_leave(R);
+  }
+  return;
+#endif
   dyn_static_for<(AHEAD < NP ? AHEAD : NP)>([&](auto I) DYN_INLINE_LAMBDA { q[decltype(I)::value % QN] = load(decltype(I)::value); });
   __builtin_amdgcn_sched_barrier(0);
   dyn_static_for<NP / U>([&](auto I) DYN_INLINE_LAMBDA {

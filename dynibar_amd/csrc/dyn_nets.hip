@@ -142,6 +142,9 @@ constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2,
 #ifndef DYN_POINTS_DUO
 #define DYN_POINTS_DUO (DYN_ENGINE_B6 && DYN_SPLIT_TERMS == 3 ? 1 : 0)
 #endif
+#ifndef DYN_POINTS_PERSIST
+#define DYN_POINTS_PERSIST 0
+#endif
 #if DYN_POINTS_DUO
 #define PTS_CP 16
 #define PTS_CHUNK (PTS_CP * B6_PAIR_FLOATS)
@@ -1031,12 +1034,41 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
 #define SB_VL_LD 132              // V of one head: [32 features][128 points + pad]
 #define SB_VL_FLOATS (32 * SB_VL_LD)
 
+// workgroup barrier that publishes LDS writes only: `__syncthreads()` also waits for vmcnt(0), i.e. for the weight ring's DMA pieces in flight
+// (round 4: the attention's eight barriers per pass no longer drain the ring's queue)
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__AMDGCN__) && DYN_POINTS_DUO
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+#else
+  __syncthreads();
+#endif
+}
+
 // DYN = false: DynibarStatic (no positional encoding; outputs sigma and the point part of rgb_fc.0)
 // DYN = true : DynibarDynamic (+ sinusoid positional encoding, ref_pts_fc, rgb_fc on [feature | PE(view dir)]; outputs raw [R,S,4])
 // PHASE 0: the whole chain in one launch (rays of <= 128 samples: a ray's tiles sit in one workgroup and K / V never leave the chip).
 // Longer rays run it in two launches: PHASE 1 ends after the Q/K/V projections and stores g, q, k, v per tile; PHASE 2 picks them up,
 // streams the ray's keys through LDS in blocks of 128 with a running softmax, and finishes the chain.
 constexpr int SB_CHUNKS_QKV = pts_layer_chunks(8, 129) + pts_layer_chunks(4, 129) + 3 * pts_layer_chunks(4, 64);
+// grid of k_net_points<., 0>: one workgroup per row tile -- or, in the persistent build (-DDYN_POINTS_PERSIST=1), one per CU, each walking every n_cu-th tile
+static dim3 points_grid(dim3 full) {
+#if DYN_POINTS_DUO && DYN_POINTS_PERSIST
+  static int n_cu[DYN_MAX_DEVICES] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int slot = (dev >= 0 && dev < DYN_MAX_DEVICES) ? dev : 0;
+  if (n_cu[slot] == 0) {
+    hipDeviceProp_t prop;
+    n_cu[slot] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  static const int no_persist = getenv("DYN_POINTS_NO_PERSIST") != nullptr;  // developer A/B: one workgroup per row tile, like the long-ray phases
+  return (no_persist || full.x <= (unsigned)n_cu[slot]) ? full : dim3((unsigned)n_cu[slot]);
+#else
+  return full;
+#endif
+}
+
 template <bool DYN, int PHASE>
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p) {
   constexpr int PHASE_KID = 1;
@@ -1057,13 +1089,37 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   DYN_PHASE_RING_KID(ring, 1);
 
   const int TPR = p.TPR;
-  const long tile = (long)blockIdx.x * 4 + wave;
+  const float one_h0 = h == 0 ? 1.0f : 0.0f;
+  // -DDYN_POINTS_PERSIST=1 (measured in round 4, NOT the default): PHASE 0 as a persistent kernel -- one workgroup per CU walks row tiles blockIdx.x,
+  // + gridDim.x, ...; the tail of a pass pulls the next tile's geometry_fc inputs into the L2 (one dword per 16 bytes, summed into a value nobody
+  // reads; holding the 129 inputs themselves through the tail layers costs 80 spilled registers) and requests the next pass's first weight chunks.
+  // Motive: cycle stamps show a workgroup's first 15 k of ~104 k cycles going into its own start (132 KB of inputs at the rate a CU gets from HBM,
+  // the first weight chunks) with nothing else resident on the CU.  Result: k_net_points 487 us against 465-475 us with one workgroup per row tile,
+  // frame +2 ms: the prefetch doubles the L2 -> CU traffic of the inputs and the static tile assignment loses the dispatcher's balancing.
+  constexpr bool PERSIST = DYN_POINTS_PERSIST && DYN_POINTS_DUO && PHASE == 0;
+  const long n_wg = (p.n_tiles_b + 3) / 4;
+  // the geometry_fc inputs of row tile wgi: this lane's 33 float4 records
+  auto gin_src = [&](long wgi, bool& valid_) DYN_INLINE_LAMBDA {
+    const long tile_ = wgi * 4 + wave;
+    const long ray_ = tile_ / TPR;
+    valid_ = (ray_ < p.R) && ((int)(tile_ - ray_ * TPR) * 32 + j < p.S);
+    return reinterpret_cast<const float4*>(p.ws + p.o.off_gin) + (tile_ < p.n_tiles_b ? tile_ : 0) * SB_GIN_RECS * 64 + lane;
+  };
+#if DYN_POINTS_DUO
+  ring.wrap = PERSIST ? 1 : 0;
+#endif
+  long wgi = blockIdx.x;
+  do {  // (a loop only in the persistent form)
+  const bool more = PERSIST && wgi + gridDim.x < n_wg;
+#if DYN_POINTS_DUO
+  ring.more = more;
+#endif
+  const long tile = wgi * 4 + wave;
   const long ray = tile / TPR;
   const int kt_self = (int)(tile - ray * TPR);
   const int smp = kt_self * 32 + j;
   const bool valid = (ray < p.R) && (smp < p.S);
   const long point = valid ? ray * p.S + smp : 0;
-  const float one_h0 = h == 0 ? 1.0f : 0.0f;
   const float nvalid = valid ? p.ws[p.o.off_nvalid + point] : 0.f;
 
   float4* hand = reinterpret_cast<float4*>(p.ws + p.o.off_qkvg) + (PHASE == 0 ? 0 : tile * 4096) + lane;  // [which][t][q][64 lanes]
@@ -1084,13 +1140,14 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     f32x16 a9[8];
     {
       float gin[129];
-      const float4* src = reinterpret_cast<const float4*>(p.ws + p.o.off_gin) + (tile < p.n_tiles_b ? tile : 0) * SB_GIN_RECS * 64 + lane;
+      bool gv;
+      const float4* src = gin_src(wgi, gv);
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const float4 v = valid ? nt_load4<4>(src + i * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = gv ? nt_load4<4>(src + i * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
         gin[i * 4] = v.x; gin[i * 4 + 1] = v.y; gin[i * 4 + 2] = v.z; gin[i * 4 + 3] = v.w;
       }
-      gin[128] = valid ? src[32 * 64].x : (h == 1 ? 1.0f : 0.f);
+      gin[128] = gv ? src[32 * 64].x : (h == 1 ? 1.0f : 0.f);
       acc_zero(a9);
       PTS_LAYER(8, 129)(ring, a9, [&](int s) { return gin[s]; });
     }
@@ -1237,7 +1294,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     u32x4v* Kimg = reinterpret_cast<u32x4v*>(Kl);  // [key tile (wave)][group m][hi | mid][64 lanes]
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
-      __syncthreads();  // the previous head's K/V images are no longer read
+      lds_barrier();  // the previous head's K/V images are no longer read
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float kv[8];
@@ -1258,7 +1315,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
         for (int e = 0; e < 8; ++e) qv[e] = qh[hd][8 * m + e] * inv_temp;
         split8(qv, qhi[m], qmid[m]);
       }
-      __syncthreads();
+      lds_barrier();
       f32x16 sc[4];
       acc_zero(sc);
 #pragma unroll
@@ -1428,6 +1485,13 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
       for (int r = 0; r < 16; ++r) g[t][r] = (o[t][r] - mu) * rstd * gam[t * 16 + r] + bet[t * 16 + r];
   }
   DYN_PHASE(4);  // fc + LayerNorm done
+  float pf[SB_GIN_RECS];  // (persistent form) one dword of every 16 bytes of the next pass's geometry_fc inputs: pulled into the L2 ~14 k cycles ahead
+  if (PERSIST) {
+    bool gv;
+    const float* nsrc = reinterpret_cast<const float*>(gin_src(more ? wgi + gridDim.x : wgi, gv));
+#pragma unroll
+    for (int i = 0; i < SB_GIN_RECS; ++i) pf[i] = (more && gv) ? nsrc[i * 256] : 0.f;
+  }
   if (!DYN) {
     f32x16 a[4];
     acc_zero(a);
@@ -1498,6 +1562,24 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     if (valid && h == 0) reinterpret_cast<float4*>(p.raw)[point] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   }
   DYN_PHASE(20);
+#if DYN_POINTS_DUO
+  if (PERSIST) {
+    // the prefetched dwords are summed HERE, behind everything the pass computes (the sum starts from a value the last stores produced, so hipcc cannot
+    // raise the additions -- and their wait for the loads -- into the tail layers)
+    float sink = nvalid;
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(sink));
+#endif
+#pragma unroll
+    for (int i = 0; i < SB_GIN_RECS; ++i) sink += pf[i];
+#if defined(__AMDGCN__)
+    asm volatile("" ::"v"(sink));
+#endif
+    ring3_next_pass(ring);
+  }
+#endif
+  wgi += gridDim.x;
+  } while (PERSIST && wgi < n_wg);  // row tiles of this workgroup
 }
 
 // ===================================================================================================================
@@ -1613,7 +1695,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<32>, grid_a, blk_v, lds_a, stream, a);
   if (a.TPR <= 4) {
-    DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 0>), grid_b, blk, lds_b, stream, a);
+    DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 0>), points_grid(grid_b), blk, lds_b, stream, a);
   } else {
     DYN_LAUNCH(DYN_K_STATIC_POINTS_QKV, "k_static_points_qkv", (k_net_points<false, 1>), grid_b, blk, lds_b, stream, a);
     DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 2>), grid_b, blk, lds_b, stream, a);
@@ -1837,7 +1919,7 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk_v, lds_a, stream, a);
   else DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<32>, grid_a, blk_v, lds_a, stream, a);
   if (a.TPR <= 4) {
-    DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", (k_net_points<true, 0>), grid_b, blk, lds_b, stream, a);
+    DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", (k_net_points<true, 0>), points_grid(grid_b), blk, lds_b, stream, a);
   } else {
     DYN_LAUNCH(DYN_K_DYNAMIC_POINTS_QKV, "k_dynamic_points_qkv", (k_net_points<true, 1>), grid_b, blk, lds_b, stream, a);
     DYN_LAUNCH(DYN_K_DYNAMIC_POINTS, "k_dynamic_points", (k_net_points<true, 2>), grid_b, blk, lds_b, stream, a);

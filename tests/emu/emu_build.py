@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, 'dynibar_amd', 'csrc')
 OUT_DIR = os.path.join(HERE, '_build')
 OUT = os.path.join(OUT_DIR, 'libdynibar_emu.so')
 CXX = os.environ.get('EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
-UNITS = [('dyn_geometry.hip', ['-ffp-contract=off']), ('dyn_nets.hip', []), ('dyn_encoder.hip', []), ('dyn_train.hip', [])]
+UNITS = [('dyn_geometry.hip', ['-ffp-contract=off']), ('dyn_nets.hip', []), ('dyn_encoder.hip', []), ('dyn_train.hip', []), ('dyn_comm.hip', [])]
 
 
 def build(opt='-O2', sanitize=False):

@@ -31,3 +31,10 @@ def test_dense_rows_dynamic_and_static(emu):
   """View counts from 9 that are not powers of two run the dense-row flavour (cross-view reductions through LDS tables): 13 dynamic and 20 static views."""
   parity.check_dynamic_net(emu, 'many', S=32, R=1)
   parity.check_static_net(emu, 'many', S=32, R=1)
+
+
+def test_point_kernel_walks_several_row_tiles(emu):
+  """12 rays x 32 samples = 3 workgroups of k_net_points.  (In a -DDYN_POINTS_PERSIST=1 build an emulator with fewer "CUs" than workgroups makes some run a second
+  pass: slot rotation of the weight ring, the next pass's first chunks requested in the tail of the first.)"""
+  parity.check_static_net(emu, "small", S=32, R=12)
+  parity.check_dynamic_net(emu, "small", S=32, R=12, shift=5.0)

@@ -22,7 +22,7 @@ if '--build' in sys.argv:
   common = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
   subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG)])
   subprocess.check_call([hipcc] + common + ['-DDYN_PHASE_TIMING', '-ffp-contract=off'] + os.environ.get('PHASE_FLAGS', '').split() + ['-c', os.path.join(CSRC, 'dyn_geometry.hip'), '-o', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG)])
-  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_encoder.o'), os.path.join(CSRC, 'dyn_train.o'), '-o', LIB])
+  subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', os.path.join(CSRC, 'dyn_geometry_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_nets_phase%s.o' % TAG), os.path.join(CSRC, 'dyn_encoder.o'), os.path.join(CSRC, 'dyn_train.o'), os.path.join(CSRC, 'dyn_comm.o'), '-ldl', '-o', LIB])
   sys.exit(0)
 
 os.environ['DYNIBAR_HIP_LIB'] = LIB
