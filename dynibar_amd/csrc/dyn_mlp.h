@@ -1085,6 +1085,53 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
   });
 }
 
+// One Linear layer whose packed pairs are RESIDENT in LDS (`w`: pair p at w + p * B6_PAIR_FLOATS, in consumption order): no ring, no barriers.  For a
+// kernel whose whole weight set fits the LDS (k_static_blend: 104 KiB) and whose workgroups stay on the CU and walk many row tiles: the weights are
+// copied once per workgroup instead of streamed once per 128 rows.  Schedule as mlp_layer_b6 (pair-granular pipeline, the next k-group's operand in slices).
+template <int NT, int NSLOTS, int AHEAD = B6_AHEAD, class Feed>
+__device__ __forceinline__ void mlp_layer_b6_lds(const float* w, f32x16 (&acc)[NT], Feed&& feed) {
+  constexpr int NG = (NSLOTS + 7) / 8, NPR = NG * NT;
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "output tiles per layer");
+  const int lane = threadIdx.x & 63;
+  u32x4v bh, bm, bl, nh, nm, nl;
+  b6_split_pairs<NSLOTS, 0, 4>(feed, 0, bh, bm, bl);
+  nh = bh; nm = bm; nl = bl;
+  B6A q[AHEAD + 1];
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < NPR) q[i] = b6_load_a(w + i * B6_PAIR_FLOATS, lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int pr = 0; pr < NPR; ++pr) {
+    const int g = pr / NT, t = pr % NT;
+    if (pr + AHEAD < NPR) q[(pr + AHEAD) % (AHEAD + 1)] = b6_load_a(w + (pr + AHEAD) * B6_PAIR_FLOATS, lane);
+    if (g + 1 < NG) {
+      if (NT == 1) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
+      if (NT == 2 && t == 0) b6_split_pairs<NSLOTS, 0, 2>(feed, g + 1, nh, nm, nl);
+      if (NT == 2 && t == 1) b6_split_pairs<NSLOTS, 2, 4>(feed, g + 1, nh, nm, nl);
+      if (NT == 4 && t == 0) b6_split_pairs<NSLOTS, 0, 1>(feed, g + 1, nh, nm, nl);
+      if (NT == 4 && t == 1) b6_split_pairs<NSLOTS, 1, 2>(feed, g + 1, nh, nm, nl);
+      if (NT == 4 && t == 2) b6_split_pairs<NSLOTS, 2, 3>(feed, g + 1, nh, nm, nl);
+      if (NT == 4 && t == 3) b6_split_pairs<NSLOTS, 3, 4>(feed, g + 1, nh, nm, nl);
+      if (NT == 8 && t == 0) b6_split_pairs<NSLOTS, 0, 1>(feed, g + 1, nh, nm, nl);
+      if (NT == 8 && t == 2) b6_split_pairs<NSLOTS, 1, 2>(feed, g + 1, nh, nm, nl);
+      if (NT == 8 && t == 4) b6_split_pairs<NSLOTS, 2, 3>(feed, g + 1, nh, nm, nl);
+      if (NT == 8 && t == 6) b6_split_pairs<NSLOTS, 3, 4>(feed, g + 1, nh, nm, nl);
+    }
+    const B6A& cur = q[pr % (AHEAD + 1)];
+#if DYN_SPLIT_TERMS == 6
+    acc[t] = mfma_bf16(cur.lo, bh, acc[t]);
+    acc[t] = mfma_bf16(cur.hi, bl, acc[t]);
+    acc[t] = mfma_bf16(cur.mid, bm, acc[t]);
+#endif
+    acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
+    acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
+    acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
+    if (t == NT - 1) { bh = nh; bm = nm; bl = nl; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The same layer shared out over the waves of a workgroup: all waves stream the chunks of an NT-tile layer, wave w evaluates only
 // output tile `my_tile` (for NCOL column tiles of 32 rows each; feed(c, s) is the lane's activation of column tile c, slot s).
 // Used where the rows are few and shared by the whole workgroup (per-point statistics pooled over the workgroup's points).

@@ -1051,6 +1051,18 @@ __device__ __forceinline__ void lds_barrier() {
 // Longer rays run it in two launches: PHASE 1 ends after the Q/K/V projections and stores g, q, k, v per tile; PHASE 2 picks them up,
 // streams the ray's keys through LDS in blocks of 128 with a running softmax, and finishes the chain.
 constexpr int SB_CHUNKS_QKV = pts_layer_chunks(8, 129) + pts_layer_chunks(4, 129) + 3 * pts_layer_chunks(4, 64);
+static int dyn_cu_count() {
+  static int n_cu[DYN_MAX_DEVICES] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int slot = (dev >= 0 && dev < DYN_MAX_DEVICES) ? dev : 0;
+  if (n_cu[slot] == 0) {
+    hipDeviceProp_t prop;
+    n_cu[slot] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n_cu[slot];
+}
+
 // grid of k_net_points<., 0>: one workgroup per row tile -- or, in the persistent build (-DDYN_POINTS_PERSIST=1), one per CU, each walking every n_cu-th tile
 static dim3 points_grid(dim3 full) {
 #if DYN_POINTS_DUO && DYN_POINTS_PERSIST
@@ -1657,6 +1669,100 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
   }
   DYN_PHASE(20);
 }
+// ---- round 4: the blend with its weights RESIDENT in LDS, as persistent workgroups ------------------------------------------------------------------
+// rgb_fc.0's per-view part and rgb_fc.2 are 52 packed pairs = 104 KiB: they fit the LDS.  The streaming form above moves three 48 KiB chunks through a
+// one-slot ring per 128 rows -- 2.25 x the bytes of the parked x the kernel is there to stream, through the same L2 -> CU path, with the chunk waits
+// (8 k of a workgroup's 28-35 k cycles, tools/phasebench.py) covered only by whatever else is resident.  Here one workgroup per CU copies the 52 pairs
+// once and walks row tiles; the layers read their A fragments from the resident image (mlp_layer_b6_lds: no ring, no barriers), so in the lane-segment
+// flavour the twelve waves of a CU run free of each other, and in the dense flavour only the cross-view reductions still synchronise.
+#ifndef DYN_BLEND_WS
+#define DYN_BLEND_WS (DYN_ENGINE_B6 && DYN_SPLIT_TERMS == 3 ? 1 : 0)
+#endif
+#define SC_L11_PAIRS (((SC_L11_STEPS + 7) / 8) * 4)
+#define SC_L12_PAIRS ((64 / 8) * 2)
+#define SC_WS_FLOATS ((SC_L11_PAIRS + SC_L12_PAIRS) * B6_PAIR_FLOATS)
+#define DYN_BLEND_WS_THREADS 768
+#if DYN_BLEND_WS
+template <int VSEG, int THREADS>
+__device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
+  float* lds = reinterpret_cast<float*>(dyn_smem);
+  float* ctab = lds + SC_WS_FLOATS;  // [SC_CT] (+ the dense flavour's scalar tables behind it)
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+  for (int i = tid; i < SC_CT; i += THREADS) ctab[i] = p.blob[ST_OFF_CTC + i];
+  {
+    // the used pairs of stream C (chunks of B6_CHUNK_PAIRS pairs; the last chunk of a layer is partly filled) -> one compact image
+    constexpr int CP = B6_CHUNK_PAIRS, L11_CH = net_layer_chunks(4, SC_L11_STEPS);
+    const float4* src = reinterpret_cast<const float4*>(p.blob + ST_OFF_C);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < SC_WS_FLOATS / 4; i += THREADS) {
+      const int pair = i / (B6_PAIR_FLOATS / 4), within = i - pair * (B6_PAIR_FLOATS / 4);
+      const int sp = pair < SC_L11_PAIRS ? pair : L11_CH * CP + (pair - SC_L11_PAIRS);  // pair index in the chunked stream
+      dst[i] = src[(long)sp * (B6_PAIR_FLOATS / 4) + within];
+    }
+  }
+  __syncthreads();
+  const float* w11 = lds;
+  const float* w12 = lds + SC_L11_PAIRS * B6_PAIR_FLOATS;
+  const int V = p.V;
+  constexpr int NW = THREADS / 64;
+  const DenseRows dr = dense_rows(V, p.PT, ctab + SC_CT);
+  const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
+  const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
+  // lane-segment flavour: every wave walks its own tiles; dense flavour: the workgroup walks blocks of NW tiles together (its reductions use barriers)
+  const long n_units = VSEG == 0 ? (p.n_tiles_a + NW - 1) / NW : p.n_tiles_a;
+  const long first = VSEG == 0 ? blockIdx.x : (long)blockIdx.x * NW + wave, step = VSEG == 0 ? gridDim.x : (long)gridDim.x * NW;
+  for (long u = first; u < n_units; u += step) {
+    const long tile = VSEG == 0 ? u * NW + wave : u;
+    const bool tile_ok = tile < p.n_tiles_a;
+    const long point = VSEG == 0 ? u * p.PT + p_local : tile * p.PT + p_local;
+    const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
+    const long pv = valid ? point * V + view : 0;
+    const float msk = valid ? p.mask[pv] : 0.f;
+    const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float vis2 = tile_ok ? p.ws[p.o.off_vis + tile * 64 + lane] : 0.f;
+    float rgb_in[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      rgb_in[0] = p.rgb_feat[pv * 35]; rgb_in[1] = p.rgb_feat[pv * 35 + 1]; rgb_in[2] = p.rgb_feat[pv * 35 + 2];
+    }
+    f32x16 a[4];
+    {
+      f32x16 x[4];
+      const float4* xw = reinterpret_cast<const float4*>(p.ws + p.o.off_x) + (tile_ok ? tile : 0) * 16 * 64 + lane;
+      const float4* hg = reinterpret_cast<const float4*>(p.ws + p.o.off_hg) + (valid ? point_rec(p, point, h, SB_HG_RECS) : 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = tile_ok ? nt_load4<8>(xw + (t * 4 + q) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
+          const float4 b = valid ? hg[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+          a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
+        }
+      const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
+      mlp_layer_b6_lds<4, SC_L11_STEPS>(w11, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
+    }
+    f32x16 b2[2];
+    acc_init_bias<2>(b2, ctab + 80);
+    mlp_layer_b6_lds<2, 64>(w12, b2, [&](int s) { return elu_s(a[s / 16][s % 16]); });
+    acc_elu_s(b2);
+    float logit = row_dot<2>(b2, ctab) + ctab[64];
+    if (msk == 0.f) logit = -1e9f;
+    if (VSEG == 0 ? p_local >= p.PT : view >= V) logit = -3.0e38f;  // padding rows take no share even when every real view is masked (uniform 1/V then)
+    const float mx = views_max<VSEG>(dr, logit);
+    const float e = (VSEG == 0 && p_local >= p.PT) ? 0.f : __expf(logit - mx);
+    const float bw = e / views_sum<VSEG>(dr, e);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = views_sum<VSEG>(dr, rgb_in[c] * bw);
+      if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
+    }
+  }
+}
+template <int VSEG>
+__global__ void __launch_bounds__(DYN_BLEND_WS_THREADS, 1) k_static_blend_ws(StaticArgs p) { static_blend_ws_body<VSEG, DYN_BLEND_WS_THREADS>(p); }
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense_ws(StaticArgs p) { static_blend_ws_body<0, DYN_VIEW_THREADS>(p); }
+#endif
+
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_BLEND_THREADS, 3) k_static_blend(StaticArgs p) { static_blend_body<VSEG, DYN_BLEND_THREADS>(p); }
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense(StaticArgs p) { static_blend_body<0, DYN_VIEW_THREADS>(p); }
@@ -1700,6 +1806,25 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
     DYN_LAUNCH(DYN_K_STATIC_POINTS_QKV, "k_static_points_qkv", (k_net_points<false, 1>), grid_b, blk, lds_b, stream, a);
     DYN_LAUNCH(DYN_K_STATIC_POINTS, "k_static_points", (k_net_points<false, 2>), grid_b, blk, lds_b, stream, a);
   }
+#if DYN_BLEND_WS
+  static const int blend_stream = getenv("DYN_BLEND_STREAM") != nullptr;  // developer A/B: the streaming (round-3) form
+  if (!blend_stream) {
+    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS) * sizeof(float);
+    const unsigned n_cu = (unsigned)dyn_cu_count();
+    if (a.o.dense) {
+      const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64);
+      DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense_ws, dim3(nb < n_cu ? nb : n_cu), blk_v, lds_w, stream, a);
+    } else {
+      const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_BLEND_WS_THREADS / 64);
+      const dim3 gw(nb < n_cu ? nb : n_cu), bw_(DYN_BLEND_WS_THREADS);
+      if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_ws<4>, gw, bw_, lds_w, stream, a);
+      else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_ws<8>, gw, bw_, lds_w, stream, a);
+      else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_ws<16>, gw, bw_, lds_w, stream, a);
+      else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_ws<32>, gw, bw_, lds_w, stream, a);
+    }
+    return 0;
+  }
+#endif
   if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense, grid_a, blk_v, lds_c + DENSE_SCALARS * sizeof(float), stream, a);
   else if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<4>, grid_c, blk_c, lds_c, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend<8>, grid_c, blk_c, lds_c, stream, a);
