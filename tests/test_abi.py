@@ -39,6 +39,18 @@ def test_invalid_arguments_are_reported():
     _lib.call('dyn_sample_along_ray', None, None)
 
 
+def test_gather_entry_validates_without_a_device():
+  """dyn_gather_tiles / dyn_comm_* (the RCCL pixel gather): exported, argument-checked on the host, RCCL resolved at run time (no link dependency)."""
+  lib = _lib.lib()
+  assert lib.dyn_comm_available() in (0, 1)
+  assert lib.dyn_gather_tiles(None, None, 0, 0, None, None) == -1 and b'dyn_gather_tiles' in lib.dyn_last_error()
+  assert lib.dyn_comm_init_rank(None, 0, None, 0) == -1 and b'dyn_comm_init_rank' in lib.dyn_last_error()
+  assert lib.dyn_comm_destroy(None) == 0  # destroying nothing is not an error
+  import subprocess
+  out = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
+  assert 'librccl' not in out, 'the kernels\' library must not link RCCL (a PyTorch host has loaded its own copy)'
+
+
 def test_weight_packing_runs_on_the_host():
   """Packing is host code: it must work (and validate its input) without a GPU."""
   from dynibar_amd import ops, synthetic as syn
