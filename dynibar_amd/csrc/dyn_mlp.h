@@ -19,6 +19,10 @@
 //    MFMAs, one workgroup barrier per chunk.  Biases are accumulator initial values (LDS tables) or one extra k-slot fed with 1.
 //  * the first one (kept for A/B builds, -DDYN_ENGINE_B6=0; first half of this file): native fp32 MFMA (v_mfma_f32_32x32x2_f32),
 //    16 KiB chunks (DYN_CHUNK) in a 2-deep ring, bias folded into K as one extra k-step.
+// Three layer loops on the shipped engine (round 4): mlp_layer_b6 (two-slot ring, pair-granular pipeline: the kernels that run two or three waves per
+// SIMD -- k_static_views, k_dynamic_views, k_selftest), mlp_layer_b6_duo (three-slot ring with a mid-chunk barrier, two output tiles interleaved, A
+// fragments four pairs ahead: the kernels that run ONE wave per SIMD -- k_motion_mlp, k_net_points) and mlp_layer_b6_lds (weights resident in LDS,
+// no ring: k_static_blend, whose 104 KiB of weights fit).
 #pragma once
 #include <utility>
 
