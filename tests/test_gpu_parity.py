@@ -170,15 +170,17 @@ def test_module_helper_exports(dev, golden_dir, name):
 
 
 def test_fp32_class_engine_build(dev):
-  """libdynibar_hip_x6.so (6-term bf16 split, fp32-class products): engine self-test at 2e-6 and static net parity, in a subprocess
-  because a process binds one library."""
+  """libdynibar_hip_x6.so (6-term bf16 split, fp32-class products): engine self-test at 2e-6, static net parity, and -- the interleaved layer loop
+  with six partial products per pair (k_motion_mlp) beside the round-3 loop (k_net_points keeps it in this build) -- MotionMLP and the dynamic
+  net, in a subprocess because a process binds one library."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   lib = os.path.join(root, 'dynibar_amd', 'csrc', 'libdynibar_hip_x6.so')
   assert os.path.exists(lib), 'python -m dynibar_amd.build builds both engine variants'
   code = ("import sys; sys.path[:0] = [%r, %r]; import parity; from dynibar_amd import _lib; assert _lib.lib().dyn_mlp_split_terms() == 6; "
-          "parity.check_mlp_selftest('cuda:0', 500); e = parity.check_static_net('cuda:0', 'small', S=64); print('ok', e)") % (root, os.path.join(root, 'tests'))
+          "parity.check_mlp_selftest('cuda:0', 500); e = parity.check_static_net('cuda:0', 'small', S=64); "
+          "parity.check_motion('cuda:0', 'small', S=64); parity.check_dynamic_net('cuda:0', 'small', S=64, shift=5.0); print('ok', e)") % (root, os.path.join(root, 'tests'))
   r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DYNIBAR_HIP_LIB=lib), capture_output=True, text=True, timeout=600)
   assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
 
