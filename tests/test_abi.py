@@ -76,3 +76,39 @@ def test_product_package_does_not_import_the_oracle():
       if f.endswith(('.py', '.hip', '.h')):
         text = open(os.path.join(dirpath, f)).read()
         assert 'import oracle' not in text and 'from oracle' not in text and '/root/reference' not in text, f'{f} reaches for test infrastructure'
+
+
+def test_cross_axis_quirk_shapes_are_refused_not_misrendered():
+  """render_ray.py:375,392 call torch.cross without dim: with exactly 3 views or 3 samples the reference crosses over that axis.  The kernels never
+  do, so those shapes raise; a 3-ray chunk (the possible tail of a frame) is rendered with the intended cross product behind a warning."""
+  import warnings
+  from dynibar_amd import ops
+  ops.check_cross_axis_quirk(4096, 64, 8)  # shipped shapes pass silently
+  with pytest.raises(ValueError, match='torch.cross'):
+    ops.check_cross_axis_quirk(16, 3, 8)
+  with pytest.raises(ValueError, match='torch.cross'):
+    ops.check_cross_axis_quirk(16, 64, 3)
+  ops._CROSS_WARNED.clear()
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    ops.check_cross_axis_quirk(3, 64, 8)
+    ops.check_cross_axis_quirk(3, 64, 8)  # once per process
+  assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == 1
+
+
+def test_state_dict_encoder_source_with_trainable_tensors_takes_the_training_form():
+  """feature_network.ResNet wrapping a {name: tensor} source: tensors that require grad make the call carry a graph (train_encoder), like a module's
+  parameters do -- it must not silently run the forward-only kernels and leave the optimizer's tensors without gradients."""
+  from dynibar_amd import feature_network, synthetic as syn
+  sd = {k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(0).items()}
+  net = feature_network.ResNet.from_module(sd)
+  assert net._trains() is False
+  for v in sd.values():
+    v.requires_grad_(True)
+  assert net._trains() is True
+  with torch.no_grad():
+    assert net._trains() is False
+  k0 = net._state()[1]
+  with torch.no_grad():
+    next(iter(sd.values())).add_(1.0)  # an optimizer step on the source changes the packing key
+  assert net._state()[1] != k0
