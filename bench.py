@@ -44,8 +44,8 @@ KIND = {0: 'native fp32 MFMA', 1: 'bf16', 2: 'f16'}
 
 
 def split_peak(terms):
-  """Matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs: the network kernels multiply fp32 operands as exact sums of 16-bit parts and keep
-  `terms` partial products per product on the 16-bit matrix pipe (csrc/dyn_mlp.h), so the ceiling is the dense 16-bit peak / terms
+  """Matrix-pipe ceiling for ALGORITHMIC fp32 FLOPs: the network kernels split every fp32 operand into 16-bit parts (two half floats = 22 mantissa bits
+  in the shipped engine, three bf16 = all 24 in the 6-term build) and keep `terms` partial products per product on the 16-bit matrix pipe (csrc/dyn_mlp.h), so the ceiling is the dense 16-bit peak / terms
   (0 = the native fp32 MFMA engine)."""
   return FP32_MFMA_PEAK_TFLOPS if terms == 0 else HALF_MFMA_PEAK_TFLOPS / terms
 
@@ -159,6 +159,14 @@ def pmc_clock(a):
     return None, note
   v = got['k_static_views']
   return {'grbm_gui_active': v.get('GRBM_GUI_ACTIVE'), 'mfma_busy_cycles': v.get('SQ_VALU_MFMA_BUSY_CYCLES'), 'avg_us_under_profiler': v.get('avg_us')}, note
+
+
+def pmc_insts(a):
+  """Instruction mix of the network kernels from one more --pmc child: SQ_INSTS_VALU counts every VALU-class instruction a wave issued (MFMAs included),
+  SQ_INSTS_MFMA the matrix instructions, SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE how much of the launch the shader engines had waves resident (the slow-state
+  diagnostic of the one-workgroup-per-CU kernels: DESIGN.md section 5)."""
+  got, note = pmc_traffic(a, counters=('SQ_INSTS_VALU SQ_INSTS_MFMA', 'SQ_BUSY_CYCLES GRBM_GUI_ACTIVE'), raw=True)
+  return got, note
 
 
 def pmc_traffic(a, counters=('FETCH_SIZE', 'WRITE_SIZE'), raw=False):
@@ -711,7 +719,14 @@ def main():
   net_tflops = static_net_flops_per_point(S, V) * R * S / (net_ms * 1e-3) / 1e12
   pg = kernels['k_project_gather']
   pg_bytes = gather_bytes(R, S, V)
-  engine = 'f32' if terms == 0 else f'f32 ({KIND[kind]}x{terms} split-product MFMA: fp32 operands as exact sums of {KIND[kind]} parts, f32 accumulate)'
+  if terms == 0:
+    engine = 'f32'
+  elif kind == 2:
+    engine = ('f32 in / f32 accumulate; products from two half-float parts per operand (22-bit operands, 3 of the 4 partial products on the f16 matrix pipe, '
+              '~2^-20 relative per product); the exact 6-term bf16 build is tested beside it')
+  else:
+    engine = f'f32 in / f32 accumulate; products from {"three" if terms == 6 else "two"} bf16 parts per operand, {terms} partial products on the bf16 matrix pipe'
+
 
   traffic, traffic_note, clock = None, 'skipped (--no-traffic)', None
   if not a.no_traffic and world == 1:
@@ -724,6 +739,72 @@ def main():
                'note': 'k_static_views under the profiler: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs). '
                        'The 2500 TFLOP/s dense peak assumes 2.4 GHz; frac_at_effective_clock rescales it to the clock the power budget allowed'}
   tr = lambda k: (traffic[k]['bytes'] if traffic and k in traffic else None)
+  insts = None
+  if not a.no_traffic and world == 1:
+    insts, _ = pmc_insts(a)
+  # VALU work per matrix instruction of the dominant kernel -- the lever DESIGN.md section 4 names (the chain sits at its issue bound): tracked per run
+  mfma_static = 894 * (R * S * V // 32) if V == 8 else None  # MFMAs per launch from the ISA: 894 per wave of 32 point-views (8-view flavour)
+  if clock is not None and insts and 'k_static_views' in insts:
+    iv = insts['k_static_views']
+    n_valu, n_mfma = iv.get('SQ_INSTS_VALU'), iv.get('SQ_INSTS_MFMA') or mfma_static
+    if n_valu and n_mfma:
+      non_mfma = n_valu - n_mfma if n_valu > n_mfma else n_valu
+      clock.update(valu_insts_per_launch=n_valu, mfma_insts_per_launch=n_mfma, valu_per_mfma=non_mfma / n_mfma, valu_per_product_triple=3.0 * non_mfma / n_mfma,
+                   valu_note='SQ_INSTS_VALU (VALU-class instructions issued, matrix instructions included) and SQ_INSTS_MFMA (or, if that counter is '
+                             'unavailable, 894 MFMAs per wave from the ISA) per launch; valu_per_product_triple = non-matrix VALU per three partial products')
+
+  # secondary rooflines live INSIDE `roofline` so that a driver which keeps only that object still carries them
+  def hbm_obj(kernel, nbytes, ms, traffic_bytes=None, **kw):
+    o = {'kernel': kernel, 'bound': 'hbm', 'achieved': nbytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+         'frac': nbytes / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes, 'traffic': traffic_bytes}
+    o.update(kw)
+    return o
+
+  secondary = {'project_gather_v8': hbm_obj('k_project_gather_tile', pg_bytes, pg['avg_ms'], tr('k_project_gather_tile'),
+                                            note='north_star target: >= 0.50 of the HBM roofline on the fused projection / gather kernel')}
+  k11 = (extra.get('views_11') or {}).get('kernels_avg_ms') or {}
+  if 'k_project_gather' in k11:
+    secondary['project_gather_v11'] = hbm_obj('k_project_gather_tile', gather_bytes(R, S, 11), k11['k_project_gather'],
+                                              note='the same kernel at the 11 static views of the Nvidia eval (extra.views_11)')
+  if 'k_static_blend' in kernels:
+    # compulsory bytes of the blend: per point-view the parked x (512), vis (4), the source colour (12), ray_diff (16), mask (4); per point the
+    # point part of rgb_fc.0 (512) in, rgb out (12)
+    blend_bytes = R * S * V * (512 + 4 + 12 + 16 + 4) + R * S * (512 + 12)
+    secondary['static_blend'] = hbm_obj('k_static_blend_ws', blend_bytes, kernels['k_static_blend']['avg_ms'],
+                                        tr('k_static_blend_ws') or tr('k_static_blend'),
+                                        note='streams the parked per-view feature x back in: HBM-bound; the plain-copy ceiling of the part is ~6.3 TB/s')
+  secondary['static_net'] = {'kernels': 'k_static_ref_feat + k_static_views + k_static_points + k_static_blend', 'bound': 'mfma', 'achieved': net_tflops, 'peak': peak,
+                             'unit': 'TFLOP/s', 'frac': net_tflops / peak, 'avg_ms': net_ms, 'frac_vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS}
+
+  # the two-state behaviour of the one-workgroup-per-CU kernels: their time against what their FLOPs predict from the fast state
+  # (k_net_points<static>: 0.285 of the split ceiling, k_motion_mlp: 0.51, both read at ~2.0 GHz), rescaled to this run's clock; > 1.25 x = slow state
+  sclk = None
+  try:
+    sclk = float(np.mean(extra['power_under_step_loop']['shader_clock_mhz'])) / 1e3
+  except Exception:
+    pass
+  clk_scale = (2.0 / sclk) if sclk else 1.0
+  state = {'what': 'one-workgroup-per-CU kernels against their fast-state expectation (FLOPs / (fast-state fraction x split-MFMA ceiling), rescaled by 2.0 GHz / '
+                   'measured shader clock); slow_state = observed > 1.25 x expected: a co-tenant holding registers / LDS on the CUs, not a regression of the code',
+           'shader_clock_ghz': sclk}
+  if 'k_static_points' in kernels:
+    fl = (0.361e6 + 0.033e6 * (S / 64.0)) * R * S
+    exp_us = fl / (0.285 * peak * 1e12) * 1e6 * clk_scale
+    obs_us = kernels['k_static_points']['avg_ms'] * 1e3
+    state['k_net_points'] = {'observed_us': obs_us, 'expected_us': exp_us, 'ratio': obs_us / exp_us, 'slow_state': bool(obs_us > 1.25 * exp_us),
+                             'vs_k_static_views': obs_us / (dom['avg_ms'] * 1e3)}
+  fkm = ((extra.get('frame_nvi_288x512') or {}).get('kernel_ms_per_frame_rank0') or {})
+  if 'k_motion_mlp' in fkm and world == 1:
+    fl = 1.062e6 * 147456 * (64 + 128) * 1.0  # motion MLP FLOPs per frame: every coarse + fine sample point once
+    exp_ms = fl / (0.51 * peak * 1e12) * 1e3 * clk_scale
+    state['k_motion_mlp'] = {'observed_ms_per_frame': fkm['k_motion_mlp'], 'expected_ms_per_frame': exp_ms, 'ratio': fkm['k_motion_mlp'] / exp_ms,
+                             'slow_state': bool(fkm['k_motion_mlp'] > 1.25 * exp_ms)}
+  if insts:
+    for kn in ('k_net_points', 'k_static_views'):
+      iv = insts.get(kn) or {}
+      if iv.get('SQ_BUSY_CYCLES') and iv.get('GRBM_GUI_ACTIVE'):
+        state.setdefault('sq_busy_over_gui_active', {})[kn] = iv['SQ_BUSY_CYCLES'] / iv['GRBM_GUI_ACTIVE']
+  state['any_slow'] = any(isinstance(v, dict) and v.get('slow_state') for v in state.values())
 
   res = {
       'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps,
@@ -736,20 +817,26 @@ def main():
       'roofline': {'kernel': 'k_static_views', 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                    'frac': achieved / peak, 'traffic': tr('k_static_views'), 'traffic_note': traffic_note, 'avg_launch_ms': dom['avg_ms'],
                    'algorithmic_flops_per_launch': flops_launch,
-                   'peak_note': f'fp32 operands as exact sums of two {KIND[kind]} parts, {terms} partial products per product on the 16-bit matrix pipe, fp32 '
-                                f'accumulation: peak = 2500 TFLOP/s dense / {terms}; against the native fp32 MFMA peak (157.3 TFLOP/s) see frac_vs_fp32_mfma_peak',
+                   'peak_note': f'fp32 operands split into {KIND[kind]} parts (two per operand in the shipped engine: 22 mantissa bits, activations by truncation), {terms} '
+                                f'partial products per product on the 16-bit matrix pipe, fp32 accumulation: ceiling for ALGORITHMIC fp32 FLOPs = 2500 TFLOP/s dense / {terms}; '
+                                'against the native fp32 MFMA peak (157.3 TFLOP/s) see frac_vs_fp32_mfma_peak',
                    'frac_vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS, 'clock': clock,
-                   'frac_at_effective_clock': (achieved / (peak * clock['effective_shader_clock_ghz'] / 2.4)) if clock else None},
-      'roofline_static_net': {'bound': 'mfma', 'achieved': net_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': net_tflops / peak, 'avg_ms': net_ms,
-                              'frac_vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS},
-      'roofline_project_gather': {'kernel': 'k_project_gather_tile', 'bound': 'hbm', 'achieved': pg_bytes / (pg['avg_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
-                                  'unit': 'GB/s', 'frac': pg_bytes / (pg['avg_ms'] * 1e-3) / (HBM_PEAK_GBPS * 1e9), 'avg_launch_ms': pg['avg_ms'],
-                                  'algorithmic_bytes_per_launch': pg_bytes, 'traffic': tr('k_project_gather_tile')},
+                   'frac_at_effective_clock': (achieved / (peak * clock['effective_shader_clock_ghz'] / 2.4)) if clock else None,
+                   'secondary': secondary, 'state': state,
+                   'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()}},
+      'cpu_baseline': None,  # (filled below; kept in front of the long `extra` object)
+      'check_vs_oracle': None,
+      'multi_gpu': multi,
+      'roofline_static_net': secondary['static_net'],
+      'roofline_project_gather': secondary['project_gather_v8'],
       'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()},
       'traffic_per_launch': traffic,
-      'multi_gpu': multi,
       'extra': extra,
   }
+  if multi is not None and world == 1:
+    multi['note'] = ('ONE rank: the collective path (RCCL all-gather per step, tiled frame) ran with a process group of one; two or more ranks on RCCL have '
+                     'only run under gloo on CPU (tests/test_distributed_cpu.py) -- the id broadcast, unequal tiles and deferred-entry collectives meet RCCL '
+                     'with N > 1 for the first time on the driver\'s node')
 
   if a.cpu_rays > 0 and world == 1:
     # the oracle (test infrastructure) is used here ONLY as the timed CPU baseline and as the checker of this run's pixels

@@ -31,18 +31,31 @@ struct Rccl {
   bool ok;
 };
 
-void* rccl_symbol(const char* name) {
-  void* p = dlsym(RTLD_DEFAULT, name);
-  if (p) return p;
-  static void* handle = nullptr;
-  if (!handle) {
+// ONE source for the whole table: a communicator is only valid inside the library instance that made it, so the entry points must not mix two
+// RCCL copies (a host that exposes only part of NCCL globally, a preloaded shim).  If ncclAllGather is already visible in the process image, the
+// library that defines it is found with dladdr and re-opened with RTLD_NOLOAD, and every symbol comes from that handle; otherwise every symbol
+// comes from the librccl this file opens itself.
+void* rccl_handle() {
+  static void* handle = [] () -> void* {
+    if (void* p = dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+      Dl_info info;
+      if (dladdr(p, &info) && info.dli_fname) {
+        if (void* h = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD)) return h;
+      }
+    }
     const char* env = getenv("DYNIBAR_RCCL_LIB");
     const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
-      if (n && (handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!n) continue;
+      if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return h;
     }
-  }
-  return handle ? dlsym(handle, name) : nullptr;
+    return nullptr;
+  }();
+  return handle;
+}
+void* rccl_symbol(const char* name) {
+  void* h = rccl_handle();
+  return h ? dlsym(h, name) : nullptr;
 }
 
 const Rccl& rccl() {

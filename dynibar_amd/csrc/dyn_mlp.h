@@ -378,12 +378,75 @@ struct WeightRing6 {
   int next, total;
   int skip_at, skip_n;  // chunks [skip_at, skip_at + skip_n) of the stream are not ring traffic (their user reads them straight from global)
   int round;            // floats moved by the whole workgroup per DMA instruction (threads * 4)
+  int half;             // wave-uniform (SGPR): 0 for waves 0-3 of the workgroup, 1 for waves 4-7 (the SIMD partners)
+  // spread DMA (B6_DMA_SPREAD, round 5): the pieces of chunk `fill` go out one at a time between the MFMAs of the chunk before it
+  unsigned lds_wave;    // LDS byte address of this wave's slice of buffer 0 (+ 512 floats), wave-uniform (an SGPR)
+  unsigned lane_off;    // byte offset, from the start of a chunk, of this lane's 16 bytes of the wave's slice (+ 512 floats)
+  int fill, issued;     // chunk being requested (-1: none) and how many of this wave's pieces of it have gone out
   int nbuf;             // 2: double buffer (chunk c + 1 streams in under chunk c); 1: one 48 KiB buffer (several small workgroups per CU
                         // hide each other's exposed DMA instead)
 #ifdef DYN_PHASE_TIMING
   int kid;
 #endif
 };
+
+__device__ __forceinline__ void ring6_prio_static(const WeightRing6& R);  // (issue-priority forms: see B6_PRIO_MODE below)
+
+// Round 5: WHERE the two-slot ring's LDS-DMA goes out.  Rounds 1-4 requested the whole next chunk right behind the chunk barrier: all eight
+// waves of the workgroup issue their six 1 KiB pieces at the same moment, the L2 -> LDS path takes one piece per ~37 cycles (48 KiB per ~1800
+// cycles, tools/motionbench.py `dmaonly`), the request queue backs up and every wave -- both waves of every SIMD, they have just left the same
+// barrier -- stands at its `global_load_lds` until its pieces are accepted.  Timing-only builds of k_static_views<8> (tools/experiments/r05_gpu_calls,
+// call 2 and 3): no ring at all 1451 us, the barrier alone 1518, the DMA without the barrier 1868-1877, everything 1798-1873: the barrier costs
+// nothing, the burst costs 19 %.  B6_DMA_SPREAD = 1: ring6_acquire only opens the window (fill = c + 1); the layer loop hands out one piece at a
+// time between the MFMAs of the first two thirds of chunk c (ring6_feed), SGPR base + 32-bit lane offset as in the three-slot ring.
+#ifndef B6_DMA_SPREAD
+#define B6_DMA_SPREAD 1
+#endif
+#ifndef B6_DMA_WINDOW_NUM  /* the pieces go out over the first NUM / DEN of the chunk's pairs */
+#define B6_DMA_WINDOW_NUM 2
+#define B6_DMA_WINDOW_DEN 3
+#endif
+template <int OFF>
+__device__ __forceinline__ void b6_dma_piece(const float* g_uniform, unsigned lane_off, unsigned l, float* l_emu) {
+#if defined(__AMDGCN__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
+#pragma clang diagnostic pop
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g_uniform + lane_off),
+                                   (__attribute__((address_space(3))) void*)l_emu, 16, OFF, 0);
+#endif
+}
+__device__ __forceinline__ int ring6_pieces(const WeightRing6& R) { return B6_CHUNK / R.round; }  // 1 KiB pieces per wave and chunk (6 at 8 waves)
+// piece k of this wave's slice of chunk R.fill
+__device__ __forceinline__ void ring6_piece(const WeightRing6& R, int k) {
+  const int waves = R.round / 256, per_wave = B6_CHUNK / waves;
+  const int grp = k / 6, i = k % 6;
+  const int chunk = R.fill;
+  const float* gu = R.gbase + (long)(chunk + (chunk >= R.skip_at ? R.skip_n : 0)) * B6_CHUNK + grp * 1536;
+  const int slot = R.nbuf == 2 ? (chunk & 1) : 0;
+  const unsigned l = R.lds_wave + (unsigned)((slot * B6_CHUNK + grp * 1536) * sizeof(float));
+  float* le = R.buf + slot * B6_CHUNK + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
+  if (i == 0) b6_dma_piece<-2048>(gu, R.lane_off, l, le);
+  if (i == 1) b6_dma_piece<-1024>(gu, R.lane_off, l, le);
+  if (i == 2) b6_dma_piece<0>(gu, R.lane_off, l, le);
+  if (i == 3) b6_dma_piece<1024>(gu, R.lane_off, l, le);
+  if (i == 4) b6_dma_piece<2048>(gu, R.lane_off, l, le);
+  if (i == 5) b6_dma_piece<3072>(gu, R.lane_off, l, le);
+}
+// pair `pr` of the `npc` pairs of the chunk being consumed: pieces of the next chunk due by now (all of them by two thirds of the chunk, so that
+// the last one has a third of a chunk to land before the barrier that publishes it)
+__device__ __forceinline__ void ring6_feed(WeightRing6& R, int pr, int npc) {
+#if B6_DMA_SPREAD
+  if (R.fill < 0) return;
+  const int n = ring6_pieces(R);
+  const int den = (B6_DMA_WINDOW_NUM * npc + B6_DMA_WINDOW_DEN - 1) / B6_DMA_WINDOW_DEN > 0 ? (B6_DMA_WINDOW_NUM * npc + B6_DMA_WINDOW_DEN - 1) / B6_DMA_WINDOW_DEN : 1;
+  int want = (n * (pr + 1) + den - 1) / den;
+  if (want > n) want = n;
+  for (; R.issued < want; ++R.issued) ring6_piece(R, R.issued);
+#endif
+}
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
   // Every wave moves one contiguous slice of the chunk (6 KiB at 8 waves, 12 KiB at 4) as 1 KiB pieces.  The instruction's immediate
@@ -432,7 +495,26 @@ __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, 
   R.skip_n = skip_n;
   R.round = (threads > 0 ? threads : (int)blockDim.x) * 4;
   R.nbuf = nbuf;
+#if defined(__AMDGCN__)
+  R.half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+#else
+  R.half = (int)threadIdx.x >> 8;
+#endif
+  {
+    const int waves = R.round / 256, per_wave = B6_CHUNK / waves;
+#if defined(__AMDGCN__)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    R.lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + wave * per_wave + 512);
+#else
+    const int wave = (int)threadIdx.x >> 6;
+    R.lds_wave = 0;
+#endif
+    R.lane_off = (unsigned)((wave * per_wave + 512 + (threadIdx.x & 63) * 4) * sizeof(float));
+  }
+  R.fill = -1;
+  R.issued = 0;
   DYN_PHASE_RING_KID(R, 0);
+  ring6_prio_static(R);
   ring6_issue(R, 0);
 }
 __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
@@ -449,6 +531,22 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
     DYN_PHASE_WAIT(R, c);
     return R.buf;
   }
+#if B6_EXP_NO_RING == 1
+  { const int c = R.next++; return R.buf + (c & 1) * B6_CHUNK; }
+#elif B6_EXP_NO_RING == 2  // the barrier alone: no DMA, no wait for it
+  { __builtin_amdgcn_s_barrier(); const int c = R.next++; return R.buf + (c & 1) * B6_CHUNK; }
+#elif B6_EXP_NO_RING == 3  // the DMA and the wait for the wave's own pieces, no barrier
+  { __builtin_amdgcn_s_waitcnt(0x0F70); const int c = R.next++; if (c + 1 < R.total) ring6_issue(R, c + 1); return R.buf + (c & 1) * B6_CHUNK; }
+#elif B6_EXP_NO_RING == 4  // the DMA alone: issued, never waited for, no barrier
+  { const int c = R.next++; if (c + 1 < R.total) ring6_issue(R, c + 1); return R.buf + (c & 1) * B6_CHUNK; }
+#endif
+#if B6_DMA_SPREAD
+  if (R.fill >= 0) {  // whatever the consumer of the previous chunk did not hand out itself (a layer loop that feeds leaves nothing here)
+    const int n = ring6_pieces(R);
+    for (; R.issued < n; ++R.issued) ring6_piece(R, R.issued);
+    R.fill = -1;
+  }
+#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #ifdef DYN_PHASE_SKEW
   const unsigned long long skew_t1 = __builtin_readcyclecounter();
@@ -465,7 +563,12 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   }
 #endif
   DYN_PHASE_WAIT(R, c);
+#if B6_DMA_SPREAD
+  R.fill = c + 1 < R.total ? c + 1 : -1;  // the window of chunk c + 1 opens: its slot (chunk c - 1's) is free behind this barrier
+  R.issued = 0;
+#else
   if (c + 1 < R.total) ring6_issue(R, c + 1);
+#endif
   return R.buf + (c & 1) * B6_CHUNK;
 }
 
@@ -480,18 +583,52 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
 #ifndef B6_SPREAD
 #define B6_SPREAD 0
 #endif
+#ifndef B6_SPLIT_ONE_ASM
+#define B6_SPLIT_ONE_ASM 0  /* round 5, measured: -310 s_nop in the view chain, time unchanged; k_static_blend_ws 361 -> 383 us (the two parts no longer spread) */
+#endif
 #ifndef B6_PRIO_STATIC
 #define B6_PRIO_STATIC 0
 #endif
 #ifndef B6_PRIO_FLIP
 #define B6_PRIO_FLIP 2
 #endif
-// the two waves of a SIMD (wave w and w + 4 of an 8-wave workgroup) take turns at the higher issue priority
+// Round 5: what those builds really executed.  The condition `(threadIdx.x >> 8) ^ phase` is a per-lane value to hipcc, so the if / else
+// became an exec-masked region WITHOUT a branch -- s_and_saveexec, s_xor, `s_setprio a`, s_andn2_saveexec, `s_setprio b`, s_or: scalar
+// instructions ignore the exec mask, both s_setprio ran in every wave and the second one won.  Every wave therefore toggled its priority
+// by PROGRAM POSITION (0 after even flip sites, 1 after odd ones) -- no wave-pair alternation, no static half ever existed -- at six
+// scalar instructions and two exec hazards per site (864 of the view chain's 9323 instructions).  B6_PRIO_MODE names the forms:
+//   0  no priority changes
+//   1  position toggle: one unconditional `s_setprio (site & 1)` per flip site (what rounds 3-4 shipped, minus the exec-mask junk)
+//   2  wave-pair alternation proper (the condition in an SGPR, a scalar branch)
+//   3  static: the younger half (waves 4-7) at priority 1 from the start, no flips      4: the older half
+//   5  the exec-masked form itself, bit for bit as rounds 3-4 shipped it
+// Measured in round 5 (tools/abbench.py, k_static_views<8> us / frame ms, same box, alternating processes; gpurun_out/r5c1_ab.txt, r5c4, r5c5): mode 5 1705 /
+// 699.8, mode 1 1721 / 703.7, mode 0 1723 / 704.9, mode 2 1712 / 704.1, mode 3 1737 / 705.4, mode 4 1721 / 704.6 -- issue priority does not move this
+// kernel in any form, and the 864 scalar instructions of mode 5 are free (a wave's scalar issue is not what it waits for); the junk even measures
+// 1-2 % FASTER than its clean equivalents in every session (1871 vs 1907 on another box), so it stays.
+#ifndef B6_PRIO_MODE
+#define B6_PRIO_MODE 5
+#endif
 __device__ __forceinline__ void ring6_prio_flip(const WeightRing6& R, int phase) {
 #if defined(__AMDGCN__)
   if (R.round != 8 * 256) return;
+#if B6_PRIO_MODE == 1
+  if (phase & 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#elif B6_PRIO_MODE == 5
+  // the form rounds 3-4 shipped, kept bit for bit: a per-lane condition, hence the exec-masked region in which BOTH s_setprio execute
   if ((((int)threadIdx.x >> 8) ^ phase) & 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
+#elif B6_PRIO_MODE == 2
+  if ((R.half ^ phase) & 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+}
+__device__ __forceinline__ void ring6_prio_static(const WeightRing6& R) {
+#if defined(__AMDGCN__) && (B6_PRIO_MODE == 3 || B6_PRIO_MODE == 4)
+  if (R.round != 8 * 256) return;
+  if (R.half == (B6_PRIO_MODE == 3 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
 #endif
 }
 
@@ -504,9 +641,15 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 #if defined(__AMDGCN__)
   // three instructions per pair: the mixed-precision fma reads the half part, subtracts it from the fp32 value exactly and writes the
   // residual as a half (round to nearest) straight into its slot of the packed register
+  // (ONE asm statement: between two statements hipcc puts an `s_nop 0` -- 310 of them in the view chain)
   unsigned m;
+#if B6_SPLIT_ONE_ASM
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(m) : "v"(hi), "v"(a), "v"(b));
+#else
   asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(hi), "v"(a));
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(hi), "v"(b));
+#endif
   mid = m;
 #else
   const float ra = a - (float)h[0], rb = b - (float)h[1];
@@ -529,7 +672,23 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 #endif
 }
 
+// timing-only decomposition builds of the two-wave layer loop (round 5, tools/experiments/r05_gpu_calls; results are garbage with any of them):
+//   B6_EXP_NO_MFMA   the matrix instructions are dropped (their operands stay live): what everything else costs
+//   B6_EXP_NO_LDSA   no LDS reads of the A fragments          B6_EXP_NO_RING   no chunk barriers, no LDS-DMA after the first chunk
+#ifndef B6_EXP_NO_MFMA
+#define B6_EXP_NO_MFMA 0
+#endif
+#ifndef B6_EXP_NO_LDSA
+#define B6_EXP_NO_LDSA 0
+#endif
+#ifndef B6_EXP_NO_RING
+#define B6_EXP_NO_RING 0
+#endif
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {  // the split engine's MFMA (bf16 or half parts)
+#if B6_EXP_NO_MFMA && defined(__AMDGCN__)
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+#endif
 #if DYN_SPLIT_F16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 #else
@@ -549,6 +708,13 @@ struct B6A {
 __device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
   const u32x4v* w = reinterpret_cast<const u32x4v*>(pair) + lane;
   B6A a;
+#if B6_EXP_NO_LDSA && defined(__AMDGCN__)
+  {  // (the fragments become functions of the address only: no LDS traffic, a few VALU moves instead)
+    const unsigned v = (unsigned)(size_t)pair ^ (unsigned)lane;
+    a.hi = u32x4v{v, v + 1u, v + 2u, v + 3u}; a.mid = u32x4v{v + 4u, v + 5u, v + 6u, v + 7u}; a.lo = a.hi;
+    return a;
+  }
+#endif
   a.hi = w[0]; a.mid = w[64];
 #if DYN_SPLIT_PARTS == 3
   a.lo = w[128];
@@ -608,12 +774,10 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
       if (pr < npc) {
         const int gi = pr / NT, t = pr % NT;
         const int g = c * GPC + gi;
-#if B6_PRIO_FLIP
-        // alternate the issue priority of the two waves of a SIMD every B6_PRIO_FLIP pairs (see ring6_prio_flip)
+        ring6_feed(R, pr, npc);
+#if B6_PRIO_FLIP && (B6_PRIO_MODE == 1 || B6_PRIO_MODE == 2 || B6_PRIO_MODE == 5)
+        // issue priority every B6_PRIO_FLIP pairs (see ring6_prio_flip)
         if (pr % B6_PRIO_FLIP == 0) ring6_prio_flip(R, (pr / B6_PRIO_FLIP) & 1);
-#endif
-#if B6_PRIO_STATIC
-        if (pr == 0 && c == 0) ring6_prio_flip(R, B6_PRIO_STATIC & 1);  // 1: the older half (waves 0-3) high, 2: the younger half high
 #endif
 #if B6_SPREAD
         // B6_SPREAD: the first of the three dependent MFMAs goes out BEFORE this pair's VALU slice and the A prefetch, which then issue under it

@@ -44,7 +44,7 @@ void pack_layer(std::vector<float>& out, int NT, int NSTEPS, const SlotFn& fn) {
 }
 
 // B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
-int g_pack_chunk_pairs = B6_CHUNK_PAIRS;  // pairs per chunk of the stream being packed (the point kernels' streams use PTS_CP)
+thread_local int g_pack_chunk_pairs = B6_CHUNK_PAIRS;  // pairs per chunk of the stream being packed (the point kernels' streams use PTS_CP); per host thread: two threads may pack at once
 void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
   const int CPAIRS = g_pack_chunk_pairs, CFLOATS = CPAIRS * B6_PAIR_FLOATS;
   const int NG = (NSLOTS + 7) / 8, GPC = CPAIRS / NT, NCH = (NG + GPC - 1) / GPC;
@@ -1099,6 +1099,9 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   else
     pts_ring_init(ring, p.blob + (DYN ? DY_OFF_B : ST_OFF_B), PHASE == 1 ? SB_CHUNKS_QKV : (DYN ? DB_CHUNKS : SB_CHUNKS), lds);
   DYN_PHASE_RING_KID(ring, 1);
+  // The three-slot ring's own barrier waits for vmcnt only (ring3_barrier) and gfx950's s_barrier does not imply an LDS wait: publish the constant
+  // table to the other waves here, once per workgroup, instead of relying on the first full barrier of the attention coming before its first read.
+  lds_barrier();
 
   const int TPR = p.TPR;
   const float one_h0 = h == 0 ? 1.0f : 0.0f;

@@ -54,7 +54,7 @@ float f16_to_f32(unsigned short h) {
   memcpy(&f, &u2, 4);
   return f;
 }
-static bool g_pack_range_error = false;  // set when a weight does not fit the half-float range
+static thread_local bool g_pack_range_error = false;  // set when a weight does not fit the half-float range (per host thread: pack calls may run concurrently)
 
 
 // one weight -> the engine's parts (hi | mid | lo as 16-bit patterns)

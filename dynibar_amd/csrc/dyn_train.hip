@@ -2656,6 +2656,15 @@ __device__ __forceinline__ float tr_scan_sum(float v, int lane) {
   }
   return v;
 }
+// inclusive SUFFIX sum over the wavefront: lane l gets sum_{l' >= l} v(l')
+__device__ __forceinline__ float tr_rscan_sum(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(v, o);
+    if (lane + o < 64) v += t;
+  }
+  return v;
+}
 __device__ __forceinline__ float tr_scan_prod(float v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -2673,23 +2682,26 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(const float* __rest
   if (r >= R) return;  // (whole wavefronts)
   const float g0 = drgb ? drgb[r * 3] : 0.f, g1 = drgb ? drgb[r * 3 + 1] : 0.f, g2 = drgb ? drgb[r * 3 + 2] : 0.f;
   const float gd = ddepth ? ddepth[r] : 0.f;
-  // pass 1: total = sum_j dw_j w_j
-  float total = 0.f;
-  for (int i0 = 0; i0 < S; i0 += 64) {
-    const int i = i0 + lane;
-    float term = 0.f;
-    if (i < S) {
-      const long o = (long)r * S + i;
-      const float4 c = *reinterpret_cast<const float4*>(raw + o * 4);
-      const float dw = g0 * c.x + g1 * c.y + g2 * c.z + gd * z_vals[o] + (dweights ? dweights[o] : 0.f);
-      term = dw * weights[o];
-    }
-    total += wave_sum(term);
+  // The suffix sums  sum_{j>i} dw_j w_j  are formed DIRECTLY, walking the 64-sample blocks from the far end of the ray (round 5).  Rounds 2-4 took them
+  // as total - prefix_i: far down a ray the suffix is a small difference of two large sums, its error (~1e-7 of the TOTAL, the same accumulated
+  // rounding for neighbouring samples) is coherent along the ray, and the weight gradients of everything behind sigma -- sums over the samples --
+  // came out 3e-4 of their largest entry off at 200 samples per ray while the oracle's own fp32 autograd is at 3e-6 (tools/grad_rootcause.py).
+  // pass 1 (forward): the transmittance entering each block, parked in lane b of `Tin` for block b
+  const int nb = (S + 63) / 64;
+  float Tin = 1.0f, T_run = 1.0f;
+  for (int b = 0; b < nb; ++b) {
+    const int i = b * 64 + lane;
+    const bool ok = i < S;
+    const float a = ok ? alpha[(long)r * S + i] : 0.f;
+    const float one_m = ok ? 1.0f - a + 1e-10f : 1.0f;
+    const float incl = tr_scan_prod(one_m, lane);
+    if (lane == (b & 63)) Tin = T_run;
+    T_run *= __shfl(incl, 63);
   }
-  // pass 2: transmittance as a prefix product, suffix sums as total - prefix
-  float T_in = 1.0f, prefix_in = 0.f;
-  for (int i0 = 0; i0 < S; i0 += 64) {
-    const int i = i0 + lane;
+  // pass 2 (backward over the blocks): transmittance as a prefix product inside the block, suffix sums by a reverse scan + the carry of the later blocks
+  float suffix_in = 0.f;
+  for (int b = nb - 1; b >= 0; --b) {
+    const int i = b * 64 + lane;
     const bool ok = i < S;
     const long o = (long)r * S + (ok ? i : S - 1);
     const float4 c = *reinterpret_cast<const float4*>(raw + o * 4);
@@ -2698,23 +2710,25 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(const float* __rest
     const float one_m = ok ? 1.0f - a + 1e-10f : 1.0f;
     const float incl = tr_scan_prod(one_m, lane);
     float T = __shfl_up(incl, 1);
-    T = (lane == 0 ? 1.0f : T) * T_in;
-    const float prefix = prefix_in + tr_scan_sum(ok ? dw * w : 0.f, lane);
+    T = (lane == 0 ? 1.0f : T) * __shfl(Tin, b & 63);
+    const float sfx_incl = tr_rscan_sum(ok ? dw * w : 0.f, lane);
+    float sfx = __shfl_down(sfx_incl, 1);
+    sfx = (lane == 63 ? 0.f : sfx) + suffix_in;  // sum over the samples behind this one
     if (ok) {
-      const float dalpha = dw * T - (total - prefix) / one_m;
+      const float dalpha = dw * T - sfx / one_m;
       const float sg = c.w;
       const float sp = sg > 20.0f ? sg : log1pf(expf(sg));
       const float dist = (i == S - 1) ? 1e10f : 1.0f;
       const float dsp = dalpha * expf(-sp * dist) * dist;
       *reinterpret_cast<float4*>(draw + o * 4) = make_float4(g0 * w, g1 * w, g2 * w, sg > 20.0f ? dsp : dsp * tr_sigmoid(sg));
     }
-    T_in *= __shfl(incl, 63);
-    prefix_in = __shfl(prefix, 63);
+    suffix_in += __shfl(sfx_incl, 0);
   }
 }
 extern "C" int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
                                        const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream) {
   DYN_REQUIRE(raw && z_vals && alpha && weights && draw && R > 0 && S > 0, "dyn_train_composite_bwd: bad arguments");
+  DYN_REQUIRE(S <= 4096, "dyn_train_composite_bwd: at most 4096 samples per ray (64 blocks of 64: the per-block transmittance is parked in the lanes)");
   DYN_REQUIRE(((size_t)raw | (size_t)draw) % 16 == 0, "dyn_train_composite_bwd: raw / draw must be 16-byte aligned (float4 accesses)");
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite_bwd", k_train_composite_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw,
              z_vals, alpha, weights, drgb, ddepth, dweights, R, S, draw);
@@ -2848,46 +2862,56 @@ __global__ void __launch_bounds__(256) k_train_composite2_bwd(const float* __res
     gs[c] = g + (g_rgb_st ? g_rgb_st[r * 3 + c] : 0.f);
   }
   const float gz = g_depth ? g_depth[r] : 0.f;
-  float total = 0.f, T_in = 1.0f, prefix_in = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {  // pass 0: total = sum_i Q_i T_i; pass 1: the gradients
-    T_in = 1.0f;
-    for (int i0 = 0; i0 < S; i0 += 64) {
-      const int i = i0 + lane;
-      const bool ok = i < S;
-      const long o = (long)r * S + (ok ? i : S - 1);
-      const float4 cd = *reinterpret_cast<const float4*>(raw_dy + o * 4), cs = *reinterpret_cast<const float4*>(raw_st + o * 4);
-      float dd, ds;
-      const float ad = tr_alpha(cd.w, i == S - 1, dd), as = tr_alpha(cs.w, i == S - 1, ds);
-      const float A = 1.0f - (1.0f - as) * (1.0f - ad);
-      const float Wd = gd[0] * cd.x + gd[1] * cd.y + gd[2] * cd.z + (g_wd ? g_wd[o] : 0.f);
-      const float Ws = gs[0] * cs.x + gs[1] * cs.y + gs[2] * cs.z + (g_ws ? g_ws[o] : 0.f);
-      const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
-      const float one_m = ok ? 1.0f - A + 1e-10f : 1.0f;
-      const float incl = tr_scan_prod(one_m, lane);
-      float T = __shfl_up(incl, 1);
-      T = (lane == 0 ? 1.0f : T) * T_in;
-      const float term = ok ? (Wd * ad + Ws * as + Ww * A) * T : 0.f;
-      if (pass == 0) {
-        total += wave_sum(term);
-      } else {
-        const float prefix = prefix_in + tr_scan_sum(term, lane);
-        if (ok) {
-          const float dA = Ww * T - (total - prefix) / one_m;
-          const float dad = Wd * T + dA * (1.0f - as), das = Ws * T + dA * (1.0f - ad);
-          const float wd = ad * T, ws = as * T;
-          *reinterpret_cast<float4*>(draw_dy + o * 4) = make_float4(gd[0] * wd, gd[1] * wd, gd[2] * wd, dad * dd);
-          *reinterpret_cast<float4*>(draw_st + o * 4) = make_float4(gs[0] * ws, gs[1] * ws, gs[2] * ws, das * ds);
-        }
-        prefix_in = __shfl(prefix, 63);
-      }
-      T_in *= __shfl(incl, 63);
+  // (suffix sums formed directly from the far end of the ray, not as total - prefix: see k_train_composite_bwd)
+  const int nb = (S + 63) / 64;
+  float Tin = 1.0f, T_run = 1.0f;
+  for (int b = 0; b < nb; ++b) {  // pass 0: the transmittance entering each block, parked in lane b
+    const int i = b * 64 + lane;
+    const bool ok = i < S;
+    const long o = (long)r * S + (ok ? i : S - 1);
+    float dd, ds;
+    const float ad = tr_alpha(raw_dy[o * 4 + 3], i == S - 1, dd), as = tr_alpha(raw_st[o * 4 + 3], i == S - 1, ds);
+    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
+    const float one_m = ok ? 1.0f - A + 1e-10f : 1.0f;
+    const float incl = tr_scan_prod(one_m, lane);
+    if (lane == (b & 63)) Tin = T_run;
+    T_run *= __shfl(incl, 63);
+  }
+  float suffix_in = 0.f;
+  for (int b = nb - 1; b >= 0; --b) {  // pass 1: the gradients, blocks from the far end
+    const int i = b * 64 + lane;
+    const bool ok = i < S;
+    const long o = (long)r * S + (ok ? i : S - 1);
+    const float4 cd = *reinterpret_cast<const float4*>(raw_dy + o * 4), cs = *reinterpret_cast<const float4*>(raw_st + o * 4);
+    float dd, ds;
+    const float ad = tr_alpha(cd.w, i == S - 1, dd), as = tr_alpha(cs.w, i == S - 1, ds);
+    const float A = 1.0f - (1.0f - as) * (1.0f - ad);
+    const float Wd = gd[0] * cd.x + gd[1] * cd.y + gd[2] * cd.z + (g_wd ? g_wd[o] : 0.f);
+    const float Ws = gs[0] * cs.x + gs[1] * cs.y + gs[2] * cs.z + (g_ws ? g_ws[o] : 0.f);
+    const float Ww = gz * z_vals[o] + (g_w ? g_w[o] : 0.f);
+    const float one_m = ok ? 1.0f - A + 1e-10f : 1.0f;
+    const float incl = tr_scan_prod(one_m, lane);
+    float T = __shfl_up(incl, 1);
+    T = (lane == 0 ? 1.0f : T) * __shfl(Tin, b & 63);
+    const float term = ok ? (Wd * ad + Ws * as + Ww * A) * T : 0.f;
+    const float sfx_incl = tr_rscan_sum(term, lane);
+    float sfx = __shfl_down(sfx_incl, 1);
+    sfx = (lane == 63 ? 0.f : sfx) + suffix_in;
+    if (ok) {
+      const float dA = Ww * T - sfx / one_m;
+      const float dad = Wd * T + dA * (1.0f - as), das = Ws * T + dA * (1.0f - ad);
+      const float wd = ad * T, ws = as * T;
+      *reinterpret_cast<float4*>(draw_dy + o * 4) = make_float4(gd[0] * wd, gd[1] * wd, gd[2] * wd, dad * dd);
+      *reinterpret_cast<float4*>(draw_st + o * 4) = make_float4(gs[0] * ws, gs[1] * ws, gs[2] * ws, das * ds);
     }
+    suffix_in += __shfl(sfx_incl, 0);
   }
 }
 extern "C" int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
                                         const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R,
                                         int S, float* draw_dy, float* draw_st, void* stream) {
   DYN_REQUIRE(raw_dy && raw_st && z_vals && draw_dy && draw_st && R > 0 && S > 0, "dyn_train_composite2_bwd: bad arguments");
+  DYN_REQUIRE(S <= 4096, "dyn_train_composite2_bwd: at most 4096 samples per ray (64 blocks of 64: the per-block transmittance is parked in the lanes)");
   DYN_REQUIRE(((size_t)raw_dy | (size_t)raw_st | (size_t)draw_dy | (size_t)draw_st) % 16 == 0,
               "dyn_train_composite2_bwd: raw / draw tensors must be 16-byte aligned (float4 accesses)");
   DYN_LAUNCH(DYN_K_TRAIN_ROWS, "dyn_train_composite2_bwd", k_train_composite2_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw_dy,

@@ -286,17 +286,23 @@ _CROSS_WARNED = []
 def check_cross_axis_quirk(R, S, V):
   """The reference forms the Pluecker moments with ``torch.cross`` WITHOUT ``dim`` (render_ray.py:375, :392), which crosses over the FIRST axis of
   size 3: with exactly 3 source views or 3 samples per ray -- or, for a chunk of exactly 3 rays, over the rays -- it does not cross over xyz.  The
-  kernels (and the oracle) always cross over xyz.  No shipped configuration has 3 views or 3 samples, so those shapes are refused instead of silently
-  rendering something the reference would not; a 3-ray chunk can occur as the tail of a frame (H x W mod chunk_size == 3): it is rendered with the
-  intended cross product and a one-time warning says so."""
-  if S == 3 or V == 3:
+  kernels (and the oracle) always cross over xyz, which is what the code means.  The reference still RUNS those shapes, so a user with 3 static source
+  views must not be blocked: every such shape is rendered with the xyz cross product and a one-time RuntimeWarning says that the result differs from
+  the reference's there (a 3-ray chunk can occur as the tail of a frame: H x W mod chunk_size == 3).  ``DYNIBAR_STRICT_CROSS_QUIRK=1`` turns the
+  S == 3 / V == 3 warning into a ValueError for callers who would rather stop than diverge ("Known divergence")."""
+  if not (S == 3 or V == 3 or R == 3):
+    return
+  import os
+  if (S == 3 or V == 3) and os.environ.get('DYNIBAR_STRICT_CROSS_QUIRK', '0') == '1':
     raise ValueError(f'DynibarStatic with S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the '
-                     'first axis of size 3 for this shape, which the kernels do not reproduce (no shipped configuration uses it)')
-  if R == 3 and not _CROSS_WARNED:
+                     'first axis of size 3 for this shape, which the kernels do not reproduce (DYNIBAR_STRICT_CROSS_QUIRK=1)')
+  if not _CROSS_WARNED:
     import warnings
     _CROSS_WARNED.append(1)
-    warnings.warn('a chunk of exactly 3 rays: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the RAY axis here; '
-                  'dynibar_amd renders the intended xyz cross product', RuntimeWarning, stacklevel=3)
+    axis = 'VIEW' if V == 3 else ('SAMPLE' if S == 3 else 'RAY')
+    warnings.warn(f'R={R} rays, S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the {axis} axis '
+                  'for this shape; dynibar_amd renders the intended xyz cross product (results differ from the reference for this shape only)',
+                  RuntimeWarning, stacklevel=3)
 
 
 class StaticNet:

@@ -57,13 +57,36 @@ def _dist():
 _ABI_COMMS = {}
 
 
-def abi_communicator(dist, world, rank, device):
-  """ncclComm_t (a ctypes.c_void_p) of this package's own for dyn_gather_tiles on `device`: rank 0 draws the 128-byte id (dyn_comm_unique_id),
-  torch.distributed carries it to the other ranks, every rank joins (dyn_comm_init_rank).  One per (world, rank, device), kept for the process."""
+def _destroy_abi_comms():
+  """ncclCommDestroy for every communicator this module made (atexit, and whenever the default process group has changed): RCCL warns or hangs at
+  teardown with live communicators."""
   import ctypes
   from ._lib import call
-  key = (world, rank, device.index)
+  for key in list(_ABI_COMMS):
+    comm = _ABI_COMMS.pop(key)
+    try:
+      call('dyn_comm_destroy', comm)
+    except Exception:  # teardown: the device or RCCL may already be gone
+      pass
+
+
+def abi_communicator(dist, world, rank, device):
+  """ncclComm_t (a ctypes.c_void_p) of this package's own for dyn_gather_tiles on `device`: rank 0 draws the 128-byte id (dyn_comm_unique_id),
+  torch.distributed carries it to the other ranks, every rank joins (dyn_comm_init_rank).  One per (process group, world, rank, device): the key holds
+  the identity of the default process group, so a destroy_process_group() + re-init with other members never reuses a stale communicator (the
+  old ones are destroyed first); all of them are destroyed at interpreter exit."""
+  import ctypes
+  from ._lib import call
+  group = getattr(getattr(dist, 'group', None), 'WORLD', None)
+  key = (id(group), world, rank, device.index)
   if key not in _ABI_COMMS:
+    if _ABI_COMMS:
+      _destroy_abi_comms()  # the process group changed under us
+    else:
+      import atexit
+      if not getattr(abi_communicator, '_hooked', False):
+        atexit.register(_destroy_abi_comms)
+        abi_communicator._hooked = True
     idbuf = (ctypes.c_char * 128)()
     if rank == 0:
       call('dyn_comm_unique_id', idbuf)
@@ -299,6 +322,25 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank, count=None, eager=No
   return frame
 
 
+BALANCED_CHUNKS = os.environ.get('DYNIBAR_BALANCED_CHUNKS', 'tiled')  # 'tiled': when the frame is tiled across ranks; 'always'; 'never'
+
+
+def chunk_bounds(lo, hi, chunk_size, balanced):
+  """[(a, b)] covering [lo, hi).  The reference walks range(lo, hi, chunk_size) (render_image.py:68): a rank's tile of 18 432 rays at chunk_size 8192
+  would render as 8192 + 8192 + 2048, and the 2048-ray tail pays the full start-up of the one-workgroup-per-CU kernels for a quarter of the rays.
+  Balanced: the same NUMBER of chunks, equal sizes rounded up to 64 rays (18 432 -> 3 x 6144); results do not depend on the chunking (every ray is
+  independent: tests/test_distributed_cpu.py, the chunk-invariance GPU test), only the per-chunk lists of 4-D entries change their split points,
+  and under tiling those are rank-local already."""
+  n = hi - lo
+  if n <= 0:
+    return []
+  if not balanced or n <= chunk_size:
+    return [(i, min(i + chunk_size, hi)) for i in range(lo, hi, chunk_size)]
+  k = (n + chunk_size - 1) // chunk_size
+  size = min(chunk_size, ((n + k - 1) // k + 63) // 64 * 64)
+  return [(i, min(i + size, hi)) for i in range(lo, hi, size)]
+
+
 def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
   dist, world, rank = _dist()
   n_rays = ray_batch['ray_o'].shape[0]
@@ -307,14 +349,21 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
   if count == 0:
     lo, hi = 0, 1  # an empty tile still joins the collectives: render one placeholder ray for the key / shape structure, contribute none
   chunks = {g: [] for g in group_names}
+  balanced = BALANCED_CHUNKS == 'always' or (BALANCED_CHUNKS == 'tiled' and world > 1)
+  bounds = chunk_bounds(lo, hi, chunk_size, balanced)
   t0 = _clock() if FRAME_STATS is not None else 0.0
-  for i in range(lo, hi, chunk_size):
-    ret = render_chunk(slice_ray_batch(ray_batch, i, min(i + chunk_size, hi)))
+  chunk_ms = []
+  for a, b in bounds:
+    tc = _clock() if FRAME_STATS is not None else 0.0
+    ret = render_chunk(slice_ray_batch(ray_batch, a, b))
     for g in group_names:
       if ret.get(g) is not None:
         chunks[g].append(ret[g])
+    if FRAME_STATS is not None:
+      chunk_ms.append((_clock() - tc) * 1e3)
   if FRAME_STATS is not None:
-    FRAME_STATS.update(tile_rays=count, render_ms=(_clock() - t0) * 1e3, gather_ms=0.0, gather_bytes=0)
+    FRAME_STATS.update(tile_rays=count, render_ms=(_clock() - t0) * 1e3, gather_ms=0.0, gather_bytes=0,
+                       chunk_rays=[b - a for a, b in bounds], chunk_ms=chunk_ms)
   return chunks, n_rays, dist, world, rank, count
 
 

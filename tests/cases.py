@@ -32,6 +32,9 @@ def scene_case(name):
       # the training shape of configs/train_kid-running.txt at a size the oracle's autograd runs on the device in seconds: 64 samples,
       # 7 + 3 dynamic views at the reference and at the anchor frame, 15 static views, hundreds of rays (tests/parity.check_train_mono_large)
       'train_large': dict(seed=31, H=144, W=256, V=10, n_static=15, smooth=True, R=256),
+      # BASELINE configs[0] at its stated size: 288 x 512 images, 72 x 128 x 32 white-noise feature maps, 8 static source
+      # views, 512 rays x 64 samples -- the one named configuration whose size an oracle run affords in full (seconds)
+      'config0': dict(seed=40, H=288, W=512, V=7, n_static=8, smooth=False, R=512),
   }[name]
   R = cfg.pop('R')
   seed = cfg['seed']

@@ -403,6 +403,82 @@ def check_mlp_selftest(device, rows=1000):
   assert_close(y, ref, lim, 0.0, f'mlp engine self-test (split terms {terms}, kind {kind})')
 
 
+def check_mlp_selftest_ranges(device, rows=512):
+  """The inference engine at the edges of the half-float split's range (dyn_mlp.h: DYN_SPLIT_F16), through the same two chained 64-wide layers as the
+  self-test, against an fp64 reference:
+    * activations of 1e-6 .. 6e-5: the first part of such an operand is a SUBNORMAL half (an absolute grid of 2^-24 = 6e-8), the second part is below
+      that grid: the operand is good to +-3e-8 absolute, not to 2^-22 relative -- fp32's own epsilon at O(1), invisible next to an O(1) bias;
+    * activations of 7e4 .. 1.2e5: beyond the largest half (65504) the truncating convert saturates and the second part absorbs the rest with 11 bits:
+      the product degrades gracefully to ~2^-12 relative instead of overflowing -- up to 2 x 65504; an activation beyond 131008 overflows the second
+      part too and the result is not finite (measured in round 5: the weights of the `huge` case are scaled so that the hidden layer stays inside).
+  THE RANGE OF THE ENGINE is therefore |activation| < 65504 at full precision, < 131008 degraded, undefined beyond -- for every value that enters a
+  Linear layer, the weighted variances over the views included (features up to ~250 in magnitude).  Returns the measured errors (margin table)."""
+  import ctypes
+  from dynibar_amd import _lib
+  terms, kind = _lib.lib().dyn_mlp_split_terms(), _lib.lib().dyn_mlp_split_kind()
+  g = torch.Generator().manual_seed(3)
+  W0 = (torch.rand(64, 64, generator=g) - 0.5) * 0.4
+  b = torch.rand(64, generator=g) - 0.5
+  out = {}
+  for tag, lo, hi, wscale in (('tiny', 1e-6, 6e-5, 1.0), ('huge', 7e4, 1.2e5, 0.15)):
+    W = (W0 * wscale).contiguous()
+    mag = lo + (hi - lo) * torch.rand(rows, 64, generator=g)
+    x = mag * torch.where(torch.rand(rows, 64, generator=g) < 0.5, -1.0, 1.0)
+    xd = x.to(device)
+    y = torch.full((rows, 64), float('nan'), device=device)
+    buf = torch.zeros(2 * 3 * 4096, device=device)
+    _lib.call('dyn_mlp_selftest', ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(b.data_ptr()), _lib.ptr(xd), _lib.ptr(y), rows, _lib.ptr(buf), _lib.stream_of(xd))
+    Wd, bd = W.double(), b.double()
+    h1 = F.elu(F.linear(x.double(), Wd, bd))
+    ref = F.elu(F.linear(h1, Wd, bd))
+    scale = F.linear(h1.abs(), Wd.abs(), bd.abs())  # sum |w| |h| + |b|: what the products of the last layer are made of
+    err = (cpu(y).double() - ref).abs()
+    assert float(h1.abs().max()) < 131008.0, f'{tag}: the test itself left the stated range (hidden activation {float(h1.abs().max()):.3g})'
+    assert bool(torch.isfinite(cpu(y)).all()), f'{tag} activations: non-finite output'
+    if tag == 'tiny' or not (terms == 3 and kind == 2):
+      lim = torch.full_like(err, 3e-6) if tag == 'tiny' else 3e-6 * scale
+    else:
+      lim = 6e-4 * scale  # two half parts past the half range: 2^-11 relative on the part of the operand beyond 65504
+    record_margin(f'mlp engine, activations {lo:g}..{hi:g} (hidden up to {float(h1.abs().max()):.3g}; split terms {terms}, kind {kind}); worst relative to '
+                  f'sum|w||h| {float((err / scale).max()):.2e}', err, lim)
+    assert bool((err <= lim).all()), f'{tag} activations: max err {float(err.max()):.3e}, relative to sum|w||h| {float((err / scale).max()):.3e}'
+    out[tag] = float((err / scale).max())
+  return out
+
+
+def check_static_net_feature_range(device, scale, name='small', S=16, rtol=None):
+  """One k_static_views / k_net_points / k_static_blend pass whose gathered FEATURE channels (the 32 learned channels; colours stay in [0,1]) are scaled
+  towards the edges of the engine's range: x 3e-5 puts them at 1e-6 .. 6e-5 (subnormal first parts); x 60 puts them at up to ~250, where their weighted
+  VARIANCE over the views -- an input of base_fc.0 like any other -- reaches the largest half (6e4): the upper edge of the range in terms of features.
+  Against the oracle in fp64 on the same scaled inputs, the limit relative to the raw outputs' own magnitude plus what fp32 itself costs there."""
+  scene, o, d, sd, _, st = static_inputs(name, S)
+  rgb_feat = st['rgb_feat'].clone()
+  rgb_feat[..., 3:] *= scale
+  net_args = (sd, st['pts'], st['ref_rays_coords'], st['src_rays_coords'], rgb_feat, F.normalize(d, dim=-1), st['ray_diff'], st['mask'])
+  raw_ref = O.static_net(*net_args, True, False)
+  raw_ref64 = O.static_net({k: v.double() for k, v in sd.items()}, *[a.double() for a in net_args[1:]], True, False)
+  sdev = to_dev(scene, device)
+  views = ops.SourceViews(sdev['camera'], sdev['static_src_rgbs'], sdev['static_src_cameras'], sdev['static_featmaps'])
+  net = ops.StaticNet(_weights('init')['net_coarse_st'], device, True, False)
+  raw = cpu(net(views, o.to(device), d.to(device), st['pts'].to(device), rgb_feat.to(device), st['ray_diff'].to(device), st['mask'].to(device))).double()
+  dead = raw_ref64[..., 3] < -1e8
+  live = ~dead
+  assert bool(torch.isfinite(raw).all()), f'feature scale {scale:g}: non-finite output'
+  # fp32 oracle vs fp64 oracle = what fp32 arithmetic itself costs on these inputs; the kernels get the stated tolerance on top of it
+  own = (raw_ref.double() - raw_ref64).abs()
+  rtol = (1e-4 if scale < 1 else 2e-3) if rtol is None else rtol  # (x 60: variances of ~6e4 carry 22 bits here, 24 in the reference: measured 9e-4 on sigma)
+  sig_scale = raw_ref64[..., 3][live].abs().max().clamp(min=1.0)
+  err_rgb = (raw[..., :3] - raw_ref64[..., :3]).abs()
+  err_sig = (raw[..., 3] - raw_ref64[..., 3]).abs()[live]
+  lim_rgb = 1e-4 + (rtol if scale > 1 else 0.0) + 4 * own[..., :3]
+  lim_sig = rtol * sig_scale + 1e-4 + 4 * own[..., 3][live]
+  record_margin(f'static net, feature channels x {scale:g}: rgb', err_rgb, lim_rgb)
+  record_margin(f'static net, feature channels x {scale:g}: sigma (scale {float(sig_scale):.3g})', err_sig, lim_sig)
+  assert bool((err_rgb <= lim_rgb).all()), f'feature scale {scale:g}: rgb err {float(err_rgb.max()):.3e}'
+  assert bool((err_sig <= lim_sig).all()), f'feature scale {scale:g}: sigma err {float(err_sig.max()):.3e} of {float(sig_scale):.3g}'
+  return float(err_rgb.max()), float((err_sig / sig_scale).max())
+
+
 def dynamic_inputs(name, S, R=None, weights='init'):
   """Oracle-side stage tensors of the dynamic branch (motion MLP -> trajectory points -> projection) for a seeded scene."""
   scene, o, d, uv, _ = cases.scene_case(name)

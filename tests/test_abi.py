@@ -78,12 +78,24 @@ def test_product_package_does_not_import_the_oracle():
         assert 'import oracle' not in text and 'from oracle' not in text and '/root/reference' not in text, f'{f} reaches for test infrastructure'
 
 
-def test_cross_axis_quirk_shapes_are_refused_not_misrendered():
-  """render_ray.py:375,392 call torch.cross without dim: with exactly 3 views or 3 samples the reference crosses over that axis.  The kernels never
-  do, so those shapes raise; a 3-ray chunk (the possible tail of a frame) is rendered with the intended cross product behind a warning."""
+def test_cross_axis_quirk_shapes_warn_once_and_can_be_refused(monkeypatch):
+  """render_ray.py:375,392 call torch.cross without dim: with exactly 3 views, 3 samples or a 3-ray chunk the reference crosses over that axis.  The
+  kernels never do; the reference still runs those shapes, so they render (xyz cross product) behind a one-time RuntimeWarning, and
+  DYNIBAR_STRICT_CROSS_QUIRK=1 refuses the two shapes no frame tail can produce."""
   import warnings
   from dynibar_amd import ops
-  ops.check_cross_axis_quirk(4096, 64, 8)  # shipped shapes pass silently
+  monkeypatch.delenv('DYNIBAR_STRICT_CROSS_QUIRK', raising=False)
+  ops._CROSS_WARNED.clear()
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    ops.check_cross_axis_quirk(4096, 64, 8)  # shipped shapes pass silently
+    assert not w
+    ops.check_cross_axis_quirk(16, 64, 3)
+    ops.check_cross_axis_quirk(16, 3, 8)
+    ops.check_cross_axis_quirk(3, 64, 8)  # once per process
+  msgs = [x for x in w if issubclass(x.category, RuntimeWarning)]
+  assert len(msgs) == 1 and 'VIEW axis' in str(msgs[0].message)
+  monkeypatch.setenv('DYNIBAR_STRICT_CROSS_QUIRK', '1')
   with pytest.raises(ValueError, match='torch.cross'):
     ops.check_cross_axis_quirk(16, 3, 8)
   with pytest.raises(ValueError, match='torch.cross'):
@@ -91,9 +103,9 @@ def test_cross_axis_quirk_shapes_are_refused_not_misrendered():
   ops._CROSS_WARNED.clear()
   with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter('always')
-    ops.check_cross_axis_quirk(3, 64, 8)
-    ops.check_cross_axis_quirk(3, 64, 8)  # once per process
-  assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == 1
+    ops.check_cross_axis_quirk(3, 64, 8)  # a frame's tail chunk is never refused
+  assert len(w) == 1
+  ops._CROSS_WARNED.clear()
 
 
 def test_state_dict_encoder_source_with_trainable_tensors_takes_the_training_form():

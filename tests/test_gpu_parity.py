@@ -45,6 +45,17 @@ def test_mlp_engine(dev):
   parity.check_mlp_selftest(dev, rows=1000)
 
 
+def test_mlp_engine_at_the_edges_of_the_half_float_range(dev):
+  """activations of 1e-6..6e-5 (subnormal first parts) and 7e4..1.2e5 (saturated first parts) through the INFERENCE engine's layer loop, as the
+  training GEMM's range checks do for dyn_train_gemm; measured errors land in the margin table"""
+  parity.check_mlp_selftest_ranges(dev)
+
+
+@pytest.mark.parametrize('scale', [3e-5, 60.0])
+def test_static_net_with_features_at_the_edges_of_the_half_float_range(dev, scale):
+  parity.check_static_net_feature_range(dev, scale)
+
+
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64), dict(name='harsh', S=40, aa=False, mask_rgb=True),
                                 dict(name='noise', S=128), dict(name='small', S=32, R=3), dict(name='small', S=256, R=6), dict(name='harsh', S=160, R=5)])
 def test_static_net(dev, kw):
@@ -54,6 +65,15 @@ def test_static_net(dev, kw):
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
+
+
+def test_static_pass_at_baseline_config0_size_every_ray(dev):
+  """BASELINE configs[0] at its stated size -- 512 rays x 64 samples x 8 views, 288 x 512 images, white-noise 32-channel feature maps -- through
+  sample -> gather -> DynibarStatic -> composite (render_ray.py:1009-1071's static composition) against the oracle on EVERY ray: the kernels start
+  from the reference's own fp32 K.inv(c2w), so no ray is dropped and no projection allowance is added (rgb / weights 1e-4, depth 2e-4 relative,
+  ray mask bit-exact)."""
+  err = parity.check_static_pass(dev, 'config0', same_matrix=True)
+  assert err < 1e-4
 
 
 @pytest.mark.parametrize('name', ['small', 'harsh'])
