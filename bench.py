@@ -403,6 +403,7 @@ def main():
                        'render_ms': [round(v, 3) for v in every_rank(fst.get('render_ms', 0.0))],
                        'gather_and_copy_ms': [round(v, 3) for v in every_rank(fst.get('gather_ms', 0.0))],
                        'gather_payload_bytes_per_rank': int(fst.get('gather_bytes', 0)),
+                       'chunk_rays_rank0': fst.get('chunk_rays'), 'chunk_ms_rank0': fst.get('chunk_ms'),
                        'note': 'render_ms: the chunk loop over the rank\'s own ray tile; gather_and_copy_ms: the packed [rays,5] all-gather + the copy of the frame\'s pixels '
                                'to the host (render_image.FRAME_STATS: the device is synchronised between the two stages for this frame only)'},
           'kernel_ms_per_frame_rank0': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},

@@ -514,6 +514,9 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #ifndef PGT_UNROLL
 #define PGT_UNROLL 4
 #endif
+#ifndef PGT_ONE_BARRIER
+#define PGT_ONE_BARRIER 1  /* ray_diff / mask tiles in their own LDS (P V 20 bytes behind the feature tile): one barrier per workgroup instead of three */
+#endif
 #ifndef PGT_EXP
 #define PGT_EXP 0  /* developer decomposition builds (tools/build_variant.py): 1 no feature-tap loads, 2 no rgb_feat stores, 3 all taps from one line, 4 no RGB taps */
 #endif
@@ -619,6 +622,12 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
     normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
     rd = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
     mk = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
+#if PGT_ONE_BARRIER
+    if (v < V) {  // ray_diff / mask have their own LDS behind the feature tile: written here, they leave with the tile behind the ONE barrier
+      reinterpret_cast<float4*>(tile + P * V * C)[row] = rd;
+      (tile + P * V * C + P * V * 4)[row] = (pt < q.n_pts) ? mk : 0.0f;
+    }
+#endif
     if (v < V) {
       tile[row * C + 0] = fmaf(d.x, tt.w_se, fmaf(c.x, tt.w_sw, fmaf(b.x, tt.w_ne, a.x * tt.w_nw)));
       tile[row * C + 1] = fmaf(d.y, tt.w_se, fmaf(c.y, tt.w_sw, fmaf(b.y, tt.w_ne, a.y * tt.w_nw)));
@@ -685,6 +694,11 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
     for (int i = (nflt & ~3) + tid; i < nflt; i += nthr) nt_store1<1>(dst + i, tile[i]);
 #endif
   }
+#if PGT_ONE_BARRIER
+  // ---- ray_diff [P][V] float4 and mask [P][V]: their own LDS behind the tile (round 5: no second and third barrier, no LDS phase between the bursts) ----
+  float4* rdt = reinterpret_cast<float4*>(tile + P * V * C);
+  float* mkt = tile + P * V * C + P * V * 4;
+#else
   __syncthreads();
   // ---- ray_diff [P][V] float4 and mask [P][V] through the same LDS ----
   float4* rdt = reinterpret_cast<float4*>(tile);
@@ -694,6 +708,7 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
     mkt[row] = (pt < q.n_pts) ? mk : 0.0f;
   }
   __syncthreads();
+#endif
   {
     const int nrow = (int)npt * V;
     float4* dst4 = ray_diff + p0 * V;
@@ -747,9 +762,10 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   // 9- to 11-wave workgroup per CU measured 3-5 % faster than three 6-wave workgroups with an idle view slot (tools/k1sweep.py, round 4: 11 views 172 vs
   // 177-181 us; at 15 views the two-views-per-wave form wins, 201 vs 221 us) --, else 32 (two views per wave)
   static const int force_p = getenv("DYN_PG_P") ? atoi(getenv("DYN_PG_P")) : 0;  // developer A/B
-  const int P = force_p ? force_p : ((((size_t)64 * p->V * C * 4 <= 72 * 1024 && p->V <= 16) || (p->V >= 9 && p->V <= 11 && (size_t)64 * p->V * C * 4 <= 120 * 1024)) ? 64 : 32);
+  const int CL = C + (PGT_ONE_BARRIER ? 5 : 0);  // floats of LDS per (point, view): the feature row (+ ray_diff 4 + mask 1)
+  const int P = force_p ? force_p : ((((size_t)64 * p->V * CL * 4 <= 80 * 1024 && p->V <= 16) || (p->V >= 9 && p->V <= 11 && (size_t)64 * p->V * CL * 4 <= 120 * 1024)) ? 64 : 32);
   const int waves = (p->V * P + 63) / 64;
-  const size_t lds = (size_t)P * p->V * C * sizeof(float);
+  const size_t lds = (size_t)P * p->V * (C + (PGT_ONE_BARRIER ? 5 : 0)) * sizeof(float);
   if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);
   PGTile q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
@@ -763,7 +779,11 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   const long nblocks = 8 * q.tiles_per_xcd;
   static const int no_pref = getenv("DYN_PG_NOPREF") != nullptr;  // developer A/B
   q.pref_wgs = no_pref ? 0 : (int)(nblocks < 512 ? nblocks : 512);  // the first resident generation of workgroups (2 per CU)
-  if (P == 64)
+  if (P == 16)
+    DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<16>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
+               p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+  else if (P == 64)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<64>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
                reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);

@@ -402,6 +402,9 @@ __device__ __forceinline__ void ring6_prio_static(const WeightRing6& R);  // (is
 #ifndef B6_DMA_SPREAD
 #define B6_DMA_SPREAD 1
 #endif
+#ifndef B6_DMA_POLICY  /* cache policy of the weight pieces: "" (plain), " nt", " sc1", " sc0 sc1" */
+#define B6_DMA_POLICY ""
+#endif
 #ifndef B6_DMA_WINDOW_NUM  /* the pieces go out over the first NUM / DEN of the chunk's pairs */
 #define B6_DMA_WINDOW_NUM 2
 #define B6_DMA_WINDOW_DEN 3
@@ -411,7 +414,7 @@ __device__ __forceinline__ void b6_dma_piece(const float* g_uniform, unsigned la
 #if defined(__AMDGCN__)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" B6_DMA_POLICY ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
 #pragma clang diagnostic pop
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g_uniform + lane_off),

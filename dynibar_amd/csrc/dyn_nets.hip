@@ -126,7 +126,11 @@ enum {
 };
 
 // k-step counts / tiles of every layer (shared by the packer and the kernels)
-#define SA_L1_STEPS 52   /* ray_dir_fc.0: 45 cos|sin pairs + 7 raw pairs (13 raw inputs + bias) */
+/* ray_dir_fc.0 (round 5: in two parts).  Its 103 inputs are [PE(pts) 33 | PE(source-ray Pluecker) 66 | ray_diff 4]: the first 33 are the same for
+ * every view of a point, so their columns are applied once per point for the whole workgroup (L1P, like base_fc.0's statistics) and only the
+ * per-view columns remain per row (L1V): 5 k-groups x 8 tiles x 3 products per wave instead of 7 (-39 of 894 MFMAs, -13 of 393 weight pairs streamed). */
+#define SA_L1P_STEPS 17  /* per point: 15 cos|sin pairs of pts + (x, y), (z, -) */
+#define SA_L1V_STEPS 36  /* per view: 30 cos|sin pairs of the Pluecker coordinates + 6 raw pairs (Pluecker 6, ray_diff 4, bias, -) */
 #define SA_L2_STEPS 128  /* ray_dir_fc.2: 256 (bias = accumulator init) */
 #define SA_NX 37         /* registers holding the 70-channel per-view feature (18 gathered + 16 + 3 computed) */
 #define SA_L3_STEPS (3 * SA_NX + 1)
@@ -134,7 +138,7 @@ enum {
 #define SA_L3V_STEPS (SA_NX + 1)  /* per-view part: the 70 channels + bias */
 #define SA_L4_STEPS 128  /* base_fc.2 (bias = accumulator init) */
 #define SA_L5_STEPS 64   /* vis_fc.0 / vis_fc.2 / vis_fc2.0 */
-constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3P_STEPS) + net_layer_chunks(8, SA_L3V_STEPS) +
+constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1P_STEPS) + net_layer_chunks(8, SA_L1V_STEPS) + net_layer_chunks(2, SA_L2_STEPS) + net_layer_chunks(8, SA_L3P_STEPS) + net_layer_chunks(8, SA_L3V_STEPS) +
                           net_layer_chunks(4, SA_L4_STEPS) + 3 * net_layer_chunks(4, SA_L5_STEPS);
 // The point kernels (k_net_points) run one wave per SIMD on the interleaved layer loop with the three-slot ring (dyn_mlp.h, round 4).  Their LDS also
 // holds the ray attention's K / V images (32.5 KiB), so their weight streams are packed in chunks of PTS_CP = 16 pairs (32 KiB; 3 slots = 96 KiB,
@@ -214,18 +218,25 @@ __host__ __device__ constexpr int sa_c70(int q, int h) {
   return h == 0 ? 35 + 32 + (q - 34) : -1;
 }
 
-// reference column of ray_dir_fc.0's input for k-step s, half h  (-1: unused, -2: bias)
-static int sa_l1_col(int s, int h) {
-  if (s < 45) {
-    const int c = s / 5, fi = s % 5;  // coordinate 0..8 (pts xyz, Pluecker 6), frequency index
-    if (c < 3) return 3 + (h * 5 + fi) * 3 + c;
-    return 33 + 6 + (h * 5 + fi) * 6 + (c - 3);
+// reference column of ray_dir_fc.0's input for k-step s, half h  (-1: unused, -2: bias): the per-point part ...
+static int sa_l1p_col(int s, int h) {
+  if (s < 15) {
+    const int c = s / 5, fi = s % 5;  // coordinate of pts, frequency index
+    return 3 + (h * 5 + fi) * 3 + c;
   }
-  const int k = (s - 45) * 2 + h;  // raw list: pts(3), Pluecker(6), ray_diff(4), ONE
-  if (k < 3) return k;
-  if (k < 9) return 33 + (k - 3);
-  if (k < 13) return 99 + (k - 9);
-  return -2;
+  const int k = (s - 15) * 2 + h;  // raw list: pts(3), -
+  return k < 3 ? k : -1;
+}
+// ... and the per-view part
+static int sa_l1v_col(int s, int h) {
+  if (s < 30) {
+    const int c = s / 5, fi = s % 5;  // Pluecker coordinate 0..5, frequency index
+    return 33 + 6 + (h * 5 + fi) * 6 + c;
+  }
+  const int k = (s - 30) * 2 + h;  // raw list: Pluecker(6), ray_diff(4), ONE, -
+  if (k < 6) return 33 + k;
+  if (k < 10) return 99 + (k - 6);
+  return k == 10 ? -2 : -1;
 }
 
 extern "C" size_t dyn_static_net_blob_floats(void) { return ST_BLOB_FLOATS; }
@@ -242,8 +253,12 @@ extern "C" int dyn_static_net_pack(const float* const* T, int F, float* blob, si
   {
     const float *W = T[ST_RAYDIR0_W], *b = T[ST_RAYDIR0_B];
     // (ELU_PRE / ELU_POST: the layers whose outputs only feed ELUs hold log2(e) times their value, their consumers ln(2) -- elu_s, dyn_mlp.h)
-    pack_net_layer(o, 8, SA_L1_STEPS, scaled([=](int t, int i, int s, int h) -> float {
-      const int n = 32 * t + i, c = sa_l1_col(s, h);
+    pack_net_layer(o, 8, SA_L1P_STEPS, scaled([=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i, c = sa_l1p_col(s, h);
+      return c >= 0 ? W[n * 103 + c] : 0.f;
+    }, DYN_ELU_PRE));
+    pack_net_layer(o, 8, SA_L1V_STEPS, scaled([=](int t, int i, int s, int h) -> float {
+      const int n = 32 * t + i, c = sa_l1v_col(s, h);
       return c >= 0 ? W[n * 103 + c] : (c == -2 ? b[n] : 0.f);
     }, DYN_ELU_PRE));
   }
@@ -490,7 +505,27 @@ __device__ __forceinline__ long point_rec(const StaticArgs& p, long point, int h
 // LDS: pool [2 NX slots][2 halves][32 points], res [256 features][32 points].
 // -------------------------------------------------------------------------------------------------------------------
 #define POOL_FLOATS(NX) (2 * (NX) * 2 * 32)
-#define RES_FLOATS (256 * 32)
+// res: the per-point tiles on their way back to the rows, POINT-major [32 points][256 features + 4] (round 5; rounds 1-4: feature-major, 16 + 128 four-byte
+// LDS accesses per lane and exchange): a lane's four consecutive registers are four consecutive features, so a tile leaves in 4 and comes back in 32
+// sixteen-byte accesses; the stride of 260 floats puts the 16 lanes of a quarter-wave 4 banks apart on the way in, and on the way out the lanes of a
+// point read one address (a broadcast).
+#define RES_STRIDE 260
+#define RES_FLOATS (RES_STRIDE * 32)
+__device__ __forceinline__ void res_put(float* res, int wave, int j, int h, const f32x16& acc) {
+  float4* d = reinterpret_cast<float4*>(res + j * RES_STRIDE + wave * 32 + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[2 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+}
+__device__ __forceinline__ void res_get(const float* res, int col, int h, f32x16 (&a1)[8]) {
+  const float4* s4 = reinterpret_cast<const float4*>(res + col * RES_STRIDE + 4 * h);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = s4[t * 8 + 2 * q];
+      a1[t][4 * q] = v.x; a1[t][4 * q + 1] = v.y; a1[t][4 * q + 2] = v.z; a1[t][4 * q + 3] = v.w;
+    }
+}
 
 // ---- dense rows (VSEG == 0): any number of views without padding ------------------------------------------------------------------
 // The lane segments above want the views of a point in a power-of-two group of lanes, so 11 views occupy 16 lanes and 31 % of the
@@ -651,14 +686,10 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     f32x16 accp[1];
     acc_zero(accp);
     b6_tile_apply<2 * NX>(pw, accp[0], [&](int s) { return pool[(s * 2 + h) * 32 + j]; });
-#pragma unroll
-    for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
+    res_put(res, wave, j, h, accp[0]);
     __syncthreads();
     const int col = dr->p_local < dr->PTW ? dr->p_local : dr->PTW - 1;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[t][r] = res[(t * 32 + dyn_fi(r, h)) * 32 + col];
+    res_get(res, col, h, a1);
   } else if (VSEG >= 8) {
     static_assert(DYN_VIEW_THREADS / 64 == 8, "one output tile of base_fc.0 per wave");
     constexpr int PT = 32 / VSEG;
@@ -712,13 +743,9 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     net_layer_tile<8, 2 * NX, 1>(ring, wave, accp, [&](int, int s) { return pool[(s * 2 + h) * 32 + j]; });
 #endif
     DYN_PHASE(7);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) res[(wave * 32 + dyn_fi(r, h)) * 32 + j] = accp[0][r];
+    res_put(res, wave, j, h, accp[0]);
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[t][r] = res[(t * 32 + dyn_fi(r, h)) * 32 + col];
+    res_get(res, col, h, a1);
     DYN_PHASE(8);
   } else {
     acc_zero(a1);
@@ -925,14 +952,16 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[ST_OFF_CTA + i];
   NetRing ring;
   DYN_PHASE(0);
-  // the per-point part of base_fc.0 (VSEG >= 8) is read straight from the stream by each wave, not through the ring
-  constexpr int SA_POOLED_AT = net_layer_chunks(8, SA_L1_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
+  // the per-point layers (ray_dir_fc.0's pts columns, base_fc.0's statistics columns: VSEG >= 8 and the dense flavour) are read straight from the stream
+  // by each wave, not through the ring: the ring starts behind L1P and skips L3P.  VSEG = 4 (64 points per workgroup: the tiles do not fit the LDS)
+  // runs both as ordinary per-view layers through the ring.
+  static_assert(DYN_ENGINE_B6, "the view chain is written for the split engine");
+  constexpr bool POOLED = VSEG >= 8 || VSEG == 0;
+  constexpr int SA_L1P_CHUNKS = net_layer_chunks(8, SA_L1P_STEPS);
+  constexpr int SA_POOLED_AT = SA_L1P_CHUNKS + net_layer_chunks(8, SA_L1V_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
   constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
-#if DYN_ENGINE_B6
-  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds, SA_POOLED_AT, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
-#else
-  net_ring_init(ring, p.blob + ST_OFF_A, SA_CHUNKS, lds);
-#endif
+  net_ring_init(ring, p.blob + ST_OFF_A + (POOLED ? (size_t)SA_L1P_CHUNKS * NET_CHUNK : 0), SA_CHUNKS - (POOLED ? SA_L1P_CHUNKS : 0), lds,
+                SA_POOLED_AT - (POOLED ? SA_L1P_CHUNKS : 0), POOLED ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -956,30 +985,58 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   }
   float xin[SA_NX];
   f32x16 a1[8];
-  {
-    // Pluecker coordinates of the source ray through the sample (render_ray.py:380-396)
-    float c9[9];
-    c9[0] = px; c9[1] = py; c9[2] = pz;
-    unit3(px - cx, py - cy, pz - cz, c9[3], c9[4], c9[5]);
-    c9[6] = cy * c9[5] - cz * c9[4];
-    c9[7] = cz * c9[3] - cx * c9[5];
-    c9[8] = cx * c9[4] - cy * c9[3];
-    float in1[SA_L1_STEPS];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) octave_embed<5>(c9[c], h, in1 + c * 5);
-    // raw inputs [pts | Pluecker | ray_diff | 1], even entries to half 0, odd ones to half 1.  Written as selects between scalars: a
-    // select between two elements of a local array becomes a lane-indexed load of the array from scratch memory (64 B per lane)
-    const bool h0 = h == 0;
-    in1[45] = h0 ? c9[0] : c9[1];
-    in1[46] = h0 ? c9[2] : c9[3];
-    in1[47] = h0 ? c9[4] : c9[5];
-    in1[48] = h0 ? c9[6] : c9[7];
-    in1[49] = h0 ? c9[8] : rd.x;
-    in1[50] = h0 ? rd.y : rd.z;
-    in1[51] = h0 ? rd.w : 1.0f;
+  const bool h0 = h == 0;
+  if constexpr (POOLED) {
+    // ---- ray_dir_fc.0, per-point part: output tile `wave` for the workgroup's points (column j = the point's index in the workgroup) ----
+    B6TileW<SA_L1P_STEPS> pw1;
+    b6_tile_prefetch<8, SA_L1P_STEPS>(p.blob + ST_OFF_A, wave, pw1);
+    const int npw = VSEG == 0 ? p.PT : (DYN_VIEW_THREADS / 64) * p.PT;  // points of this workgroup
+    const long qp = (long)blockIdx.x * npw + j;
+    const bool qok = j < npw && qp < p.n_pts;
+    const float qx = qok ? p.pts[qp * 3] : 0.f, qy = qok ? p.pts[qp * 3 + 1] : 0.f, qz = qok ? p.pts[qp * 3 + 2] : 0.f;
+    float in1p[SA_L1P_STEPS];
+    octave_embed<5>(qx, h, in1p);
+    octave_embed<5>(qy, h, in1p + 5);
+    octave_embed<5>(qz, h, in1p + 10);
+    in1p[15] = h0 ? qx : qy;
+    in1p[16] = h0 ? qz : 0.f;
+    f32x16 accp[1];
+    acc_zero(accp);
+    b6_tile_apply<SA_L1P_STEPS>(pw1, accp[0], [&](int s) { return in1p[s]; });
+    float* res = ctab + SA_CT + POOL_FLOATS(SA_NX);
+    res_put(res, wave, j, h, accp[0]);
+    __syncthreads();
+    res_get(res, VSEG == 0 ? (dr.p_local < dr.PTW ? dr.p_local : dr.PTW - 1) : wave * p.PT + p_local, h, a1);
+  } else {
+    float in1p[SA_L1P_STEPS];
+    octave_embed<5>(px, h, in1p);
+    octave_embed<5>(py, h, in1p + 5);
+    octave_embed<5>(pz, h, in1p + 10);
+    in1p[15] = h0 ? px : py;
+    in1p[16] = h0 ? pz : 0.f;
     acc_zero(a1);
+    net_layer<8, SA_L1P_STEPS>(ring, a1, [&](int s) { return in1p[s]; });
+  }
+  {
+    // ---- per-view part: Pluecker coordinates of the source ray through the sample (render_ray.py:380-396), ray_diff, bias ----
+    float c6[6];
+    unit3(px - cx, py - cy, pz - cz, c6[0], c6[1], c6[2]);
+    c6[3] = cy * c6[2] - cz * c6[1];
+    c6[4] = cz * c6[0] - cx * c6[2];
+    c6[5] = cx * c6[1] - cy * c6[0];
+    float in1[SA_L1V_STEPS];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) octave_embed<5>(c6[c], h, in1 + c * 5);
+    // raw inputs [Pluecker | ray_diff | 1 | -], even entries to half 0, odd ones to half 1.  Written as selects between scalars: a
+    // select between two elements of a local array becomes a lane-indexed load of the array from scratch memory (64 B per lane)
+    in1[30] = h0 ? c6[0] : c6[1];
+    in1[31] = h0 ? c6[2] : c6[3];
+    in1[32] = h0 ? c6[4] : c6[5];
+    in1[33] = h0 ? rd.x : rd.y;
+    in1[34] = h0 ? rd.z : rd.w;
+    in1[35] = h0 ? 1.0f : 0.0f;
     DYN_PHASE(1);
-    net_layer<8, SA_L1_STEPS>(ring, a1, [&](int s) { return in1[s]; });
+    net_layer<8, SA_L1V_STEPS>(ring, a1, [&](int s) { return in1[s]; });
     DYN_PHASE(2);
   }
   {

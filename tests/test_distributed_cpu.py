@@ -231,3 +231,20 @@ def test_gradient_allreduce_two_ranks():
     assert n > 1
     for i, got in enumerate(grads):
       np.testing.assert_allclose(got, ((per_rank[0][i] + per_rank[1][i]) / 2).numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_balanced_chunks_cover_the_tile_without_a_short_tail():
+  """render_image.chunk_bounds: the reference's range(lo, hi, chunk_size) leaves a short tail chunk (18 432 rays -> 8192 + 8192 + 2048); the balanced
+  form keeps the number of chunks and evens them out (3 x 6144), covers [lo, hi) exactly once and never exceeds chunk_size"""
+  from dynibar_amd.render_image import chunk_bounds
+  assert chunk_bounds(0, 18432, 8192, False) == [(0, 8192), (8192, 16384), (16384, 18432)]
+  assert chunk_bounds(0, 18432, 8192, True) == [(0, 6144), (6144, 12288), (12288, 18432)]
+  assert chunk_bounds(5, 5, 8192, True) == []
+  assert chunk_bounds(0, 100, 8192, True) == [(0, 100)]
+  for lo, hi, cs in ((0, 147456, 8192), (36864, 55296, 8192), (7, 20011, 4096), (0, 8193, 8192), (3, 130, 64)):
+    for bal in (False, True):
+      b = chunk_bounds(lo, hi, cs, bal)
+      assert b[0][0] == lo and b[-1][1] == hi and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(0 < y - x <= cs for x, y in b)
+      assert len(b) == -(-(hi - lo) // cs)
+    sizes = [y - x for x, y in chunk_bounds(lo, hi, cs, True)]
+    assert max(sizes) - min(sizes) <= 64 + (max(sizes) - sizes[-1])  # equal up to the 64-ray rounding; only the last chunk may be shorter

@@ -35,8 +35,14 @@ for V in VIEWS:
 print('K1RESULT ' + json.dumps(out))
 '''
 views = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '7,8,11,15'.split(','))]
-for P in ('', '32', '64'):
+# optional: argv[2] = comma list of tile overrides ('' = the library's rule), argv[3] = comma list of library tags (libdynibar_hip_<tag>.so; 'base' = default)
+plist = sys.argv[2].split(',') if len(sys.argv) > 2 else ['', '32', '64']
+libs = sys.argv[3].split(',') if len(sys.argv) > 3 else ['base']
+for lib, P in [(l, q) for l in libs for q in plist]:
   env = dict(os.environ)
+  if lib != 'base':
+    env['DYNIBAR_HIP_LIB'] = os.path.join(ROOT, 'dynibar_amd', 'csrc', f'libdynibar_hip_{lib}.so')
+    print(f'[{lib}]', end=' ')
   if P: env['DYN_PG_P'] = P
   pr = subprocess.run([sys.executable, '-c', (CHILD % ROOT).replace('VIEWS', repr(views))], env=env, capture_output=True, text=True, timeout=600)
   line = [l for l in pr.stdout.splitlines() if l.startswith('K1RESULT ')]
