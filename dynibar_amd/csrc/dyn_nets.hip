@@ -389,7 +389,7 @@ static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   w.n_tiles_b = (long)R * w.TPR;
   size_t o = 0;
   w.off_x = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64 * 64;
-  w.off_vis = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 64;
+  w.off_vis = o; o += dynamic ? 0 : (size_t)w.n_tiles_a * 128;  // per tile [32 rows] float4 {vis2, r, g, b}: what the blend needs of a row besides x
   w.off_gin = o; o += (size_t)w.n_tiles_b * SB_GIN_RECS * 256;
   w.off_nvalid = o; o += (size_t)((w.n_pts + 3) & ~3L);
   w.off_hg = o; o += dynamic ? 0 : (size_t)w.n_tiles_b * SB_HG_RECS * 256;
@@ -770,11 +770,11 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
 template <int VSEG, bool STORE_X>
 __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const StaticArgs& p, const float* ctab, float wgt, float msk,
                                            long tile, long point, bool valid, int view, int seg_base, const DenseRows* dr = nullptr,
-                                           float* lds_base = nullptr) {
+                                           float* lds_base = nullptr, int v_const = 0) {
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int V = p.V;
+  const int V = v_const > 0 ? v_const : p.V;  // (a compile-time count in the kernels instantiated for one: the reduction loops over the views unroll)
   f32x16 x[4];
   {
     acc_init_bias<4>(x, ctab + 272);
@@ -824,7 +824,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) nt_store4<4>(xw + (t * 4 + q) * 64, make_float4(x[t][q * 4], x[t][q * 4 + 1], x[t][q * 4 + 2], x[t][q * 4 + 3]));
-    nt_store1<4>(p.ws + p.o.off_vis + tile * 64 + lane, vis2);
+    if (h == 0) nt_store1<4>(p.ws + p.o.off_vis + (tile * 32 + (lane & 31)) * 4, vis2);  // (.x of the row's record; its colour went out with the gather loads)
   }
   DYN_PHASE(18);
   if constexpr (VSEG == 0) {
@@ -942,8 +942,11 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
 // ===================================================================================================================
 // A: per point-view chain
 // ===================================================================================================================
-template <int VSEG>
+// VC > 0 (dense flavour only): the view count as a compile-time constant -- the per-row division by V, the (point, slot) task loops of the LDS reductions
+// and their loads unroll (round 5: instantiated for the 11 static views of the Nvidia evaluation, the kernel that is 42 % of its frame)
+template <int VSEG, int VC = 0>
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs p) {
+  static_assert(VC == 0 || VSEG == 0, "a compile-time view count is a dense-rows specialisation");
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   float* lds = reinterpret_cast<float*>(dyn_smem);
@@ -963,15 +966,16 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   net_ring_init(ring, p.blob + ST_OFF_A + (POOLED ? (size_t)SA_L1P_CHUNKS * NET_CHUNK : 0), SA_CHUNKS - (POOLED ? SA_L1P_CHUNKS : 0), lds,
                 SA_POOLED_AT - (POOLED ? SA_L1P_CHUNKS : 0), POOLED ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 
-  const int V = p.V;
+  const int V = VC > 0 ? VC : p.V;
+  const int PT = VC > 0 ? 256 / VC : p.PT;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // VSEG > 0: views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding.
   // VSEG == 0 (dense rows): the workgroup's 256 rows are the point-views of its PT = 256 / V points in order, no padding between points.
-  const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  const DenseRows dr = dense_rows(V, PT, lds + LDS_FLOATS - DENSE_SCALARS);
   const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
-  const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
-  const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
+  const long point = VSEG == 0 ? (long)blockIdx.x * PT + p_local : tile * PT + p_local;
+  const bool valid = (VSEG == 0 ? p_local < PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
 
@@ -990,7 +994,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     // ---- ray_dir_fc.0, per-point part: output tile `wave` for the workgroup's points (column j = the point's index in the workgroup) ----
     B6TileW<SA_L1P_STEPS> pw1;
     b6_tile_prefetch<8, SA_L1P_STEPS>(p.blob + ST_OFF_A, wave, pw1);
-    const int npw = VSEG == 0 ? p.PT : (DYN_VIEW_THREADS / 64) * p.PT;  // points of this workgroup
+    const int npw = VSEG == 0 ? PT : (DYN_VIEW_THREADS / 64) * PT;  // points of this workgroup
     const long qp = (long)blockIdx.x * npw + j;
     const bool qok = j < npw && qp < p.n_pts;
     const float qx = qok ? p.pts[qp * 3] : 0.f, qy = qok ? p.pts[qp * 3 + 1] : 0.f, qz = qok ? p.pts[qp * 3 + 2] : 0.f;
@@ -1006,7 +1010,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     float* res = ctab + SA_CT + POOL_FLOATS(SA_NX);
     res_put(res, wave, j, h, accp[0]);
     __syncthreads();
-    res_get(res, VSEG == 0 ? (dr.p_local < dr.PTW ? dr.p_local : dr.PTW - 1) : wave * p.PT + p_local, h, a1);
+    res_get(res, VSEG == 0 ? (dr.p_local < dr.PTW ? dr.p_local : dr.PTW - 1) : wave * PT + p_local, h, a1);
   } else {
     float in1p[SA_L1P_STEPS];
     octave_embed<5>(px, h, in1p);
@@ -1059,6 +1063,12 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     for (int r = 0; r < 16; ++r) xin[18 + r] = a2[0][r] * rf[dyn_fi(r, h)];
 #pragma unroll
     for (int r = 0; r < 3; ++r) xin[34 + r] = h == 0 ? a2[1][r] * rf[32 + r] : 0.f;
+    // The source colour of the row goes into the row's record next to vis2 (round 5): the blend kernel used to fetch it from rgb_feat, 12 bytes out of
+    // every 140-byte row -- i.e. nearly every 128-byte line of that 294 MB tensor a second time.  (.yzw here, .x = vis2 at the end of the chain.)
+    if (h == 0 && tile < p.n_tiles_a) {
+      float* rec = p.ws + p.o.off_vis + (tile * 32 + j) * 4;
+      nt_store1<4>(rec + 1, xin[0]); nt_store1<4>(rec + 2, xin[1]); nt_store1<4>(rec + 3, xin[2]);
+    }
   }
   DYN_PHASE(4);
   if (p.mask_rgb) {
@@ -1069,7 +1079,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   float wgt;
   if (p.anti_alias) {
     // padding lanes (and, in the dense flavour, the idle tail rows, which shadow the last point) never set the minimum over the views
-    const float e = ((VSEG == 0 ? p_local < p.PT : view < V)) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;
+    const float e = ((VSEG == 0 ? p_local < PT : view < V)) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;
     wgt = (e - views_min<VSEG>(dr, e)) * msk;
   } else {
     wgt = msk;
@@ -1080,7 +1090,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   DYN_PHASE(5);
   base_fc0<VSEG, SA_NX>(ring, p.blob + ST_OFF_A + (size_t)SA_POOLED_AT * NET_CHUNK, xin, wgt, V, view, p_local, ctab + SA_CT, a1, &dr, wraw / (wraw + 1e-8f));
   DYN_PHASE(10);
-  views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base, &dr, lds);
+  views_tail<VSEG, true>(ring, a1, p, ctab, wgt, msk, tile, point, valid, view, seg_base, &dr, lds, VC);
   DYN_PHASE(20);
 }
 
@@ -1690,11 +1700,9 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
 
   const float msk = valid ? p.mask[pv] : 0.f;
   const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float vis2 = tile_ok ? p.ws[p.o.off_vis + tile * 64 + lane] : 0.f;
-  float rgb_in[3] = {0.f, 0.f, 0.f};
-  if (valid) {
-    rgb_in[0] = p.rgb_feat[pv * 35]; rgb_in[1] = p.rgb_feat[pv * 35 + 1]; rgb_in[2] = p.rgb_feat[pv * 35 + 2];
-  }
+  const float4 vrec = tile_ok ? reinterpret_cast<const float4*>(p.ws + p.o.off_vis)[tile * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);  // {vis2, r, g, b} of the row
+  const float vis2 = vrec.x;
+  const float rgb_in[3] = {valid ? vrec.y : 0.f, valid ? vrec.z : 0.f, valid ? vrec.w : 0.f};
   f32x16 a[4];
   {
     f32x16 x[4];
@@ -1779,11 +1787,9 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
     const long pv = valid ? point * V + view : 0;
     const float msk = valid ? p.mask[pv] : 0.f;
     const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float vis2 = tile_ok ? p.ws[p.o.off_vis + tile * 64 + lane] : 0.f;
-    float rgb_in[3] = {0.f, 0.f, 0.f};
-    if (valid) {
-      rgb_in[0] = p.rgb_feat[pv * 35]; rgb_in[1] = p.rgb_feat[pv * 35 + 1]; rgb_in[2] = p.rgb_feat[pv * 35 + 2];
-    }
+    const float4 vrec = tile_ok ? reinterpret_cast<const float4*>(p.ws + p.o.off_vis)[tile * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);  // {vis2, r, g, b} of the row
+    const float vis2 = vrec.x;
+    const float rgb_in[3] = {valid ? vrec.y : 0.f, valid ? vrec.z : 0.f, valid ? vrec.w : 0.f};
     f32x16 a[4];
     {
       f32x16 x[4];
@@ -1855,7 +1861,8 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   const size_t lds_b = (PTS_RING_SLOTS * PTS_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (NET_CHUNK + SC_CT) * sizeof(float);
   const dim3 grid_c(dyn_cdiv(a.n_tiles_a, DYN_BLEND_THREADS / 64)), blk_c(DYN_BLEND_THREADS);
-  if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  if (a.o.dense && a.V == 11) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", (k_static_views<0, 11>), grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  else if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
   else if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<16>, grid_a, blk_v, lds_a, stream, a);

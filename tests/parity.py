@@ -2001,7 +2001,11 @@ def check_train_dual(device, name='small', S=16, R=None, weights='init', shift=5
   for k, ref in g_ref.items():  # every gradient of BOTH branches, one limit
     assert got[k] is not None, f'{tag}: no gradient for {k}'
     scale = float(ref.abs().max())
-    assert_close(cpu(got[k]).reshape(ref.shape), ref, 2e-4 * scale + 2e-6 * gmax, 1e-3, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
+    # round 5: 8e-5 of the tensor's largest gradient (rounds 2-4: 2e-4).  The old limit had been fitted to a defect: the compositing backward formed
+    # its suffix sums as total - prefix, whose coherent rounding along a 200-sample ray put 3e-4 of max|g| into every gradient behind sigma
+    # (tools/grad_rootcause.py; `few`, S = 200 used 0.96 of the limit).  With the suffix sums formed directly the same tensors are at 4-6e-6 -- the
+    # oracle's own fp32 against fp64 -- and the worst tensor of all six cases uses 0.19 of the OLD limit.
+    assert_close(cpu(got[k]).reshape(ref.shape), ref, 8e-5 * scale + 8e-7 * gmax, 4e-4, f'{tag} grad {k} (max |g| {scale:.2e})', extra=sens[k])
     if scale > 1e-3 * gmax:
       worst = max(worst, float((cpu(got[k]).reshape(ref.shape) - ref).abs().max()) / scale)
   return worst
