@@ -514,6 +514,9 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #ifndef PGT_UNROLL
 #define PGT_UNROLL 4
 #endif
+#ifndef PGT_DEFAULT_P
+#define PGT_DEFAULT_P 16
+#endif
 #ifndef PGT_ONE_BARRIER
 #define PGT_ONE_BARRIER 1  /* ray_diff / mask tiles in their own LDS (P V 20 bytes behind the feature tile): one barrier per workgroup instead of three */
 #endif
@@ -762,8 +765,12 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   // 9- to 11-wave workgroup per CU measured 3-5 % faster than three 6-wave workgroups with an idle view slot (tools/k1sweep.py, round 4: 11 views 172 vs
   // 177-181 us; at 15 views the two-views-per-wave form wins, 201 vs 221 us) --, else 32 (two views per wave)
   static const int force_p = getenv("DYN_PG_P") ? atoi(getenv("DYN_PG_P")) : 0;  // developer A/B
-  const int CL = C + (PGT_ONE_BARRIER ? 5 : 0);  // floats of LDS per (point, view): the feature row (+ ray_diff 4 + mask 1)
-  const int P = force_p ? force_p : ((((size_t)64 * p->V * CL * 4 <= 80 * 1024 && p->V <= 16) || (p->V >= 9 && p->V <= 11 && (size_t)64 * p->V * CL * 4 <= 120 * 1024)) ? 64 : 32);
+  // Points per tile.  Rounds 2-4 chose the tallest tile that left two workgroups per CU (P = 64, one view per wave; P = 32 beyond 8 views) from sweeps of the kernel
+  // ALONE with the maps evicted between launches (tools/k1sweep.py).  Round 5 measured it INSIDE the pipeline (bench step, DYN_PG_P forced; gpurun_out/r5c9_k1_v11.txt,
+  // r5c10_k1.txt): P = 16 -- four views per wave, 2-4 waves and 20-40 KiB per workgroup, five to eight independent workgroups per CU whose load and store phases
+  // overlap -- is the fastest at every view count: 7 views 88.0 -> 85.1 us, 8 views 91.7 -> 89.4 (0.504 of 8 TB/s), 11 views 143.0 -> 124.3 (0.42 -> 0.50),
+  // 15 views 165.1 -> 163.9; frame 24.1 -> 22.9 ms.  (The stand-alone sweep had P = 16 at +12 % for 8 views: there the cold maps dominate and taller tiles re-use taps.)
+  const int P = force_p ? force_p : PGT_DEFAULT_P;
   const int waves = (p->V * P + 63) / 64;
   const size_t lds = (size_t)P * p->V * (C + (PGT_ONE_BARRIER ? 5 : 0)) * sizeof(float);
   if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);
@@ -778,8 +785,17 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   q.tiles_per_xcd = (q.ntile + 7) / 8;
   const long nblocks = 8 * q.tiles_per_xcd;
   static const int no_pref = getenv("DYN_PG_NOPREF") != nullptr;  // developer A/B
-  q.pref_wgs = no_pref ? 0 : (int)(nblocks < 512 ? nblocks : 512);  // the first resident generation of workgroups (2 per CU)
-  if (P == 16)
+  // the first resident generation of workgroups shares the streaming of the maps: min(8, LDS / tile) per CU x 256 CUs (round 5, 8 views, P = 16: 256 workgroups
+  // 101.7 us, 512: 87.8, 2048: 84.7 = 0.53 of 8 TB/s; 11 views: 132.9 / 124.8 / 126.1)
+  static const int pref_env = getenv("DYN_PG_PREF") ? atoi(getenv("DYN_PG_PREF")) : 0;  // developer A/B
+  const long per_cu = (long)(160 * 1024) / (long)lds < 8 ? (long)(160 * 1024) / (long)lds : 8;
+  const long pref_n = pref_env > 0 ? pref_env : 256 * (per_cu > 1 ? per_cu : 1);
+  q.pref_wgs = no_pref ? 0 : (int)(nblocks < pref_n ? nblocks : pref_n);
+  if (P == 8)
+    DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<8>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
+               p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+  else if (P == 16)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<16>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
                reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);

@@ -9,16 +9,13 @@
 // leave the register file between layers: no LDS round trip, no transposes.  The summation order over K is a
 // pack-time permutation of the reference's (results agree to fp32 round-off, not bitwise; tolerance 1e-4 per north_star).
 //
-// Two engines share that structure (selected at build time, DYN_ENGINE_B6):
-//  * the shipped one ("B6", second half of this file): fp32 operands split exactly into two 16-bit parts, products on the 16-bit matrix
-//    pipe with fp32 accumulation.  Default build (DYN_SPLIT_F16 = 1): IEEE half parts (22 mantissa bits), three partial products
-//    hi.hi + hi.mid + mid.hi on v_mfma_f32_32x32x16_f16 -- fp32-class products.  Variant builds keep bf16 parts
-//    (v_mfma_f32_32x32x16_bf16; DYN_SPLIT_TERMS = 3 or 6 partial products).  Weights are split and packed on the host
-//    (dyn_nets.hip: pack_layer_b6) into a stream of 48 KiB chunks in consumption order and DMA'd global->LDS
-//    (global_load_lds_dwordx4) into a ring shared by the 4 or 8 waves of a workgroup: chunk c+1 in flight while chunk c feeds the
-//    MFMAs, one workgroup barrier per chunk.  Biases are accumulator initial values (LDS tables) or one extra k-slot fed with 1.
-//  * the first one (kept for A/B builds, -DDYN_ENGINE_B6=0; first half of this file): native fp32 MFMA (v_mfma_f32_32x32x2_f32),
-//    16 KiB chunks (DYN_CHUNK) in a 2-deep ring, bias folded into K as one extra k-step.
+// The engine (second half of this file, "B6" in the code): fp32 operands split into 16-bit parts, products on the 16-bit matrix pipe with fp32
+//    accumulation.  Default build (DYN_SPLIT_F16 = 1): IEEE half parts (22 mantissa bits), three partial products hi.hi + hi.mid + mid.hi on
+//    v_mfma_f32_32x32x16_f16 -- fp32-class products.  The x6 build keeps bf16 parts (v_mfma_f32_32x32x16_bf16, DYN_SPLIT_TERMS = 6: all 24 bits).
+//    Weights are split and packed on the host (dyn_nets.hip: pack_layer_b6) into a stream of 48 KiB chunks in consumption order and DMA'd global->LDS
+//    (global_load_lds_dwordx4) into a ring shared by the 4 or 8 waves of a workgroup.  Biases are accumulator initial values (LDS tables) or one extra
+//    k-slot fed with 1.  (The round-1 engine on the native fp32 MFMA, v_mfma_f32_32x32x2_f32, was removed in round 5; the long-ray attention of
+//    k_net_points still multiplies with that instruction directly: mfma32 below.)
 // Three layer loops on the shipped engine (round 4): mlp_layer_b6 (two-slot ring, pair-granular pipeline: the kernels that run two or three waves per
 // SIMD -- k_static_views, k_dynamic_views, k_selftest), mlp_layer_b6_duo (three-slot ring with a mid-chunk barrier, two output tiles interleaved, A
 // fragments four pairs ahead: the kernels that run ONE wave per SIMD -- k_motion_mlp, k_net_points) and mlp_layer_b6_lds (weights resident in LDS,
@@ -28,89 +25,13 @@
 
 #include "dyn_device.h"
 
-#define DYN_CHUNK 4096        // floats per weight chunk (16 KiB)
 #define DYN_NET_THREADS 256   // workgroup of the point-level kernels: 4 waves share one weight ring
 #define DYN_VIEW_THREADS 512  // workgroup of the view-level kernels: 8 waves (2 per SIMD) share one weight ring
 
 // feature index (within a 32-feature tile) held in register r by a lane of half h
 __host__ __device__ constexpr int dyn_fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-struct WeightRing {
-  const float* gsrc;  // stream + tid*4 (per-thread source of the DMA)
-  float* buf;         // LDS: 2 chunks
-  int next;           // next chunk to consume
-  int total;          // chunks in the stream
-};
-
-__device__ __forceinline__ void ring_issue(const WeightRing& R, int chunk) {
-  const float* g = R.gsrc + (long)chunk * DYN_CHUNK;
-  // wave-uniform LDS base; the hardware adds lane*16 bytes.  One round = blockDim.x * 16 bytes.
-  float* l = R.buf + (chunk & 1) * DYN_CHUNK + (threadIdx.x >> 6) * 256;
-  const int round = blockDim.x * 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i * round < DYN_CHUNK)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * round),
-                                       (__attribute__((address_space(3))) void*)(l + i * round), 16, 0, 0);
-}
-
-__device__ __forceinline__ void ring_init(WeightRing& R, const float* stream, int total, float* lds) {
-  R.gsrc = stream + threadIdx.x * 4;
-  R.buf = lds;
-  R.next = 0;
-  R.total = total;
-  ring_issue(R, 0);
-}
-
-// Returns the LDS image of the next chunk.  The barrier both publishes every wave's part of that chunk (each wave first
-// drains its own DMA: s_waitcnt vmcnt(0)) and retires all reads of the other buffer, which is then refilled.
-__device__ __forceinline__ const float* ring_acquire(WeightRing& R) {
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-  __syncthreads();
-  const int c = R.next++;
-  if (c + 1 < R.total) ring_issue(R, c + 1);
-  return R.buf + (c & 1) * DYN_CHUNK;
-}
-
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-
-// One Linear layer: NT output tiles of 32 features, NSTEPS k-steps (2 input features each).  feed(s) returns the lane's B
-// operand (its activation for k-step s); s is a compile-time constant after unrolling.
-template <int NT, int NSTEPS, class Feed>
-__device__ __forceinline__ void mlp_layer(WeightRing& R, f32x16 (&acc)[NT], Feed&& feed) {
-  constexpr int NSG = (NSTEPS + 3) / 4;
-  constexpr int SGC = 16 / NT;
-  constexpr int NCH = (NSG + SGC - 1) / SGC;
-  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8 || NT == 16, "tiles per layer must divide 16");
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float* buf = ring_acquire(R);
-#pragma unroll
-    for (int g = 0; g < SGC; ++g) {
-      const int sg = c * SGC + g;
-      if (sg < NSG) {
-        // the lane's B operands of this group of four k-steps (evaluated once, shared by all output tiles)
-        const float b0 = (sg * 4 + 0 < NSTEPS) ? feed(sg * 4 + 0) : 0.f;
-        const float b1 = (sg * 4 + 1 < NSTEPS) ? feed(sg * 4 + 1) : 0.f;
-        const float b2 = (sg * 4 + 2 < NSTEPS) ? feed(sg * 4 + 2) : 0.f;
-        const float b3 = (sg * 4 + 3 < NSTEPS) ? feed(sg * 4 + 3) : 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float4 a = *reinterpret_cast<const float4*>(buf + ((g * NT + t) * 64 + lane) * 4);
-          if (sg * 4 + 0 < NSTEPS) acc[t] = mfma32(a.x, b0, acc[t]);
-          if (sg * 4 + 1 < NSTEPS) acc[t] = mfma32(a.y, b1, acc[t]);
-          if (sg * 4 + 2 < NSTEPS) acc[t] = mfma32(a.z, b2, acc[t]);
-          if (sg * 4 + 3 < NSTEPS) acc[t] = mfma32(a.w, b3, acc[t]);
-        }
-      }
-    }
-  }
-}
-
-__host__ __device__ constexpr int dyn_layer_chunks(int NT, int NSTEPS) {
-  return (((NSTEPS + 3) / 4) + (16 / NT) - 1) / (16 / NT);
-}
 
 template <int NT>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
@@ -327,9 +248,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
-#ifndef B6_SCHED
-#define B6_SCHED 0  /* sched_group_barrier pinning: blows up hipcc compile time on these fully unrolled kernels; keep off */
-#endif
 #define B6_PAIR_FLOATS (DYN_SPLIT_PARTS * 256)        // parts x 64 lanes x 4 dwords
 #define B6_CHUNK (B6_CHUNK_PAIRS * B6_PAIR_FLOATS)  // floats per chunk (48 KiB)
 
@@ -366,12 +284,6 @@ extern "C" int dyn_debug_skew_reset(void) { unsigned long long z[32] = {0}; retu
 #define DYN_PHASE_RING_KID(R, k)
 #endif
 
-#ifndef B6_ASM_DMA
-#define B6_ASM_DMA 0  /* the two-slot ring's LDS-DMA pieces as inline asm (see ring6_issue) */
-#endif
-#ifndef B6_PINNED
-#define B6_PINNED 0   /* mlp_layer_b6: the three partial products of a pair pinned back to back, the pair's LDS reads and operand slice in front of them */
-#endif
 struct WeightRing6 {
   const float* gbase;  // the packed stream (uniform)
   float* buf;
@@ -462,19 +374,6 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp)
     if (grp * 1536 < per_wave) {
-#if B6_ASM_DMA && defined(__AMDGCN__)
-      // inline asm: hipcc books the builtin as an access to both memories and, while one is pending, turns every LDS wait into lgkmcnt(0) (round 4,
-      // see mlp_layer_b6_duo) -- with it the A-fragment look-ahead (B6_AHEAD) never had a chance to work.  The ring waits for its pieces itself.
-      const float* gg = g + grp * 1536;
-      const unsigned ll = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(l + grp * 1536));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-      asm volatile("s_mov_b32 m0, %1\n\t"
-                   "global_load_lds_dwordx4 %0, off offset:-2048\n\tglobal_load_lds_dwordx4 %0, off offset:-1024\n\tglobal_load_lds_dwordx4 %0, off\n\t"
-                   "global_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
-                   ::"v"(gg), "s"(ll) : "m0", "memory");
-#pragma clang diagnostic pop
-#else
       const auto* gg = (const __attribute__((address_space(1))) void*)(g + grp * 1536);
       auto* ll = (__attribute__((address_space(3))) void*)(l + grp * 1536);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, -2048, 0);
@@ -483,7 +382,6 @@ __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 1024, 0);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 2048, 0);
       __builtin_amdgcn_global_load_lds(gg, ll, 16, 3072, 0);
-#endif
     }
 }
 // threads: the workgroup size.  Kernels pass their compile-time constant: the piece loop of ring6_issue then unrolls without branches
@@ -575,22 +473,11 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   return R.buf + (c & 1) * B6_CHUNK;
 }
 
-// Issue-priority experiments of round 3 (measured on k_static_views, 4096 rays x 64 x 8 views, two rounds each against the same build without):
-//   B6_PRIO_FLIP = n: the two waves of a SIMD swap issue priority every n (k-group, tile) pairs.  n = 1: -1.1 %, n = 2: -1.4 % (kept), 4: -0.7 %,
-//     6: -0.8 %, 12: +7 %.  Without it the older wave wins every arbitration, reaches each chunk barrier ~2 k cycles early and parks while its
-//     partner finishes alone; fine-grained alternation keeps the pair closer together at no cost in registers.
-//   B6_PRIO_STATIC (one half of the workgroup permanently at priority 1, either half): +7 %.
-//   A feedback scheme (progress counters in LDS, the wave ahead lowers its priority): +6 % -- its bookkeeping costs more than it returns.
-//   B6_SPREAD (first MFMA of a triple ahead of the pair's VALU slice): +1..2 %, although the same change hides more fillers in a synthetic loop
-//     (tools/ubench/mfma_acc_file.hip): the engine's slices are LDS reads and dependent ELU chains, not independent FMAs.
-#ifndef B6_SPREAD
-#define B6_SPREAD 0
-#endif
+// Issue priority in the two-wave layer loop.  Round 3 recorded "swap the priority of the two waves of a SIMD every n pairs: n = 2 -1.4 % (kept); one half
+// static: +7 %; a feedback scheme: +6 %; first MFMA of a triple ahead of the pair's VALU slice: +1..2 %".  None of those builds did what the text said
+// (see "Round 5" below); the switches of the dropped ones were removed in round 5.  B6_PRIO_FLIP = pairs between two flip sites.
 #ifndef B6_SPLIT_ONE_ASM
 #define B6_SPLIT_ONE_ASM 0  /* round 5, measured: -310 s_nop in the view chain, time unchanged; k_static_blend_ws 361 -> 383 us (the two parts no longer spread) */
-#endif
-#ifndef B6_PRIO_STATIC
-#define B6_PRIO_STATIC 0
 #endif
 #ifndef B6_PRIO_FLIP
 #define B6_PRIO_FLIP 2
@@ -747,9 +634,6 @@ __device__ __forceinline__ void b6_split_pairs(Feed& feed, int g, u32x4v& bh, u3
 #ifndef B6_AHEAD
 #define B6_AHEAD 1  // pairs of A operands in flight from LDS ahead of the pair whose MFMAs issue
 #endif
-#ifndef B6_VALU_PER_PAIR
-#define B6_VALU_PER_PAIR 1  // 1: the next k-group's B operand is produced in NT slices, one beside each tile; 0: all beside tile 0
-#endif
 template <int NT, int NSLOTS, int AHEAD = B6_AHEAD, class Feed>
 __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], Feed&& feed) {
   constexpr int NG = (NSLOTS + 7) / 8;
@@ -782,15 +666,8 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         // issue priority every B6_PRIO_FLIP pairs (see ring6_prio_flip)
         if (pr % B6_PRIO_FLIP == 0) ring6_prio_flip(R, (pr / B6_PRIO_FLIP) & 1);
 #endif
-#if B6_SPREAD
-        // B6_SPREAD: the first of the three dependent MFMAs goes out BEFORE this pair's VALU slice and the A prefetch, which then issue under it
-        const B6A& cur0 = q[pr % (AHEAD + 1)];
-        acc[t] = mfma_bf16(cur0.mid, bh, acc[t]);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (pr + AHEAD < npc) q[(pr + AHEAD) % (AHEAD + 1)] = b6_load_a(buf + (pr + AHEAD) * B6_PAIR_FLOATS, lane);
         if (g + 1 < NG) {
-#if B6_VALU_PER_PAIR
           // this tile's share of the next k-group's operand: pairs [4 t / NT, 4 (t + 1) / NT)
           if (NT == 1) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
           if (NT == 2 && t == 0) b6_split_pairs<NSLOTS, 0, 2>(feed, g + 1, nh, nm, nl);
@@ -803,9 +680,6 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
           if (NT == 8 && t == 2) b6_split_pairs<NSLOTS, 1, 2>(feed, g + 1, nh, nm, nl);
           if (NT == 8 && t == 4) b6_split_pairs<NSLOTS, 2, 3>(feed, g + 1, nh, nm, nl);
           if (NT == 8 && t == 6) b6_split_pairs<NSLOTS, 3, 4>(feed, g + 1, nh, nm, nl);
-#else
-          if (t == 0) b6_split_pairs<NSLOTS, 0, 4>(feed, g + 1, nh, nm, nl);
-#endif
         }
         const B6A& cur = q[pr % (AHEAD + 1)];
         // smallest partial products first
@@ -814,25 +688,9 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         acc[t] = mfma_bf16(cur.hi, bl, acc[t]);
         acc[t] = mfma_bf16(cur.mid, bm, acc[t]);
 #endif
-#if B6_SPREAD
-        __builtin_amdgcn_sched_barrier(0);
-#else
-#if B6_PINNED && defined(__AMDGCN__)
-        // nothing between the three products: an instruction between two MFMAs on one accumulator costs ~43 cycles of the matrix pipe, and hipcc
-        // put the next pair's two ds_read_b128 between the first and the second (the empty asm statements tie the products to their place)
-        asm volatile("" : "+v"(bh), "+v"(bm));
         acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
         acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
-        asm volatile("" : "+v"(acc[t]));
-#else
-        acc[t] = mfma_bf16(cur.mid, bh, acc[t]);
-#endif
-#endif
-#if !(B6_PINNED && defined(__AMDGCN__)) || B6_SPREAD
-        acc[t] = mfma_bf16(cur.hi, bm, acc[t]);
-        acc[t] = mfma_bf16(cur.hi, bh, acc[t]);
-#endif
         if (t == NT - 1) { bh = nh; bm = nm; bl = nl; }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1303,52 +1161,6 @@ __device__ __forceinline__ void mlp_layer_b6_lds(const float* w, f32x16 (&acc)[N
   }
 }
 
-// The same layer shared out over the waves of a workgroup: all waves stream the chunks of an NT-tile layer, wave w evaluates only
-// output tile `my_tile` (for NCOL column tiles of 32 rows each; feed(c, s) is the lane's activation of column tile c, slot s).
-// Used where the rows are few and shared by the whole workgroup (per-point statistics pooled over the workgroup's points).
-template <int NT, int NSLOTS, int NCOL, class Feed>
-__device__ __forceinline__ void mlp_layer_b6_tile(WeightRing6& R, int my_tile, f32x16 (&acc)[NCOL], Feed&& feed) {
-  constexpr int NG = (NSLOTS + 7) / 8;
-  constexpr int GPC = B6_CHUNK_PAIRS / NT;
-  constexpr int NCH = (NG + GPC - 1) / GPC;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float* buf = ring6_acquire(R);
-#pragma unroll
-    for (int gi = 0; gi < GPC; ++gi) {
-      const int g = c * GPC + gi;
-      if (g < NG) {
-        const u32x4v* w = reinterpret_cast<const u32x4v*>(buf + (gi * NT + my_tile) * B6_PAIR_FLOATS) + lane;
-        const u32x4v ah = w[0], am = w[64];
-#if DYN_SPLIT_PARTS == 3
-        const u32x4v al = w[128];
-#endif
-#pragma unroll
-        for (int col = 0; col < NCOL; ++col) {
-          u32x4v bh, bm, bl;
-#pragma unroll
-          for (int p2 = 0; p2 < 4; ++p2) {
-            const float v0 = (g * 8 + 2 * p2 < NSLOTS) ? feed(col, g * 8 + 2 * p2) : 0.f;
-            const float v1 = (g * 8 + 2 * p2 + 1 < NSLOTS) ? feed(col, g * 8 + 2 * p2 + 1) : 0.f;
-            unsigned h_, m_, l_;
-            split3_pair(v0, v1, h_, m_, l_);
-            bh[p2] = h_; bm[p2] = m_; bl[p2] = l_;
-          }
-#if DYN_SPLIT_TERMS == 6
-          acc[col] = mfma_bf16(al, bh, acc[col]);
-          acc[col] = mfma_bf16(ah, bl, acc[col]);
-          acc[col] = mfma_bf16(am, bm, acc[col]);
-#endif
-          acc[col] = mfma_bf16(am, bh, acc[col]);
-          acc[col] = mfma_bf16(ah, bm, acc[col]);
-          acc[col] = mfma_bf16(ah, bh, acc[col]);
-        }
-      }
-    }
-  }
-}
-
 // One output tile of an NT-tile layer whose packed chunks the wave reads straight from global memory into registers, no ring and no
 // barriers (the layer's rows are shared by the whole workgroup and every wave needs a different eighth of the weights, so staging
 // them through LDS would cost whole chunks of DMA and barriers for a handful of MFMAs per wave).  b6_tile_prefetch is issued early
@@ -1383,52 +1195,11 @@ __device__ __forceinline__ void b6_tile_apply(const B6TileW<NSLOTS>& w, f32x16& 
   }
 }
 
-template <int NT, int NSTEPS, int NCOL, class Feed>
-__device__ __forceinline__ void mlp_layer_tile(WeightRing& R, int my_tile, f32x16 (&acc)[NCOL], Feed&& feed) {
-  constexpr int NSG = (NSTEPS + 3) / 4;
-  constexpr int SGC = 16 / NT;
-  constexpr int NCH = (NSG + SGC - 1) / SGC;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float* buf = ring_acquire(R);
-#pragma unroll
-    for (int g = 0; g < SGC; ++g) {
-      const int sg = c * SGC + g;
-      if (sg < NSG) {
-        const float4 a = *reinterpret_cast<const float4*>(buf + ((g * NT + my_tile) * 64 + lane) * 4);
-#pragma unroll
-        for (int col = 0; col < NCOL; ++col) {
-          if (sg * 4 + 0 < NSTEPS) acc[col] = mfma32(a.x, feed(col, sg * 4 + 0), acc[col]);
-          if (sg * 4 + 1 < NSTEPS) acc[col] = mfma32(a.y, feed(col, sg * 4 + 1), acc[col]);
-          if (sg * 4 + 2 < NSTEPS) acc[col] = mfma32(a.z, feed(col, sg * 4 + 2), acc[col]);
-          if (sg * 4 + 3 < NSTEPS) acc[col] = mfma32(a.w, feed(col, sg * 4 + 3), acc[col]);
-        }
-      }
-    }
-  }
-}
-
-// ---- engine selection for the network kernels (A/B builds: -DDYN_ENGINE_B6=0 selects the fp32 MFMA engine) --------------
-#ifndef DYN_ENGINE_B6
-#define DYN_ENGINE_B6 1
-#endif
-#if DYN_ENGINE_B6
+// ---- the names the network kernels use for the two-slot ring and its layer loop ---------------------------------------
 typedef WeightRing6 NetRing;
 #define NET_CHUNK B6_CHUNK
 #define net_ring_init ring6_init
 #define net_ring_init_t(R, stream, total, lds, threads) ring6_init(R, stream, total, lds, 1 << 30, 0, threads)
 #define net_ring_init_1(R, stream, total, lds, threads) ring6_init(R, stream, total, lds, 1 << 30, 0, threads, 1)
 #define net_layer mlp_layer_b6
-#define net_layer_tile mlp_layer_b6_tile
 __host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return b6_layer_chunks(NT, NSLOTS); }
-#else
-typedef WeightRing NetRing;
-#define NET_CHUNK DYN_CHUNK
-#define net_ring_init ring_init
-#define net_ring_init_t(R, stream, total, lds, threads) ring_init(R, stream, total, lds)
-#define net_ring_init_1(R, stream, total, lds, threads) ring_init(R, stream, total, lds)
-#define net_layer mlp_layer
-#define net_layer_tile mlp_layer_tile
-__host__ __device__ constexpr int net_layer_chunks(int NT, int NSLOTS) { return dyn_layer_chunks(NT, NSLOTS); }
-#endif

@@ -25,24 +25,6 @@ namespace {
 // value of the packed A operand for (output tile t, row i, k-step s, half h)
 using SlotFn = std::function<float(int t, int i, int s, int h)>;
 
-void pack_layer(std::vector<float>& out, int NT, int NSTEPS, const SlotFn& fn) {
-  const int NSG = (NSTEPS + 3) / 4, SGC = 16 / NT, NCH = (NSG + SGC - 1) / SGC;
-  const size_t base = out.size();
-  out.resize(base + (size_t)NCH * DYN_CHUNK, 0.f);
-  for (int c = 0; c < NCH; ++c)
-    for (int g = 0; g < SGC; ++g) {
-      const int sg = c * SGC + g;
-      if (sg >= NSG) continue;
-      for (int t = 0; t < NT; ++t)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int q = 0; q < 4; ++q) {
-            const int s = sg * 4 + q;
-            if (s >= NSTEPS) continue;
-            out[base + (size_t)c * DYN_CHUNK + ((g * NT + t) * 64 + lane) * 4 + q] = fn(t, lane & 31, s, lane >> 5);
-          }
-    }
-}
-
 // B6 engine image of one layer (dyn_mlp.h): per (k-group of 8 slots, output tile) three lane-linear 1 KiB parts [hi | mid | lo]
 thread_local int g_pack_chunk_pairs = B6_CHUNK_PAIRS;  // pairs per chunk of the stream being packed (the point kernels' streams use PTS_CP); per host thread: two threads may pack at once
 void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
@@ -72,11 +54,7 @@ void pack_layer_b6(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn
 }
 
 void pack_net_layer(std::vector<float>& out, int NT, int NSLOTS, const SlotFn& fn) {
-#if DYN_ENGINE_B6
   pack_layer_b6(out, NT, NSLOTS, fn);
-#else
-  pack_layer(out, NT, NSLOTS, fn);
-#endif
 }
 
 // input feature of a chained layer: k-step s, half h -> feature of the previous layer's output (D layout)
@@ -144,7 +122,7 @@ constexpr int SA_CHUNKS = net_layer_chunks(8, SA_L1P_STEPS) + net_layer_chunks(8
 // holds the ray attention's K / V images (32.5 KiB), so their weight streams are packed in chunks of PTS_CP = 16 pairs (32 KiB; 3 slots = 96 KiB,
 // what the two 48 KiB slots took).  DYN_POINTS_DUO = 0: the round-3 form (A/B builds; the 6-term bf16 build keeps it: its pairs are 3 KiB).
 #ifndef DYN_POINTS_DUO
-#define DYN_POINTS_DUO (DYN_ENGINE_B6 && DYN_SPLIT_TERMS == 3 ? 1 : 0)
+#define DYN_POINTS_DUO (DYN_SPLIT_TERMS == 3 ? 1 : 0)
 #endif
 #ifndef DYN_POINTS_PERSIST
 #define DYN_POINTS_PERSIST 0
@@ -695,11 +673,9 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     constexpr int PT = 32 / VSEG;
     float* res = pool + POOL_FLOATS(NX);
     const int col = wave * PT + p_local;
-#if DYN_ENGINE_B6
     // this wave's output tile of the per-point part: weights straight from the packed stream into registers, in flight during the statistics
     B6TileW<2 * NX> pw;
     b6_tile_prefetch<8, 2 * NX>(pooled_w, wave, pw);
-#endif
     // all statistics first, one predicated block of stores after: a branch per feature would split the DPP reductions into
     // basic blocks and keep their lane moves from folding into the adds
     float pm[NX], pvr[NX];
@@ -737,11 +713,7 @@ __device__ __forceinline__ void base_fc0(NetRing& ring, const float* pooled_w, c
     __syncthreads();
     f32x16 accp[1];
     acc_zero(accp);
-#if DYN_ENGINE_B6
     b6_tile_apply<2 * NX>(pw, accp[0], [&](int s) { return pool[(s * 2 + h) * 32 + j]; });
-#else
-    net_layer_tile<8, 2 * NX, 1>(ring, wave, accp, [&](int, int s) { return pool[(s * 2 + h) * 32 + j]; });
-#endif
     DYN_PHASE(7);
     res_put(res, wave, j, h, accp[0]);
     __syncthreads();
@@ -958,7 +930,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   // the per-point layers (ray_dir_fc.0's pts columns, base_fc.0's statistics columns: VSEG >= 8 and the dense flavour) are read straight from the stream
   // by each wave, not through the ring: the ring starts behind L1P and skips L3P.  VSEG = 4 (64 points per workgroup: the tiles do not fit the LDS)
   // runs both as ordinary per-view layers through the ring.
-  static_assert(DYN_ENGINE_B6, "the view chain is written for the split engine");
   constexpr bool POOLED = VSEG >= 8 || VSEG == 0;
   constexpr int SA_L1P_CHUNKS = net_layer_chunks(8, SA_L1P_STEPS);
   constexpr int SA_POOLED_AT = SA_L1P_CHUNKS + net_layer_chunks(8, SA_L1V_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
@@ -1360,7 +1331,6 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
     }
     const int wave0 = wave - kt_self;                   // first wave of this ray inside the workgroup
     DYN_PHASE(2);  // Q, K, V projections done
-#if DYN_ENGINE_B6
     // The attention matmuls on the split engine too (round 2; the native fp32 MFMA needs 16 instructions of 64 cycles per 32 x 32 x 32 block,
     // the split engine 6 of 32).  scores^T [key x query] = K . q^T: A = a key tile's K in ITS lanes' register order (feature of slot e of group
     // m = fi(8 m + e, h): the same enumeration on both operands), deposited in LDS as hi | mid half-float images; B = this wave's q.
@@ -1465,73 +1435,6 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
         }
       att[hd] = oh;
     }
-#else
-#pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-      __syncthreads();  // the previous head's K/V images are no longer read
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        reinterpret_cast<float4*>(Kl)[(wave * 4 + q) * 64 + lane] =
-            make_float4(kh[hd][q * 4], kh[hd][q * 4 + 1], kh[hd][q * 4 + 2], kh[hd][q * 4 + 3]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Vl[dyn_fi(r, h) * SB_VL_LD + wave * 32 + j] = vh[hd][r];
-      __syncthreads();
-      f32x16 sc[4];
-      acc_zero(sc);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kt < TPR) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 a = reinterpret_cast<const float4*>(Kl)[((wave0 + kt) * 4 + q) * 64 + lane];
-            sc[kt] = mfma32(a.x, qh[hd][q * 4 + 0] * inv_temp, sc[kt]);
-            sc[kt] = mfma32(a.y, qh[hd][q * 4 + 1] * inv_temp, sc[kt]);
-            sc[kt] = mfma32(a.z, qh[hd][q * 4 + 2] * inv_temp, sc[kt]);
-            sc[kt] = mfma32(a.w, qh[hd][q * 4 + 3] * inv_temp, sc[kt]);
-          }
-        }
-      // softmax over the keys; register r of half h is key kt*32 + fi(r,h)
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool key_ok = (kt < TPR) && (kt * 32 + dyn_fi(r, h) < p.S);
-          float v = q_ok ? sc[kt][r] : -1e9f;
-          v = key_ok ? v : -3.0e38f;
-          sc[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = sc[kt][r] > -1.0e38f ? __expf(sc[kt][r] - mx) : 0.f;
-          sc[kt][r] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;
-      f32x16 oh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oh[r] = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kt < TPR) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(Vl + j * SB_VL_LD + (wave0 + kt) * 32 + 8 * q + 4 * h);
-            oh = mfma32(a.x, sc[kt][q * 4 + 0] * inv, oh);
-            oh = mfma32(a.y, sc[kt][q * 4 + 1] * inv, oh);
-            oh = mfma32(a.z, sc[kt][q * 4 + 2] * inv, oh);
-            oh = mfma32(a.w, sc[kt][q * 4 + 3] * inv, oh);
-          }
-        }
-      att[hd] = oh;
-    }
-#endif
   }
   {
     f32x16 o[4];
@@ -1744,7 +1647,7 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
 // once and walks row tiles; the layers read their A fragments from the resident image (mlp_layer_b6_lds: no ring, no barriers), so in the lane-segment
 // flavour the twelve waves of a CU run free of each other, and in the dense flavour only the cross-view reductions still synchronise.
 #ifndef DYN_BLEND_WS
-#define DYN_BLEND_WS (DYN_ENGINE_B6 && DYN_SPLIT_TERMS == 3 ? 1 : 0)
+#define DYN_BLEND_WS (DYN_SPLIT_TERMS == 3 ? 1 : 0)
 #endif
 #define SC_L11_PAIRS (((SC_L11_STEPS + 7) / 8) * 4)
 #define SC_L12_PAIRS ((64 / 8) * 2)
@@ -2051,11 +1954,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
   for (int i = tid; i < SA_CT; i += DYN_VIEW_THREADS) ctab[i] = p.blob[DY_OFF_CTA + i];
   NetRing ring;
   constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
-#if DYN_ENGINE_B6
   net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds, 0, (VSEG >= 8 || VSEG == 0) ? net_layer_chunks(8, DA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
-#else
-  net_ring_init(ring, p.blob + DY_OFF_A, DA_CHUNKS, lds);
-#endif
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -2204,7 +2103,7 @@ __device__ __forceinline__ void motion_embed(const float (&c4)[4], const float* 
 
 // DYN_MOTION_DUO = 1 (default): the interleaved layer loop on the three-slot ring (dyn_mlp.h, round 4); 0: the round-3 form (A/B builds)
 #ifndef DYN_MOTION_DUO
-#define DYN_MOTION_DUO (DYN_ENGINE_B6 ? 1 : 0)
+#define DYN_MOTION_DUO 1
 #endif
 #if DYN_MOTION_DUO
 typedef WeightRing3 MotionRing;
@@ -2282,16 +2181,10 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
 }
 
 extern "C" int dyn_mlp_split_terms(void) {
-#if DYN_ENGINE_B6
   return DYN_SPLIT_TERMS;
-#else
-  return 0;  // native fp32 MFMA engine
-#endif
 }
 extern "C" int dyn_mlp_split_kind(void) {  // 0: native fp32 MFMA, 1: bf16 parts, 2: half-float parts
-#if !DYN_ENGINE_B6
-  return 0;
-#elif DYN_SPLIT_F16
+#if DYN_SPLIT_F16
   return 2;
 #else
   return 1;

@@ -14,7 +14,7 @@ python $OLDPWD/tools/rocpd_summary.py stats $(find $OUT/bench_stats -name '*.db'
 rocprofv3 --kernel-trace --stats -d $OUT/frame_stats -- $FRAME > $OUT/frame_stats.log 2>&1
 python $OLDPWD/tools/rocpd_summary.py stats $(find $OUT/frame_stats -name '*.db' | head -1) > $OUT/${TAG}_frame_kernel_stats.txt 2>&1
 DBS_B=""; DBS_F=""
-for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $C -d $OUT/bench_pmc_$N -- $BENCH > $OUT/bench_pmc_$N.log 2>&1
   DBS_B="$DBS_B $(find $OUT/bench_pmc_$N -name '*.db' | head -1)"
