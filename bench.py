@@ -382,8 +382,6 @@ def main():
       smp, rb = fc.sampler()
       fc.render(smp, rb)  # warm-up: packs the six networks, prepares the source views
       fence()
-      if lib is not None:
-        lib.dyn_profile_enable(1)
       render_image.FRAME_STATS = {}  # opt-in stage clocks of the next frame (they synchronise the device between the stages)
       t0 = time.perf_counter()
       ret = fc.render(smp, rb)
@@ -392,13 +390,21 @@ def main():
       fst, render_image.FRAME_STATS = render_image.FRAME_STATS, None
       fk = {}
       if lib is not None:
+        # the per-kernel breakdown comes from ONE MORE frame on a single stream: the timed frame above alternates its chunks over
+        # render_image.CHUNK_STREAMS streams, and HIP-event brackets of overlapping kernels would count the overlap twice
+        n_streams, render_image.CHUNK_STREAMS = render_image.CHUNK_STREAMS, 1
+        lib.dyn_profile_enable(1)
+        fc.render(smp, rb)
+        fence()
         lib.dyn_profile_enable(0)
+        render_image.CHUNK_STREAMS = n_streams
         fk = read_kernels(lib)
       n_frame_rays = rb['ray_o'].shape[0]
       extra['frame_nvi_288x512'] = {
           'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
                   + ('rays tiled over %d ranks, one packed [rays,5] all-gather: strong scaling' % world if world > 1 else 'one GPU'),
           'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': n_frame_rays / fdt, 'gather': render_image.GATHER if multi_rank else None,
+          'chunk_streams': getattr(render_image, 'CHUNK_STREAMS', 1),
           'per_rank': {'tile_rays': [int(v) for v in every_rank(fst.get('tile_rays', 0))],
                        'render_ms': [round(v, 3) for v in every_rank(fst.get('render_ms', 0.0))],
                        'gather_and_copy_ms': [round(v, 3) for v in every_rank(fst.get('gather_ms', 0.0))],
@@ -406,7 +412,7 @@ def main():
                        'chunk_rays_rank0': fst.get('chunk_rays'), 'chunk_ms_rank0': fst.get('chunk_ms'),
                        'note': 'render_ms: the chunk loop over the rank\'s own ray tile; gather_and_copy_ms: the packed [rays,5] all-gather + the copy of the frame\'s pixels '
                                'to the host (render_image.FRAME_STATS: the device is synchronised between the two stages for this frame only)'},
-          'kernel_ms_per_frame_rank0': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},
+          'kernel_ms_per_frame_rank0_one_stream': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},
           'pixels_check': [float(ret['outputs_fine_ref']['rgb'].mean()), float(ret['outputs_fine_ref']['depth'].mean())]}
       if dry:
         extra['frame_nvi_288x512']['what'] = 'DRY RUN: %d x %d stub rays through the real render_single_image_nvi on %d gloo rank(s)' % (fc.H, fc.W, world)
@@ -794,7 +800,7 @@ def main():
     obs_us = kernels['k_static_points']['avg_ms'] * 1e3
     state['k_net_points'] = {'observed_us': obs_us, 'expected_us': exp_us, 'ratio': obs_us / exp_us, 'slow_state': bool(obs_us > 1.25 * exp_us),
                              'vs_k_static_views': obs_us / (dom['avg_ms'] * 1e3)}
-  fkm = ((extra.get('frame_nvi_288x512') or {}).get('kernel_ms_per_frame_rank0') or {})
+  fkm = ((extra.get('frame_nvi_288x512') or {}).get('kernel_ms_per_frame_rank0_one_stream') or {})
   if 'k_motion_mlp' in fkm and world == 1:
     fl = 1.062e6 * 147456 * (64 + 128) * 1.0  # motion MLP FLOPs per frame: every coarse + fine sample point once
     exp_ms = fl / (0.51 * peak * 1e12) * 1e3 * clk_scale

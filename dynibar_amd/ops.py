@@ -319,15 +319,13 @@ class StaticNet:
     self.blob = _pack('dyn_static_net_pack', 'dyn_static_net_blob_floats', STATIC_TENSORS, sd, F, 'static',
                       optional=() if anti_alias_pooling else ('s',)).to(device)
     self.anti_alias_pooling, self.mask_rgb = int(bool(anti_alias_pooling)), int(bool(mask_rgb))
-    self._ws = None
+    self._ws = _Workspace()
 
   def workspace(self, R, S, V, device):
     need = int(_lib.lib().dyn_static_net_workspace_bytes(R, S, V))
     if need == 0:
       raise ValueError(f'dyn_static_net: unsupported shape R={R} S={S} V={V}')
-    if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != torch.device(device):
-      self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
-    return self._ws, need
+    return self._ws.get(need, device), need
 
   def __call__(self, views: SourceViews, ray_o, ray_d, pts, rgb_feat, ray_diff, mask):
     """-> raw [R,S,4]  (k_static_ref_feat, k_static_views, k_static_points, k_static_blend)."""
@@ -361,15 +359,21 @@ def _strip_module(state_dict):
 
 
 class _Workspace:
+  """A network's scratch between its kernels, kept across calls -- ONE PER STREAM: two ray chunks in flight on two streams (render_image.CHUNK_STREAMS)
+  must not share it, and a buffer that only ever serves one stream needs no cross-stream bookkeeping with the caching allocator."""
+
   def __init__(self):
-    self.buf = None
+    self.bufs = {}
 
   def get(self, need, device):
     if need == 0:
       raise ValueError('unsupported network shape (R, S, V)')
-    if self.buf is None or self.buf.numel() * 4 < need or self.buf.device != torch.device(device):
-      self.buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
-    return self.buf
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    buf = self.bufs.get(key)
+    if buf is None or buf.numel() * 4 < need:
+      buf = self.bufs[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    return buf
 
 
 class DynamicNet:

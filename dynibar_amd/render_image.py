@@ -322,6 +322,17 @@ def _assemble(per_chunk, n_rays, Hs, Ws, dist, world, rank, count=None, eager=No
   return frame
 
 
+CHUNK_STREAMS = int(os.environ.get('DYNIBAR_CHUNK_STREAMS', '2'))  # HIP streams the chunks of a frame alternate over (1: the caller's stream only)
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+  key = (dev.index, n)
+  if key not in _SIDE_STREAMS:
+    _SIDE_STREAMS[key] = [torch.cuda.Stream(dev) for _ in range(n)]
+  return _SIDE_STREAMS[key]
+
+
 BALANCED_CHUNKS = os.environ.get('DYNIBAR_BALANCED_CHUNKS', 'tiled')  # 'tiled': when the frame is tiled across ranks; 'always'; 'never'
 
 
@@ -364,15 +375,43 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
       marks.append(e)
 
   mark()
-  for a, b in bounds:
-    ret = render_chunk(slice_ray_batch(ray_batch, a, b))
-    for g in group_names:
-      if ret.get(g) is not None:
-        chunks[g].append(ret[g])
+  dev = ray_batch['ray_o'].device
+  n_streams = CHUNK_STREAMS if (dev.type == 'cuda' and len(bounds) > 2) else 1
+  if n_streams > 1:
+    # Chunks are independent, so consecutive chunks go to alternating side streams: the device then fills the tail of one chunk's kernels (and the idle
+    # CUs under its one-workgroup-per-CU kernels, which leave 27 KB of LDS and 56 registers per lane free) with the next chunk's small and HBM-bound
+    # kernels -- sampling, the projection / gather, compositing.  The first chunk fills the per-view caches (projection matrices, channels-last maps,
+    # packed networks): the second stream starts behind it; after that the two streams run free.  Outputs are handed to the caller's stream at the end.
+    cur = torch.cuda.current_stream(dev)
+    side = _side_streams(dev, n_streams)
+    for st in side:
+      st.wait_stream(cur)
+    for i, (a, b) in enumerate(bounds):
+      st = side[i % n_streams]
+      if i == 1:
+        for other in side[1:]:
+          other.wait_stream(side[0])
+      with torch.cuda.stream(st):
+        ret = render_chunk(slice_ray_batch(ray_batch, a, b))
+        for g in group_names:
+          if ret.get(g) is not None:
+            for v in ret[g].values():
+              if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
+            chunks[g].append(ret[g])
+    for st in side:
+      cur.wait_stream(st)
     mark()
+  else:
+    for a, b in bounds:
+      ret = render_chunk(slice_ray_batch(ray_batch, a, b))
+      for g in group_names:
+        if ret.get(g) is not None:
+          chunks[g].append(ret[g])
+      mark()
   if FRAME_STATS is not None:
     FRAME_STATS.update(tile_rays=count, render_ms=(_clock() - t0) * 1e3, gather_ms=0.0, gather_bytes=0, chunk_rays=[b - a for a, b in bounds],
-                       chunk_ms=[round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)])
+                       chunk_ms=[round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)], chunk_streams=n_streams)
   return chunks, n_rays, dist, world, rank, count
 
 

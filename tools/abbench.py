@@ -33,6 +33,8 @@ if FRAME:
   smp, rb = fc.sampler(); fc.render(smp, rb); torch.cuda.synchronize()
   e0.record(); fc.render(smp, rb); e1.record(); torch.cuda.synchronize()
   out['frame_ms'] = e0.elapsed_time(e1)
+  from dynibar_amd import render_image
+  render_image.CHUNK_STREAMS = 1  # (the per-kernel breakdown on one stream: overlapped kernels would be counted twice)
   L.dyn_profile_enable(1)
   fc.render(smp, rb); torch.cuda.synchronize()
   L.dyn_profile_enable(0)

@@ -18,15 +18,17 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from frame_case import FrameCase
 fc = FrameCase(dev, a.H, a.W, a.vdy, a.vst, a.chunk)
 lib = _lib.lib()
-for f in range(a.frames + 1):
-  if f == 1:
+print(f'chunk streams: {render_image.CHUNK_STREAMS} (the per-kernel breakdown below is taken on ONE stream: overlapped kernels would be counted twice)', flush=True)
+for f in range(2 * a.frames + 1):
+  if f == a.frames + 1:
+    render_image.CHUNK_STREAMS = 1
     lib.dyn_profile_enable(1)
   torch.cuda.synchronize(); t0 = time.perf_counter()
   smp, rb = fc.sampler()
   torch.cuda.synchronize(); t1 = time.perf_counter()
   ret = fc.render(smp, rb)
   torch.cuda.synchronize(); t2 = time.perf_counter()
-  print(f'frame {f}: sampler {1e3 * (t1 - t0):.1f} ms, render {1e3 * (t2 - t1):.1f} ms, {a.H * a.W / (t2 - t1):.0f} rays/s', flush=True)
+  print(f'frame {f}{" (one stream, kernels timed)" if f > a.frames else ""}: sampler {1e3 * (t1 - t0):.1f} ms, render {1e3 * (t2 - t1):.1f} ms, {a.H * a.W / (t2 - t1):.0f} rays/s', flush=True)
 lib.dyn_profile_enable(0)
 nk = lib.dyn_profile_count(); ms = (ctypes.c_float * nk)(); cnt = (ctypes.c_int * nk)(); lib.dyn_profile_read(ms, cnt)
 tot = sum(ms[i] for i in range(nk))
