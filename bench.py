@@ -810,7 +810,9 @@ def main():
     for kn in ('k_net_points', 'k_static_views'):
       iv = insts.get(kn) or {}
       if iv.get('SQ_BUSY_CYCLES') and iv.get('GRBM_GUI_ACTIVE'):
-        state.setdefault('sq_busy_over_gui_active', {})[kn] = iv['SQ_BUSY_CYCLES'] / iv['GRBM_GUI_ACTIVE']
+        # (SQ_BUSY_CYCLES is summed over the 32 shader engines, GRBM_GUI_ACTIVE over the 8 XCDs: / 4 = the fraction of the launch the SEs had waves resident;
+        #  ~0.95 in the fast state, ~0.5 when half of a one-workgroup-per-CU kernel's workgroups cannot be placed)
+        state.setdefault('se_busy_fraction', {})[kn] = iv['SQ_BUSY_CYCLES'] / iv['GRBM_GUI_ACTIVE'] / 4.0
   state['any_slow'] = any(isinstance(v, dict) and v.get('slow_state') for v in state.values())
 
   res = {
