@@ -375,6 +375,7 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
       marks.append(e)
 
   mark()
+  spans = []
   dev = ray_batch['ray_o'].device
   n_streams = CHUNK_STREAMS if (dev.type == 'cuda' and len(bounds) > 2) else 1
   if n_streams > 1:
@@ -392,7 +393,12 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
         for other in side[1:]:
           other.wait_stream(side[0])
       with torch.cuda.stream(st):
+        if timed:  # the chunk's own span on its stream (spans of chunks on different streams overlap: their sum exceeds the frame)
+          spans.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+          spans[-1][0].record()
         ret = render_chunk(slice_ray_batch(ray_batch, a, b))
+        if timed:
+          spans[-1][1].record()
         for g in group_names:
           if ret.get(g) is not None:
             for v in ret[g].values():
@@ -411,7 +417,8 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
       mark()
   if FRAME_STATS is not None:
     FRAME_STATS.update(tile_rays=count, render_ms=(_clock() - t0) * 1e3, gather_ms=0.0, gather_bytes=0, chunk_rays=[b - a for a, b in bounds],
-                       chunk_ms=[round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)], chunk_streams=n_streams)
+                       chunk_ms=([round(e0.elapsed_time(e1), 3) for e0, e1 in spans] if spans else
+                                 [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)]), chunk_streams=n_streams)
   return chunks, n_rays, dist, world, rank, count
 
 
