@@ -1044,6 +1044,37 @@ def check_render_image_nvi(device, golden, chunk_size=80):
   return ret
 
 
+def check_chunk_stream_invariance(device, chunk_size=40):
+  """render_single_image_nvi with its chunks on 1, 2 and 3 alternating HIP streams (render_image.CHUNK_STREAMS; per-stream network workspaces): identical
+  bits in every entry.  (Round 5 found the failure mode this guards: two chunks in flight sharing one network workspace.)"""
+  import types
+  from dynibar_amd import projection, render_image, sample_ray
+  data, cfeat, ffeat = image_case(device)
+  smp = sample_ray.RaySamplerSingleImage(data, device)
+  rb = smp.get_all()
+  model = make_model(device)
+  args = types.SimpleNamespace(anti_alias_pooling=True, mask_rgb=False, occ_weights_mode=0, frame_outputs='all')
+  fidx, temb, toff = cases.time_args(7)
+  outs = []
+  prev = render_image.CHUNK_STREAMS
+  try:
+    for n in (1, 2, 3, 2):
+      render_image.CHUNK_STREAMS = n
+      ret = render_image.render_single_image_nvi((fidx, None), (temb.to(device), None), (toff, None), smp, rb, model, projection.Projector(device),
+                                                 chunk_size, 64, args, inv_uniform=True, N_importance=64, det=True, coarse_featmaps=cfeat,
+                                                 fine_featmaps=ffeat, is_train=False)
+      outs.append({(g, k): v.clone() if isinstance(v, torch.Tensor) else v for g in ('outputs_coarse_ref', 'outputs_fine_ref') for k, v in ret[g].items()})
+  finally:
+    render_image.CHUNK_STREAMS = prev
+  n = 0
+  for other in outs[1:]:
+    for key, v in outs[0].items():
+      if isinstance(v, torch.Tensor):
+        assert_bitexact(other[key], v, f'chunk streams: {key}')
+        n += 1
+  return n
+
+
 def check_checkpoint_render_chain(device, g_img, g_enc, tmpdir, chunk_size=80):
   """Section 8f-4 on the device: both checkpoint files of the reference (model.py:424-441 coarse / monocular, :177-190 fine) are WRITTEN with torch.save
   from nn.Module state dicts (de-parallelised like model.py:13-15; the encoders with the decoder layers forward never runs riding along, optimizer /

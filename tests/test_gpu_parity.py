@@ -134,6 +134,10 @@ def test_render_single_image_nvi(dev, golden_dir):
   parity.check_render_image_nvi(dev, _golden(golden_dir, 'image_nvi.npz'))
 
 
+def test_frame_is_identical_on_one_two_and_three_chunk_streams(dev):
+  assert parity.check_chunk_stream_invariance(dev) > 0
+
+
 def test_render_single_image_mono(dev, golden_dir):
   parity.check_render_image_mono(dev, _golden(golden_dir, 'image_mono.npz'))
 
