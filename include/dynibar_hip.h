@@ -432,7 +432,8 @@ int dyn_train_blend_bwd(const float* draw, const float* blend, const float* mask
                         float* dlogit, long dlogit_stride, float* dsigma, long dsigma_stride, void* stream);
 
 /* backward of raw2outputs_vanilla (render_ray.py:134-201): alpha, weights as saved by dyn_composite; drgb [R,3], ddepth [R],
- * dweights [R,S] (each may be NULL) -> draw [R,S,4] */
+ * dweights [R,S] (each may be NULL) -> draw [R,S,4].  S <= 4096.  The sums over the samples BEHIND a sample are formed directly, walking the ray from
+ * its far end (not as total - prefix: far down a ray that difference is pure rounding, coherent along the ray). */
 int dyn_train_composite_bwd(const float* raw, const float* z_vals, const float* alpha, const float* weights, const float* drgb,
                             const float* ddepth, const float* dweights, int R, int S, float* draw, void* stream);
 
@@ -458,7 +459,7 @@ int dyn_train_dynamic_head_bwd(const float* draw, const float* raw, const float*
                                void* stream);
 
 /* backward of raw2outputs (render_ray.py:246-330): upstream gradients of rgb, rgb_static, rgb_dy [R,3], depth [R], weights_dy, weights_st,
- * weights [R,S] (each may be NULL) -> draw_dy, draw_st [R,S,4] */
+ * weights [R,S] (each may be NULL) -> draw_dy, draw_st [R,S,4].  S <= 4096; suffix sums as in dyn_train_composite_bwd. */
 int dyn_train_composite2_bwd(const float* raw_dy, const float* raw_st, const float* z_vals, const float* g_rgb, const float* g_rgb_st,
                              const float* g_rgb_dy, const float* g_depth, const float* g_wd, const float* g_ws, const float* g_w, int R, int S,
                              float* draw_dy, float* draw_st, void* stream);
