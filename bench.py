@@ -802,7 +802,8 @@ def main():
                              'vs_k_static_views': obs_us / (dom['avg_ms'] * 1e3)}
   fkm = ((extra.get('frame_nvi_288x512') or {}).get('kernel_ms_per_frame_rank0_one_stream') or {})
   if 'k_motion_mlp' in fkm and world == 1:
-    fl = 1.062e6 * 147456 * (64 + 128) * 1.0  # motion MLP FLOPs per frame: every coarse + fine sample point once
+    fl = 1.062e6 * 147456 * (58 + 115) * 1.0  # motion MLP FLOPs per frame: the coarse (64) + fine (128) sample points that keep their coefficients
+    # (the last round(0.1 S) samples of a ray are zeroed by the reference, render_ray.py:684, and are no longer evaluated: SURVEY 8d's 1.062 MFLOP x 173 of 192 samples)
     exp_ms = fl / (0.51 * peak * 1e12) * 1e3 * clk_scale
     state['k_motion_mlp'] = {'observed_ms_per_frame': fkm['k_motion_mlp'], 'expected_ms_per_frame': exp_ms, 'ratio': fkm['k_motion_mlp'] / exp_ms,
                              'slow_state': bool(fkm['k_motion_mlp'] > 1.25 * exp_ms)}

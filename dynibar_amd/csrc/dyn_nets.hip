@@ -2117,15 +2117,31 @@ typedef NetRing MotionRing;
 #define motion_layer net_layer
 #endif
 
+// The last n_zero_last samples of every ray carry no motion: raw_coeff[:, -n_last:, :] *= 0 (render_ray.py:684).  Rounds 1-4 evaluated the chain for them
+// and multiplied by zero; since round 5 the launch covers only the S - n_zero_last samples per ray that keep their coefficients (a tenth fewer rows at the
+// reference's n_last = round(0.1 S)) and k_motion_zero_tail writes the zeros.  (+0 where c x 0 gave -0 for a negative c: every consumer adds or multiplies
+// them into sums that are equal either way; a NON-FINITE chain output no longer turns into NaN there.)
+__global__ void __launch_bounds__(256) k_motion_zero_tail(long R, int S, int n_zero_last, int n_out, float* __restrict__ coeff) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_ray = (long)n_zero_last * n_out;
+  if (i >= R * per_ray) return;
+  const long ray = i / per_ray;
+  coeff[(ray * S + (S - n_zero_last)) * n_out + (i - ray * per_ray)] = 0.f;
+}
+
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1)
-k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, const float* __restrict__ time, long n_pts, int S, int n_zero_last,
+k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, const float* __restrict__ time, long n_kept, int S, int n_zero_last,
              int n_out, float inv_div, float* __restrict__ coeff) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   MotionRing ring;
   motion_ring_init(ring, blob, MO_CHUNKS, lds);
-  const long point = ((long)blockIdx.x * 4 + wave) * 32 + j;
-  const bool valid = point < n_pts;
+  // row -> (ray, sample) over the samples that keep their coefficients
+  const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
+  const bool valid = row < n_kept;
+  const int Sk = S - n_zero_last;
+  const long ray = (valid ? row : 0) / Sk;
+  const long point = ray * S + ((valid ? row : 0) - ray * Sk);
   float c4[4] = {0.f, 0.f, 0.f, time[0]};
   if (valid) { c4[0] = pts[point * 3]; c4[1] = pts[point * 3 + 1]; c4[2] = pts[point * 3 + 2]; }
   const float* freq = blob + MO_OFF_FREQ;
@@ -2159,13 +2175,10 @@ k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, cons
   acc_zero(c1);
   motion_layer<1, 129>(ring, c1, [&](int s) { return s < 128 ? relu1(b[s / 16][s % 16]) : one_h0; });
   if (valid) {
-    // raw_coeff[:, -n_zero_last:, :] *= 0 (render_ray.py:684): the last samples of every ray carry no motion
-    const int smp = (int)(point % S);
-    const float keep = (smp >= S - n_zero_last) ? 0.f : inv_div;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = dyn_fi(r, h);
-      if (f < n_out) coeff[point * n_out + f] = c1[0][r] * keep;
+      if (f < n_out) coeff[point * n_out + f] = c1[0][r] * inv_div;
     }
   }
 }
@@ -2174,9 +2187,14 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
                               float sf_mag_div, float* coeff, void* stream) {
   DYN_REQUIRE(blob && pts && time && coeff, "dyn_motion_mlp: null pointer");
   DYN_REQUIRE(R > 0 && S > 0 && num_basis >= 1 && 3 * num_basis <= 32 && n_zero_last >= 0 && sf_mag_div != 0.f, "dyn_motion_mlp: bad argument");
-  const long n_pts = (long)R * S;
-  DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_pts, 128)), dim3(DYN_NET_THREADS), MOTION_RING_SLOTS * NET_CHUNK * sizeof(float),
-             (hipStream_t)stream, blob, pts, time, n_pts, S, n_zero_last, 3 * num_basis, 1.0f / sf_mag_div, coeff);
+  const int nz = n_zero_last < S ? n_zero_last : S;
+  const long n_kept = (long)R * (S - nz);
+  if (n_kept > 0)
+    DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_kept, 128)), dim3(DYN_NET_THREADS), MOTION_RING_SLOTS * NET_CHUNK * sizeof(float),
+               (hipStream_t)stream, blob, pts, time, n_kept, S, nz, 3 * num_basis, 1.0f / sf_mag_div, coeff);
+  if (nz > 0)
+    DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_zero_tail", k_motion_zero_tail, dim3(dyn_cdiv((long)R * nz * 3 * num_basis, 256)), dim3(256), 0, (hipStream_t)stream, (long)R, S, nz,
+               3 * num_basis, coeff);
   return 0;
 }
 
