@@ -512,7 +512,7 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 // this kernel had just written) is a by-product.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef PGT_UNROLL
-#define PGT_UNROLL 4
+#define PGT_UNROLL 2  /* tap instructions in flight per pass (x 4 taps).  With P = 16, inside the pipeline: 1: 83.5 / 120.1 us at 8 / 11 views, 2: 82.2-83.1 / 115.2-115.6, 3: 85.3 / 119.6, 4 (rounds 2-4): 83.5-85.0 / 119.7-121.6, 8: spills */
 #endif
 #ifndef PGT_DEFAULT_P
 #define PGT_DEFAULT_P 16
