@@ -785,11 +785,10 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   q.tiles_per_xcd = (q.ntile + 7) / 8;
   const long nblocks = 8 * q.tiles_per_xcd;
   static const int no_pref = getenv("DYN_PG_NOPREF") != nullptr;  // developer A/B
-  // the first resident generation of workgroups shares the streaming of the maps: min(8, LDS / tile) per CU x 256 CUs (round 5, 8 views, P = 16: 256 workgroups
-  // 101.7 us, 512: 87.8, 2048: 84.7 = 0.53 of 8 TB/s; 11 views: 132.9 / 124.8 / 126.1)
+  // the first 1024 workgroups (four per CU) share the streaming of the maps (round 5, inside the pipeline, P = 16, us at 8 / 11 views: none 120.7 / 195.2,
+  // 256 workgroups 101.7 / 132.9, 512: 87.8 / 124.8, 1024: 81.9 / 117.7, 1280-2048: 83.7-84.7 / 118.9-120.7, 4096: 86.5 / 126.9)
   static const int pref_env = getenv("DYN_PG_PREF") ? atoi(getenv("DYN_PG_PREF")) : 0;  // developer A/B
-  const long per_cu = (long)(160 * 1024) / (long)lds < 8 ? (long)(160 * 1024) / (long)lds : 8;
-  const long pref_n = pref_env > 0 ? pref_env : 256 * (per_cu > 1 ? per_cu : 1);
+  const long pref_n = pref_env > 0 ? pref_env : 1024;
   q.pref_wgs = no_pref ? 0 : (int)(nblocks < pref_n ? nblocks : pref_n);
   if (P == 8)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<8>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
