@@ -272,8 +272,8 @@ def main():
   ap.add_argument('--samples', type=int, default=64)
   ap.add_argument('--views', type=int, default=8)
   ap.add_argument('--cpu-rays', type=int, default=1024, help='rays of the same workload timed on the host oracle (0 = skip)')
-  ap.add_argument('--no-x6', action='store_true', help='(kept for old command lines; the bf16 6-term leg is off unless --x6)')
-  ap.add_argument('--x6', action='store_true', help='also time the bf16 6-term split engine build (libdynibar_hip_x6.so)')
+  ap.add_argument('--no-x6', action='store_true', help='skip the leg that times the exact 6-term bf16 split engine (libdynibar_hip_x6.so) beside the shipped one')
+  ap.add_argument('--x6', action='store_true', help='(kept for old command lines: the 6-term leg is on by default since round 6)')
   ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (11 views, full frame)')
   ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc child runs that measure HBM traffic per launch')
   ap.add_argument('--dry-run', action='store_true', help='rehearse the (multi-rank) control flow on CPU ranks over gloo with a stub of the kernel layer; numbers are meaningless')
@@ -281,10 +281,12 @@ def main():
                   'multi-rank code path -- per-step pixel all-gather, barrier-bracketed fences, the ray-tiled frame leg -- so that this path runs on a single MI355X')
   ap.add_argument('--gather', choices=('torch', 'abi'), default=None, help="the frame leg's pixel gather: torch.distributed (default) or the C-ABI's dyn_gather_tiles")
   ap.add_argument('--frame-only', action='store_true', help='of the extra legs only the full frame (tests)')
-  ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
+  ap.add_argument('--dump-rgb', default=None, help=argparse.SUPPRESS)  # (child of the x6 leg: the last step's colours of the first cpu-rays rays as .npy)
+  ap.add_argument('--child', nargs='?', const='plain', default=None, help=argparse.SUPPRESS)  # 'plain': no baseline / extra legs; 'check': keep the oracle check (x6 leg)
   a = ap.parse_args()
+  a.x6 = not a.no_x6
   if a.child:
-    a.cpu_rays, a.no_extra, a.no_traffic, a.x6 = 0, True, True, False
+    a.cpu_rays, a.no_extra, a.no_traffic, a.x6 = 0 if a.child == 'plain' else a.cpu_rays, True, True, False
   if a.dry_run:
     a.cpu_rays, a.no_traffic, a.x6 = 0, True, False
 
@@ -319,6 +321,46 @@ def main():
     from dynibar_amd import _lib
     lib = _lib.lib()
   sync = (lambda: None) if dry else torch.cuda.synchronize
+
+  # ---- N > 1 readiness, BEFORE anything is timed: does RCCL see all N ranks, through torch.distributed and through the package's own communicator? ----
+  readiness = None
+  if multi_rank:
+    readiness = {'world_size': world, 'backend': dist.get_backend()}
+    names = [None] * world
+    dist.all_gather_object(names, 'cpu (dry run)' if dry else '%s #%d' % (torch.cuda.get_device_name(dev), local_rank))
+    readiness['devices'] = names
+    probe = torch.full((1,), float(rank), dtype=torch.float32, device=dev)
+    got = torch.empty(world, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(got, probe)
+    readiness['torch_allgather_ranks_seen'] = int((got == torch.arange(world, dtype=torch.float32, device=dev)).sum().item())
+    assert readiness['torch_allgather_ranks_seen'] == world, f'all_gather saw {readiness["torch_allgather_ranks_seen"]} of {world} ranks'
+    if not dry:
+      try:
+        from dynibar_amd import render_image as _ri
+        from dynibar_amd._lib import call as _call, ptr as _ptr, stream_of as _stream_of
+        comm = _ri.abi_communicator(dist, world, rank, dev)  # rank 0 draws the id, torch.distributed carries it, every rank joins (ncclCommInitRank)
+        nr, rk = ctypes.c_int(0), ctypes.c_int(-1)
+        _call('dyn_comm_size_rank', comm, ctypes.byref(nr), ctypes.byref(rk))  # ncclCommCount / ncclCommUserRank of that communicator
+        readiness['rccl_ranks'], readiness['rccl_rank_of_rank0'] = int(nr.value), int(rk.value) if rank == 0 else None
+        rows = 3 + rank  # (the real frame pads unequal tiles to the largest: the same shape here)
+        tile = 3 + world - 1
+        send = torch.zeros((tile, 5), dtype=torch.float32, device=dev)
+        send[:rows] = float(rank + 1)
+        recv = torch.empty((world * tile, 5), dtype=torch.float32, device=dev)
+        _call('dyn_gather_tiles', _ptr(send), _ptr(recv), tile, 5, comm, _stream_of(send))
+        sync()
+        want = torch.zeros((world, tile, 5), dtype=torch.float32, device=dev)
+        for r_ in range(world):
+          want[r_, :3 + r_] = float(r_ + 1)
+        readiness['dyn_gather_tiles_ok'] = bool(torch.equal(recv.view(world, tile, 5), want))
+      except Exception as e:  # the package's own communicator is an option of the frame leg (--gather abi): its failure must not cost the headline
+        readiness['rccl_ranks'] = None
+        readiness['abi_communicator_error'] = str(e)[:300]
+      seen = [None] * world
+      dist.all_gather_object(seen, readiness.get('rccl_ranks'))
+      readiness['rccl_ranks_every_rank'] = seen
+      if readiness.get('rccl_ranks') is not None:
+        assert readiness['rccl_ranks'] == world, f'the RCCL communicator has {readiness["rccl_ranks"]} ranks, expected {world}'
 
   R, S, V = a.rays, a.samples, a.views
   wl = (DryStep if dry else StaticStep)(dev, R, S, V, rank)
@@ -367,7 +409,8 @@ def main():
     fence()
     ag = max_over_ranks(time.perf_counter() - t0)
     multi = {'per_rank_ms_per_step': [round(v / a.steps * 1e3, 4) for v in every_rank(dt_own)], 'allgather_alone_ms_per_step': ag / a.steps * 1e3,
-             'allgather_bytes_per_rank_per_step': int(send.numel() * 4), 'backend': dist.get_backend()}
+             'allgather_bytes_per_rank_per_step': int(send.numel() * 4), 'backend': dist.get_backend(), 'readiness': readiness,
+             'rccl_ranks': (readiness or {}).get('rccl_ranks'), 'devices': (readiness or {}).get('devices')}
 
   # ---- extra legs (every rank takes part in the frame leg: the ray tiles are a collective effort) ----
   extra = {}
@@ -393,12 +436,15 @@ def main():
         # the per-kernel breakdown comes from ONE MORE frame on a single stream: the timed frame above alternates its chunks over
         # render_image.CHUNK_STREAMS streams, and HIP-event brackets of overlapping kernels would count the overlap twice
         n_streams, render_image.CHUNK_STREAMS = render_image.CHUNK_STREAMS, 1
+        from dynibar_amd import ops as _ops_mod
+        _ops_mod.GATHER_STATS = {}
         lib.dyn_profile_enable(1)
         fc.render(smp, rb)
         fence()
         lib.dyn_profile_enable(0)
         render_image.CHUNK_STREAMS = n_streams
         fk = read_kernels(lib)
+        frame_gather, _ops_mod.GATHER_STATS = _ops_mod.GATHER_STATS, None
       n_frame_rays = rb['ray_o'].shape[0]
       extra['frame_nvi_288x512'] = {
           'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
@@ -413,6 +459,8 @@ def main():
                        'note': 'render_ms: the chunk loop over the rank\'s own ray tile; gather_and_copy_ms: the packed [rays,5] all-gather + the copy of the frame\'s pixels '
                                'to the host (render_image.FRAME_STATS: the device is synchronised between the two stages for this frame only)'},
           'kernel_ms_per_frame_rank0_one_stream': {k: round(v['avg_ms'] * v['launches'], 3) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]['avg_ms'] * kv[1]['launches'])},
+          'gather_algorithmic_bytes_rank0': (frame_gather or {}).get('bytes') if lib is not None else None,
+          'gather_calls_rank0': (frame_gather or {}).get('calls') if lib is not None else None,
           'pixels_check': [float(ret['outputs_fine_ref']['rgb'].mean()), float(ret['outputs_fine_ref']['depth'].mean())]}
       if dry:
         extra['frame_nvi_288x512']['what'] = 'DRY RUN: %d x %d stub rays through the real render_single_image_nvi on %d gloo rank(s)' % (fc.H, fc.W, world)
@@ -430,6 +478,15 @@ def main():
         del wl11
       except Exception as e:
         extra['views_11'] = {'error': str(e)[:300]}
+      try:
+        # K1 alone at the dynamic branch's 7 views, inside the same alternation with the network kernels (the V = 7 tile of the frame)
+        wl7 = StaticStep(dev, R, S, 7, rank)
+        _, dt7, k7 = timed(lib, wl7.step, 5, 2, fence)
+        extra['views_7'] = {'what': 'the same step at 7 source views (the dynamic branch\'s count): priced for its k_project_gather only',
+                            'ms_per_step': dt7 / 5 * 1e3, 'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in k7.items()}}
+        del wl7
+      except Exception as e:
+        extra['views_7'] = {'error': str(e)[:300]}
       try:
         # the package power and the shader clock WHILE the step runs back to back (rocm-smi samples beside a 4 s loop of the same step): the 2500 TFLOP/s
         # peak the roofline is priced against assumes 2.4 GHz, the part clocks down to its power cap under these kernels
@@ -744,7 +801,7 @@ def main():
       clock = {'effective_shader_clock_ghz': ghz, 'nominal_ghz': 2.4,
                'mfma_pipe_busy_frac': (ck['mfma_busy_cycles'] / (ck['grbm_gui_active'] / 8.0 * 1024.0)) if ck.get('mfma_busy_cycles') else None,
                'note': 'k_static_views under the profiler: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs). '
-                       'The 2500 TFLOP/s dense peak assumes 2.4 GHz; frac_at_effective_clock rescales it to the clock the power budget allowed'}
+                       'The 2500 TFLOP/s dense peak assumes 2.4 GHz; frac_of_throttled_peak rescales it to the clock the power budget allowed'}
   tr = lambda k: (traffic[k]['bytes'] if traffic and k in traffic else None)
   insts = None
   if not a.no_traffic and world == 1:
@@ -783,38 +840,79 @@ def main():
   secondary['static_net'] = {'kernels': 'k_static_ref_feat + k_static_views + k_static_points + k_static_blend', 'bound': 'mfma', 'achieved': net_tflops, 'peak': peak,
                              'unit': 'TFLOP/s', 'frac': net_tflops / peak, 'avg_ms': net_ms, 'frac_vs_fp32_mfma_peak': net_tflops / FP32_MFMA_PEAK_TFLOPS}
 
-  # the two-state behaviour of the one-workgroup-per-CU kernels: their time against what their FLOPs predict from the fast state
-  # (k_net_points<static>: 0.285 of the split ceiling, k_motion_mlp: 0.51, both read at ~2.0 GHz), rescaled to this run's clock; > 1.25 x = slow state
+  # The one-workgroup-per-CU kernels, priced by their own FLOPs (a slow KERNEL shows as a low fraction) and, separately, the signature of the slow STATE some
+  # sessions of rounds 4-5 showed (a co-tenant holding registers / LDS: the shader engines have waves resident only ~half of the launch, SQ_BUSY_CYCLES)
   sclk = None
   try:
     sclk = float(np.mean(extra['power_under_step_loop']['shader_clock_mhz'])) / 1e3
   except Exception:
     pass
-  clk_scale = (2.0 / sclk) if sclk else 1.0
-  state = {'what': 'one-workgroup-per-CU kernels against their fast-state expectation (FLOPs / (fast-state fraction x split-MFMA ceiling), rescaled by 2.0 GHz / '
-                   'measured shader clock); slow_state = observed > 1.25 x expected: a co-tenant holding registers / LDS on the CUs, not a regression of the code',
+  state = {'what': 'one-workgroup-per-CU kernels: algorithmic FLOPs / time / split-MFMA ceiling (nominal clock), and the fraction of the launch the shader engines had '
+                   'waves resident (SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE / 4: ~0.95 normally, ~0.5 in the slow state of rounds 4-5); slow_state = that fraction < 0.75',
            'shader_clock_ghz': sclk}
+  points_frac = motion_frac = dyn_points_frac = None
   if 'k_static_points' in kernels:
     fl = (0.361e6 + 0.033e6 * (S / 64.0)) * R * S
-    exp_us = fl / (0.285 * peak * 1e12) * 1e6 * clk_scale
     obs_us = kernels['k_static_points']['avg_ms'] * 1e3
-    state['k_net_points'] = {'observed_us': obs_us, 'expected_us': exp_us, 'ratio': obs_us / exp_us, 'slow_state': bool(obs_us > 1.25 * exp_us),
-                             'vs_k_static_views': obs_us / (dom['avg_ms'] * 1e3)}
+    points_frac = fl / (obs_us * 1e-6) / (peak * 1e12)
+    state['k_net_points'] = {'observed_us': obs_us, 'algorithmic_flops_per_launch': fl, 'frac': points_frac, 'vs_k_static_views': obs_us / (dom['avg_ms'] * 1e3)}
   fkm = ((extra.get('frame_nvi_288x512') or {}).get('kernel_ms_per_frame_rank0_one_stream') or {})
   if 'k_motion_mlp' in fkm and world == 1:
     fl = 1.062e6 * 147456 * (58 + 115) * 1.0  # motion MLP FLOPs per frame: the coarse (64) + fine (128) sample points that keep their coefficients
     # (the last round(0.1 S) samples of a ray are zeroed by the reference, render_ray.py:684, and are no longer evaluated: SURVEY 8d's 1.062 MFLOP x 173 of 192 samples)
-    exp_ms = fl / (0.51 * peak * 1e12) * 1e3 * clk_scale
-    state['k_motion_mlp'] = {'observed_ms_per_frame': fkm['k_motion_mlp'], 'expected_ms_per_frame': exp_ms, 'ratio': fkm['k_motion_mlp'] / exp_ms,
-                             'slow_state': bool(fkm['k_motion_mlp'] > 1.25 * exp_ms)}
+    motion_frac = fl / (fkm['k_motion_mlp'] * 1e-3) / (peak * 1e12)
+    state['k_motion_mlp'] = {'observed_ms_per_frame': fkm['k_motion_mlp'], 'algorithmic_flops_per_frame': fl, 'frac': motion_frac}
   if insts:
     for kn in ('k_net_points', 'k_static_views'):
       iv = insts.get(kn) or {}
       if iv.get('SQ_BUSY_CYCLES') and iv.get('GRBM_GUI_ACTIVE'):
-        # (SQ_BUSY_CYCLES is summed over the 32 shader engines, GRBM_GUI_ACTIVE over the 8 XCDs: / 4 = the fraction of the launch the SEs had waves resident;
-        #  ~0.95 in the fast state, ~0.5 when half of a one-workgroup-per-CU kernel's workgroups cannot be placed)
+        # (SQ_BUSY_CYCLES is summed over the 32 shader engines, GRBM_GUI_ACTIVE over the 8 XCDs: / 4 = the fraction of the launch the SEs had waves resident)
         state.setdefault('se_busy_fraction', {})[kn] = iv['SQ_BUSY_CYCLES'] / iv['GRBM_GUI_ACTIVE'] / 4.0
-  state['any_slow'] = any(isinstance(v, dict) and v.get('slow_state') for v in state.values())
+  seb = (state.get('se_busy_fraction') or {}).get('k_net_points')
+  state['any_slow'] = bool(seb is not None and seb < 0.75)
+
+  # ---- every fraction a reviewer recomputes, as SCALARS directly under `roofline` (a driver that keeps scalars only still carries them) ----
+  flat = {}
+  flat['k1_v8_us'] = pg['avg_ms'] * 1e3
+  flat['k1_v8_frac'] = pg_bytes / (pg['avg_ms'] * 1e-3) / (HBM_PEAK_GBPS * 1e9)
+  if 'k_project_gather' in k11:
+    flat['k1_v11_us'] = k11['k_project_gather'] * 1e3
+    flat['k1_v11_frac'] = gather_bytes(R, S, 11) / (k11['k_project_gather'] * 1e-3) / (HBM_PEAK_GBPS * 1e9)
+  k7 = (extra.get('views_7') or {}).get('kernels_avg_ms') or {}
+  if 'k_project_gather' in k7:
+    flat['k1_v7_us'] = k7['k_project_gather'] * 1e3
+    flat['k1_v7_frac'] = gather_bytes(R, S, 7) / (k7['k_project_gather'] * 1e-3) / (HBM_PEAK_GBPS * 1e9)
+  fr = extra.get('frame_nvi_288x512') or {}
+  if fr.get('gather_algorithmic_bytes_rank0') and 'k_project_gather' in fkm and world == 1:
+    flat['k1_inframe_ms'] = fkm['k_project_gather']
+    flat['k1_inframe_frac'] = fr['gather_algorithmic_bytes_rank0'] / (fkm['k_project_gather'] * 1e-3) / (HBM_PEAK_GBPS * 1e9)
+  if 'static_blend' in secondary:
+    flat['blend_us'] = kernels['k_static_blend']['avg_ms'] * 1e3
+    flat['blend_frac'] = secondary['static_blend']['frac']
+    if secondary['static_blend'].get('traffic'):
+      flat['blend_traffic_over_compulsory'] = secondary['static_blend']['traffic'] / secondary['static_blend']['algorithmic_bytes_per_launch']
+  if points_frac is not None:
+    flat['points_us'] = kernels['k_static_points']['avg_ms'] * 1e3
+    flat['points_frac'] = points_frac
+  if motion_frac is not None:
+    flat['motion_frac'] = motion_frac
+  if fr.get('ms_per_frame') and world == 1:
+    flat['frame_ms'] = fr['ms_per_frame']
+    flat['frame_frac'] = 1.64e9 * 147456 / (fr['ms_per_frame'] * 1e-3) / (peak * 1e12)  # 1.64 GFLOP per ray of the Nvidia eval (64 + 128 samples, 7 + 11 views)
+    for kk, nm in (('k_static_views', 'frame_static_views_ms'), ('k_dynamic_views', 'frame_dynamic_views_ms'), ('k_static_points', 'frame_static_points_ms'),
+                   ('k_dynamic_points', 'frame_dynamic_points_ms'), ('k_motion_mlp', 'frame_motion_ms'), ('k_static_blend', 'frame_blend_ms'),
+                   ('k_trajectory_points', 'frame_trajectory_points_ms')):
+      if kk in fkm:
+        flat[nm] = fkm[kk]
+  if 'views_11' in extra and 'k_static_views_vs_8_views' in extra['views_11']:
+    flat['views_11_over_8'] = extra['views_11']['k_static_views_vs_8_views']
+  if clock:
+    flat['mfma_busy'] = clock.get('mfma_pipe_busy_frac')
+    flat['valu_per_mfma'] = clock.get('valu_per_mfma')
+    flat['effective_clock_ghz_under_profiler'] = clock.get('effective_shader_clock_ghz')
+  flat['shader_clock_ghz'] = sclk
+  flat['any_slow'] = state['any_slow']
+  flat['step_frac'] = static_net_flops_per_point(S, V) * R * S / (dt / a.steps) / (peak * 1e12)  # one rank's whole step (SURVEY 8d FLOPs of DynibarStatic) against the split ceiling
 
   res = {
       'metric': 'rays/sec (64 samples x 8 src views)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': a.steps,
@@ -831,7 +929,10 @@ def main():
                                 f'partial products per product on the 16-bit matrix pipe, fp32 accumulation: ceiling for ALGORITHMIC fp32 FLOPs = 2500 TFLOP/s dense / {terms}; '
                                 'against the native fp32 MFMA peak (157.3 TFLOP/s) see frac_vs_fp32_mfma_peak',
                    'frac_vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS, 'clock': clock,
-                   'frac_at_effective_clock': (achieved / (peak * clock['effective_shader_clock_ghz'] / 2.4)) if clock else None,
+                   'frac_of_throttled_peak': (achieved / (peak * clock['effective_shader_clock_ghz'] / 2.4)) if clock else None,
+                   'frac_of_throttled_peak_note': 'NOT a roofline fraction: `frac` with the peak rescaled to the clock the power cap allowed under the profiler; says how much of '
+                                                  'the distance to the nominal-clock peak is clock and how much is the kernel',
+                   **flat,
                    'secondary': secondary, 'state': state,
                    'kernels_avg_ms': {k: round(v['avg_ms'], 5) for k, v in kernels.items()}},
       'cpu_baseline': None,  # (filled below; kept in front of the long `extra` object)
@@ -884,15 +985,34 @@ def main():
     res['check_vs_oracle'] = {'rays': n, 'max_abs_rgb_err': float(err.max()), 'psnr_db': (10 * np.log10(1.0 / mse)) if mse > 0 else float('inf')}
   x6 = os.path.join(ROOT, 'dynibar_amd', 'csrc', 'libdynibar_hip_x6.so')
   if world == 1 and a.x6 and os.path.exists(x6) and not os.environ.get('DYNIBAR_HIP_LIB'):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', '--steps', str(max(5, a.steps // 2)), '--warmup', '2',
-                        '--rays', str(R), '--samples', str(S), '--views', str(V)], env=dict(os.environ, DYNIBAR_HIP_LIB=x6),
-                       capture_output=True, text=True, timeout=600)
+    # the SAME step on the exact engine (three bf16 parts per operand, all 6 partial products down to 2^-18: fp32-class products; ceiling 2500 / 6 TFLOP/s):
+    # what exact fp32-class arithmetic costs on this path, and its own distance from the oracle on the same rays
+    import tempfile
+    dump = os.path.join(tempfile.gettempdir(), 'dynibar_x6_rgb_%d.npy' % os.getpid())
     try:
+      r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', '--steps', str(max(5, a.steps // 2)), '--warmup', '2',
+                          '--rays', str(R), '--samples', str(S), '--views', str(V), '--dump-rgb', dump], env=dict(os.environ, DYNIBAR_HIP_LIB=x6),
+                         capture_output=True, text=True, timeout=600)
       d6 = json.loads(r.stdout.strip().splitlines()[-1])
-      res['bf16x6_engine'] = {'value': d6['value'], 'unit': 'rays/s', 'ms_per_step': d6['ms_per_step'], 'dtype': d6['dtype'],
-                              'k_static_views_ms': d6['kernels_avg_ms']['k_static_views']}
+      res['x6_engine'] = {'what': 'the same step on libdynibar_hip_x6.so (three bf16 parts per operand, 6 partial products: exact fp32-class products)',
+                          'value': d6['value'], 'unit': 'rays/s', 'ms_per_step': d6['ms_per_step'], 'dtype': d6['dtype'],
+                          'k_static_views_ms': d6['kernels_avg_ms']['k_static_views'], 'roofline_frac_of_its_own_peak': d6['roofline']['frac'], 'peak': d6['roofline']['peak']}
+      res['roofline']['x6_rays_per_s'] = d6['value']
+      res['roofline']['x6_over_shipped_time'] = d6['ms_per_step'] / (dt / a.steps * 1e3)
+      if res.get('check_vs_oracle') and os.path.exists(dump):
+        rgb6 = torch.from_numpy(np.load(dump))
+        n6 = min(rgb6.shape[0], ref['rgb'].shape[0])
+        e6 = float((rgb6[:n6] - ref['rgb'][:n6]).abs().max())
+        res['x6_engine']['max_abs_rgb_err_vs_oracle'] = e6
+        res['roofline']['x6_max_abs_rgb_err'] = e6
+        res['roofline']['shipped_max_abs_rgb_err'] = res['check_vs_oracle']['max_abs_rgb_err']
     except Exception as e:  # the extra leg must never cost the main line
-      res['bf16x6_engine'] = {'error': str(e)[:200]}
+      res['x6_engine'] = {'error': str(e)[:200]}
+    finally:
+      if os.path.exists(dump):
+        os.remove(dump)
+  if a.dump_rgb:
+    np.save(a.dump_rgb, out['rgb'][:max(a.cpu_rays, 1024)].detach().cpu().numpy())
   print(json.dumps(res))
   if multi_rank:
     dist.destroy_process_group()

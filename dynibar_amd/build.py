@@ -51,21 +51,26 @@ def build(force=False, verbose=True):
     return OUT
   if os.path.exists(STAMP):
     os.remove(STAMP)
-  objs = []
+  # the translation units are independent: compile them (and the 6-term flavour of the network unit) side by side
+  from concurrent.futures import ThreadPoolExecutor
+  jobs = []
   for src, flags in units:
     obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-    cmd = [hipcc] + COMMON + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
-    if verbose:
-      print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    objs.append(obj)
-  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-ldl', '-o', OUT]
-  if verbose:
-    print(' '.join(cmd), flush=True)
-  subprocess.check_call(cmd)
+    jobs.append((obj, [hipcc] + COMMON + flags + ['-c', os.path.join(CSRC, src), '-o', obj]))
   # the same library with the fp32-class 6-term split engine: used by the precision A/B test and bench leg
   obj6 = os.path.join(CSRC, 'dyn_nets_x6.o')
-  cmd = [hipcc] + COMMON + ['-DDYN_SPLIT_TERMS=6', '-DDYN_SPLIT_F16=0', '-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', obj6]
+  jobs.append((obj6, [hipcc] + COMMON + ['-DDYN_SPLIT_TERMS=6', '-DDYN_SPLIT_F16=0', '-c', os.path.join(CSRC, 'dyn_nets.hip'), '-o', obj6]))
+
+  def run(job):
+    if verbose:
+      print(' '.join(job[1]), flush=True)
+    subprocess.check_call(job[1])
+    return job[0]
+
+  with ThreadPoolExecutor(max_workers=int(os.environ.get('DYNIBAR_BUILD_JOBS', '6'))) as ex:
+    built = list(ex.map(run, jobs))
+  objs = built[:-1]
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-ldl', '-o', OUT]
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)

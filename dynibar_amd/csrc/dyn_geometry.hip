@@ -36,7 +36,7 @@ static const char* const g_prof_names[DYN_K_COUNT] = {
     "k_fine_samples", "k_static_ref_feat", "k_static_views", "k_static_points", "k_static_blend", "k_selftest", "k_dynamic_time_feat",
     "k_dynamic_views", "k_dynamic_points", "k_motion_mlp", "k_trajectory_points", "k_render_flows", "k_expected_scene_flow", "k_image_rays",
     "k_static_points_qkv", "k_dynamic_points_qkv", "k_enc_conv7", "k_enc_conv3", "k_enc_conv1", "k_enc_block_out",
-    "k_train_gemm", "k_train_rows", "k_train_attn", "k_gather_bwd"};
+    "k_train_gemm", "k_train_rows", "k_train_attn", "k_gather_bwd", "k_motion_zero_tail", "k_ragged_plan"};
 
 static void prof_flush(int slot) {
   for (int i = 0; i < g_prof.used[slot]; ++i) {
@@ -517,12 +517,6 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
 #ifndef PGT_DEFAULT_P
 #define PGT_DEFAULT_P 16
 #endif
-#ifndef PGT_ONE_BARRIER
-#define PGT_ONE_BARRIER 1  /* ray_diff / mask tiles in their own LDS (P V 20 bytes behind the feature tile): one barrier per workgroup instead of three */
-#endif
-#ifndef PGT_EXP
-#define PGT_EXP 0  /* developer decomposition builds (tools/build_variant.py): 1 no feature-tap loads, 2 no rgb_feat stores, 3 all taps from one line, 4 no RGB taps */
-#endif
 struct PGTile {
   int R, S, V, H, W, Hf, Wf, F;
   float img_h, img_w, inv_wm1, inv_hm1, mask_thresh;
@@ -611,26 +605,20 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   {
     const Taps tt = make_taps(nx, ny, q.W, q.H);
     const float* img = src_rgb + (long)vv * q.H * q.W * 3;
-#if PGT_EXP == 4
-    const f32x3u a = {nx, ny, nx}, b = a, c = a, d = a;
-#else
     const f32x3u a = *reinterpret_cast<const f32x3u*>(img + (tt.y0 * q.W + tt.x0) * 3);
     const f32x3u b = *reinterpret_cast<const f32x3u*>(img + (tt.y0 * q.W + tt.x1) * 3);
     const f32x3u c = *reinterpret_cast<const f32x3u*>(img + (tt.y1 * q.W + tt.x0) * 3);
     const f32x3u d = *reinterpret_cast<const f32x3u*>(img + (tt.y1 * q.W + tt.x1) * 3);
-#endif
     float ax, ay, az, bx, by, bz, dx, dy, dz;
     normalize3(query_center[0] - sx, query_center[1] - sy, query_center[2] - sz, ax, ay, az);
     normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
     normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
     rd = make_float4(dx, dy, dz, ax * bx + ay * by + az * bz);
     mk = (inb && (hz > 0.f)) ? 1.0f : 0.0f;
-#if PGT_ONE_BARRIER
-    if (v < V) {  // ray_diff / mask have their own LDS behind the feature tile: written here, they leave with the tile behind the ONE barrier
+    if (v < V) {  // ray_diff / mask have their own LDS behind the feature tile (P V 20 bytes): written here, they leave with the tile behind the ONE barrier
       reinterpret_cast<float4*>(tile + P * V * C)[row] = rd;
       (tile + P * V * C + P * V * 4)[row] = (pt < q.n_pts) ? mk : 0.0f;
     }
-#endif
     if (v < V) {
       tile[row * C + 0] = fmaf(d.x, tt.w_se, fmaf(c.x, tt.w_sw, fmaf(b.x, tt.w_ne, a.x * tt.w_nw)));
       tile[row * C + 1] = fmaf(d.y, tt.w_se, fmaf(c.y, tt.w_sw, fmaf(b.y, tt.w_ne, a.y * tt.w_nw)));
@@ -652,20 +640,10 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
 #pragma unroll
     for (int u = 0; u < PGT_UNROLL; ++u) {
       const int src = (it0 + u) * RPI + rsub < 63 ? (it0 + u) * RPI + rsub : 63;
-#if PGT_EXP == 1
-      const float zz = __shfl(tf.w_nw, src) * 1e-30f;
-      ta[u] = tb[u] = tc[u] = td[u] = make_float4(zz, zz, zz, zz);
-#elif PGT_EXP == 3
-      ta[u] = feat4[(__shfl(o_nw, src) & 7) + c4];
-      tb[u] = feat4[(__shfl(o_ne, src) & 7) + c4];
-      tc[u] = feat4[(__shfl(o_sw, src) & 7) + c4];
-      td[u] = feat4[(__shfl(o_se, src) & 7) + c4];
-#else
       ta[u] = feat4[__shfl(o_nw, src) + c4];
       tb[u] = feat4[__shfl(o_ne, src) + c4];
       tc[u] = feat4[__shfl(o_sw, src) + c4];
       td[u] = feat4[__shfl(o_se, src) + c4];
-#endif
       w0[u] = __shfl(tf.w_nw, src); w1[u] = __shfl(tf.w_ne, src); w2[u] = __shfl(tf.w_sw, src); w3[u] = __shfl(tf.w_se, src);
     }
 #pragma unroll
@@ -690,28 +668,12 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
     float* dst = rgb_feat + p0 * V * C;
     const float4* src4 = reinterpret_cast<const float4*>(tile);
     float4* dst4 = reinterpret_cast<float4*>(dst);
-#if PGT_EXP == 2
-    for (int i = tid; i < (nflt >> 2); i += nthr) if (src4[i].x == 1.2345e-33f) nt_store4<1>(dst4 + i, src4[i]);
-#else
     for (int i = tid; i < (nflt >> 2); i += nthr) nt_store4<1>(dst4 + i, src4[i]);
     for (int i = (nflt & ~3) + tid; i < nflt; i += nthr) nt_store1<1>(dst + i, tile[i]);
-#endif
   }
-#if PGT_ONE_BARRIER
   // ---- ray_diff [P][V] float4 and mask [P][V]: their own LDS behind the tile (round 5: no second and third barrier, no LDS phase between the bursts) ----
   float4* rdt = reinterpret_cast<float4*>(tile + P * V * C);
   float* mkt = tile + P * V * C + P * V * 4;
-#else
-  __syncthreads();
-  // ---- ray_diff [P][V] float4 and mask [P][V] through the same LDS ----
-  float4* rdt = reinterpret_cast<float4*>(tile);
-  float* mkt = tile + P * V * 4;
-  if (v < V) {
-    rdt[row] = rd;
-    mkt[row] = (pt < q.n_pts) ? mk : 0.0f;
-  }
-  __syncthreads();
-#endif
   {
     const int nrow = (int)npt * V;
     float4* dst4 = ray_diff + p0 * V;
@@ -770,9 +732,10 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   // r5c10_k1.txt): P = 16 -- four views per wave, 2-4 waves and 20-40 KiB per workgroup, five to eight independent workgroups per CU whose load and store phases
   // overlap -- is the fastest at every view count: 7 views 88.0 -> 85.1 us, 8 views 91.7 -> 89.4 (0.504 of 8 TB/s), 11 views 143.0 -> 124.3 (0.42 -> 0.50),
   // 15 views 165.1 -> 163.9; frame 24.1 -> 22.9 ms.  (The stand-alone sweep had P = 16 at +12 % for 8 views: there the cold maps dominate and taller tiles re-use taps.)
+  DYN_REQUIRE(force_p == 0 || force_p == 8 || force_p == 16 || force_p == 32 || force_p == 64, "dyn_project_gather: DYN_PG_P must be 8, 16, 32 or 64 (got %d)", force_p);
   const int P = force_p ? force_p : PGT_DEFAULT_P;
   const int waves = (p->V * P + 63) / 64;
-  const size_t lds = (size_t)P * p->V * (C + (PGT_ONE_BARRIER ? 5 : 0)) * sizeof(float);
+  const size_t lds = (size_t)P * p->V * (C + 5) * sizeof(float);
   if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);
   PGTile q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;

@@ -32,7 +32,7 @@ enum DynKernelSlot {
   DYN_K_FINE_SAMPLES, DYN_K_STATIC_REF, DYN_K_STATIC_VIEWS, DYN_K_STATIC_POINTS, DYN_K_STATIC_BLEND, DYN_K_SELFTEST, DYN_K_DYNAMIC_TIME, DYN_K_DYNAMIC_VIEWS, DYN_K_DYNAMIC_POINTS, DYN_K_MOTION_MLP,
   DYN_K_TRAJECTORY, DYN_K_RENDER_FLOWS, DYN_K_SCENE_FLOW, DYN_K_IMAGE_RAYS, DYN_K_STATIC_POINTS_QKV, DYN_K_DYNAMIC_POINTS_QKV,
   DYN_K_ENC_CONV7, DYN_K_ENC_CONV3, DYN_K_ENC_CONV1, DYN_K_ENC_BLOCK,
-  DYN_K_TRAIN_GEMM, DYN_K_TRAIN_ROWS, DYN_K_TRAIN_ATTN, DYN_K_TRAIN_GATHER_BWD, DYN_K_COUNT
+  DYN_K_TRAIN_GEMM, DYN_K_TRAIN_ROWS, DYN_K_TRAIN_ATTN, DYN_K_TRAIN_GATHER_BWD, DYN_K_MOTION_TAIL, DYN_K_STATIC_PLAN, DYN_K_COUNT
 };
 void dyn_prof_begin(int slot, hipStream_t stream);
 void dyn_prof_end(int slot, hipStream_t stream);

@@ -58,16 +58,12 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const float* ta
 // instead of a compare + select (which also hides worse under the matrix pipe, tools/ubench/mfma_valu_kind.hip)
 __device__ __forceinline__ float elu1(float v) { return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f); }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + __expf(-v)); }
-// ELU in the exponent's own domain (DYN_ELU3): a layer whose output only feeds ELUs is packed with weights and bias times log2(e), so its
+// ELU in the exponent's own domain: a layer whose output only feeds ELUs is packed with weights and bias times log2(e), so its
 // accumulators hold u = v log2(e); elu_s(u) = log2(e) ELU(v) = med3(u, 2^u log2(e) - log2(e), 0) is three instructions (v_exp_f32 takes u as it
 // is: the multiply by log2(e) of __expf is gone; the subtraction rides in the fma), and the consumer -- always a Linear or a dot-product
 // table -- is packed times ln(2).  float(log2 e) float(ln 2) = 1 + 4e-9: invisible next to the split products' 2^-20.
-#ifndef DYN_ELU3
-#define DYN_ELU3 1
-#endif
 #define DYN_LOG2E 1.44269504088896340736
 #define DYN_LN2 0.69314718055994530942
-#if DYN_ELU3
 #define DYN_ELU_PRE DYN_LOG2E  /* pack-time factor of a layer (weights and bias) whose output goes through elu_s */
 #define DYN_ELU_POST DYN_LN2   /* pack-time factor of the weights that consume elu_s outputs */
 __device__ __forceinline__ float elu_s(float u) {
@@ -77,11 +73,6 @@ __device__ __forceinline__ float elu_s(float u) {
   return __builtin_amdgcn_fmed3f(u, fmaf(exp2f(u), (float)DYN_LOG2E, -(float)DYN_LOG2E), 0.0f);
 #endif
 }
-#else
-#define DYN_ELU_PRE 1.0
-#define DYN_ELU_POST 1.0
-__device__ __forceinline__ float elu_s(float u) { return elu1(u); }
-#endif
 
 template <int NT>
 __device__ __forceinline__ void acc_elu(f32x16 (&acc)[NT]) {
@@ -291,7 +282,7 @@ struct WeightRing6 {
   int skip_at, skip_n;  // chunks [skip_at, skip_at + skip_n) of the stream are not ring traffic (their user reads them straight from global)
   int round;            // floats moved by the whole workgroup per DMA instruction (threads * 4)
   int half;             // wave-uniform (SGPR): 0 for waves 0-3 of the workgroup, 1 for waves 4-7 (the SIMD partners)
-  // spread DMA (B6_DMA_SPREAD, round 5): the pieces of chunk `fill` go out one at a time between the MFMAs of the chunk before it
+  // spread DMA (round 5): the pieces of chunk `fill` go out one at a time between the MFMAs of the chunk before it
   unsigned lds_wave;    // LDS byte address of this wave's slice of buffer 0 (+ 512 floats), wave-uniform (an SGPR)
   unsigned lane_off;    // byte offset, from the start of a chunk, of this lane's 16 bytes of the wave's slice (+ 512 floats)
   int fill, issued;     // chunk being requested (-1: none) and how many of this wave's pieces of it have gone out
@@ -309,11 +300,8 @@ __device__ __forceinline__ void ring6_prio_static(const WeightRing6& R);  // (is
 // cycles, tools/motionbench.py `dmaonly`), the request queue backs up and every wave -- both waves of every SIMD, they have just left the same
 // barrier -- stands at its `global_load_lds` until its pieces are accepted.  Timing-only builds of k_static_views<8> (tools/experiments/r05_gpu_calls,
 // call 2 and 3): no ring at all 1451 us, the barrier alone 1518, the DMA without the barrier 1868-1877, everything 1798-1873: the barrier costs
-// nothing, the burst costs 19 %.  B6_DMA_SPREAD = 1: ring6_acquire only opens the window (fill = c + 1); the layer loop hands out one piece at a
+// nothing, the burst costs 19 %.  Since round 5 ring6_acquire only opens the window (fill = c + 1); the layer loop hands out one piece at a
 // time between the MFMAs of the first two thirds of chunk c (ring6_feed), SGPR base + 32-bit lane offset as in the three-slot ring.
-#ifndef B6_DMA_SPREAD
-#define B6_DMA_SPREAD 1
-#endif
 #ifndef B6_DMA_POLICY  /* cache policy of the weight pieces: "" (plain), " nt", " sc1", " sc0 sc1" */
 #define B6_DMA_POLICY ""
 #endif
@@ -353,14 +341,12 @@ __device__ __forceinline__ void ring6_piece(const WeightRing6& R, int k) {
 // pair `pr` of the `npc` pairs of the chunk being consumed: pieces of the next chunk due by now (all of them by two thirds of the chunk, so that
 // the last one has a third of a chunk to land before the barrier that publishes it)
 __device__ __forceinline__ void ring6_feed(WeightRing6& R, int pr, int npc) {
-#if B6_DMA_SPREAD
   if (R.fill < 0) return;
   const int n = ring6_pieces(R);
   const int den = (B6_DMA_WINDOW_NUM * npc + B6_DMA_WINDOW_DEN - 1) / B6_DMA_WINDOW_DEN > 0 ? (B6_DMA_WINDOW_NUM * npc + B6_DMA_WINDOW_DEN - 1) / B6_DMA_WINDOW_DEN : 1;
   int want = (n * (pr + 1) + den - 1) / den;
   if (want > n) want = n;
   for (; R.issued < want; ++R.issued) ring6_piece(R, R.issued);
-#endif
 }
 
 __device__ __forceinline__ void ring6_issue(const WeightRing6& R, int chunk) {
@@ -432,22 +418,11 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
     DYN_PHASE_WAIT(R, c);
     return R.buf;
   }
-#if B6_EXP_NO_RING == 1
-  { const int c = R.next++; return R.buf + (c & 1) * B6_CHUNK; }
-#elif B6_EXP_NO_RING == 2  // the barrier alone: no DMA, no wait for it
-  { __builtin_amdgcn_s_barrier(); const int c = R.next++; return R.buf + (c & 1) * B6_CHUNK; }
-#elif B6_EXP_NO_RING == 3  // the DMA and the wait for the wave's own pieces, no barrier
-  { __builtin_amdgcn_s_waitcnt(0x0F70); const int c = R.next++; if (c + 1 < R.total) ring6_issue(R, c + 1); return R.buf + (c & 1) * B6_CHUNK; }
-#elif B6_EXP_NO_RING == 4  // the DMA alone: issued, never waited for, no barrier
-  { const int c = R.next++; if (c + 1 < R.total) ring6_issue(R, c + 1); return R.buf + (c & 1) * B6_CHUNK; }
-#endif
-#if B6_DMA_SPREAD
   if (R.fill >= 0) {  // whatever the consumer of the previous chunk did not hand out itself (a layer loop that feeds leaves nothing here)
     const int n = ring6_pieces(R);
     for (; R.issued < n; ++R.issued) ring6_piece(R, R.issued);
     R.fill = -1;
   }
-#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #ifdef DYN_PHASE_SKEW
   const unsigned long long skew_t1 = __builtin_readcyclecounter();
@@ -464,21 +439,14 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   }
 #endif
   DYN_PHASE_WAIT(R, c);
-#if B6_DMA_SPREAD
   R.fill = c + 1 < R.total ? c + 1 : -1;  // the window of chunk c + 1 opens: its slot (chunk c - 1's) is free behind this barrier
   R.issued = 0;
-#else
-  if (c + 1 < R.total) ring6_issue(R, c + 1);
-#endif
   return R.buf + (c & 1) * B6_CHUNK;
 }
 
 // Issue priority in the two-wave layer loop.  Round 3 recorded "swap the priority of the two waves of a SIMD every n pairs: n = 2 -1.4 % (kept); one half
 // static: +7 %; a feedback scheme: +6 %; first MFMA of a triple ahead of the pair's VALU slice: +1..2 %".  None of those builds did what the text said
 // (see "Round 5" below); the switches of the dropped ones were removed in round 5.  B6_PRIO_FLIP = pairs between two flip sites.
-#ifndef B6_SPLIT_ONE_ASM
-#define B6_SPLIT_ONE_ASM 0  /* round 5, measured: -310 s_nop in the view chain, time unchanged; k_static_blend_ws 361 -> 383 us (the two parts no longer spread) */
-#endif
 #ifndef B6_PRIO_FLIP
 #define B6_PRIO_FLIP 2
 #endif
@@ -531,15 +499,11 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 #if defined(__AMDGCN__)
   // three instructions per pair: the mixed-precision fma reads the half part, subtracts it from the fp32 value exactly and writes the
   // residual as a half (round to nearest) straight into its slot of the packed register
-  // (ONE asm statement: between two statements hipcc puts an `s_nop 0` -- 310 of them in the view chain)
+  // (two statements: hipcc puts an `s_nop 0` between them -- 310 in the view chain, free -- but as one statement the two parts no longer
+  //  spread between the MFMAs and k_static_blend_ws measured 6 % slower, round 5)
   unsigned m;
-#if B6_SPLIT_ONE_ASM
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(m) : "v"(hi), "v"(a), "v"(b));
-#else
   asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(hi), "v"(a));
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(hi), "v"(b));
-#endif
   mid = m;
 #else
   const float ra = a - (float)h[0], rb = b - (float)h[1];
@@ -562,23 +526,7 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 #endif
 }
 
-// timing-only decomposition builds of the two-wave layer loop (round 5, tools/experiments/r05_gpu_calls; results are garbage with any of them):
-//   B6_EXP_NO_MFMA   the matrix instructions are dropped (their operands stay live): what everything else costs
-//   B6_EXP_NO_LDSA   no LDS reads of the A fragments          B6_EXP_NO_RING   no chunk barriers, no LDS-DMA after the first chunk
-#ifndef B6_EXP_NO_MFMA
-#define B6_EXP_NO_MFMA 0
-#endif
-#ifndef B6_EXP_NO_LDSA
-#define B6_EXP_NO_LDSA 0
-#endif
-#ifndef B6_EXP_NO_RING
-#define B6_EXP_NO_RING 0
-#endif
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4v a, u32x4v b, f32x16 c) {  // the split engine's MFMA (bf16 or half parts)
-#if B6_EXP_NO_MFMA && defined(__AMDGCN__)
-  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-#endif
 #if DYN_SPLIT_F16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 #else
@@ -598,13 +546,6 @@ struct B6A {
 __device__ __forceinline__ B6A b6_load_a(const float* pair, int lane) {
   const u32x4v* w = reinterpret_cast<const u32x4v*>(pair) + lane;
   B6A a;
-#if B6_EXP_NO_LDSA && defined(__AMDGCN__)
-  {  // (the fragments become functions of the address only: no LDS traffic, a few VALU moves instead)
-    const unsigned v = (unsigned)(size_t)pair ^ (unsigned)lane;
-    a.hi = u32x4v{v, v + 1u, v + 2u, v + 3u}; a.mid = u32x4v{v + 4u, v + 5u, v + 6u, v + 7u}; a.lo = a.hi;
-    return a;
-  }
-#endif
   a.hi = w[0]; a.mid = w[64];
 #if DYN_SPLIT_PARTS == 3
   a.lo = w[128];
@@ -722,26 +663,6 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
 #define B6D_AHEAD 4  // pairs of A fragments in flight from LDS (even)
 #endif
 #define B6D_SLOTS 3
-// timing-only decomposition builds (tools/motionbench.py; results are garbage with any of them): B6D_NO_DMA = no pieces after the first two
-// chunks, B6D_NO_BARRIER = no chunk barrier, B6D_NO_LDS = A fragments loaded once per layer, B6D_DMA_BURST = all pieces right behind the barrier
-#ifndef B6D_NO_DMA
-#define B6D_NO_DMA 0
-#endif
-#ifndef B6D_NO_BARRIER
-#define B6D_NO_BARRIER 0
-#endif
-#ifndef B6D_NO_LDS
-#define B6D_NO_LDS 0
-#endif
-#ifndef B6D_DMA_BURST
-#define B6D_DMA_BURST 0
-#endif
-#ifndef B6D_NO_MFMA
-#define B6D_NO_MFMA 0  /* the matrix instructions left out (their operands are still produced and consumed): what everything else costs */
-#endif
-#ifndef B6D_DMA_SADDR
-#define B6D_DMA_SADDR 1  /* 1: the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction: -1.5 % of k_motion_mlp) */
-#endif
 struct WeightRing3 {
   const float* gbase;  // the packed stream (uniform)
   const float* glane;  // this lane's source of the wave's slice of chunk 0 (+ 512 floats: the middle of a six-piece group, see ring6_issue)
@@ -770,11 +691,8 @@ __device__ __forceinline__ void ring3_dma(const float* g, float* l_emu, unsigned
 #if defined(__AMDGCN__)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-#if B6D_DMA_SADDR
+  // the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction: -1.5 % of k_motion_mlp)
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
-#else
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(g), "s"(l), "n"(OFF) : "m0", "memory");
-#endif
 #pragma clang diagnostic pop
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l_emu, 16, OFF, 0);
@@ -787,7 +705,7 @@ __device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int
   const int grp = k / 6, i = k % 6;
   const int sc = chunk >= R.total ? chunk - R.total : chunk;  // chunks `total`, `total + 1` of a pass are chunks 0, 1 of the next one
   const float* g = R.glane + (long)sc * R.cf + grp * 1536;
-  const float* gu = R.gbase + (long)sc * R.cf + grp * 1536;  // (B6D_DMA_SADDR: uniform base; the lane's offset within the wave's slice is R.lane_off)
+  const float* gu = R.gbase + (long)sc * R.cf + grp * 1536;  // (uniform base; the lane's offset within the wave's slice is R.lane_off)
   const unsigned l = R.lds_slot[chunk % B6D_SLOTS] + (unsigned)(grp * 1536 * sizeof(float));
   float* le = R.slot[chunk % B6D_SLOTS] + (threadIdx.x >> 6) * per_wave + 512 + grp * 1536;  // (emulator build)
   if (i == 0) ring3_dma<-2048>(g, le, l, gu, R.lane_off);
@@ -800,9 +718,6 @@ __device__ __forceinline__ void ring3_piece(const WeightRing3& R, int chunk, int
 // ALLOW: DMA pieces of this wave that may still be in flight behind the barrier (the youngest ones: loads complete in order)
 template <int ALLOW = 0>
 __device__ __forceinline__ void ring3_barrier() {
-#if B6D_NO_BARRIER
-  return;
-#endif
 #if defined(__AMDGCN__)
   static_assert(ALLOW >= 0 && ALLOW < 16, "vmcnt immediate");
   __builtin_amdgcn_s_waitcnt(0x0F70 | ALLOW);  // vmcnt(ALLOW): this wave's older DMA pieces have landed (LDS reads in flight stay in flight)
@@ -864,11 +779,11 @@ __device__ __forceinline__ const float* ring3_slot(const WeightRing3& R, int chu
 #define B6D_DMA_MARGIN 4
 #endif
 __device__ __forceinline__ void ring3_feed(WeightRing3& R, int half, int num, int den) {
-  if (R.fill < 0 || B6D_NO_DMA) return;
+  if (R.fill < 0) return;
   if (R.fill >= R.total && !R.more) return;  // (the next pass's first chunks: only if there is a next pass)
   const int n = ring3_pieces(R), h0 = n / 2;
   int want = half == 0 ? (h0 * num + den - 1) / den : h0 + ((n - h0) * num + den - 1) / den;
-  if (B6D_DMA_BURST || want > n) want = n;
+  if (want > n) want = n;
   for (; R.issued < want; ++R.issued) ring3_piece(R, R.fill, R.issued);
 }
 // the middle of chunk R.next (once per chunk)
@@ -879,7 +794,6 @@ __device__ __forceinline__ void ring3_mid(WeightRing3& R) {
   DYN_PHASE_WAIT(R, R.next);
   R.fill = (R.next + 2 < R.total || R.wrap) ? R.next + 2 : -1;
   R.issued = 0;
-  if (B6D_DMA_BURST) ring3_feed(R, 1, 1, 1);
 }
 __device__ __forceinline__ void ring3_leave(WeightRing3& R) {
   if (R.wrap && R.next == R.total - 1) ring3_feed(R, 1, 1, 1);  // the window of the next pass's chunk 1 ends with this pass
@@ -932,12 +846,7 @@ __device__ __forceinline__ void dyn_static_for(F&& f) {
 __device__ __forceinline__ f32x16 mfma_pinned(const u32x4v& a, u32x4v& b, f32x16 c) {
 #if defined(__AMDGCN__)
   asm volatile("" : "+v"(b));  // (the B operand: redefined in place, one chain per k-group -- touching the A fragment instead makes hipcc copy it for its second use)
-#if B6D_NO_MFMA
-  asm volatile("" ::"v"(a));
-  f32x16 d = c;
-#else
   f32x16 d = mfma_bf16(a, b, c);
-#endif
   asm volatile("" : "+a"(d));
   return d;
 #else
@@ -962,7 +871,6 @@ __device__ __forceinline__ void mlp_layer_b6_duo(WeightRing3& R, f32x16 (&acc)[N
   float v0 = 0.f, v1 = 0.f;  // the pair of slots being prepared
   B6A q[QN];
   auto load = [&](int P) DYN_INLINE_LAMBDA {
-    if (B6D_NO_LDS && P >= AHEAD + U) return q[P % QN];
     return b6_load_a(ring3_slot(R, c0 + P / CP) + (P % CP) * B6_PAIR_FLOATS, lane);
   };
   ring3_enter(R);

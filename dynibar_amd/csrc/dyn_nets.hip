@@ -341,12 +341,35 @@ static bool dense_views(int V) {
   return (V >= 9 && V <= 12) || (V >= 17 && V <= 26);
 }
 struct StaticWs {
-  bool dense;
+  bool dense, ragged;
   long n_pts, n_tiles_a, n_tiles_b;
   int PT, TPR;  // points per A tile; B tiles per ray (1, 2, 4 or -- rays of more than 128 samples -- a multiple of 4)
   size_t off_x, off_vis, off_gin, off_nvalid, off_hg, off_ref, total;  // dynamic net: off_x/off_vis/off_hg unused, off_ref = time feature
   size_t off_qkvg;  // long rays only: per B tile [g | q | k | v][4][4][64 lanes][4] (the two-pass point chain hands these over)
+  // ragged dense rows (round 6): the plan of a launch -- see k_ragged_points
+  long n_seg, n_wg_max;
+  size_t off_bits, off_emin, off_segcnt, off_segstart, off_wgstart;  // [n_pts] u32, [n_pts] f32, [n_seg] i32, [n_seg][RAG_SEG_WGS] i32, [1 + n_wg_max + 1] i32 (n_wg first)
+  size_t off_rowtab, off_ptab;  // per workgroup: [256] u16 (point | view << 8 of every row) and [RAG_PTAB] i32 (row offsets of its points, then n_rows, first point, points)
 };
+// Ragged dense rows (round 6).  A (point, view) row whose mask is 0 contributes exactly nothing to any output of the reference: its pooling weight, its
+// visibility and its blending weight are products with the mask (mlp_network.py:463-471, 484-488) and its logit is filled with -1e9 before the softmax
+// (:523-525), i.e. exp(-1e9 - max) = 0 in fp32.  The reference and rounds 1-5 evaluate such rows anyway: 11-14 % of the rows of the synthetic scenes.  In the
+// dense-rows flavour (V = 9..12, 17..26: the 11 static views of the Nvidia evaluation) a workgroup's 256 rows are now the VALID rows of consecutive points --
+// as many points as fit, at most 32 (the per-point tiles of base_fc.0 / ray_dir_fc.0 are one 32-column MFMA tile) -- so the matrix work, the parked x and the
+// blend's stream shrink by the masked fraction.  A point without any valid view keeps ONE row (its view 0, mask 0): every point then owns a column and a
+// record, and what the reference does for it -- sigma -1e9, colour = the plain mean of the V gathered colours, the uniform softmax over equal logits --
+// is reproduced by the blend from rgb_feat.  The anti-alias pooling weight needs min_v exp(|s| (d_v - 1)) over ALL views, masked ones included
+// (mlp_network.py:465-468): the plan carries it per point.
+// The plan (four small launches per network call): k_ragged_points: per point the valid-view bit mask and that minimum; k_ragged_segments: one thread per
+// segment of RAG_SEG consecutive points packs its points greedily into workgroups (rows <= 256, points <= 32); k_ragged_scatter: exclusive scan of the
+// segments' workgroup counts and the flat list wg_start[0 .. n_wg]; k_ragged_tables: per workgroup the row table (row -> point, view) and the row offsets
+// of its points, so that a consumer workgroup starts with ONE round trip to memory (its own table) in front of its input loads.  The launch grid is the
+// upper bound n_wg_max; surplus workgroups leave at once.
+#define RAG_SEG 1024      /* points per planning segment (its last workgroup is partly filled: ~1.2 % of the rows at 11 views) */
+#define RAG_SEG_WGS 160   /* workgroups a segment can need: ceil(1024 / 7) (26 views: >= 9 points fit 256 rows; short of 32 points only by the row limit) + slack */
+#define RAG_MAX_PTS 32
+#define RAG_PTAB 36       /* ints per workgroup: pbase[0..32], then first point, number of points, 0 */
+
 #define DYN_MAX_SAMPLES 256  // samples per ray the point chain is built for (sinusoid table, LDS key blocks of 128)
 // Per-point records handed between the view kernels and the point kernel are lane-coalesced for the point kernel: record i (a float4)
 // of the point at (ray, sample) sits at [tile = ray * TPR + sample / 32][i][lane = sample % 32 + 32 * half].  (A point-major layout
@@ -354,14 +377,27 @@ struct StaticWs {
 #define SB_GIN_RECS 33  // geometry_fc input per (point, half): 16 x mean, 16 x var, then [mean weight | 1], 0, 0, 0
 #define SB_HG_RECS 16   // point part of rgb_fc.0 per (point, half)
 
+#ifndef DYN_BLEND_WS
+#define DYN_BLEND_WS (DYN_SPLIT_TERMS == 3 ? 1 : 0)
+#endif
+static bool ragged_rows_enabled() {
+  static const int off = getenv("DYN_RAGGED") ? (atoi(getenv("DYN_RAGGED")) == 0) : 0;  // developer A/B: DYN_RAGGED=0 evaluates every row (rounds 1-5)
+  static const int blend_stream = getenv("DYN_BLEND_STREAM") != nullptr;                  // (the streaming blend of round 3 has no ragged form)
+  return DYN_BLEND_WS && !off && !blend_stream;  // (the 6-term build keeps the streaming blend: no ragged rows there)
+}
 static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   StaticWs w;
   w.n_pts = (long)R * S;
   // points per wave: views are padded to a power-of-two lane segment; or (dense rows: view counts from 9 that are not a power of two)
   // points per 256-row workgroup, whose 8 waves are 8 tiles of the parked-feature buffer
   w.dense = dense_views(V);
+  w.ragged = w.dense && ragged_rows_enabled();
   w.PT = w.dense ? 256 / V : 32 / (V <= 4 ? 4 : (V <= 8 ? 8 : (V <= 16 ? 16 : 32)));
   w.n_tiles_a = w.dense ? ((w.n_pts + w.PT - 1) / w.PT) * 8 : (w.n_pts + w.PT - 1) / w.PT;
+  w.n_seg = (w.n_pts + RAG_SEG - 1) / RAG_SEG;
+  // a ragged workgroup holds at least 256 / V points unless its segment ends: never more workgroups than the regular partition + one per segment
+  w.n_wg_max = w.ragged ? (w.n_pts + w.PT - 1) / w.PT + w.n_seg : 0;
+  if (w.ragged) w.n_tiles_a = w.n_wg_max * 8;
   int tpr = (S + 31) / 32;
   w.TPR = tpr <= 1 ? 1 : (tpr <= 2 ? 2 : ((tpr + 3) / 4) * 4);
   w.n_tiles_b = (long)R * w.TPR;
@@ -374,6 +410,13 @@ static StaticWs static_ws(int R, int S, int V, bool dynamic = false) {
   w.off_ref = o; o += dynamic ? 64 : (size_t)R * 36;
   o = (o + 3) & ~(size_t)3;
   w.off_qkvg = o; o += w.TPR > 4 ? (size_t)w.n_tiles_b * 4 * 4096 : 0;
+  w.off_bits = o; o += w.ragged ? (size_t)((w.n_pts + 3) & ~3L) : 0;
+  w.off_emin = o; o += w.ragged ? (size_t)((w.n_pts + 3) & ~3L) : 0;
+  w.off_segcnt = o; o += w.ragged ? (size_t)((w.n_seg + 3) & ~3L) : 0;
+  w.off_segstart = o; o += w.ragged ? (size_t)w.n_seg * RAG_SEG_WGS : 0;
+  w.off_wgstart = o; o += w.ragged ? (size_t)((w.n_wg_max + 2 + 3) & ~3L) : 0;
+  w.off_rowtab = o; o += w.ragged ? (size_t)w.n_wg_max * 128 : 0;
+  w.off_ptab = o; o += w.ragged ? (size_t)w.n_wg_max * RAG_PTAB : 0;
   w.total = o;
   return w;
 }
@@ -466,6 +509,12 @@ struct StaticArgs {
   float* raw;             // [R,S,4]
   float* ws;
   StaticWs o;
+  // ragged dense rows: the plan of this launch (null / unused in the other flavours)
+  const unsigned* rg_bits;         // [n_pts] bit v set: mask[point, v] != 0
+  const float* rg_emin;            // [n_pts] min over all V views of exp(|s| (ray_diff.w - 1)) (anti-alias pooling only)
+  const int* rg_wg;                // [0]: n_wg, [1 .. n_wg + 1]: first point of every workgroup
+  const unsigned short* rg_rowtab; // [n_wg][256]
+  const int* rg_ptab;              // [n_wg][RAG_PTAB]
 };
 // float4 index of record 0 of (point, half) in a [tile][n_rec][64 lanes] buffer (see SB_GIN_RECS); record i is i * 64 further
 __device__ __forceinline__ long point_rec(const StaticArgs& p, long point, int h, int n_rec) {
@@ -516,17 +565,154 @@ __device__ __forceinline__ void res_get(const float* res, int col, int h, f32x16
 #define DENSE_EXTRA 2304   /* floats added to the view kernels' LDS in the dense flavour (table space behind `res`) */
 struct DenseRows {
   int V, PTW, rw, p_local, view, base;  // base: first row of this row's point (clamped for the idle tail rows)
+  int cnt;                              // rows of this row's point: V, or -- ragged -- its valid views (>= 1)
   float* scal;                          // [2][256]
+  const int* pbase;                     // ragged: [PTW + 1] first row of every point of the workgroup (LDS); regular: null (point p starts at row p V)
+  long point0;                          // first point of the workgroup
+  int n_rows;                           // rows in use (regular: PTW V)
 };
-__device__ __forceinline__ DenseRows dense_rows(int V, int PTW, float* scal) {
+__device__ __forceinline__ DenseRows dense_rows(int V, int PTW, float* scal, long wgi = -1) {
   DenseRows d;
   d.V = V; d.PTW = PTW; d.scal = scal;
   d.rw = (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
   d.p_local = d.rw / V;
   d.view = d.rw - d.p_local * V;
   d.base = (d.p_local < PTW ? d.p_local : PTW - 1) * V;
+  d.cnt = V;
+  d.pbase = nullptr;
+  d.point0 = (wgi >= 0 ? wgi : (long)blockIdx.x) * PTW;
+  d.n_rows = PTW * V;
   return d;
 }
+// first row / number of rows of point `pnt` of the workgroup (the (point, slot) task loops of the LDS reductions)
+__device__ __forceinline__ int dense_pt_base(const DenseRows& d, int pnt) { return d.pbase != nullptr ? d.pbase[pnt] : pnt * d.V; }
+__device__ __forceinline__ int dense_pt_cnt(const DenseRows& d, int pnt) { return d.pbase != nullptr ? d.pbase[pnt + 1] - d.pbase[pnt] : d.V; }
+
+// Ragged rows of workgroup (or persistent unit) `wgi` from the plan's tables: row -> (point of the workgroup, view) and the row offsets of its points
+// (`pbase`: RAG_PTAB ints of LDS that stay for the kernel's (point, slot) task loops).  Every thread of the workgroup calls this (one barrier inside).
+__device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* rowtab, const int* ptab, long wgi, float* scal, int* pbase) {
+  const int tid = threadIdx.x;
+  DenseRows d;
+  d.rw = (tid >> 6) * 32 + (tid & 31);
+  const unsigned short ri = rowtab[wgi * 256 + d.rw];
+  if (tid < RAG_PTAB) pbase[tid] = ptab[wgi * RAG_PTAB + tid];
+  __syncthreads();
+  d.V = V; d.scal = scal; d.pbase = pbase;
+  d.n_rows = pbase[32];
+  d.point0 = pbase[33];
+  d.PTW = pbase[34];
+  const bool live = d.rw < d.n_rows;
+  d.p_local = live ? (ri & 0xff) : RAG_MAX_PTS + 1;  // idle rows: beyond every point (they shadow the last point's rows like the regular flavour's tail rows)
+  d.view = live ? (ri >> 8) : 0;
+  const int pc = live ? d.p_local : d.PTW - 1;
+  d.base = pbase[pc];
+  d.cnt = pbase[pc + 1] - pbase[pc];
+  return d;
+}
+
+// ---- the plan of a ragged launch ----
+// e of the anti-alias pooling weight (mlp_network.py:463-466); one function so that the plan's minimum over all views and the rows' own values are the same bits
+__device__ __forceinline__ float aa_exp(float s_abs, float dot) { return expf(s_abs * (dot - 1.0f)); }
+
+__global__ void __launch_bounds__(256) k_ragged_points(long n_pts, int V, const float* __restrict__ mask, const float4* __restrict__ ray_diff, const float* __restrict__ s_abs,
+                                                       unsigned* __restrict__ bits, float* __restrict__ emin) {
+  const long pt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= n_pts) return;
+  unsigned b = 0u;
+  float m = 3.0e38f;
+  const float sa = s_abs != nullptr ? s_abs[0] : 0.f;
+  for (int v = 0; v < V; ++v) {
+    if (mask[pt * V + v] != 0.f) b |= 1u << v;
+    if (s_abs != nullptr) m = fminf(m, aa_exp(sa, ray_diff[pt * V + v].w));
+  }
+  bits[pt] = b;
+  if (s_abs != nullptr) emin[pt] = m;
+}
+
+// one thread per segment: greedy packing of the segment's points into workgroups (rows <= 256, points <= RAG_MAX_PTS)
+__global__ void __launch_bounds__(64) k_ragged_segments(long n_pts, long n_seg, const unsigned* __restrict__ bits, int* __restrict__ seg_cnt, int* __restrict__ seg_start) {
+  const long seg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= n_seg) return;
+  const long p0 = seg * RAG_SEG, p1 = p0 + RAG_SEG < n_pts ? p0 + RAG_SEG : n_pts;
+  int* out = seg_start + seg * RAG_SEG_WGS;
+  int n_wg = 0, rows = 0, pts = 0;
+  out[n_wg++] = 0;
+  for (long p = p0; p < p1; ++p) {
+    const unsigned b = bits[p];
+    const int n = b != 0u ? __popc(b) : 1;
+    if (rows + n > 256 || pts == RAG_MAX_PTS) {
+      out[n_wg++] = (int)(p - p0);
+      rows = 0; pts = 0;
+    }
+    rows += n; pts += 1;
+  }
+  seg_cnt[seg] = n_wg;
+}
+
+// one block: exclusive scan of the segments' workgroup counts, then wg[0] = n_wg, wg[1 + i] = first point of workgroup i, wg[1 + n_wg] = n_pts
+__global__ void __launch_bounds__(1024) k_ragged_scatter(long n_pts, long n_seg, const int* __restrict__ seg_cnt, const int* __restrict__ seg_start, int* __restrict__ wg) {
+  int* part = reinterpret_cast<int*>(dyn_smem);  // [1024] + the running total behind it
+  int& carry = part[1024];
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (long s0 = 0; s0 < n_seg; s0 += 1024) {
+    const long seg = s0 + tid;
+    const int n = seg < n_seg ? seg_cnt[seg] : 0;
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      const int t = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    const int base = carry + part[tid] - n;
+    if (seg < n_seg)
+      for (int i = 0; i < n; ++i) wg[1 + base + i] = (int)(seg * RAG_SEG) + seg_start[seg * RAG_SEG_WGS + i];
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    wg[0] = carry;
+    wg[1 + carry] = (int)n_pts;
+  }
+}
+
+// one wave per workgroup of the plan: its row table and the row offsets of its points
+__global__ void __launch_bounds__(64) k_ragged_tables(const unsigned* __restrict__ bits_g, const int* __restrict__ wg, unsigned short* __restrict__ rowtab, int* __restrict__ ptab) {
+  const long wgi = blockIdx.x;
+  if (wgi >= wg[0]) return;
+  const int tid = threadIdx.x, i = tid & 31;
+  const int p0 = wg[1 + wgi], np = wg[2 + wgi] - p0;
+  const bool own = tid < 32 && i < np;  // lanes 0..31 own the points, the upper half idles along (the shuffles want the whole wave)
+  const unsigned bits = own ? bits_g[p0 + i] : 0u;
+  const int n = own ? (bits != 0u ? __popc(bits) : 1) : 0;
+  int incl = n;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int t = __shfl_up(incl, off, 32);
+    if (i >= off) incl += t;
+  }
+  unsigned short* rt = rowtab + wgi * 256;
+  int* pt = ptab + wgi * RAG_PTAB;
+  const int total = __shfl(incl, 31);
+  for (int r = total + tid; r < 256; r += 64) rt[r] = 0;  // idle rows
+  if (tid < 32) {
+    pt[i] = incl - n;
+    if (i == 31) { pt[32] = incl; pt[33] = p0; pt[34] = np; pt[35] = 0; }
+    int r = incl - n;
+    if (own) {
+      if (bits == 0u) {
+        rt[r] = (unsigned short)i;  // the placeholder row of a point without valid views: its view 0 (mask 0)
+      } else {
+        for (unsigned b = bits; b != 0u; b &= b - 1u) rt[r++] = (unsigned short)(i | ((__ffs(b) - 1) << 8));
+      }
+    }
+  }
+}
+
 // all-reduce of one value per row over the rows of the row's point (two values per round with the second table)
 template <class Op>
 __device__ __forceinline__ float dense_all(const DenseRows& d, float v, float ident, Op op) {
@@ -536,8 +722,8 @@ __device__ __forceinline__ float dense_all(const DenseRows& d, float v, float id
   const float* src = d.scal + d.base;
   float a0 = ident, a1 = ident, a2 = ident, a3 = ident;
   int k = 0;
-  for (; k + 4 <= d.V; k += 4) { a0 = op(a0, src[k]); a1 = op(a1, src[k + 1]); a2 = op(a2, src[k + 2]); a3 = op(a3, src[k + 3]); }
-  for (; k < d.V; ++k) a0 = op(a0, src[k]);
+  for (; k + 4 <= d.cnt; k += 4) { a0 = op(a0, src[k]); a1 = op(a1, src[k + 1]); a2 = op(a2, src[k + 2]); a3 = op(a3, src[k + 3]); }
+  for (; k < d.cnt; ++k) a0 = op(a0, src[k]);
   __syncthreads();
   return op(op(a0, a1), op(a2, a3));
 }
@@ -547,8 +733,8 @@ __device__ __forceinline__ void dense_all2(const DenseRows& d, float v0, float v
   const float* src = d.scal + d.base;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   int k = 0;
-  for (; k + 2 <= d.V; k += 2) { a0 += src[k]; a1 += src[k + 1]; b0 += src[256 + k]; b1 += src[256 + k + 1]; }
-  for (; k < d.V; ++k) { a0 += src[k]; b0 += src[256 + k]; }
+  for (; k + 2 <= d.cnt; k += 2) { a0 += src[k]; a1 += src[k + 1]; b0 += src[256 + k]; b1 += src[256 + k + 1]; }
+  for (; k < d.cnt; ++k) { a0 += src[k]; b0 += src[256 + k]; }
   __syncthreads();
   s0 = a0 + a1; s1 = b0 + b1;
 }
@@ -594,24 +780,25 @@ __device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float
     const int total = d.PTW * 2 * nq;
     for (int task = tid; task < total; task += DYN_VIEW_THREADS) {
       const int pnt = task / (2 * nq), rem = task - pnt * (2 * nq), hh = rem / nq, qq = rem - hh * nq;
-      const float* src = tab + pnt * d.V * RS + hh * (4 * QPH) + qq * 4;
-      const float* w = wrow + pnt * d.V;
+      const int pb = dense_pt_base(d, pnt), pn = dense_pt_cnt(d, pnt);
+      const float* src = tab + pb * RS + hh * (4 * QPH) + qq * 4;
+      const float* w = wrow + pb;
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
       int k = 0;
-      for (; k + 2 <= d.V; k += 2) {
+      for (; k + 2 <= pn; k += 2) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
         const float w0 = w[k], w1 = w[k + 1];
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
         m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
       }
-      if (k < d.V) {
+      if (k < pn) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
         const float w0 = w[k];
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
       }
       const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
       float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
-      for (k = 0; k + 2 <= d.V; k += 2) {
+      for (k = 0; k + 2 <= pn; k += 2) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
         const float w0 = w[k], w1 = w[k + 1];
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
@@ -622,7 +809,7 @@ __device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float
           v1[e] = fmaf(w1, d1 * d1, v1[e]);
         }
       }
-      if (k < d.V) {
+      if (k < pn) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
         const float w0 = w[k];
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
@@ -813,7 +1000,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     constexpr int XS = 132;
     float* tab = lds_base;             // [256 rows][XS]
     float* wrow = lds_base + 256 * XS;  // [256] w2 of every row
-    const long point0 = (long)blockIdx.x * d.PTW;
+    const long point0 = d.point0;
     // (the last dense_all2 barrier also retired every wave's reads of the constant tables and of the weight ring)
     {
       float4* mine = reinterpret_cast<float4*>(tab + d.rw * XS) + h;
@@ -826,24 +1013,25 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
     __syncthreads();
     for (int task = tid; task < d.PTW * 32; task += DYN_VIEW_THREADS) {
       const int pnt = task >> 5, qd = task & 31;  // quad qd = 8 t + 2 q + half: features 32 t + 8 q + 4 half + (0..3)
-      const float* src = tab + pnt * V * XS + qd * 4;
-      const float* w = wrow + pnt * V;
+      const int pb = dense_pt_base(d, pnt), pn = dense_pt_cnt(d, pnt);  // (regular flavour: pnt V and V -- a constant in the instantiations with a compile-time view count)
+      const float* src = tab + pb * XS + qd * 4;
+      const float* w = wrow + pb;
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
       int k = 0;
-      for (; k + 2 <= V; k += 2) {
+      for (; k + 2 <= pn; k += 2) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
         const float w0 = w[k], w1 = w[k + 1];
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
         m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
       }
-      if (k < V) {
+      if (k < pn) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
         const float w0 = w[k];
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
       }
       const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
       float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
-      for (k = 0; k + 2 <= V; k += 2) {
+      for (k = 0; k + 2 <= pn; k += 2) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
         const float w0 = w[k], w1 = w[k + 1];
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, b0[4] = {x1.x, x1.y, x1.z, x1.w};
@@ -854,7 +1042,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
           v1[e] = fmaf(w1, d1 * d1, v1[e]);
         }
       }
-      if (k < V) {
+      if (k < pn) {
         const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
         const float w0 = w[k];
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
@@ -872,7 +1060,7 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
         nt_store4<4>(gin + (16 + g) * 64, make_float4(v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2], v0[3] + v1[3]));
       }
     }
-    if (valid && view == 0) {
+    if (valid && d.rw == d.base) {  // the point's first row (view 0 in the regular flavour)
       float4* gin = reinterpret_cast<float4*>(p.ws + p.o.off_gin) + point_rec(p, point, h, SB_GIN_RECS);
       gin[32 * 64] = make_float4(h == 0 ? wmean : 1.0f, 0.f, 0.f, 0.f);
       if (h == 0) p.ws[p.o.off_nvalid + point] = nvalid;
@@ -916,9 +1104,12 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
 // ===================================================================================================================
 // VC > 0 (dense flavour only): the view count as a compile-time constant -- the per-row division by V, the (point, slot) task loops of the LDS reductions
 // and their loads unroll (round 5: instantiated for the 11 static views of the Nvidia evaluation, the kernel that is 42 % of its frame)
-template <int VSEG, int VC = 0>
+// RAG (dense flavour only): ragged rows -- the workgroup's rows are the valid (point, view) pairs of the points the launch's plan gives it (k_ragged_*)
+template <int VSEG, int VC = 0, bool RAG = false>
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs p) {
   static_assert(VC == 0 || VSEG == 0, "a compile-time view count is a dense-rows specialisation");
+  static_assert(!RAG || VSEG == 0, "ragged rows are a dense-rows flavour");
+  if (RAG && (int)blockIdx.x >= p.rg_wg[0]) return;  // the grid is the plan's upper bound
   constexpr int PHASE_KID = 0;
   (void)PHASE_KID;
   float* lds = reinterpret_cast<float*>(dyn_smem);
@@ -938,14 +1129,16 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
                 SA_POOLED_AT - (POOLED ? SA_L1P_CHUNKS : 0), POOLED ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 
   const int V = VC > 0 ? VC : p.V;
-  const int PT = VC > 0 ? 256 / VC : p.PT;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
   // VSEG > 0: views occupy a power-of-two segment of VSEG >= V lanes (PT = 32 / VSEG points per wave); lanes view >= V are padding.
-  // VSEG == 0 (dense rows): the workgroup's 256 rows are the point-views of its PT = 256 / V points in order, no padding between points.
-  const DenseRows dr = dense_rows(V, PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  // VSEG == 0 (dense rows): the workgroup's 256 rows are the point-views of its PT = 256 / V points in order, no padding between points --
+  // or (RAG) the valid point-views of the plan's points for this workgroup (the row offsets of its points: RAG_PTAB ints of LDS behind everything else).
+  const DenseRows dr = RAG ? ragged_rows(V, p.rg_rowtab, p.rg_ptab, blockIdx.x, lds + LDS_FLOATS - DENSE_SCALARS, reinterpret_cast<int*>(lds + LDS_FLOATS))
+                           : dense_rows(V, VC > 0 ? 256 / VC : p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  const int PT = RAG ? dr.PTW : (VC > 0 ? 256 / VC : p.PT);
   const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
-  const long point = VSEG == 0 ? (long)blockIdx.x * PT + p_local : tile * PT + p_local;
+  const long point = VSEG == 0 ? dr.point0 + p_local : tile * PT + p_local;
   const bool valid = (VSEG == 0 ? p_local < PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
@@ -966,7 +1159,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     B6TileW<SA_L1P_STEPS> pw1;
     b6_tile_prefetch<8, SA_L1P_STEPS>(p.blob + ST_OFF_A, wave, pw1);
     const int npw = VSEG == 0 ? PT : (DYN_VIEW_THREADS / 64) * PT;  // points of this workgroup
-    const long qp = (long)blockIdx.x * npw + j;
+    const long qp = VSEG == 0 ? dr.point0 + j : (long)blockIdx.x * npw + j;
     const bool qok = j < npw && qp < p.n_pts;
     const float qx = qok ? p.pts[qp * 3] : 0.f, qy = qok ? p.pts[qp * 3 + 1] : 0.f, qz = qok ? p.pts[qp * 3 + 2] : 0.f;
     float in1p[SA_L1P_STEPS];
@@ -1050,8 +1243,10 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   float wgt;
   if (p.anti_alias) {
     // padding lanes (and, in the dense flavour, the idle tail rows, which shadow the last point) never set the minimum over the views
-    const float e = ((VSEG == 0 ? p_local < PT : view < V)) ? expf(ctab[258] * (rd.w - 1.0f)) : 3.0e38f;
-    wgt = (e - views_min<VSEG>(dr, e)) * msk;
+    const float e = ((VSEG == 0 ? p_local < PT : view < V)) ? aa_exp(ctab[258], rd.w) : 3.0e38f;
+    // (ragged rows: the minimum runs over ALL views of the point, masked ones included -- mlp_network.py:465-468 --, so it comes from the plan)
+    const float emin = RAG ? (valid ? p.rg_emin[point] : e) : views_min<VSEG>(dr, e);
+    wgt = (e - emin) * msk;
   } else {
     wgt = msk;
   }
@@ -1601,11 +1796,12 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
   const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
   const long pv = valid ? point * V + view : 0;
 
-  const float msk = valid ? p.mask[pv] : 0.f;
+  float msk = valid ? p.mask[pv] : 0.f;
   const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 vrec = tile_ok ? reinterpret_cast<const float4*>(p.ws + p.o.off_vis)[tile * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);  // {vis2, r, g, b} of the row
   const float vis2 = vrec.x;
   const float rgb_in[3] = {valid ? vrec.y : 0.f, valid ? vrec.z : 0.f, valid ? vrec.w : 0.f};
+  if (p.mask_rgb && !((rgb_in[0] + rgb_in[1]) + rgb_in[2] > 1e-3f)) msk = 0.f;  // mask = mask * rgb_mask also feeds the masked_fill (mlp_network.py:458-460, 523)
   f32x16 a[4];
   {
     f32x16 x[4];
@@ -1636,7 +1832,7 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float v = views_sum<VSEG>(dr, rgb_in[c] * bw);
-    if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
+    if (valid && (VSEG == 0 ? dr.rw == dr.base : view == 0) && h == 0) p.raw[point * 4 + c] = v;
   }
   DYN_PHASE(20);
 }
@@ -1646,15 +1842,12 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
 // (8 k of a workgroup's 28-35 k cycles, tools/phasebench.py) covered only by whatever else is resident.  Here one workgroup per CU copies the 52 pairs
 // once and walks row tiles; the layers read their A fragments from the resident image (mlp_layer_b6_lds: no ring, no barriers), so in the lane-segment
 // flavour the twelve waves of a CU run free of each other, and in the dense flavour only the cross-view reductions still synchronise.
-#ifndef DYN_BLEND_WS
-#define DYN_BLEND_WS (DYN_SPLIT_TERMS == 3 ? 1 : 0)
-#endif
 #define SC_L11_PAIRS (((SC_L11_STEPS + 7) / 8) * 4)
 #define SC_L12_PAIRS ((64 / 8) * 2)
 #define SC_WS_FLOATS ((SC_L11_PAIRS + SC_L12_PAIRS) * B6_PAIR_FLOATS)
 #define DYN_BLEND_WS_THREADS 768
 #if DYN_BLEND_WS
-template <int VSEG, int THREADS>
+template <int VSEG, int THREADS, bool RAG = false>
 __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + SC_WS_FLOATS;  // [SC_CT] (+ the dense flavour's scalar tables behind it)
@@ -1676,23 +1869,33 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
   const float* w12 = lds + SC_L11_PAIRS * B6_PAIR_FLOATS;
   const int V = p.V;
   constexpr int NW = THREADS / 64;
-  const DenseRows dr = dense_rows(V, p.PT, ctab + SC_CT);
-  const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
-  const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
-  // lane-segment flavour: every wave walks its own tiles; dense flavour: the workgroup walks blocks of NW tiles together (its reductions use barriers)
-  const long n_units = VSEG == 0 ? (p.n_tiles_a + NW - 1) / NW : p.n_tiles_a;
+  int* pbase = reinterpret_cast<int*>(ctab + SC_CT + DENSE_SCALARS);  // (ragged rows: RAG_PTAB ints behind the scalar tables)
+  DenseRows dr = dense_rows(V, p.PT, ctab + SC_CT, 0);
+  // lane-segment flavour: every wave walks its own tiles; dense flavour: the workgroup walks blocks of NW tiles together (its reductions use barriers);
+  // ragged dense flavour: the blocks are the plan's workgroups (the row tables of the view kernel that parked x)
+  const long n_units = RAG ? p.rg_wg[0] : (VSEG == 0 ? (p.n_tiles_a + NW - 1) / NW : p.n_tiles_a);
   const long first = VSEG == 0 ? blockIdx.x : (long)blockIdx.x * NW + wave, step = VSEG == 0 ? gridDim.x : (long)gridDim.x * NW;
   for (long u = first; u < n_units; u += step) {
+    if (RAG) {
+      __syncthreads();  // every wave has left the previous unit's tables
+      dr = ragged_rows(V, p.rg_rowtab, p.rg_ptab, u, ctab + SC_CT, pbase);
+    } else if (VSEG == 0) {
+      dr.point0 = u * p.PT;
+    }
+    const int PT = RAG ? dr.PTW : p.PT;
+    const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
+    const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
     const long tile = VSEG == 0 ? u * NW + wave : u;
     const bool tile_ok = tile < p.n_tiles_a;
-    const long point = VSEG == 0 ? u * p.PT + p_local : tile * p.PT + p_local;
-    const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
+    const long point = VSEG == 0 ? dr.point0 + p_local : tile * PT + p_local;
+    const bool valid = (VSEG == 0 ? p_local < PT : view < V) && (point < p.n_pts);
     const long pv = valid ? point * V + view : 0;
-    const float msk = valid ? p.mask[pv] : 0.f;
+    float msk = valid ? p.mask[pv] : 0.f;
     const float4 rd = valid ? reinterpret_cast<const float4*>(p.ray_diff)[pv] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 vrec = tile_ok ? reinterpret_cast<const float4*>(p.ws + p.o.off_vis)[tile * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);  // {vis2, r, g, b} of the row
     const float vis2 = vrec.x;
     const float rgb_in[3] = {valid ? vrec.y : 0.f, valid ? vrec.z : 0.f, valid ? vrec.w : 0.f};
+    if (p.mask_rgb && !((rgb_in[0] + rgb_in[1]) + rgb_in[2] > 1e-3f)) msk = 0.f;  // mask = mask * rgb_mask also feeds the masked_fill (mlp_network.py:458-460, 523)
     f32x16 a[4];
     {
       f32x16 x[4];
@@ -1716,20 +1919,31 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
     acc_elu_s(b2);
     float logit = row_dot<2>(b2, ctab) + ctab[64];
     if (msk == 0.f) logit = -1e9f;
-    if (VSEG == 0 ? p_local >= p.PT : view >= V) logit = -3.0e38f;  // padding rows take no share even when every real view is masked (uniform 1/V then)
+    if (VSEG == 0 ? p_local >= PT : view >= V) logit = -3.0e38f;  // padding rows take no share even when every real view is masked (uniform 1/V then)
     const float mx = views_max<VSEG>(dr, logit);
-    const float e = (VSEG == 0 && p_local >= p.PT) ? 0.f : __expf(logit - mx);
+    const float e = (VSEG == 0 && p_local >= PT) ? 0.f : __expf(logit - mx);
     const float bw = e / views_sum<VSEG>(dr, e);
+    const bool writer = valid && (VSEG == 0 ? dr.rw == dr.base : view == 0) && h == 0;  // the point's first row
+    // Ragged rows: a point whose views are ALL masked by the projection keeps one placeholder row; the reference's softmax over V equal logits of -1e9 gives
+    // every view 1 / V, its colour is the plain mean of the V gathered colours (mlp_network.py:523-526): taken from rgb_feat here, the rows that held them are gone
+    // (the same holds when mask_rgb has masked every remaining row: `nvalid` is the view kernel's sum of the final masks)
+    const bool all_masked = RAG && writer && p.ws[p.o.off_nvalid + point] == 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float v = views_sum<VSEG>(dr, rgb_in[c] * bw);
-      if (valid && view == 0 && h == 0) p.raw[point * 4 + c] = v;
+      float v = views_sum<VSEG>(dr, rgb_in[c] * bw);
+      if (all_masked) {
+        const float wv = 1.0f / (float)V;
+        v = 0.f;
+        for (int k = 0; k < V; ++k) v += p.rgb_feat[(point * V + k) * 35 + c] * wv;
+      }
+      if (writer) p.raw[point * 4 + c] = v;
     }
   }
 }
 template <int VSEG>
 __global__ void __launch_bounds__(DYN_BLEND_WS_THREADS, 1) k_static_blend_ws(StaticArgs p) { static_blend_ws_body<VSEG, DYN_BLEND_WS_THREADS>(p); }
-__global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense_ws(StaticArgs p) { static_blend_ws_body<0, DYN_VIEW_THREADS>(p); }
+template <bool RAG>
+__global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense_ws(StaticArgs p) { static_blend_ws_body<0, DYN_VIEW_THREADS, RAG>(p); }
 #endif
 
 template <int VSEG>
@@ -1738,6 +1952,25 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 1) k_static_blend_dense(Stat
 
 
 // -------------------------------------------------------------------------------------------------------------------
+// the plan of a ragged launch (see StaticWs): fills a.rg_* from the workspace and runs the four planning kernels on `stream`
+static int ragged_plan(StaticArgs& a, const float* s_abs, hipStream_t stream) {
+  unsigned* bits = reinterpret_cast<unsigned*>(a.ws + a.o.off_bits);
+  float* emin = a.ws + a.o.off_emin;
+  int* seg_cnt = reinterpret_cast<int*>(a.ws + a.o.off_segcnt);
+  int* seg_start = reinterpret_cast<int*>(a.ws + a.o.off_segstart);
+  int* wg = reinterpret_cast<int*>(a.ws + a.o.off_wgstart);
+  unsigned short* rowtab = reinterpret_cast<unsigned short*>(a.ws + a.o.off_rowtab);
+  int* ptab = reinterpret_cast<int*>(a.ws + a.o.off_ptab);
+  a.rg_bits = bits; a.rg_emin = emin; a.rg_wg = wg; a.rg_rowtab = rowtab; a.rg_ptab = ptab;
+  DYN_REQUIRE(a.n_pts < (1L << 31), "ragged plan: R * S must stay below 2^31 points");
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_points", k_ragged_points, dim3(dyn_cdiv(a.n_pts, 256)), dim3(256), 0, stream, a.n_pts, a.V, a.mask,
+             reinterpret_cast<const float4*>(a.ray_diff), s_abs, bits, emin);
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_segments", k_ragged_segments, dim3(dyn_cdiv(a.o.n_seg, 64)), dim3(64), 0, stream, a.n_pts, a.o.n_seg, bits, seg_cnt, seg_start);
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_scatter", k_ragged_scatter, dim3(1), dim3(1024), 1028 * sizeof(int), stream, a.n_pts, a.o.n_seg, seg_cnt, seg_start, wg);
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_tables", k_ragged_tables, dim3((unsigned)a.o.n_wg_max), dim3(64), 0, stream, bits, wg, rowtab, ptab);
+  return 0;
+}
+
 extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   DYN_REQUIRE(q, "dyn_static_net: null params");
   DYN_REQUIRE(q->R > 0 && q->S > 0 && q->V > 0, "dyn_static_net: empty problem");
@@ -1756,6 +1989,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   a.n_pts = a.o.n_pts; a.n_tiles_a = a.o.n_tiles_a; a.n_tiles_b = a.o.n_tiles_b;
   a.blob = q->blob; a.pts = q->pts; a.rgb_feat = q->rgb_feat; a.ray_diff = q->ray_diff; a.mask = q->mask; a.centers = q->centers;
   a.raw = q->raw; a.ws = (float*)q->workspace;
+  a.rg_bits = nullptr; a.rg_emin = nullptr; a.rg_wg = nullptr; a.rg_rowtab = nullptr; a.rg_ptab = nullptr;
 
   DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
@@ -1764,7 +1998,14 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   const size_t lds_b = (PTS_RING_SLOTS * PTS_CHUNK + SB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
   const size_t lds_c = (NET_CHUNK + SC_CT) * sizeof(float);
   const dim3 grid_c(dyn_cdiv(a.n_tiles_a, DYN_BLEND_THREADS / 64)), blk_c(DYN_BLEND_THREADS);
-  if (a.o.dense && a.V == 11) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", (k_static_views<0, 11>), grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  const size_t lds_rag = (DENSE_EXTRA + RAG_PTAB) * sizeof(float);
+  if (a.o.ragged) {
+    const int rc = ragged_plan(a, a.anti_alias ? a.blob + ST_OFF_CTA + 258 : nullptr, stream);
+    if (rc != 0) return rc;
+  }
+  if (a.o.ragged && a.V == 11) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", (k_static_views<0, 11, true>), grid_a, blk_v, lds_a + lds_rag, stream, a);
+  else if (a.o.ragged) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", (k_static_views<0, 0, true>), grid_a, blk_v, lds_a + lds_rag, stream, a);
+  else if (a.o.dense && a.V == 11) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", (k_static_views<0, 11>), grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
   else if (a.o.dense) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
   else if (q->V <= 4) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_STATIC_VIEWS, "k_static_views", k_static_views<8>, grid_a, blk_v, lds_a, stream, a);
@@ -1779,11 +2020,12 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
 #if DYN_BLEND_WS
   static const int blend_stream = getenv("DYN_BLEND_STREAM") != nullptr;  // developer A/B: the streaming (round-3) form
   if (!blend_stream) {
-    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS) * sizeof(float);
+    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS + RAG_PTAB) * sizeof(float);
     const unsigned n_cu = (unsigned)dyn_cu_count();
     if (a.o.dense) {
       const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64);
-      DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense_ws, dim3(nb < n_cu ? nb : n_cu), blk_v, lds_w, stream, a);
+      if (a.o.ragged) DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense_ws<true>, dim3(nb < n_cu ? nb : n_cu), blk_v, lds_w, stream, a);
+      else DYN_LAUNCH(DYN_K_STATIC_BLEND, "k_static_blend", k_static_blend_dense_ws<false>, dim3(nb < n_cu ? nb : n_cu), blk_v, lds_w, stream, a);
     } else {
       const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_BLEND_WS_THREADS / 64);
       const dim3 gw(nb < n_cu ? nb : n_cu), bw_(DYN_BLEND_WS_THREADS);
@@ -1946,8 +2188,10 @@ __global__ void __launch_bounds__(256) k_dynamic_time_feat(const float* __restri
 }
 
 // per point-view chain of the dynamic net: (rgb_feat + direction_feat) -> mean/var (mask weights) -> base_fc -> shared tail
-template <int VSEG>
+template <int VSEG, bool RAG = false>
 __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArgs p) {
+  static_assert(!RAG || VSEG == 0, "ragged rows are a dense-rows flavour");
+  if (RAG && (int)blockIdx.x >= p.rg_wg[0]) return;  // the grid is the plan's upper bound
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + 2 * NET_CHUNK;  // [SA_CT]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -1958,12 +2202,14 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_dynamic_views(StaticArg
 
   const int V = p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
-  // row -> (point, view): power-of-two lane segments (VSEG > 0) or dense rows (VSEG == 0), as in k_static_views
-  const DenseRows dr = dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  // row -> (point, view): power-of-two lane segments (VSEG > 0), dense rows (VSEG == 0) or ragged dense rows (RAG), as in k_static_views
+  const DenseRows dr = RAG ? ragged_rows(V, p.rg_rowtab, p.rg_ptab, blockIdx.x, lds + LDS_FLOATS - DENSE_SCALARS, reinterpret_cast<int*>(lds + LDS_FLOATS))
+                           : dense_rows(V, p.PT, lds + LDS_FLOATS - DENSE_SCALARS);
+  const int PT = RAG ? dr.PTW : p.PT;
   const int p_local = VSEG == 0 ? dr.p_local : j / (VSEG == 0 ? 1 : VSEG);
   const int view = VSEG == 0 ? dr.view : (j & (VSEG - 1));
-  const long point = VSEG == 0 ? (long)blockIdx.x * p.PT + p_local : tile * p.PT + p_local;
-  const bool valid = (VSEG == 0 ? p_local < p.PT : view < V) && (point < p.n_pts);
+  const long point = VSEG == 0 ? dr.point0 + p_local : tile * PT + p_local;
+  const bool valid = (VSEG == 0 ? p_local < PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
   const float msk = valid ? p.mask[pv] : 0.f;
@@ -1999,12 +2245,17 @@ extern "C" int dyn_dynamic_net(const DynDynamicNetParams* q, void* stream_) {
   a.shift = q->shift;
   a.blob = q->blob; a.ray_d = q->ray_d; a.pts = q->pts; a.rgb_feat = q->rgb_feat; a.ray_diff = nullptr; a.mask = q->mask; a.centers = nullptr;
   a.raw = q->raw; a.ws = (float*)q->workspace;
+  a.rg_bits = nullptr; a.rg_emin = nullptr; a.rg_wg = nullptr; a.rg_rowtab = nullptr; a.rg_ptab = nullptr;
   DYN_LAUNCH(DYN_K_DYNAMIC_TIME, "k_dynamic_time_feat", k_dynamic_time_feat, dim3(1), dim3(256), 256 * sizeof(float), stream,
              q->blob + DY_OFF_TIME, q->time, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);
   const size_t lds_b = (PTS_RING_SLOTS * PTS_CHUNK + DB_CT + SB_KL_FLOATS + SB_VL_FLOATS) * sizeof(float);
-  if (a.o.dense) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
+  if (a.o.ragged) {
+    const int rc = ragged_plan(a, nullptr, stream);
+    if (rc != 0) return rc;
+    DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", (k_dynamic_views<0, true>), grid_a, blk_v, lds_a + (DENSE_EXTRA + RAG_PTAB) * sizeof(float), stream, a);
+  } else if (a.o.dense) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<0>, grid_a, blk_v, lds_a + DENSE_EXTRA * sizeof(float), stream, a);
   else if (q->V <= 4) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<4>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 8) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<8>, grid_a, blk_v, lds_a, stream, a);
   else if (q->V <= 16) DYN_LAUNCH(DYN_K_DYNAMIC_VIEWS, "k_dynamic_views", k_dynamic_views<16>, grid_a, blk_v, lds_a, stream, a);
@@ -2193,7 +2444,7 @@ extern "C" int dyn_motion_mlp(const float* blob, const float* pts, const float* 
     DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_mlp", k_motion_mlp, dim3(dyn_cdiv(n_kept, 128)), dim3(DYN_NET_THREADS), MOTION_RING_SLOTS * NET_CHUNK * sizeof(float),
                (hipStream_t)stream, blob, pts, time, n_kept, S, nz, 3 * num_basis, 1.0f / sf_mag_div, coeff);
   if (nz > 0)
-    DYN_LAUNCH(DYN_K_MOTION_MLP, "k_motion_zero_tail", k_motion_zero_tail, dim3(dyn_cdiv((long)R * nz * 3 * num_basis, 256)), dim3(256), 0, (hipStream_t)stream, (long)R, S, nz,
+    DYN_LAUNCH(DYN_K_MOTION_TAIL, "k_motion_zero_tail", k_motion_zero_tail, dim3(dyn_cdiv((long)R * nz * 3 * num_basis, 256)), dim3(256), 0, (hipStream_t)stream, (long)R, S, nz,
                3 * num_basis, coeff);
   return 0;
 }

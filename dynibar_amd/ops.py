@@ -138,6 +138,9 @@ def project_points(cams, xyz, xyz_st=None, query_camera=None, proj_matrices=None
   return pix, (front > 0 if front is not None else None), rd
 
 
+GATHER_STATS = None  # set to {} to tally calls and algorithmic bytes of project_gather (a measurement hook; never read by the product)
+
+
 def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None, pix_mask_thresh=None):
   """k_project_gather_tile -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]; with pix_mask_thresh also the per-sample
   observation mask ``mask[..., 0].sum(dim=2) > thresh`` [R,S] (render_ray.py:736-741) as a fourth result, from the same launch."""
@@ -154,6 +157,9 @@ def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None
              src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask),
              pix_mask=ptr(pix), pix_mask_thresh=float(pix_mask_thresh) if pix_mask_thresh is not None else 0.0)
   call('dyn_project_gather', ctypes.byref(p), stream_of(rgb_feat))
+  if GATHER_STATS is not None:  # opt-in tally of the launches' algorithmic bytes: bench.py prices the in-frame gather with it
+    GATHER_STATS['calls'] = GATHER_STATS.get('calls', 0) + 1
+    GATHER_STATS['bytes'] = GATHER_STATS.get('bytes', 0) + R * S * V * 160 + V * (views.Hf * views.Wf * views.F + views.H * views.W * 3) * 4 + R * (24 + 4 * S)
   if pix_mask_thresh is not None:
     return rgb_feat, ray_diff, mask, pix
   return rgb_feat, ray_diff, mask
@@ -280,15 +286,15 @@ def _infer_F(state_dict, key='ray_dir_fc.2.weight'):
   return int(w.shape[0]) - 3
 
 
-_CROSS_WARNED = []
+_CROSS_WARNED = set()  # axis kinds ('VIEW', 'SAMPLE', 'RAY') that have been reported: one warning per KIND, so that a harmless 3-ray frame tail cannot use up the report of a persistent 3-view divergence
 
 
 def check_cross_axis_quirk(R, S, V):
   """The reference forms the Pluecker moments with ``torch.cross`` WITHOUT ``dim`` (render_ray.py:375, :392), which crosses over the FIRST axis of
   size 3: with exactly 3 source views or 3 samples per ray -- or, for a chunk of exactly 3 rays, over the rays -- it does not cross over xyz.  The
   kernels (and the oracle) always cross over xyz, which is what the code means.  The reference still RUNS those shapes, so a user with 3 static source
-  views must not be blocked: every such shape is rendered with the xyz cross product and a one-time RuntimeWarning says that the result differs from
-  the reference's there (a 3-ray chunk can occur as the tail of a frame: H x W mod chunk_size == 3).  ``DYNIBAR_STRICT_CROSS_QUIRK=1`` turns the
+  views must not be blocked: every such shape is rendered with the xyz cross product and a RuntimeWarning -- once per process and per axis kind
+  (view / sample / ray) -- says that the result differs from the reference's there (a 3-ray chunk can occur as the tail of a frame: H x W mod chunk_size == 3).  ``DYNIBAR_STRICT_CROSS_QUIRK=1`` turns the
   S == 3 / V == 3 warning into a ValueError for callers who would rather stop than diverge ("Known divergence")."""
   if not (S == 3 or V == 3 or R == 3):
     return
@@ -296,10 +302,10 @@ def check_cross_axis_quirk(R, S, V):
   if (S == 3 or V == 3) and os.environ.get('DYNIBAR_STRICT_CROSS_QUIRK', '0') == '1':
     raise ValueError(f'DynibarStatic with S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the '
                      'first axis of size 3 for this shape, which the kernels do not reproduce (DYNIBAR_STRICT_CROSS_QUIRK=1)')
-  if not _CROSS_WARNED:
+  axis = 'VIEW' if V == 3 else ('SAMPLE' if S == 3 else 'RAY')
+  if axis not in _CROSS_WARNED:
     import warnings
-    _CROSS_WARNED.append(1)
-    axis = 'VIEW' if V == 3 else ('SAMPLE' if S == 3 else 'RAY')
+    _CROSS_WARNED.add(axis)
     warnings.warn(f'R={R} rays, S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the {axis} axis '
                   'for this shape; dynibar_amd renders the intended xyz cross product (results differ from the reference for this shape only)',
                   RuntimeWarning, stacklevel=3)
@@ -360,19 +366,31 @@ def _strip_module(state_dict):
 
 class _Workspace:
   """A network's scratch between its kernels, kept across calls -- ONE PER STREAM: two ray chunks in flight on two streams (render_image.CHUNK_STREAMS)
-  must not share it, and a buffer that only ever serves one stream needs no cross-stream bookkeeping with the caching allocator."""
+  must not share it, and a buffer that only ever serves one stream needs no cross-stream bookkeeping with the caching allocator.  Resident memory is
+  therefore (streams in use) x (the largest workspace asked for): about 2 GiB per stream at R = 8192, S = 64, V = 8 (INTEGRATION.md, DYNIBAR_CHUNK_STREAMS);
+  at most MAX_ENTRIES buffers are kept.  An evicted buffer whose kernels are still queued is safe: it was allocated and is freed on the stream that used it."""
+
+  MAX_ENTRIES = 4  # the chunk loop's side streams + the caller's stream (render_image.CHUNK_STREAMS + 1 by default); the least recently used entry goes first
 
   def __init__(self):
-    self.bufs = {}
+    self.bufs = {}  # (device index, stream handle) -> buffer, in order of last use
 
   def get(self, need, device):
     if need == 0:
       raise ValueError('unsupported network shape (R, S, V)')
     device = torch.device(device)
-    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
-    buf = self.bufs.get(key)
+    if device.type == 'cuda':
+      index = device.index if device.index is not None else torch.cuda.current_device()  # 'cuda' and 'cuda:0' are one device
+      device = torch.device('cuda', index)
+      key = (index, torch.cuda.current_stream(device).cuda_stream)
+    else:
+      key = (-1, 0)
+    buf = self.bufs.pop(key, None)
     if buf is None or buf.numel() * 4 < need:
-      buf = self.bufs[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+      buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    self.bufs[key] = buf  # (re-inserted: most recently used last)
+    while len(self.bufs) > self.MAX_ENTRIES:  # transient streams must not grow the resident memory without bound
+      self.bufs.pop(next(iter(self.bufs)))
     return buf
 
 

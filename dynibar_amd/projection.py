@@ -67,12 +67,22 @@ class Projector(object):
       # view sets): entries of earlier iterations can never be hit again, so under grad mode the cache is bounded to about one iteration's
       # sets instead of keeping up to 17 (maps, repacked copy) pairs alive.
       if len(self._views) > (5 if featmaps.requires_grad else 16):
+        if featmaps.is_cuda:
+          torch.cuda.synchronize(featmaps.device)  # chunks in flight on other streams (render_image.CHUNK_STREAMS) may still read the entries being dropped
         self._views.clear()
       P = self._matrices(train_cameras[0])
       v = ops.SourceViews(query_camera, train_imgs, train_cameras, featmaps, proj_matrices=P)
       # keep the keyed tensors alive so that a recycled address cannot alias a stale entry
       v._key_refs = (query_camera, train_imgs, train_cameras, featmaps)
+      # an entry is prepared on the stream of the chunk that first asks for it and may be read by chunks on other streams: readers wait for this event
+      # (normally chunk 0 fills the cache before the chunk streams fork; this also orders a miss in a later chunk)
+      v._ready = None
+      if featmaps.is_cuda:
+        v._ready = torch.cuda.Event()
+        v._ready.record(torch.cuda.current_stream(featmaps.device))
       self._views[key] = v
+    elif v._ready is not None:
+      torch.cuda.current_stream(featmaps.device).wait_event(v._ready)
     return v
 
   def compute_with_motions(self, xyz_st, xyz, query_camera, train_imgs, train_cameras, featmaps):

@@ -57,13 +57,15 @@ def _dist():
 _ABI_COMMS = {}
 
 
-def _destroy_abi_comms():
-  """ncclCommDestroy for every communicator this module made (atexit, and whenever the default process group has changed): RCCL warns or hangs at
-  teardown with live communicators."""
-  import ctypes
+def _destroy_abi_comms(keep_group=None):
+  """ncclCommDestroy for the communicators this module made (atexit: all of them; when the default process group has changed: those of OTHER groups,
+  the entries of `keep_group` -- other devices of the same group included -- stay): RCCL warns or hangs at teardown with live communicators."""
   from ._lib import call
   for key in list(_ABI_COMMS):
-    comm = _ABI_COMMS.pop(key)
+    group_ref, comm = _ABI_COMMS[key]
+    if keep_group is not None and group_ref() is keep_group:
+      continue
+    del _ABI_COMMS[key]
     try:
       call('dyn_comm_destroy', comm)
     except Exception:  # teardown: the device or RCCL may already be gone
@@ -72,34 +74,54 @@ def _destroy_abi_comms():
 
 def abi_communicator(dist, world, rank, device):
   """ncclComm_t (a ctypes.c_void_p) of this package's own for dyn_gather_tiles on `device`: rank 0 draws the 128-byte id (dyn_comm_unique_id),
-  torch.distributed carries it to the other ranks, every rank joins (dyn_comm_init_rank).  One per (process group, world, rank, device): the key holds
-  the identity of the default process group, so a destroy_process_group() + re-init with other members never reuses a stale communicator (the
-  old ones are destroyed first); all of them are destroyed at interpreter exit."""
+  torch.distributed carries it to the other ranks, every rank joins (dyn_comm_init_rank).  One per (world, rank, device) of the CURRENT default process
+  group.  An entry holds a weak reference to the group OBJECT and is only reused while that very object is still the default group (`is`, not `id()`:
+  after destroy_process_group() + re-init CPython may hand the new group the old address); entries of a group that is gone are destroyed before a new
+  communicator is made -- every rank takes that path at the same call, the re-init being collective -- and entries of other devices of the live group
+  are kept.  All of them are destroyed at interpreter exit."""
   import ctypes
+  import weakref
   from ._lib import call
   group = getattr(getattr(dist, 'group', None), 'WORLD', None)
-  key = (id(group), world, rank, device.index)
-  if key not in _ABI_COMMS:
-    if _ABI_COMMS:
-      _destroy_abi_comms()  # the process group changed under us
-    else:
-      import atexit
-      if not getattr(abi_communicator, '_hooked', False):
-        atexit.register(_destroy_abi_comms)
-        abi_communicator._hooked = True
-    idbuf = (ctypes.c_char * 128)()
-    if rank == 0:
-      call('dyn_comm_unique_id', idbuf)
-    if world > 1:
-      on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
-      t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=on)
-      dist.broadcast(t, 0)
-      idbuf = (ctypes.c_char * 128)(*bytes(t.cpu().tolist()))
-    comm = ctypes.c_void_p()
-    with torch.cuda.device(device):
-      call('dyn_comm_init_rank', ctypes.byref(comm), world, idbuf, rank)
-    _ABI_COMMS[key] = comm
-  return _ABI_COMMS[key]
+  key = (world, rank, device.index)
+  hit = _ABI_COMMS.get(key)
+  if hit is not None and hit[0]() is group:
+    return hit[1]
+  _destroy_abi_comms(keep_group=group)  # (drops a stale entry under `key` too: its group is not `group`)
+  if not getattr(abi_communicator, '_hooked', False):
+    import atexit
+    atexit.register(_destroy_abi_comms)
+    abi_communicator._hooked = True
+  idbuf = (ctypes.c_char * 128)()
+  if rank == 0:
+    call('dyn_comm_unique_id', idbuf)
+  if world > 1:
+    on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=on)
+    dist.broadcast(t, 0)
+    idbuf = (ctypes.c_char * 128)(*bytes(t.cpu().tolist()))
+  comm = ctypes.c_void_p()
+  with torch.cuda.device(device):
+    call('dyn_comm_init_rank', ctypes.byref(comm), world, idbuf, rank)
+  try:
+    ref = weakref.ref(group)
+  except TypeError:  # (a group object that cannot be weakly referenced: hold it -- identity still decides)
+    ref = (lambda g: (lambda: g))(group)
+  _ABI_COMMS[key] = (ref, comm)
+  return comm
+
+
+def _record_stream(obj, stream):
+  """Tell the caching allocator that every device tensor inside `obj` (nested dicts / lists / tuples included) is also used on `stream`."""
+  if isinstance(obj, torch.Tensor):
+    if obj.is_cuda:
+      obj.record_stream(stream)
+  elif isinstance(obj, dict):
+    for v in obj.values():
+      _record_stream(v, stream)
+  elif isinstance(obj, (list, tuple)):
+    for v in obj:
+      _record_stream(v, stream)
 
 
 def ray_tile(n_rays, world, rank):
@@ -401,9 +423,7 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
           spans[-1][1].record()
         for g in group_names:
           if ret.get(g) is not None:
-            for v in ret[g].values():
-              if isinstance(v, torch.Tensor) and v.is_cuda:
-                v.record_stream(cur)
+            _record_stream(ret[g], cur)
             chunks[g].append(ret[g])
     for st in side:
       cur.wait_stream(st)

@@ -20,6 +20,8 @@ def scene_case(name):
       'small': dict(seed=1, H=48, W=64, V=7, n_static=8, smooth=True, R=6),
       # wide baselines / rotations: many out-of-bounds and behind-camera samples
       'harsh': dict(seed=2, H=40, W=56, V=5, n_static=11, smooth=True, R=5, t_scale=3.0, r_scale=1.2, near=0.3, far=6.0),
+      # the same scene with enough rays for several workgroups and several planning segments of the ragged dense-rows flavour (48 x 64 = 3072 points x 11 static views)
+      'harsh_many': dict(seed=2, H=40, W=56, V=5, n_static=11, smooth=True, R=48, t_scale=3.0, r_scale=1.2, near=0.3, far=6.0),
       # white-noise maps (the bench's data distribution): ill-conditioned bilinear taps, looser tolerance
       'noise': dict(seed=3, H=32, W=48, V=7, n_static=8, smooth=False, R=4),
       # view counts that exercise the other lane-segment widths of the network kernels (4 and 32 lanes per point)

@@ -153,6 +153,8 @@ template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
   if (src < 0 || (src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
   return emu::unbits<T>(s[src][0]);
 }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 static inline unsigned long long __ballot(int pred) {
   auto s = emu::exchange(pred ? 1 : 0, 0);
   unsigned long long m = 0;

@@ -38,3 +38,8 @@ def test_point_kernel_walks_several_row_tiles(emu):
   pass: slot rotation of the weight ring, the next pass's first chunks requested in the tail of the first.)"""
   parity.check_static_net(emu, "small", S=32, R=12)
   parity.check_dynamic_net(emu, "small", S=32, R=12, shift=5.0)
+
+
+def test_ragged_rows_with_dark_colours(emu):
+  """11 static views (ragged dense rows) with mask_rgb removing valid rows and whole points: the blend's product mask and its all-masked path."""
+  parity.check_static_net(emu, 'harsh', S=32, R=2, mask_rgb=True, dark=0.4)

@@ -299,9 +299,19 @@ def static_inputs(name, S, R=None, weights='init'):
   return scene, o, d, sd, out, st
 
 
-def check_static_net(device, name='small', S=64, R=None, aa=True, mask_rgb=False, atol=1e-4, weights='init'):
-  """DynibarStatic on the oracle's own stage inputs (isolates the network kernels from the gather)."""
+def check_static_net(device, name='small', S=64, R=None, aa=True, mask_rgb=False, atol=1e-4, weights='init', dark=0.0):
+  """DynibarStatic on the oracle's own stage inputs (isolates the network kernels from the gather).
+  dark > 0 (with mask_rgb): that fraction of the (point, view) rows -- and ALL views of a tenth as many points -- get a black source colour, so that
+  mask_rgb (mlp_network.py:457-460) removes valid rows and whole points: the reference's masked_fill then sees the PRODUCT mask (a point whose every
+  remaining row is dark blends uniformly over all V gathered colours, projection-masked ones included)."""
   scene, o, d, sd, _, st = static_inputs(name, S, R, weights)
+  if dark > 0.0:
+    g = torch.Generator().manual_seed(77)
+    rf = st['rgb_feat'].clone()
+    row_dark = torch.rand(rf.shape[:3], generator=g) < dark
+    row_dark |= (torch.rand(rf.shape[:2], generator=g) < 0.1 * dark + 0.02)[..., None]
+    rf[..., :3] = torch.where(row_dark[..., None], torch.zeros(()), rf[..., :3])
+    st = dict(st, rgb_feat=rf)
   net_args = (sd, st['pts'], st['ref_rays_coords'], st['src_rays_coords'], st['rgb_feat'], F.normalize(d, dim=-1), st['ray_diff'], st['mask'])
   raw_ref = O.static_net(*net_args, aa, mask_rgb)
   # Conditioning of the reference itself: its anti-alias pooling weights are (e - min_v e) with e = exp(|s|(dot-1)) ~ 1, so one ulp
@@ -379,6 +389,42 @@ def check_static_pass(device, name='small', S=64, R=None, atol=1e-4, weights='in
   assert_close(cpu(out['weights'])[keep], out_ref['weights'][keep], atol, 0.0, f'{name} static pass weights', extra=ex('weights'))
   assert_bitexact((cpu(out['mask']) > 0)[keep], out_ref['mask'][keep], f'{name} static pass ray mask')
   return float((cpu(out['rgb'])[keep] - out_ref['rgb'][keep]).abs().max())
+
+
+def check_static_pass_bench_shape_every_ray(device, R=4096, S=64, V=8, block=1024):
+  """BASELINE configs[1] -- THE shape bench.py's headline is quoted on, its own scene (synthetic.make_scene(seed=0), 288 x 512 images, 72 x 128 x 32
+  white-noise maps, 8 static views) and its own rank-0 rays (sample_pixels(100), 4096 of them) -- through ONE 4096-ray pass of the HIP path
+  (sample -> gather -> DynibarStatic -> composite, the launch geometry of the bench step) against the oracle on EVERY ray.  The kernels start from
+  the reference's own fp32 K.inv(c2w): no ray is dropped, no projection allowance.  The oracle walks the rays in blocks (rays are independent;
+  a 4096-ray pass of the torch-CPU restatement needs tens of GB)."""
+  from dynibar_amd import synthetic as syn
+  sc = syn.make_scene(seed=0, H=288, W=512, V=V, F=32, n_static=V)
+  scene = {k: cases.t(v) for k, v in sc.items()}
+  o_np, d_np, _ = syn.pixel_rays(sc['camera'], syn.sample_pixels(100, 288, 512, R))
+  o, d = cases.t(o_np), cases.t(d_np)
+  w = syn.make_weights('static', 0, 32)
+  sd = O.tdict(w)
+  net = ops.StaticNet(w, device, True, False)
+  out, _ = run_static_pass(device, to_dev(scene, device), net, o.to(device), d.to(device), S, same_matrix=True)
+  out = {k: cpu(out[k]) for k in ('rgb', 'depth', 'weights', 'mask')}
+  worst = 0.0
+  for b0 in range(0, R, block):
+    ob, db = o[b0:b0 + block], d[b0:b0 + block]
+    ref = O.static_branch_pass(sd, scene, ob, db, S, True, True, True, False)
+    jit = {k: torch.zeros_like(ref[k]) for k in ('rgb', 'depth', 'weights')}
+    for js in range(2):  # +-1 ulp on exp() of the anti-alias pooling weights (see check_static_net), per element
+      ej = (torch.randint(0, 3, (ob.shape[0], S, V, 1), generator=torch.Generator().manual_seed(50 + js)).float() - 1.0) * 6e-8
+      oj = _oracle_static_graph(sd, scene, ob, db, S, True, False, ej)[0]
+      for k in jit:
+        jit[k] = torch.maximum(jit[k], 4.0 * (oj[k] - ref[k]).abs())
+    tag = f'bench shape (configs[1]) static pass, rays {b0}..{b0 + ob.shape[0]}'
+    sl = slice(b0, b0 + ob.shape[0])
+    assert_close(out['rgb'][sl], ref['rgb'], 1e-4, 0.0, f'{tag}: rgb', extra=jit['rgb'])
+    assert_close(out['depth'][sl], ref['depth'], 0.0, 2e-4, f'{tag}: depth', extra=jit['depth'])
+    assert_close(out['weights'][sl], ref['weights'], 1e-4, 0.0, f'{tag}: weights', extra=jit['weights'])
+    assert_bitexact(out['mask'][sl] > 0, ref['mask'], f'{tag}: ray mask')
+    worst = max(worst, float((out['rgb'][sl] - ref['rgb']).abs().max()))
+  return worst
 
 
 def check_mlp_selftest(device, rows=1000):

@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the N > 1 path.  The REAL ``render_single_image_nvi`` / ``_mono`` run in every rank -- ray-tile
+"""world_size-2 and -3 gloo tests (CPU) of the N > 1 path.  The REAL ``render_single_image_nvi`` / ``_mono`` run in every rank -- ray-tile
 partitioning, the reference's chunk slicing rules, the packed all-gather, the deferred per-sample entries, empty tiles -- over a stub
 of the kernel layer (``render_rays_mv`` replaced by a cheap per-ray function with the same output structure); the tiled frame must equal
 the single-process frame bit for bit (tiling must not change any per-ray value).  Results travel back as numpy arrays: a torch tensor on
@@ -94,13 +94,29 @@ def run_ranks(world, H, W, chunk, mode):
 
 @pytest.mark.parametrize('H,W,chunk,mode', [(7, 9, 10, 'lazy'), (7, 13, 64, 'all'), (7, 9, 10, 'all'), (1, 1, 8, 'lazy'), (1, 3, 2, 'all')])
 def test_two_rank_frame_equals_single_process(H, W, chunk, mode):
+  frame_equals_single_process(2, H, W, chunk, mode)
+
+
+@pytest.mark.parametrize('H,W,chunk,mode', [(1, 8, 2, 'lazy'), (1, 2, 4, 'lazy'), (5, 5, 4, 'all')])
+def test_three_rank_frame_with_unequal_and_empty_tiles(H, W, chunk, mode):
+  """world_size 3: 8 rays -> tiles of 2 / 3 / 3 rays (padded to 3 for the equal-count all-gather), 2 rays -> rank 0's tile is EMPTY (it renders a
+  placeholder ray and contributes none, yet joins every collective), 25 rays -> 8 / 8 / 9 with several chunks per tile."""
+  from dynibar_amd import render_image as RI
+  sizes = [RI.ray_tile(H * W, 3, r)[1] - RI.ray_tile(H * W, 3, r)[0] for r in range(3)]
+  assert len(set(sizes)) > 1, 'the case is meant to have unequal tiles'
+  frame_equals_single_process(3, H, W, chunk, mode)
+
+
+def frame_equals_single_process(world, H, W, chunk, mode):
   sys.path.insert(0, ROOT)
   n_rays = H * W
   ref, seen1, pend1 = run_frame(H, W, chunk, mode)
   assert sum(seen1) == n_rays
-  got = run_ranks(2, H, W, chunk, mode)
+  got = run_ranks(world, H, W, chunk, mode)
   rendered = sum(sum(s) for _, _, s, _ in got)
-  assert rendered == max(n_rays, 2) if n_rays < 2 else rendered == n_rays, 'every ray is rendered exactly once across the ranks (+ one placeholder per empty tile)'
+  from dynibar_amd import render_image as RI_
+  n_empty = sum(1 for r in range(world) if RI_.ray_tile(n_rays, world, r)[1] == RI_.ray_tile(n_rays, world, r)[0])
+  assert rendered == n_rays + n_empty, 'every ray is rendered exactly once across the ranks (+ one placeholder per empty tile)'
   for rank, out, _, pend in got:
     for grp in ref:
       assert out[grp]['__keys__'] == ref[grp]['__keys__'], 'key set / order of the tiled frame differs'

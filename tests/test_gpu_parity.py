@@ -62,6 +62,15 @@ def test_static_net(dev, kw):
   parity.check_static_net(dev, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(name='harsh_many', S=64), dict(name='harsh_many', S=40, aa=False, mask_rgb=True), dict(name='harsh_many', S=64, mask_rgb=True, dark=0.3),
+                                dict(name='harsh', S=64, mask_rgb=True, dark=0.5), dict(name='small', S=64, mask_rgb=True, dark=0.3), dict(name='many', S=64, R=3)])
+def test_static_net_ragged_rows_and_mask_rgb(dev, kw):
+  """The ragged dense-rows flavour (11 and 20 static views: rows with mask 0 are not evaluated) over several workgroups and planning segments, on a scene with
+  many out-of-bounds / behind-camera samples (points without any valid view included), and mask_rgb removing valid rows and whole points (black source
+  colours) -- also in the lane-segment flavour (8 views), whose blend must use the product mask too."""
+  parity.check_static_net(dev, **kw)
+
+
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
@@ -73,6 +82,13 @@ def test_static_pass_at_baseline_config0_size_every_ray(dev):
   from the reference's own fp32 K.inv(c2w), so no ray is dropped and no projection allowance is added (rgb / weights 1e-4, depth 2e-4 relative,
   ray mask bit-exact)."""
   err = parity.check_static_pass(dev, 'config0', same_matrix=True)
+  assert err < 1e-4
+
+
+def test_static_pass_at_the_bench_shape_every_ray(dev):
+  """BASELINE configs[1] (4096 rays x 64 samples x 8 views: the shape the headline metric is quoted on), the bench's own scene and rays, ONE 4096-ray
+  pass of the HIP path against the oracle on every one of the 4096 rays (rgb / weights 1e-4, depth 2e-4 relative, ray mask bit-exact)."""
+  err = parity.check_static_pass_bench_shape_every_ray(dev)
   assert err < 1e-4
 
 

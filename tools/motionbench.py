@@ -1,7 +1,7 @@
 """k_motion_mlp alone (developer tool): python tools/motionbench.py [--rays 8192 --samples 128] tag[=lib.so] ...
 Every variant runs in its own process (DYNIBAR_HIP_LIB), rounds alternate; reports microseconds per launch (HIP events around 10 launches),
 algorithmic TFLOP/s (1.062 MFLOP per point) and the fraction of the 833 TFLOP/s split-product ceiling.  Variants built with
-timing-only knobs (B6D_NO_DMA, B6D_NO_BARRIER, B6D_NO_LDS) compute garbage: only their time is meaningful (the check column says so)."""
+timing-only knobs (tools/experiments/r05_timing_only_switches.patch: B6D_NO_DMA, B6D_NO_BARRIER, B6D_NO_LDS) compute garbage: only their time is meaningful (the check column says so)."""
 import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'dynibar_amd', 'csrc')
