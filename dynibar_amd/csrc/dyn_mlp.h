@@ -25,6 +25,24 @@
 
 #include "dyn_device.h"
 
+// Round 6: NO FOREIGN WAVES BESIDE A ONE-WAVE-PER-SIMD KERNEL.  With two chunk streams (render_image.CHUNK_STREAMS) a rendered frame was not reproducible: 50-100 of
+// its 147 456 rays differed by up to 1e-3 from run to run, in rounds 5 and 6 alike (tools/ragged_frame_ab.py).  tools/concurrency_probe*.py traced it to ONE kernel,
+// k_static_ref_feat (40 registers, no LDS): whenever its waves shared a SIMD with a wave of k_motion_mlp or k_net_points -- the kernels that run one wave per SIMD on
+// 190-256 architectural + 208-256 accumulation registers and leave 56-64 registers of the lane free -- aligned groups of 16 lanes of it came back with slightly wrong
+// sums (one term of the 66 off), on fixed inputs; every other small kernel of the path, co-resident in the same way, stayed bit-exact, and so did everything beside the
+// two-wave kernels, which leave no room for a foreign wave.  Neither the missing M0 wait state of the LDS-DMA statements (fixed all the same) nor the function call in
+// k_motion_mlp is the cause; what is, inside the part, was not found.  What removes it, measured (profiles/r06_stream_determinism.txt): the one-wave-per-SIMD kernels and
+// k_static_ref_feat claim all 512 registers of a lane (a clobber of v255 / a255: the kernel descriptor then asks for the whole file), so no wave of another kernel is ever
+// placed beside them: 0 differing bytes in 24 + 12 probe rounds and in twelve two-stream frames against the one-stream frame.  Cost: the small kernels of the other stream
+// no longer fill those SIMDs (frame +0.6 %), k_static_ref_feat 20 -> 42 us.
+#ifndef DYN_EXCLUSIVE_CU
+#define DYN_EXCLUSIVE_CU 1
+#endif
+#if DYN_EXCLUSIVE_CU && defined(__AMDGCN__)
+#define DYN_CLAIM_REGISTER_FILE() asm volatile("; the whole register file" ::: "v255", "a255")
+#else
+#define DYN_CLAIM_REGISTER_FILE()
+#endif
 #define DYN_NET_THREADS 256   // workgroup of the point-level kernels: 4 waves share one weight ring
 #define DYN_VIEW_THREADS 512  // workgroup of the view-level kernels: 8 waves (2 per SIMD) share one weight ring
 
@@ -293,7 +311,6 @@ struct WeightRing6 {
 #endif
 };
 
-__device__ __forceinline__ void ring6_prio_static(const WeightRing6& R);  // (issue-priority forms: see B6_PRIO_MODE below)
 
 // Round 5: WHERE the two-slot ring's LDS-DMA goes out.  Rounds 1-4 requested the whole next chunk right behind the chunk barrier: all eight
 // waves of the workgroup issue their six 1 KiB pieces at the same moment, the L2 -> LDS path takes one piece per ~37 cycles (48 KiB per ~1800
@@ -314,7 +331,8 @@ __device__ __forceinline__ void b6_dma_piece(const float* g_uniform, unsigned la
 #if defined(__AMDGCN__)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" B6_DMA_POLICY ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
+  // (`s_nop 0`: the wait state the ISA asks for between an SALU write of M0 and the LDS-DMA that reads it; hipcc pads nothing inside an asm string)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" B6_DMA_POLICY ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
 #pragma clang diagnostic pop
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g_uniform + lane_off),
@@ -401,7 +419,6 @@ __device__ __forceinline__ void ring6_init(WeightRing6& R, const float* stream, 
   R.fill = -1;
   R.issued = 0;
   DYN_PHASE_RING_KID(R, 0);
-  ring6_prio_static(R);
   ring6_issue(R, 0);
 }
 __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
@@ -444,28 +461,22 @@ __device__ __forceinline__ const float* ring6_acquire(WeightRing6& R) {
   return R.buf + (c & 1) * B6_CHUNK;
 }
 
-// Issue priority in the two-wave layer loop.  Round 3 recorded "swap the priority of the two waves of a SIMD every n pairs: n = 2 -1.4 % (kept); one half
-// static: +7 %; a feedback scheme: +6 %; first MFMA of a triple ahead of the pair's VALU slice: +1..2 %".  None of those builds did what the text said
-// (see "Round 5" below); the switches of the dropped ones were removed in round 5.  B6_PRIO_FLIP = pairs between two flip sites.
+// Issue priority in the two-wave layer loop (k_static_views, k_dynamic_views).  What ships (B6_PRIO_MODE 5) is, instruction for instruction in the ISA, a PRIORITY PULSE:
+// behind every second MFMA triple the wave executes `s_setprio 1`, four VALU instructions of its next operand slice, `s_setprio 0`.  The wave that has just issued its
+// products thereby starts its VALU slice ahead of its SIMD partner, which keeps the two waves of a SIMD out of step (in step they want the matrix pipe at the same
+// moments and the VALU at the same moments: forcing them into step measured +6 %, round 3).  The source form is the one rounds 3-5 shipped -- a per-lane condition
+// `(threadIdx.x >> 8) ^ phase`, which hipcc turns into an exec-masked region WITHOUT a branch in which BOTH `s_setprio` execute (scalar instructions ignore the exec
+// mask), separated by the VALU instructions hipcc schedules between the two halves -- because it is the only form that produces exactly this pulse: round 3 thought it
+// was alternating the priority of the wave pair, round 5 found out what it really executes, round 6 read the pulse off the disassembly and tried to write it down
+// directly (`s_setprio 1` at the site, `s_setprio 0` in front of the pair's products: the pulse then spans the whole VALU slice): slower.  Measured, same box,
+// alternating processes, k_static_views<8> us / bench step ms / frame ms: mode 5 1823-1831 / 2.771-2.783 / 656-665; explicit pulse 1863 / 2.823 / 664; position toggle
+// (mode 1) 1835 / 2.799 / 725 (its waves end a layer at priority 1 and starve the other stream's kernels); no priority (mode 0) 1845 / 2.806 / 676
+// (gpurun_out/r6c1_ab.txt, r6c3_ab.txt; round 5: profiles/r05_ab_variants.txt).  B6_PRIO_FLIP = pairs between two pulses.
 #ifndef B6_PRIO_FLIP
 #define B6_PRIO_FLIP 2
 #endif
-// Round 5: what those builds really executed.  The condition `(threadIdx.x >> 8) ^ phase` is a per-lane value to hipcc, so the if / else
-// became an exec-masked region WITHOUT a branch -- s_and_saveexec, s_xor, `s_setprio a`, s_andn2_saveexec, `s_setprio b`, s_or: scalar
-// instructions ignore the exec mask, both s_setprio ran in every wave and the second one won.  Every wave therefore toggled its priority
-// by PROGRAM POSITION (0 after even flip sites, 1 after odd ones) -- no wave-pair alternation, no static half ever existed -- at six
-// scalar instructions and two exec hazards per site (864 of the view chain's 9323 instructions).  B6_PRIO_MODE names the forms:
-//   0  no priority changes
-//   1  position toggle: one unconditional `s_setprio (site & 1)` per flip site (what rounds 3-4 shipped, minus the exec-mask junk)
-//   2  wave-pair alternation proper (the condition in an SGPR, a scalar branch)
-//   3  static: the younger half (waves 4-7) at priority 1 from the start, no flips      4: the older half
-//   5  the exec-masked form itself, bit for bit as rounds 3-4 shipped it
-// Measured in round 5 (tools/abbench.py, k_static_views<8> us / frame ms, same box, alternating processes; gpurun_out/r5c1_ab.txt, r5c4, r5c5): mode 5 1705 /
-// 699.8, mode 1 1721 / 703.7, mode 0 1723 / 704.9, mode 2 1712 / 704.1, mode 3 1737 / 705.4, mode 4 1721 / 704.6 -- issue priority does not move this
-// kernel in any form, and the 864 scalar instructions of mode 5 are free (a wave's scalar issue is not what it waits for); the junk even measures
-// 1-2 % FASTER than its clean equivalents in every session (1871 vs 1907 on another box), so it stays.
 #ifndef B6_PRIO_MODE
-#define B6_PRIO_MODE 5
+#define B6_PRIO_MODE 5  /* 5: the pulse (shipped); 1: position toggle; 0: none (A/B builds) */
 #endif
 __device__ __forceinline__ void ring6_prio_flip(const WeightRing6& R, int phase) {
 #if defined(__AMDGCN__)
@@ -474,22 +485,12 @@ __device__ __forceinline__ void ring6_prio_flip(const WeightRing6& R, int phase)
   if (phase & 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 #elif B6_PRIO_MODE == 5
-  // the form rounds 3-4 shipped, kept bit for bit: a per-lane condition, hence the exec-masked region in which BOTH s_setprio execute
+  // a per-lane condition on purpose (see above): the exec-masked region in which both s_setprio execute, a few VALU instructions apart
   if ((((int)threadIdx.x >> 8) ^ phase) & 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
-#elif B6_PRIO_MODE == 2
-  if ((R.half ^ phase) & 1) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
 #endif
 #endif
 }
-__device__ __forceinline__ void ring6_prio_static(const WeightRing6& R) {
-#if defined(__AMDGCN__) && (B6_PRIO_MODE == 3 || B6_PRIO_MODE == 4)
-  if (R.round != 8 * 256) return;
-  if (R.half == (B6_PRIO_MODE == 3 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
-#endif
-}
-
 // exact three-way bf16 split of two fp32 values, each part packed as (first in the low half, second in the high half)
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
 #if DYN_SPLIT_F16
@@ -603,7 +604,7 @@ __device__ __forceinline__ void mlp_layer_b6(WeightRing6& R, f32x16 (&acc)[NT], 
         const int gi = pr / NT, t = pr % NT;
         const int g = c * GPC + gi;
         ring6_feed(R, pr, npc);
-#if B6_PRIO_FLIP && (B6_PRIO_MODE == 1 || B6_PRIO_MODE == 2 || B6_PRIO_MODE == 5)
+#if B6_PRIO_FLIP && (B6_PRIO_MODE == 1 || B6_PRIO_MODE == 5)
         // issue priority every B6_PRIO_FLIP pairs (see ring6_prio_flip)
         if (pr % B6_PRIO_FLIP == 0) ring6_prio_flip(R, (pr / B6_PRIO_FLIP) & 1);
 #endif
@@ -692,7 +693,8 @@ __device__ __forceinline__ void ring3_dma(const float* g, float* l_emu, unsigned
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
   // the piece's global address as SGPR base + 32-bit lane offset (half the address registers per instruction: -1.5 % of k_motion_mlp)
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
+  // (`s_nop 0`: the wait state between the SALU write of M0 and the LDS-DMA that reads it)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane_off), "s"(g_uniform), "s"(l), "n"(OFF) : "m0", "memory");
 #pragma clang diagnostic pop
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l_emu, 16, OFF, 0);

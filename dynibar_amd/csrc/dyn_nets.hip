@@ -469,8 +469,10 @@ __device__ __forceinline__ void octave_embed(float x, int h, float* out) {
 }
 
 // ref_feature_fc.0(PE(ref Pluecker)) per ray (mlp_network.py:434,456; render_ray.py:372-377): [R,36]
-__global__ void k_static_ref_feat(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ Wref, int R,
+// (one block per CU and all 512 registers of a lane: no other kernel's waves beside it -- csrc/dyn_mlp.h, DYN_EXCLUSIVE_CU)
+__global__ void __launch_bounds__(256, 1) k_static_ref_feat(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ Wref, int R,
                                   float* __restrict__ ref_feat) {
+  DYN_CLAIM_REGISTER_FILE();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * 36) return;
   const int r = idx / 36, ch = idx % 36;
@@ -588,25 +590,28 @@ __device__ __forceinline__ DenseRows dense_rows(int V, int PTW, float* scal, lon
 __device__ __forceinline__ int dense_pt_base(const DenseRows& d, int pnt) { return d.pbase != nullptr ? d.pbase[pnt] : pnt * d.V; }
 __device__ __forceinline__ int dense_pt_cnt(const DenseRows& d, int pnt) { return d.pbase != nullptr ? d.pbase[pnt + 1] - d.pbase[pnt] : d.V; }
 
-// Ragged rows of workgroup (or persistent unit) `wgi` from the plan's tables: row -> (point of the workgroup, view) and the row offsets of its points
-// (`pbase`: RAG_PTAB ints of LDS that stay for the kernel's (point, slot) task loops).  Every thread of the workgroup calls this (one barrier inside).
+// Ragged rows of workgroup (or persistent unit) `wgi` from the plan's tables: row -> (point of the workgroup, view), the row offsets of its points.
+// No barrier inside and ONE round trip to memory: every thread reads its own row's entry, the workgroup's scalars (rows, first point, points) are uniform
+// loads, and the row offsets of the thread's own point follow from its entry -- they are first needed by the cross-view reductions, long after the input loads.
+// `pbase` (LDS, RAG_PTAB ints, or null for a kernel without (point, slot) task loops): the copy the task loops read; the caller has a workgroup barrier between
+// this call and the first such loop (k_static_views: the exchange of the per-point ray_dir_fc.0 tile; k_dynamic_views: the first barrier of the pooled statistics).
 __device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* rowtab, const int* ptab, long wgi, float* scal, int* pbase) {
   const int tid = threadIdx.x;
+  const int* pt = ptab + wgi * RAG_PTAB;
   DenseRows d;
   d.rw = (tid >> 6) * 32 + (tid & 31);
   const unsigned short ri = rowtab[wgi * 256 + d.rw];
-  if (tid < RAG_PTAB) pbase[tid] = ptab[wgi * RAG_PTAB + tid];
-  __syncthreads();
-  d.V = V; d.scal = scal; d.pbase = pbase;
-  d.n_rows = pbase[32];
-  d.point0 = pbase[33];
-  d.PTW = pbase[34];
+  if (pbase != nullptr && tid < RAG_PTAB) pbase[tid] = pt[tid];
+  d.V = V; d.scal = scal; d.pbase = pbase != nullptr ? pbase : pt;  // (non-null marks the ragged flavour; without an LDS copy the offsets are read where they lie)
+  d.n_rows = pt[32];
+  d.point0 = pt[33];
+  d.PTW = pt[34];
   const bool live = d.rw < d.n_rows;
   d.p_local = live ? (ri & 0xff) : RAG_MAX_PTS + 1;  // idle rows: beyond every point (they shadow the last point's rows like the regular flavour's tail rows)
   d.view = live ? (ri >> 8) : 0;
   const int pc = live ? d.p_local : d.PTW - 1;
-  d.base = pbase[pc];
-  d.cnt = pbase[pc + 1] - pbase[pc];
+  d.base = pt[pc];
+  d.cnt = pt[pc + 1] - d.base;
   return d;
 }
 
@@ -1125,8 +1130,6 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   constexpr int SA_L1P_CHUNKS = net_layer_chunks(8, SA_L1P_STEPS);
   constexpr int SA_POOLED_AT = SA_L1P_CHUNKS + net_layer_chunks(8, SA_L1V_STEPS) + net_layer_chunks(2, SA_L2_STEPS);
   constexpr int LDS_FLOATS = 2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS + (VSEG == 0 ? DENSE_EXTRA : 0);
-  net_ring_init(ring, p.blob + ST_OFF_A + (POOLED ? (size_t)SA_L1P_CHUNKS * NET_CHUNK : 0), SA_CHUNKS - (POOLED ? SA_L1P_CHUNKS : 0), lds,
-                SA_POOLED_AT - (POOLED ? SA_L1P_CHUNKS : 0), POOLED ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 
   const int V = VC > 0 ? VC : p.V;
   const long tile = (long)blockIdx.x * (DYN_VIEW_THREADS / 64) + wave;
@@ -1142,6 +1145,9 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
   const bool valid = (VSEG == 0 ? p_local < PT : view < V) && (point < p.n_pts);
   const int seg_base = 0;
   const long pv = valid ? point * V + view : 0;
+  // (the ring's first chunk is requested BEHIND the ragged flavour's table loads: the row entries then arrive ahead of 48 KiB of weights)
+  net_ring_init(ring, p.blob + ST_OFF_A + (POOLED ? (size_t)SA_L1P_CHUNKS * NET_CHUNK : 0), SA_CHUNKS - (POOLED ? SA_L1P_CHUNKS : 0), lds,
+                SA_POOLED_AT - (POOLED ? SA_L1P_CHUNKS : 0), POOLED ? net_layer_chunks(8, SA_L3P_STEPS) : 0, DYN_VIEW_THREADS);
 
   // ---- gather the lane's inputs ----
   float msk = valid ? p.mask[pv] : 0.f;
@@ -1212,6 +1218,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     acc_init_bias<2>(a2, ctab + 784);
     // The gathered colours / features are first needed after ray_dir_fc: their loads are issued from inside the layer's feed (half
     // way through it), which keeps 18 registers free during the 256-wide first layer and hides the HBM latency under this layer.
+    // (requested half way through the layer; right behind the layer's first ring acquire -- slot 8 -- measured 1 % slower in round 6)
     net_layer<2, SA_L2_STEPS>(ring, a2, [&](int s) {
       if (s == 64) {
 #pragma unroll
@@ -1319,6 +1326,7 @@ __global__ void __launch_bounds__(DYN_NET_THREADS, 1) k_net_points(StaticArgs p)
   constexpr int PHASE_KID = 1;
   (void)PHASE_KID;
   DYN_PHASE(0);
+  DYN_CLAIM_REGISTER_FILE();
   float* lds = reinterpret_cast<float*>(dyn_smem);
   float* ctab = lds + PTS_RING_SLOTS * PTS_CHUNK;  // [SB_CT] / [DB_CT]
   float* Kl = ctab + (DYN ? DB_CT : SB_CT);
@@ -1845,8 +1853,15 @@ __device__ __forceinline__ void static_blend_body(StaticArgs p) {
 #define SC_L11_PAIRS (((SC_L11_STEPS + 7) / 8) * 4)
 #define SC_L12_PAIRS ((64 / 8) * 2)
 #define SC_WS_FLOATS ((SC_L11_PAIRS + SC_L12_PAIRS) * B6_PAIR_FLOATS)
-#define DYN_BLEND_WS_THREADS 768
+// 8 waves (two per SIMD: 256 registers, no spill) since round 6: with the next tile's x prefetched (DYN_BLEND_PREFETCH) the second wave of a SIMD hides what the third
+// wave of the 12-wave form (168 registers, 48 B / lane of scratch) was there to hide: 346-349 -> 334 us at the bench shape; the 12-wave form WITH the prefetch spills 108 B / lane: 436 us
+#ifndef DYN_BLEND_WS_THREADS
+#define DYN_BLEND_WS_THREADS 512
+#endif
 #if DYN_BLEND_WS
+__device__ __forceinline__ long n_units_of(const StaticArgs& p, bool rag, int vseg, int nw) {
+  return rag ? p.rg_wg[0] : (vseg == 0 ? (p.n_tiles_a + nw - 1) / nw : p.n_tiles_a);
+}
 template <int VSEG, int THREADS, bool RAG = false>
 __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
   float* lds = reinterpret_cast<float*>(dyn_smem);
@@ -1869,16 +1884,37 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
   const float* w12 = lds + SC_L11_PAIRS * B6_PAIR_FLOATS;
   const int V = p.V;
   constexpr int NW = THREADS / 64;
-  int* pbase = reinterpret_cast<int*>(ctab + SC_CT + DENSE_SCALARS);  // (ragged rows: RAG_PTAB ints behind the scalar tables)
   DenseRows dr = dense_rows(V, p.PT, ctab + SC_CT, 0);
+#ifndef DYN_BLEND_PREFETCH
+#define DYN_BLEND_PREFETCH 1
+#endif
+  // Round 6: the parked x of the NEXT tile is requested while this tile is still being worked on -- without a second register set.  x is dead once rgb_fc.0
+  // has consumed it, and rgb_fc.2 consumes its input `a` tile by tile: x tile t of the next unit is loaded into the registers a tile of `a` has just left
+  // (slots 16 t + 16 of rgb_fc.2's feed), the last one behind the layer.  The loads then have the rest of rgb_fc.2, the softmax and the blend (and, for the
+  // later tiles, the first k-groups of the next rgb_fc.0) to land, instead of standing in front of the first MFMA of their own tile.
+  f32x16 x[4];
+  auto tile_of = [&](long u_) { return VSEG == 0 ? u_ * NW + wave : u_; };
+  auto load_x = [&](long u_, int t) DYN_INLINE_LAMBDA {
+    const long tl = tile_of(u_);
+    const bool ok = u_ < n_units_of(p, RAG, VSEG, NW) && tl < p.n_tiles_a;
+    const float4* xw = reinterpret_cast<const float4*>(p.ws + p.o.off_x) + (ok ? tl : 0) * 16 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = ok ? nt_load4<8>(xw + (t * 4 + q) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
+    }
+  };
   // lane-segment flavour: every wave walks its own tiles; dense flavour: the workgroup walks blocks of NW tiles together (its reductions use barriers);
   // ragged dense flavour: the blocks are the plan's workgroups (the row tables of the view kernel that parked x)
-  const long n_units = RAG ? p.rg_wg[0] : (VSEG == 0 ? (p.n_tiles_a + NW - 1) / NW : p.n_tiles_a);
+  const long n_units = n_units_of(p, RAG, VSEG, NW);
   const long first = VSEG == 0 ? blockIdx.x : (long)blockIdx.x * NW + wave, step = VSEG == 0 ? gridDim.x : (long)gridDim.x * NW;
+  if (DYN_BLEND_PREFETCH) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_x(first, t);
+  }
   for (long u = first; u < n_units; u += step) {
     if (RAG) {
-      __syncthreads();  // every wave has left the previous unit's tables
-      dr = ragged_rows(V, p.rg_rowtab, p.rg_ptab, u, ctab + SC_CT, pbase);
+      dr = ragged_rows(V, p.rg_rowtab, p.rg_ptab, u, ctab + SC_CT, nullptr);  // (no task loops here: the row offsets stay in registers)
     } else if (VSEG == 0) {
       dr.point0 = u * p.PT;
     }
@@ -1898,24 +1934,26 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
     if (p.mask_rgb && !((rgb_in[0] + rgb_in[1]) + rgb_in[2] > 1e-3f)) msk = 0.f;  // mask = mask * rgb_mask also feeds the masked_fill (mlp_network.py:458-460, 523)
     f32x16 a[4];
     {
-      f32x16 x[4];
-      const float4* xw = reinterpret_cast<const float4*>(p.ws + p.o.off_x) + (tile_ok ? tile : 0) * 16 * 64 + lane;
       const float4* hg = reinterpret_cast<const float4*>(p.ws + p.o.off_hg) + (valid ? point_rec(p, point, h, SB_HG_RECS) : 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        if (!DYN_BLEND_PREFETCH) load_x(u, t);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 v = tile_ok ? nt_load4<8>(xw + (t * 4 + q) * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-          x[t][q * 4] = v.x; x[t][q * 4 + 1] = v.y; x[t][q * 4 + 2] = v.z; x[t][q * 4 + 3] = v.w;
           const float4 b = valid ? hg[(t * 4 + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
           a[t][q * 4] = b.x; a[t][q * 4 + 1] = b.y; a[t][q * 4 + 2] = b.z; a[t][q * 4 + 3] = b.w;
         }
+      }
       const float extra[3] = {h == 0 ? vis2 : rd.x, h == 0 ? rd.y : rd.z, h == 0 ? rd.w : 0.f};
       mlp_layer_b6_lds<4, SC_L11_STEPS>(w11, a, [&](int s) { return s < 64 ? x[s / 16][s % 16] : extra[s - 64]; });
     }
     f32x16 b2[2];
     acc_init_bias<2>(b2, ctab + 80);
-    mlp_layer_b6_lds<2, 64>(w12, b2, [&](int s) { return elu_s(a[s / 16][s % 16]); });
+    mlp_layer_b6_lds<2, 64>(w12, b2, [&](int s) {
+      const float r = elu_s(a[s / 16][s % 16]);
+      if (DYN_BLEND_PREFETCH && (s & 15) == 15) load_x(u + step, s / 16);  // tile s / 16 of `a` has just been read for the last time: its registers take the next x
+      return r;
+    });
     acc_elu_s(b2);
     float logit = row_dot<2>(b2, ctab) + ctab[64];
     if (msk == 0.f) logit = -1e9f;
@@ -2020,7 +2058,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
 #if DYN_BLEND_WS
   static const int blend_stream = getenv("DYN_BLEND_STREAM") != nullptr;  // developer A/B: the streaming (round-3) form
   if (!blend_stream) {
-    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS + RAG_PTAB) * sizeof(float);
+    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS) * sizeof(float);
     const unsigned n_cu = (unsigned)dyn_cu_count();
     if (a.o.dense) {
       const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64);
@@ -2383,6 +2421,7 @@ __global__ void __launch_bounds__(256) k_motion_zero_tail(long R, int S, int n_z
 __global__ void __launch_bounds__(DYN_NET_THREADS, 1)
 k_motion_mlp(const float* __restrict__ blob, const float* __restrict__ pts, const float* __restrict__ time, long n_kept, int S, int n_zero_last,
              int n_out, float inv_div, float* __restrict__ coeff) {
+  DYN_CLAIM_REGISTER_FILE();
   float* lds = reinterpret_cast<float*>(dyn_smem);
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
   MotionRing ring;

@@ -1121,6 +1121,36 @@ def check_chunk_stream_invariance(device, chunk_size=40):
   return n
 
 
+def check_chunk_stream_invariance_full_size(device, frames=2):
+  """The SAME invariance at the size bench.py times a frame at (BASELINE configs[2]: 288 x 512 rays, 64 + 64 samples, 7 + 11 views, chunk 8192) -- where the
+  chunks of two streams really overlap on the device.  Round 6 found the small-chunk check above blind to it: with two streams 50-100 rays of a full frame
+  differed by up to 1e-3 from run to run (k_static_ref_feat's waves beside a one-wave-per-SIMD kernel: csrc/dyn_mlp.h, DYN_EXCLUSIVE_CU).  Every ray of
+  `frames` two-stream frames (the first one cold: per-view caches and network packing inside the frame) must equal the one-stream frame bit for bit."""
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  from dynibar_amd import render_image
+  from frame_case import FrameCase
+  prev = render_image.CHUNK_STREAMS
+  keys = (('outputs_coarse_ref', 'rgb'), ('outputs_fine_ref', 'rgb'), ('outputs_fine_ref', 'depth'))
+  try:
+    outs = []
+    for n in [2] * frames + [1]:
+      render_image.CHUNK_STREAMS = n
+      fc = FrameCase(device) if not outs or n == 1 else fc  # (a fresh case for the first two-stream frame and for the one-stream frame: both start cold)
+      smp, rb = fc.sampler()
+      ret = fc.render(smp, rb)
+      torch.cuda.synchronize()
+      outs.append({k: ret[k[0]][k[1]].clone() for k in keys})
+  finally:
+    render_image.CHUNK_STREAMS = prev
+  n = 0
+  for i, o in enumerate(outs[:-1]):
+    for k in keys:
+      assert_bitexact(o[k], outs[-1][k], f'full frame, two chunk streams (frame {i}) vs one stream: {k[0]}/{k[1]}')
+      n += 1
+  return n
+
+
 def check_checkpoint_render_chain(device, g_img, g_enc, tmpdir, chunk_size=80):
   """Section 8f-4 on the device: both checkpoint files of the reference (model.py:424-441 coarse / monocular, :177-190 fine) are WRITTEN with torch.save
   from nn.Module state dicts (de-parallelised like model.py:13-15; the encoders with the decoder layers forward never runs riding along, optimizer /

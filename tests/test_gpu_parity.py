@@ -154,6 +154,12 @@ def test_frame_is_identical_on_one_two_and_three_chunk_streams(dev):
   assert parity.check_chunk_stream_invariance(dev) > 0
 
 
+def test_full_size_frame_is_identical_on_one_and_two_chunk_streams(dev):
+  """288 x 512 rays, chunk 8192: the chunks of the two streams overlap on the device for real (round 6: they did not reproduce until no foreign wave could sit
+  beside a one-wave-per-SIMD kernel)."""
+  assert parity.check_chunk_stream_invariance_full_size(dev) > 0
+
+
 def test_render_single_image_mono(dev, golden_dir):
   parity.check_render_image_mono(dev, _golden(golden_dir, 'image_mono.npz'))
 
