@@ -595,17 +595,32 @@ __device__ __forceinline__ int dense_pt_cnt(const DenseRows& d, int pnt) { retur
 // loads, and the row offsets of the thread's own point follow from its entry -- they are first needed by the cross-view reductions, long after the input loads.
 // `pbase` (LDS, RAG_PTAB ints, or null for a kernel without (point, slot) task loops): the copy the task loops read; the caller has a workgroup barrier between
 // this call and the first such loop (k_static_views: the exchange of the per-point ray_dir_fc.0 tile; k_dynamic_views: the first barrier of the pooled statistics).
-__device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* rowtab, const int* ptab, long wgi, float* scal, int* pbase) {
+// `pre`: the row's table entry and the unit's scalars if the caller has loaded them already (the persistent blend requests the next unit's one unit ahead).
+struct RaggedHead {
+  unsigned short ri;
+  int n_rows, point0, np;
+};
+__device__ __forceinline__ RaggedHead ragged_head(const unsigned short* rowtab, const int* ptab, long wgi, int rw) {
+  RaggedHead h;
+  h.ri = rowtab[wgi * 256 + rw];
+  h.n_rows = ptab[wgi * RAG_PTAB + 32];
+  h.point0 = ptab[wgi * RAG_PTAB + 33];
+  h.np = ptab[wgi * RAG_PTAB + 34];
+  return h;
+}
+__device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* rowtab, const int* ptab, long wgi, float* scal, int* pbase,
+                                                 const RaggedHead* pre = nullptr) {
   const int tid = threadIdx.x;
   const int* pt = ptab + wgi * RAG_PTAB;
   DenseRows d;
   d.rw = (tid >> 6) * 32 + (tid & 31);
-  const unsigned short ri = rowtab[wgi * 256 + d.rw];
+  const RaggedHead hd = pre != nullptr ? *pre : ragged_head(rowtab, ptab, wgi, d.rw);
+  const unsigned short ri = hd.ri;
   if (pbase != nullptr && tid < RAG_PTAB) pbase[tid] = pt[tid];
   d.V = V; d.scal = scal; d.pbase = pbase != nullptr ? pbase : pt;  // (non-null marks the ragged flavour; without an LDS copy the offsets are read where they lie)
-  d.n_rows = pt[32];
-  d.point0 = pt[33];
-  d.PTW = pt[34];
+  d.n_rows = hd.n_rows;
+  d.point0 = hd.point0;
+  d.PTW = hd.np;
   const bool live = d.rw < d.n_rows;
   d.p_local = live ? (ri & 0xff) : RAG_MAX_PTS + 1;  // idle rows: beyond every point (they shadow the last point's rows like the regular flavour's tail rows)
   d.view = live ? (ri >> 8) : 0;
@@ -619,38 +634,88 @@ __device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* ro
 // e of the anti-alias pooling weight (mlp_network.py:463-466); one function so that the plan's minimum over all views and the rows' own values are the same bits
 __device__ __forceinline__ float aa_exp(float s_abs, float dot) { return expf(s_abs * (dot - 1.0f)); }
 
+// one block = 256 consecutive points: their V masks and V ray_diff records are contiguous runs, read coalesced (16 bytes per lane for the records) and parked in LDS,
+// then one thread per point walks its V entries there (a thread per point reading its own 44-byte / 176-byte strided runs took ~100 us per call)
 __global__ void __launch_bounds__(256) k_ragged_points(long n_pts, int V, const float* __restrict__ mask, const float4* __restrict__ ray_diff, const float* __restrict__ s_abs,
                                                        unsigned* __restrict__ bits, float* __restrict__ emin) {
-  const long pt = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pt >= n_pts) return;
+  float* dw = reinterpret_cast<float*>(dyn_smem);                      // [256 V] ray_diff.w (anti-alias pooling only)
+  unsigned char* mk = reinterpret_cast<unsigned char*>(dw + 256 * V);  // [256 V] mask != 0
+  const long p0 = (long)blockIdx.x * 256;
+  const int np = (int)(n_pts - p0 < 256 ? n_pts - p0 : 256), n = np * V;
+  const bool aa = s_abs != nullptr;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    mk[i] = mask[p0 * V + i] != 0.f ? 1 : 0;
+    if (aa) dw[i] = ray_diff[p0 * V + i].w;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= np) return;
   unsigned b = 0u;
   float m = 3.0e38f;
-  const float sa = s_abs != nullptr ? s_abs[0] : 0.f;
+  const float sa = aa ? s_abs[0] : 0.f;
   for (int v = 0; v < V; ++v) {
-    if (mask[pt * V + v] != 0.f) b |= 1u << v;
-    if (s_abs != nullptr) m = fminf(m, aa_exp(sa, ray_diff[pt * V + v].w));
+    if (mk[t * V + v]) b |= 1u << v;
+    if (aa) m = fminf(m, aa_exp(sa, dw[t * V + v]));
   }
-  bits[pt] = b;
-  if (s_abs != nullptr) emin[pt] = m;
+  bits[p0 + t] = b;
+  if (aa) emin[p0 + t] = m;
 }
 
-// one thread per segment: greedy packing of the segment's points into workgroups (rows <= 256, points <= RAG_MAX_PTS)
-__global__ void __launch_bounds__(64) k_ragged_segments(long n_pts, long n_seg, const unsigned* __restrict__ bits, int* __restrict__ seg_cnt, int* __restrict__ seg_start) {
-  const long seg = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= n_seg) return;
-  const long p0 = seg * RAG_SEG, p1 = p0 + RAG_SEG < n_pts ? p0 + RAG_SEG : n_pts;
-  int* out = seg_start + seg * RAG_SEG_WGS;
-  int n_wg = 0, rows = 0, pts = 0;
-  out[n_wg++] = 0;
-  for (long p = p0; p < p1; ++p) {
-    const unsigned b = bits[p];
-    const int n = b != 0u ? __popc(b) : 1;
-    if (rows + n > 256 || pts == RAG_MAX_PTS) {
-      out[n_wg++] = (int)(p - p0);
-      rows = 0; pts = 0;
-    }
-    rows += n; pts += 1;
+// one block per segment: greedy packing of the segment's points into workgroups (rows <= 256, points <= RAG_MAX_PTS).  The block reads the segment's bit masks
+// coalesced, forms the prefix sums of the row counts in LDS, every thread finds by bisection where a workgroup STARTING at its points would end (the greedy rule
+// depends on the start only), and one thread follows that chain from point 0: ~40 dependent LDS reads instead of a 1024-step walk (a thread per segment reading
+// global memory point by point took 0.3 ms -- 14 ms per frame, most of what ragged rows had gained; the walk over LDS bytes 47-63 us)
+__global__ void __launch_bounds__(256) k_ragged_segments(long n_pts, long n_seg, const unsigned* __restrict__ bits, int* __restrict__ seg_cnt, int* __restrict__ seg_start) {
+  int* pre = reinterpret_cast<int*>(dyn_smem);                           // [RAG_SEG + 1] exclusive prefix sums of the row counts
+  int* part = pre + RAG_SEG + 4;                                         // [256] per-thread sums / their scan
+  unsigned short* nxt = reinterpret_cast<unsigned short*>(part + 256);   // [RAG_SEG] first point of the workgroup behind the one that starts here
+  const int tid = threadIdx.x;
+  const long seg = blockIdx.x;
+  const long p0 = seg * RAG_SEG;
+  const int n = (int)((p0 + RAG_SEG < n_pts ? p0 + RAG_SEG : n_pts) - p0);
+  int r4[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // thread t owns points 4 t .. 4 t + 3
+    const int i = 4 * tid + j;
+    const unsigned b = i < n ? bits[p0 + i] : 0u;
+    r4[j] = i < n ? (b != 0u ? __popc(b) : 1) : 0;
+    sum += r4[j];
   }
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan of the 256 partial sums
+    const int t = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += t;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pre[4 * tid + j] = run;
+    run += r4[j];
+  }
+  if (tid == 255) pre[RAG_SEG] = run;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = 4 * tid + j;
+    if (i < n) {
+      // the largest e in (i, min(i + RAG_MAX_PTS, n)] with pre[e] - pre[i] <= 256 (e = i + 1 always qualifies: a point has at most 32 rows)
+      int lo = i + 1, hi = i + RAG_MAX_PTS < n ? i + RAG_MAX_PTS : n;
+      const int base = pre[i];
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] - base <= 256) lo = mid; else hi = mid - 1;
+      }
+      nxt[i] = (unsigned short)lo;
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  int* out = seg_start + seg * RAG_SEG_WGS;
+  int n_wg = 0;
+  for (int i = 0; i < n; i = nxt[i]) out[n_wg++] = i;
   seg_cnt[seg] = n_wg;
 }
 
@@ -727,6 +792,8 @@ __device__ __forceinline__ float dense_all(const DenseRows& d, float v, float id
   const float* src = d.scal + d.base;
   float a0 = ident, a1 = ident, a2 = ident, a3 = ident;
   int k = 0;
+  // (the trip count is the point's own row count -- the view count, a compile-time constant, in the regular specialised kernels.  A fixed trip count of V with the
+  //  entries beyond the point's rows predicated off was measured for the ragged flavour in round 6: every load in flight at once, but 5-6 % SLOWER view kernel)
   for (; k + 4 <= d.cnt; k += 4) { a0 = op(a0, src[k]); a1 = op(a1, src[k + 1]); a2 = op(a2, src[k + 2]); a3 = op(a3, src[k + 3]); }
   for (; k < d.cnt; ++k) a0 = op(a0, src[k]);
   __syncthreads();
@@ -764,6 +831,10 @@ __device__ __forceinline__ float views_max(const DenseRows& d, float v) {
 // [quad], row stride 36 floats: the 16 lanes of a quad access start 4 banks apart, conflict-free), a (point, half, quad) task then
 // walks the V rows of its point twice (mean, then sum w (x - mean)^2 -- the same two sweeps as the lane-segment flavour) with 16-byte
 // loads.  The table behind `pool` holds 4 quads per half, so the ceil(NX / 4) quads go in rounds.
+// row k (< pn, the point's own row count) of a point's rows in a [row][stride] table of 16-byte quads, and its weight
+__device__ __forceinline__ float4 dense_quad(const float* src, int k, int stride, int) { return *reinterpret_cast<const float4*>(src + k * stride); }
+__device__ __forceinline__ float dense_w(const float* w, int k, int) { return w[k]; }
+
 template <int NX>
 __device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float (&xin)[NX], float wgt, float* pool, float* tab) {
   constexpr int QPH = 4, RS = 2 * 4 * QPH + 4;
@@ -791,21 +862,21 @@ __device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
       int k = 0;
       for (; k + 2 <= pn; k += 2) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
-        const float w0 = w[k], w1 = w[k + 1];
+        const float4 x0 = dense_quad(src, k, RS, pn), x1 = dense_quad(src, k + 1, RS, pn);
+        const float w0 = dense_w(w, k, pn), w1 = dense_w(w, k + 1, pn);
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
         m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
       }
       if (k < pn) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
-        const float w0 = w[k];
+        const float4 x0 = dense_quad(src, k, RS, pn);
+        const float w0 = dense_w(w, k, pn);
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
       }
       const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
       float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
       for (k = 0; k + 2 <= pn; k += 2) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * RS);
-        const float w0 = w[k], w1 = w[k + 1];
+        const float4 x0 = dense_quad(src, k, RS, pn), x1 = dense_quad(src, k + 1, RS, pn);
+        const float w0 = dense_w(w, k, pn), w1 = dense_w(w, k + 1, pn);
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -815,8 +886,8 @@ __device__ __forceinline__ void dense_pool_stats(const DenseRows& d, const float
         }
       }
       if (k < pn) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * RS);
-        const float w0 = w[k];
+        const float4 x0 = dense_quad(src, k, RS, pn);
+        const float w0 = dense_w(w, k, pn);
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1024,21 +1095,21 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
       int k = 0;
       for (; k + 2 <= pn; k += 2) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
-        const float w0 = w[k], w1 = w[k + 1];
+        const float4 x0 = dense_quad(src, k, XS, pn), x1 = dense_quad(src, k + 1, XS, pn);
+        const float w0 = dense_w(w, k, pn), w1 = dense_w(w, k + 1, pn);
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
         m1.x = fmaf(w1, x1.x, m1.x); m1.y = fmaf(w1, x1.y, m1.y); m1.z = fmaf(w1, x1.z, m1.z); m1.w = fmaf(w1, x1.w, m1.w);
       }
       if (k < pn) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
-        const float w0 = w[k];
+        const float4 x0 = dense_quad(src, k, XS, pn);
+        const float w0 = dense_w(w, k, pn);
         m0.x = fmaf(w0, x0.x, m0.x); m0.y = fmaf(w0, x0.y, m0.y); m0.z = fmaf(w0, x0.z, m0.z); m0.w = fmaf(w0, x0.w, m0.w);
       }
       const float mean[4] = {m0.x + m1.x, m0.y + m1.y, m0.z + m1.z, m0.w + m1.w};
       float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
       for (k = 0; k + 2 <= pn; k += 2) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS), x1 = *reinterpret_cast<const float4*>(src + (k + 1) * XS);
-        const float w0 = w[k], w1 = w[k + 1];
+        const float4 x0 = dense_quad(src, k, XS, pn), x1 = dense_quad(src, k + 1, XS, pn);
+        const float w0 = dense_w(w, k, pn), w1 = dense_w(w, k + 1, pn);
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, b0[4] = {x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1048,8 +1119,8 @@ __device__ __forceinline__ void views_tail(NetRing& ring, f32x16 (&a1)[8], const
         }
       }
       if (k < pn) {
-        const float4 x0 = *reinterpret_cast<const float4*>(src + k * XS);
-        const float w0 = w[k];
+        const float4 x0 = dense_quad(src, k, XS, pn);
+        const float w0 = dense_w(w, k, pn);
         const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1912,9 +1983,13 @@ __device__ __forceinline__ void static_blend_ws_body(StaticArgs p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) load_x(first, t);
   }
+  RaggedHead head_next = {0, 0, 0, 0};  // (ragged rows: this thread's table entry and the scalars of the NEXT unit, requested one unit ahead)
+  if (RAG && first < n_units) head_next = ragged_head(p.rg_rowtab, p.rg_ptab, first, dr.rw);
   for (long u = first; u < n_units; u += step) {
     if (RAG) {
-      dr = ragged_rows(V, p.rg_rowtab, p.rg_ptab, u, ctab + SC_CT, nullptr);  // (no task loops here: the row offsets stay in registers)
+      const RaggedHead head = head_next;
+      if (u + step < n_units) head_next = ragged_head(p.rg_rowtab, p.rg_ptab, u + step, dr.rw);
+      dr = ragged_rows(V, p.rg_rowtab, p.rg_ptab, u, ctab + SC_CT, nullptr, &head);  // (no task loops here: the row offsets stay in registers)
     } else if (VSEG == 0) {
       dr.point0 = u * p.PT;
     }
@@ -2001,9 +2076,9 @@ static int ragged_plan(StaticArgs& a, const float* s_abs, hipStream_t stream) {
   int* ptab = reinterpret_cast<int*>(a.ws + a.o.off_ptab);
   a.rg_bits = bits; a.rg_emin = emin; a.rg_wg = wg; a.rg_rowtab = rowtab; a.rg_ptab = ptab;
   DYN_REQUIRE(a.n_pts < (1L << 31), "ragged plan: R * S must stay below 2^31 points");
-  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_points", k_ragged_points, dim3(dyn_cdiv(a.n_pts, 256)), dim3(256), 0, stream, a.n_pts, a.V, a.mask,
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_points", k_ragged_points, dim3(dyn_cdiv(a.n_pts, 256)), dim3(256), (size_t)256 * a.V * 5, stream, a.n_pts, a.V, a.mask,
              reinterpret_cast<const float4*>(a.ray_diff), s_abs, bits, emin);
-  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_segments", k_ragged_segments, dim3(dyn_cdiv(a.o.n_seg, 64)), dim3(64), 0, stream, a.n_pts, a.o.n_seg, bits, seg_cnt, seg_start);
+  DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_segments", k_ragged_segments, dim3((unsigned)a.o.n_seg), dim3(256), (RAG_SEG + 4 + 256) * sizeof(int) + RAG_SEG * sizeof(unsigned short), stream, a.n_pts, a.o.n_seg, bits, seg_cnt, seg_start);
   DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_scatter", k_ragged_scatter, dim3(1), dim3(1024), 1028 * sizeof(int), stream, a.n_pts, a.o.n_seg, seg_cnt, seg_start, wg);
   DYN_LAUNCH(DYN_K_STATIC_PLAN, "k_ragged_tables", k_ragged_tables, dim3((unsigned)a.o.n_wg_max), dim3(64), 0, stream, bits, wg, rowtab, ptab);
   return 0;
@@ -2058,7 +2133,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
 #if DYN_BLEND_WS
   static const int blend_stream = getenv("DYN_BLEND_STREAM") != nullptr;  // developer A/B: the streaming (round-3) form
   if (!blend_stream) {
-    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS) * sizeof(float);
+    const size_t lds_w = (SC_WS_FLOATS + SC_CT + DENSE_SCALARS + RAG_PTAB) * sizeof(float);  // (+ padding: the fixed-trip reductions read up to V - 1 entries past a point's rows)
     const unsigned n_cu = (unsigned)dyn_cu_count();
     if (a.o.dense) {
       const unsigned nb = (unsigned)dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64);

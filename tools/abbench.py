@@ -50,15 +50,18 @@ def main():
   ap.add_argument('--rounds', type=int, default=2)
   ap.add_argument('variants', nargs='+')
   a = ap.parse_args()
-  libs = {}
+  libs, envs = {}, {}
   for v in a.variants:
     tag, _, path = v.partition('=')
-    libs[tag] = path or (os.path.join(CSRC, 'libdynibar_hip.so') if tag == 'base' else os.path.join(CSRC, f'libdynibar_hip_{tag}.so'))
+    if path.startswith('@'):  # tag=@NAME=VALUE[,NAME=VALUE]: the default library under these environment variables (e.g. noragged=@DYN_RAGGED=0)
+      envs[tag] = dict(kv.split('=', 1) for kv in path[1:].split(','))
+      path = ''
+    libs[tag] = path or (os.path.join(CSRC, 'libdynibar_hip.so') if (tag == 'base' or tag in envs) else os.path.join(CSRC, f'libdynibar_hip_{tag}.so'))
   res = {t: [] for t in libs}
   code = (CHILD % (ROOT, ROOT)).replace('ITERS', str(a.iters)).replace('FRAME', 'True' if a.frame else 'False')
   for r in range(a.rounds):
     for tag, path in libs.items():
-      env = dict(os.environ, DYNIBAR_HIP_LIB=path)
+      env = dict(os.environ, DYNIBAR_HIP_LIB=path, **envs.get(tag, {}))
       pr = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
       line = [l for l in pr.stdout.splitlines() if l.startswith('ABRESULT ')]
       if not line:
