@@ -469,31 +469,49 @@ __device__ __forceinline__ void octave_embed(float x, int h, float* out) {
 }
 
 // ref_feature_fc.0(PE(ref Pluecker)) per ray (mlp_network.py:434,456; render_ray.py:372-377): [R,36]
-// (one block per CU and all 512 registers of a lane: no other kernel's waves beside it -- csrc/dyn_mlp.h, DYN_EXCLUSIVE_CU)
+// One block = REF_RAYS rays: the 66 embedded Pluecker values of a ray are formed ONCE (rounds 1-5: by each of the ray's 35 output threads again) and parked in LDS, then one
+// thread per (ray, channel) adds its 66 products in the reference's order -- the same cosf / sinf values, the same sums, a thirty-fifth of the transcendental work.
+// (One block per CU and all 512 registers of a lane: no other kernel's waves beside it -- csrc/dyn_mlp.h, DYN_EXCLUSIVE_CU.)
+#define REF_RAYS 8
 __global__ void __launch_bounds__(256, 1) k_static_ref_feat(const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ Wref, int R,
                                   float* __restrict__ ref_feat) {
   DYN_CLAIM_REGISTER_FILE();
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * 36) return;
-  const int r = idx / 36, ch = idx % 36;
-  if (ch == 35) { ref_feat[idx] = 0.f; return; }
-  float d[3], c[6];
-  unit3(ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2], d[0], d[1], d[2]);
-  const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
-  c[0] = d[0]; c[1] = d[1]; c[2] = d[2];
-  c[3] = oy * d[2] - oz * d[1];
-  c[4] = oz * d[0] - ox * d[2];
-  c[5] = ox * d[1] - oy * d[0];
-  const float* w = Wref + ch * 66;
-  float acc = Wref[35 * 66 + ch];
-  for (int k = 0; k < 6; ++k) acc = fmaf(w[k], c[k], acc);
-  for (int fn = 0; fn < 2; ++fn)
-    for (int f = 0; f < 5; ++f)
-      for (int k = 0; k < 6; ++k) {
-        const float a = (float)(1 << f) * c[k];
-        acc = fmaf(w[6 + (fn * 5 + f) * 6 + k], fn == 0 ? cosf(a) : sinf(a), acc);
-      }
-  ref_feat[idx] = acc;
+  float* pe = reinterpret_cast<float*>(dyn_smem);  // [REF_RAYS][66]: the 6 raw coordinates, then cos(2^f c_k) for f, k, then sin(2^f c_k)
+  const int r0 = blockIdx.x * REF_RAYS;
+  for (int t = threadIdx.x; t < REF_RAYS * 66; t += 256) {
+    const int rl = t / 66, jj = t - rl * 66;
+    const int r = r0 + rl < R ? r0 + rl : R - 1;
+    float d[3], c[6];
+    unit3(ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2], d[0], d[1], d[2]);
+    const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+    c[0] = d[0]; c[1] = d[1]; c[2] = d[2];
+    c[3] = oy * d[2] - oz * d[1];
+    c[4] = oz * d[0] - ox * d[2];
+    c[5] = ox * d[1] - oy * d[0];
+    const int e = jj < 6 ? jj : (jj - 6) % 6;  // the coordinate
+    float ck = c[0];
+    ck = e == 1 ? c[1] : ck; ck = e == 2 ? c[2] : ck; ck = e == 3 ? c[3] : ck; ck = e == 4 ? c[4] : ck; ck = e == 5 ? c[5] : ck;
+    float v = ck;
+    if (jj >= 6) {
+      const int f = ((jj - 6) / 6) % 5, fn = (jj - 6) / 30;
+      const float a = (float)(1 << f) * ck;
+      v = fn == 0 ? cosf(a) : sinf(a);
+    }
+    pe[t] = v;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < REF_RAYS * 36; t += 256) {
+    const int rl = t / 36, ch = t - rl * 36;
+    if (r0 + rl >= R) continue;
+    float acc = 0.f;
+    if (ch < 35) {
+      const float* w = Wref + ch * 66;
+      const float* x = pe + rl * 66;
+      acc = Wref[35 * 66 + ch];
+      for (int j = 0; j < 66; ++j) acc = fmaf(w[j], x[j], acc);  // (raw coordinates first, then cos, then sin: the order of the reference's concatenation and of rounds 1-5)
+    }
+    ref_feat[(long)(r0 + rl) * 36 + ch] = acc;
+  }
 }
 
 struct StaticArgs {
@@ -2104,7 +2122,7 @@ extern "C" int dyn_static_net(const DynStaticNetParams* q, void* stream_) {
   a.raw = q->raw; a.ws = (float*)q->workspace;
   a.rg_bits = nullptr; a.rg_emin = nullptr; a.rg_wg = nullptr; a.rg_rowtab = nullptr; a.rg_ptab = nullptr;
 
-  DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv((long)q->R * 36, 256)), dim3(256), 0, stream, q->ray_o,
+  DYN_LAUNCH(DYN_K_STATIC_REF, "k_static_ref_feat", k_static_ref_feat, dim3(dyn_cdiv(q->R, REF_RAYS)), dim3(256), REF_RAYS * 66 * sizeof(float), stream, q->ray_o,
              q->ray_d, q->blob + ST_OFF_REF, q->R, a.ws + a.o.off_ref);
   const dim3 grid_a(dyn_cdiv(a.n_tiles_a, DYN_VIEW_THREADS / 64)), grid_b(dyn_cdiv(a.n_tiles_b, 4)), blk(DYN_NET_THREADS), blk_v(DYN_VIEW_THREADS);
   const size_t lds_a = (2 * NET_CHUNK + SA_CT + POOL_FLOATS(SA_NX) + RES_FLOATS) * sizeof(float);

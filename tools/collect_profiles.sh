@@ -6,7 +6,7 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 10 --warmup 2 --cpu-rays 0 --no-extra --no-traffic"
+BENCH="python $PWD/bench.py --steps 10 --warmup 2 --cpu-rays 0 --no-extra --no-traffic --no-x6"
 FRAME="python $PWD/tools/framebench.py --frames 1"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -- $BENCH > $OUT/bench_stats.log 2>&1
