@@ -1717,42 +1717,52 @@ extern "C" int dyn_sample_pdf(const float* bins, float* weights, const float* u,
   return 0;
 }
 
-// [normalize(d), o x normalize(d)] per target ray (render_ray.py:372-377) and per (sample, source view) (:380-396, output [R,S,V,6])
+// [normalize(d), o x normalize(d)] per target ray (render_ray.py:372-377) and per (sample, source view) (:380-396, output [R,S,V,6]).  The product runs
+// over the axis torch.cross(dim=None) picks for the call's shape -- the first of size 3 (csrc/dyn_device.h) --, like in the network kernels.
 __global__ void k_plucker_ref(const float* __restrict__ ray_o, const float* __restrict__ ray_d, int R, float* __restrict__ out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   float dx, dy, dz;
-  const float x = ray_d[r * 3], y = ray_d[r * 3 + 1], z = ray_d[r * 3 + 2];
-  const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
-  dx = x / n; dy = y / n; dz = z / n;
+  dyn_unit3(ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2], dx, dy, dz);
   const float ox = ray_o[r * 3], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+  float m[3] = {oy * dz - oz * dy, oz * dx - ox * dz, ox * dy - oy * dx};
+  if (dyn_ref_cross_axis(R) != DYN_CROSS_XYZ) dyn_ref_moment_over_rays(ray_o, ray_d, r, m);
   float* o = out + (long)r * 6;
   o[0] = dx; o[1] = dy; o[2] = dz;
-  o[3] = oy * dz - oz * dy; o[4] = oz * dx - ox * dz; o[5] = ox * dy - oy * dx;
+  o[3] = m[0]; o[4] = m[1]; o[5] = m[2];
 }
-__global__ void k_plucker_src(const float* __restrict__ pts, long pts_view_stride, const float* __restrict__ cams, long n_pts, int V, float* __restrict__ out) {
+__global__ void k_plucker_src(const float* __restrict__ pts, long pts_view_stride, const float* __restrict__ cams, int R, int S, int V, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_pts = (long)R * S;
   if (i >= n_pts * V) return;
   const long pnt = i / V;
   const int v = (int)(i - pnt * V);
-  const float* c = cams + (long)v * 34 + 18;  // c2w
-  const float cx = c[3], cy = c[7], cz = c[11];
-  const float* q = pts + (long)v * pts_view_stride + pnt * 3;
-  const float x = q[0] - cx, y = q[1] - cy, z = q[2] - cz;
-  const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
-  const float dx = x / n, dy = y / n, dz = z / n;
+  auto ctr_at = [&](int vv, float (&c3)[3]) { const float* c = cams + (long)vv * 34 + 18; c3[0] = c[3]; c3[1] = c[7]; c3[2] = c[11]; };  // c2w
+  auto pts_at = [&](int vv, int rr, int ss, float (&q)[3]) {
+    const float* s3 = pts + (long)vv * pts_view_stride + ((long)rr * S + ss) * 3;
+    q[0] = s3[0]; q[1] = s3[1]; q[2] = s3[2];
+  };
+  const int ray = (int)(pnt / S), smp = (int)(pnt - (long)ray * S);
+  float c3[3], q[3], dx, dy, dz;
+  ctr_at(v, c3);
+  pts_at(v, ray, smp, q);
+  dyn_unit3(q[0] - c3[0], q[1] - c3[1], q[2] - c3[2], dx, dy, dz);
+  float m[3] = {c3[1] * dz - c3[2] * dy, c3[2] * dx - c3[0] * dz, c3[0] * dy - c3[1] * dx};
+  const int axis = dyn_src_cross_axis(V, R, S);
+  if (axis != DYN_CROSS_XYZ) dyn_src_moment_over_axis(axis, v, ray, smp, pts_at, ctr_at, m);
   float* o = out + i * 6;
   o[0] = dx; o[1] = dy; o[2] = dz;
-  o[3] = cy * dz - cz * dy; o[4] = cz * dx - cx * dz; o[5] = cx * dy - cy * dx;
+  o[3] = m[0]; o[4] = m[1]; o[5] = m[2];
 }
 extern "C" int dyn_plucker_ref(const float* ray_o, const float* ray_d, int R, float* out, void* stream) {
   DYN_REQUIRE(ray_o && ray_d && out && R > 0, "dyn_plucker_ref: bad argument");
   DYN_LAUNCH(DYN_K_IMAGE_RAYS, "dyn_plucker_ref", k_plucker_ref, dim3(dyn_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, ray_o, ray_d, R, out);
   return 0;
 }
-extern "C" int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, long n_pts, int V, float* out, void* stream) {
-  DYN_REQUIRE(pts && cams && out && n_pts > 0 && V > 0, "dyn_plucker_src: bad argument");
+extern "C" int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, int R, int S, int V, float* out, void* stream) {
+  DYN_REQUIRE(pts && cams && out && R > 0 && S > 0 && V > 0, "dyn_plucker_src: bad argument");
+  const long n_pts = (long)R * S;
   DYN_LAUNCH(DYN_K_IMAGE_RAYS, "dyn_plucker_src", k_plucker_src, dim3(dyn_cdiv(n_pts * V, 256)), dim3(256), 0, (hipStream_t)stream, pts,
-             per_view_pts ? n_pts * 3 : 0L, cams, n_pts, V, out);
+             per_view_pts ? n_pts * 3 : 0L, cams, R, S, V, out);
   return 0;
 }

@@ -488,6 +488,11 @@ __global__ void __launch_bounds__(256, 1) k_static_ref_feat(const float* __restr
     c[3] = oy * d[2] - oz * d[1];
     c[4] = oz * d[0] - ox * d[2];
     c[5] = ox * d[1] - oy * d[0];
+    if (dyn_ref_cross_axis(R) != DYN_CROSS_XYZ) {  // a chunk of exactly 3 rays: the reference's torch.cross runs over the rays (csrc/dyn_device.h)
+      float m[3];
+      dyn_ref_moment_over_rays(ray_o, ray_d, r, m);
+      c[3] = m[0]; c[4] = m[1]; c[5] = m[2];
+    }
     const int e = jj < 6 ? jj : (jj - 6) % 6;  // the coordinate
     float ck = c[0];
     ck = e == 1 ? c[1] : ck; ck = e == 2 ? c[2] : ck; ck = e == 3 ? c[3] : ck; ck = e == 4 ? c[4] : ck; ck = e == 5 ? c[5] : ck;
@@ -1246,6 +1251,16 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     px = p.pts[point * 3]; py = p.pts[point * 3 + 1]; pz = p.pts[point * 3 + 2];
     cx = p.centers[view * 16 + 12]; cy = p.centers[view * 16 + 13]; cz = p.centers[view * 16 + 14];
   }
+  // Exactly 3 views / a chunk of exactly 3 rays / 3 samples per ray: the reference's torch.cross (render_ray.py:392, no dim) runs over that axis, not over
+  // xyz (csrc/dyn_device.h).  Those moments are formed here, before the first layer's accumulators are live; every other shape skips the branch.
+  const int cross_axis = dyn_src_cross_axis(V, p.R, p.S);
+  float mq[3] = {0.f, 0.f, 0.f};
+  if (cross_axis != DYN_CROSS_XYZ && valid) {
+    const int ray = (int)(point / p.S), smp = (int)(point - (long)ray * p.S);
+    dyn_src_moment_over_axis(cross_axis, view, ray, smp,
+        [&](int, int rr, int ss, float (&q)[3]) { const float* s3 = p.pts + ((long)rr * p.S + ss) * 3; q[0] = s3[0]; q[1] = s3[1]; q[2] = s3[2]; },
+        [&](int vv, float (&c3)[3]) { c3[0] = p.centers[vv * 16 + 12]; c3[1] = p.centers[vv * 16 + 13]; c3[2] = p.centers[vv * 16 + 14]; }, mq);
+  }
   float xin[SA_NX];
   f32x16 a1[8];
   const bool h0 = h == 0;
@@ -1287,6 +1302,7 @@ __global__ void __launch_bounds__(DYN_VIEW_THREADS, 2) k_static_views(StaticArgs
     c6[3] = cy * c6[2] - cz * c6[1];
     c6[4] = cz * c6[0] - cx * c6[2];
     c6[5] = cx * c6[1] - cy * c6[0];
+    if (cross_axis != DYN_CROSS_XYZ) { c6[3] = mq[0]; c6[4] = mq[1]; c6[5] = mq[2]; }
     float in1[SA_L1V_STEPS];
 #pragma unroll
     for (int c = 0; c < 6; ++c) octave_embed<5>(c6[c], h, in1 + c * 5);

@@ -1360,6 +1360,11 @@ __global__ void __launch_bounds__(256) k_train_static_embed(const float* __restr
     c[3] = oy * d[2] - oz * d[1];
     c[4] = oz * d[0] - ox * d[2];
     c[5] = ox * d[1] - oy * d[0];
+    if (dyn_ref_cross_axis(R) != DYN_CROSS_XYZ) {  // a batch of exactly 3 rays: the reference's torch.cross runs over the rays (csrc/dyn_device.h)
+      float m[3];
+      dyn_ref_moment_over_rays(ray_o, ray_d, r, m);
+      c[3] = m[0]; c[4] = m[1]; c[5] = m[2];
+    }
     float* o = ref_pe + (long)r * 68;
     for (int k = 0; k < 6; ++k) tr_embed(c[k], o + k, 6);
     o[66] = 0.f; o[67] = 0.f;
@@ -1384,6 +1389,15 @@ __global__ void __launch_bounds__(256) k_train_static_embed(const float* __restr
   c[3] = cy * c[2] - cz * c[1];
   c[4] = cz * c[0] - cx * c[2];
   c[5] = cx * c[1] - cy * c[0];
+  const int cross_axis = dyn_src_cross_axis(V, R, S);
+  if (cross_axis != DYN_CROSS_XYZ) {  // exactly 3 views / rays / samples: the reference's torch.cross runs over that axis, not over xyz (csrc/dyn_device.h)
+    const int ray = (int)(p / S), smp = (int)(p - (long)ray * S);
+    float m[3];
+    dyn_src_moment_over_axis(cross_axis, v, ray, smp,
+        [&](int, int rr, int ss, float (&q)[3]) { const float* s3 = pts + ((long)rr * S + ss) * 3; q[0] = s3[0]; q[1] = s3[1]; q[2] = s3[2]; },
+        [&](int vv, float (&c3)[3]) { c3[0] = centers[vv * center_stride]; c3[1] = centers[vv * center_stride + 1]; c3[2] = centers[vv * center_stride + 2]; }, m);
+    c[3] = m[0]; c[4] = m[1]; c[5] = m[2];
+  }
   for (int k = 0; k < 6; ++k) tr_embed(c[k], o + 33 + k, 6);
   const float4 rd = *reinterpret_cast<const float4*>(ray_diff + rowc * 4);
   o[99] = rd.x; o[100] = rd.y; o[101] = rd.z; o[102] = rd.w; o[103] = 0.f;

@@ -286,31 +286,6 @@ def _infer_F(state_dict, key='ray_dir_fc.2.weight'):
   return int(w.shape[0]) - 3
 
 
-_CROSS_WARNED = set()  # axis kinds ('VIEW', 'SAMPLE', 'RAY') that have been reported: one warning per KIND, so that a harmless 3-ray frame tail cannot use up the report of a persistent 3-view divergence
-
-
-def check_cross_axis_quirk(R, S, V):
-  """The reference forms the Pluecker moments with ``torch.cross`` WITHOUT ``dim`` (render_ray.py:375, :392), which crosses over the FIRST axis of
-  size 3: with exactly 3 source views or 3 samples per ray -- or, for a chunk of exactly 3 rays, over the rays -- it does not cross over xyz.  The
-  kernels (and the oracle) always cross over xyz, which is what the code means.  The reference still RUNS those shapes, so a user with 3 static source
-  views must not be blocked: every such shape is rendered with the xyz cross product and a RuntimeWarning -- once per process and per axis kind
-  (view / sample / ray) -- says that the result differs from the reference's there (a 3-ray chunk can occur as the tail of a frame: H x W mod chunk_size == 3).  ``DYNIBAR_STRICT_CROSS_QUIRK=1`` turns the
-  S == 3 / V == 3 warning into a ValueError for callers who would rather stop than diverge ("Known divergence")."""
-  if not (S == 3 or V == 3 or R == 3):
-    return
-  import os
-  if (S == 3 or V == 3) and os.environ.get('DYNIBAR_STRICT_CROSS_QUIRK', '0') == '1':
-    raise ValueError(f'DynibarStatic with S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the '
-                     'first axis of size 3 for this shape, which the kernels do not reproduce (DYNIBAR_STRICT_CROSS_QUIRK=1)')
-  axis = 'VIEW' if V == 3 else ('SAMPLE' if S == 3 else 'RAY')
-  if axis not in _CROSS_WARNED:
-    import warnings
-    _CROSS_WARNED.add(axis)
-    warnings.warn(f'R={R} rays, S={S} samples, V={V} views: the reference\'s torch.cross(dim=None) (render_ray.py:375,392) crosses over the {axis} axis '
-                  'for this shape; dynibar_amd renders the intended xyz cross product (results differ from the reference for this shape only)',
-                  RuntimeWarning, stacklevel=3)
-
-
 class StaticNet:
   """DynibarStatic (mlp_network.py:319-527) as packed MFMA operand tiles on one device.  ``state_dict``: the module's
   state dict (torch tensors or numpy arrays; a DataParallel 'module.' prefix is accepted)."""
@@ -337,7 +312,6 @@ class StaticNet:
     """-> raw [R,S,4]  (k_static_ref_feat, k_static_views, k_static_points, k_static_blend)."""
     k = _Keep()
     R, S, V = rgb_feat.shape[:3]
-    check_cross_axis_quirk(R, S, V)
     dev = rgb_feat.device
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     ws, need = self.workspace(R, S, V, dev)

@@ -177,14 +177,15 @@ def compute_ref_plucker_coordinate(ray_o, ray_d):
 
 
 def compute_src_plucker_coordinate(pts, src_cameras):
-  """(render_ray.py:380-396) pts [R,S,3] or [V,R,S,3], src_cameras [1,V,34] -> [R,S,V,6] (always crossing over xyz: DESIGN.md section 7)."""
+  """(render_ray.py:380-396) pts [R,S,3] or [V,R,S,3], src_cameras [1,V,34] -> [R,S,V,6]; the moment is crossed over the axis the reference's
+  ``torch.cross`` without ``dim`` picks for this shape (the first of size 3: csrc/dyn_device.h)."""
   k = ops._Keep()
   cams = src_cameras[0]
   V = cams.shape[0]
   per_view = pts.dim() == 4
   R, S = pts.shape[-3], pts.shape[-2]
   out = torch.empty((R, S, V, 6), dtype=torch.float32, device=pts.device)
-  ops.call('dyn_plucker_src', k(pts), int(per_view), k(cams), R * S, V, ops.ptr(out), ops.stream_of(out))
+  ops.call('dyn_plucker_src', k(pts), int(per_view), k(cams), R, S, V, ops.ptr(out), ops.stream_of(out))
   return out
 
 

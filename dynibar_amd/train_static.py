@@ -254,7 +254,6 @@ class _Step:
 def _forward(w, aa, mask_rgb, views, ray_o, ray_d, pts, rgb_feat, ray_diff, mask):
   """w: {name: device tensor}.  -> (raw [R,S,4], _Step)"""
   R, S, V = rgb_feat.shape[:3]
-  ops.check_cross_axis_quirk(R, S, V)
   P, N = R * S, R * S * V
   dev = rgb_feat.device
   st = stream_of(rgb_feat)

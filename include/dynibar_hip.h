@@ -211,11 +211,13 @@ int dyn_image_rays(const float* camera, int H, int W, int render_stride, float* 
 
 /* ---- helper exports of the reference's module surface (not on the render functions' own path, which fuses them) -------------------
  * sample_pdf (render_ray.py:19-64): bins [R,M+1], weights [R,M] (+1e-5 IN PLACE like the reference), u [R,N] or NULL (det) -> samples [R,N];
- * compute_ref_plucker_coordinate (:372-377): [R,6]; compute_src_plucker_coordinate (:380-396): pts [n_pts,3] (per_view_pts = 0) or
- * [V,n_pts,3] (per_view_pts = 1), cams [V,34] -> [n_pts,V,6]. */
+ * compute_ref_plucker_coordinate (:372-377): [R,6]; compute_src_plucker_coordinate (:380-396): pts [R,S,3] (per_view_pts = 0) or
+ * [V,R,S,3] (per_view_pts = 1), cams [V,34] -> [R,S,V,6].  Both form the moment with torch.cross WITHOUT dim in the reference (:375, :392), which
+ * crosses over the first axis of size 3 -- the views when V == 3, else the rays when R == 3, else the samples when S == 3, else xyz: these entry
+ * points (and dyn_static_net / dyn_train_static_embed, which form the moments in their kernels) do the same, so R and S are separate arguments. */
 int dyn_sample_pdf(const float* bins, float* weights, const float* u, int R, int M, int N, float* samples, void* stream);
 int dyn_plucker_ref(const float* ray_o, const float* ray_d, int R, float* out, void* stream);
-int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, long n_pts, int V, float* out, void* stream);
+int dyn_plucker_src(const float* pts, int per_view_pts, const float* cams, int R, int S, int V, float* out, void* stream);
 /* Projector.compute_projections (projection.py:32-59) and Projector.compute_angle (:61-101): xyz [V,n_pts,3] (+ xyz_st [V,n_pts,3], query_center [4] for
  * the angles), proj [V,16] from dyn_prepare_cameras -> pix [V,n_pts,2], in_front [V,n_pts] (0 / 1), ray_diff [V,n_pts,4]; either output group may be NULL. */
 int dyn_project_points(const float* xyz, const float* xyz_st, const float* proj, const float* query_center, int V, long n_pts, float* pix,

@@ -307,20 +307,27 @@ def resnet_encoder(sd, x, coarse_out_ch=32, fine_out_ch=32):
 # ----------------------------------------------------------------------------
 
 
+def cross_first_axis_of_3(a, b):
+  """``torch.cross(a, b)`` WITHOUT ``dim`` as render_ray.py:375 and :392 call it: torch crosses over the FIRST axis of size 3 (the deprecated
+  default, still what torch 2.x does) -- xyz only when no earlier axis has size 3.  With exactly 3 source views / a chunk of exactly 3 rays /
+  3 samples per ray the moments are therefore products over that axis.  Pinned against the reference's own functions run on such shapes
+  (tests/golden/cross_axis.npz)."""
+  dim = next(i for i, n in enumerate(a.shape) if n == 3)
+  return torch.linalg.cross(a, b, dim=dim)
+
+
 def ref_plucker(ray_o, ray_d):
   d = F.normalize(ray_d, dim=-1)
-  return torch.cat([d, torch.linalg.cross(ray_o, d, dim=-1)], dim=-1)
+  return torch.cat([d, cross_first_axis_of_3(ray_o, d)], dim=-1)
 
 
 def src_plucker(pts, src_cameras):
-  """pts [R,S,3] (or [V,R,S,3]), src_cameras [1,V,34] -> [R,S,V,6].
-  The reference calls torch.cross without dim (first size-3 axis); this restates the
-  intended last-axis product, identical whenever none of V,R,S equals 3."""
+  """pts [R,S,3] (or [V,R,S,3]), src_cameras [1,V,34] -> [R,S,V,6]."""
   c2w = src_cameras[0, :, -16:].reshape(-1, 4, 4)
   o = c2w[:, :3, 3].unsqueeze(1).unsqueeze(1)
   ray = (pts.unsqueeze(0) if pts.dim() == 3 else pts) - o
   ray = F.normalize(ray, dim=-1)
-  mom = torch.linalg.cross(o.expand(-1, ray.shape[1], ray.shape[2], -1), ray, dim=-1)
+  mom = cross_first_axis_of_3(o.expand(-1, ray.shape[1], ray.shape[2], -1), ray)
   return torch.cat([ray, mom], dim=-1).permute(1, 2, 0, 3)
 
 

@@ -30,13 +30,20 @@ def scene_case(name):
       # BASELINE configs[4] (stress): 16 views in both branches, rendered with 128 + 128 samples
       # configs/train_kid-running.txt shape: 7 time-offset + num_vv = 3 virtual dynamic views, 15 static views (render_monocular_bt.py:113-201)
       'kid': dict(seed=8, H=32, W=48, V=10, n_static=15, smooth=True, R=5),
-      'stress': dict(seed=7, H=32, W=48, V=16, n_static=16, smooth=True, R=4),  # not 3 rays: torch.cross without dim (reference quirk)
+      'stress': dict(seed=7, H=32, W=48, V=16, n_static=16, smooth=True, R=4),
       # the training shape of configs/train_kid-running.txt at a size the oracle's autograd runs on the device in seconds: 64 samples,
       # 7 + 3 dynamic views at the reference and at the anchor frame, 15 static views, hundreds of rays (tests/parity.check_train_mono_large)
       'train_large': dict(seed=31, H=144, W=256, V=10, n_static=15, smooth=True, R=256),
       # BASELINE configs[0] at its stated size: 288 x 512 images, 72 x 128 x 32 white-noise feature maps, 8 static source
       # views, 512 rays x 64 samples -- the one named configuration whose size an oracle run affords in full (seconds)
       'config0': dict(seed=40, H=288, W=512, V=7, n_static=8, smooth=False, R=512),
+      # shapes on which the reference's torch.cross WITHOUT dim (render_ray.py:375, :392) does not cross over xyz: exactly 3 static source views, a chunk
+      # of exactly 3 rays, (with CROSS_AXIS_SAMPLES) 3 samples per ray, and the two combinations that decide the precedence (tests/golden/cross_axis.npz)
+      'cross_views': dict(seed=51, H=32, W=48, V=5, n_static=3, smooth=True, R=5),
+      'cross_rays': dict(seed=52, H=32, W=48, V=5, n_static=8, smooth=True, R=3),
+      'cross_samples': dict(seed=53, H=32, W=48, V=5, n_static=8, smooth=True, R=4),
+      'cross_rays_views': dict(seed=54, H=32, W=48, V=5, n_static=3, smooth=True, R=3),
+      'cross_rays_samples': dict(seed=55, H=32, W=48, V=5, n_static=8, smooth=True, R=3),
   }[name]
   R = cfg.pop('R')
   seed = cfg['seed']
@@ -48,6 +55,10 @@ def scene_case(name):
   scene['featmaps_fine'] = t(fine['featmaps'])
   scene['static_featmaps_fine'] = t(fine['static_featmaps'])
   return scene, t(o), t(d), t(uv), pix
+
+
+# samples per ray of the cross-axis cases
+CROSS_AXIS_SAMPLES = {'cross_views': 8, 'cross_rays': 8, 'cross_samples': 3, 'cross_rays_views': 8, 'cross_rays_samples': 3}
 
 
 def model_weights(seed=0):

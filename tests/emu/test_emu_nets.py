@@ -1,5 +1,8 @@
 """The MFMA network kernels (weight ring, register-resident layer chains, ray attention) executed under the wave-level emulator on
 one ray, checked against the oracle.  Debugging aid for fragment maps / packing in a container without a GPU; -m gpu is authoritative."""
+import os
+
+import numpy as np
 import pytest
 
 import parity
@@ -43,3 +46,9 @@ def test_point_kernel_walks_several_row_tiles(emu):
 def test_ragged_rows_with_dark_colours(emu):
   """11 static views (ragged dense rows) with mask_rgb removing valid rows and whole points: the blend's product mask and its all-masked path."""
   parity.check_static_net(emu, 'harsh', S=32, R=2, mask_rgb=True, dark=0.4)
+
+
+@pytest.mark.parametrize('name', ['cross_views', 'cross_rays_samples'])
+def test_cross_axis_shapes(emu, golden_dir, name):
+  """3 static source views (the reference's torch.cross runs over the views) and a chunk of 3 rays x 3 samples (over the rays, for both moments)."""
+  parity.check_cross_axis(emu, dict(np.load(os.path.join(golden_dir, 'cross_axis.npz'))), name)

@@ -30,6 +30,11 @@ def test_static_bootstrap_step(emu):
   parity.check_train_static(emu, 'few', S=8, R=2)
 
 
+def test_static_bootstrap_step_three_views(emu):
+  """3 static source views: the moments of the training embed kernel follow the reference's torch.cross over the view axis (csrc/dyn_device.h)."""
+  parity.check_train_static(emu, 'cross_views', S=8, R=2)
+
+
 def test_static_bootstrap_step_kid_config(emu):
   parity.check_train_static(emu, 'few', S=8, R=2, aa=False, mask_rgb=True)
 

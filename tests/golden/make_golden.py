@@ -426,6 +426,34 @@ def mono_train_grad_goldens(name='few', S=16, R=4):
   print('mono_train_grad', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
 
 
+def cross_axis_goldens():
+  """The shapes on which render_ray.py:375 / :392 (torch.cross without dim) cross over the views, the rays or the samples instead of xyz: the
+  reference's own Pluecker functions, DynibarStatic on their outputs, and the whole static stage of render_rays_mono (vanilla compositing)."""
+  out = {}
+  weights = cases.model_weights(0)
+  proj = PJ.Projector('cpu')
+  with torch.no_grad():
+    for name, S in cases.CROSS_AXIS_SAMPLES.items():
+      scene, o, d, uv, pix = cases.scene_case(name)
+      pts, z, s = RR.sample_along_camera_ray(o, d, scene['depth_range'], S, inv_uniform=True, det=True)
+      Vs = scene['static_src_rgbs'].shape[1]
+      rf, rd, mk = proj.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), scene['camera'], scene['static_src_rgbs'],
+                                             scene['static_src_cameras'], scene['static_featmaps'])
+      refc = RR.compute_ref_plucker_coordinate(o, d)
+      srcc = RR.compute_src_plucker_coordinate(pts, scene['static_src_cameras'])
+      out[f'{name}/plucker/ref'] = npy(refc); out[f'{name}/plucker/src'] = npy(srcc)
+      ray_dir = torch.nn.functional.normalize(d, dim=-1)
+      for aa, mr in ((1, 0), (0, 1)):
+        net = NET.DynibarStatic(ref_args(aa, mr), in_feat_ch=32, n_samples=S)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in weights['net_coarse_st'].items()}, strict=False)
+        raw = net.eval()(pts, refc, srcc, rf, ray_dir, rd, mk)
+        out[f'{name}/static_net/aa{aa}_mr{mr}/raw'] = npy(raw)
+        if aa == 1:
+          flat(f'{name}/vanilla_st/', RR.raw2outputs_vanilla(raw, z, mk[..., 0].sum(dim=2) > 1), out)
+  np.savez_compressed(os.path.join(HERE, 'cross_axis.npz'), **out)
+  print('cross_axis', len(out), 'arrays', sum(v.nbytes for v in out.values()) // 1024, 'KiB')
+
+
 def camera_format_goldens():
   """Section 8f-4, data side: the reference's OWN pose parsing (llff_data_utils.py) and benchmark dataset class (eval_nvidia.py:26-200) on a synthetic
   scene directory (seeded poses_bounds_cvd.npy, dummy image files).  The packages they import for image decoding / metrics (cv2, imageio, skimage,
@@ -500,6 +528,9 @@ if __name__ == '__main__':
   if 'camera_format' in sys.argv[1:]:
     camera_format_goldens()
     sys.exit(0)
+  if 'cross_axis' in sys.argv[1:]:
+    cross_axis_goldens()
+    sys.exit(0)
   if 'mono_train_grad' in sys.argv[1:]:
     mono_train_grad_goldens()
     sys.exit(0)
@@ -535,3 +566,4 @@ if __name__ == '__main__':
   mono_kid_goldens()
   encoder_goldens()
   camera_format_goldens()
+  cross_axis_goldens()

@@ -343,6 +343,45 @@ def check_static_net(device, name='small', S=64, R=None, aa=True, mask_rgb=False
   return float(err[..., :3].max()), float(err[..., 3].max()), float(sens.max())
 
 
+def check_cross_axis(device, golden, name):
+  """The shapes on which the reference's torch.cross WITHOUT dim (render_ray.py:375, :392) crosses over the views / the rays / the samples instead of
+  xyz (csrc/dyn_device.h): the helper exports and DynibarStatic against the REAL reference's outputs on those shapes (tests/golden/cross_axis.npz),
+  then the usual oracle checks of the network and of the whole static pass."""
+  from dynibar_amd import render_ray as RR
+  g = {k[len(name) + 1:]: v for k, v in golden.items() if k.startswith(name + '/')}
+  S = cases.CROSS_AXIS_SAMPLES[name]
+  scene, o, d, sd, _, st = static_inputs(name, S)
+  dv = lambda x: x.to(device)
+  assert_close(RR.compute_ref_plucker_coordinate(dv(o), dv(d)), torch.from_numpy(g['plucker/ref']), 1e-6, 1e-6, f'{name} ref Pluecker')
+  assert_close(RR.compute_src_plucker_coordinate(dv(st['pts']), dv(scene['static_src_cameras'])), torch.from_numpy(g['plucker/src']), 2e-6, 1e-6,
+               f'{name} src Pluecker')
+  sdev = to_dev(scene, device)
+  views = ops.SourceViews(sdev['camera'], sdev['static_src_rgbs'], sdev['static_src_cameras'], sdev['static_featmaps'])
+  worst = 0.0
+  for aa, mr in ((1, 0), (0, 1)):
+    net = ops.StaticNet(_weights('init')['net_coarse_st'], device, aa, mr)
+    raw = cpu(net(views, dv(o), dv(d), dv(st['pts']), dv(st['rgb_feat']), dv(st['ray_diff']), dv(st['mask'])))
+    ref = torch.from_numpy(g[f'static_net/aa{aa}_mr{mr}/raw'])
+    dead = ref[..., 3] < -1e8
+    assert bool((raw[..., 3][dead] == ref[..., 3][dead]).all())
+    err = (raw - ref).abs()
+    err[..., 3][dead] = 0.0
+    lim = 1e-4 + 1e-4 * ref.abs()
+    if aa:  # the reference's own conditioning under +-1 ulp of exp() in the pooling weights (e - min_v e), as in check_static_net
+      net_args = (sd, st['pts'], st['ref_rays_coords'], st['src_rays_coords'], st['rgb_feat'], F.normalize(d, dim=-1), st['ray_diff'], st['mask'])
+      base = O.static_net(*net_args, True, bool(mr))
+      for k in range(3):
+        jit = (torch.randint(0, 3, st['mask'].shape, generator=torch.Generator().manual_seed(50 + k)).float() - 1.0) * 6e-8
+        lim = torch.maximum(lim, 1e-4 + 1e-4 * ref.abs() + 4.0 * (O.static_net(*net_args, True, bool(mr), exp_jitter=jit) - base).abs())
+    record_margin(f'{name} static net vs the reference itself (aa={aa}, mask_rgb={mr})', err, lim)
+    assert int((err > lim).sum()) == 0, (f'{name} aa={aa} mask_rgb={mr}: max err rgb {float(err[..., :3].max()):.3e} sigma {float(err[..., 3].max()):.3e} '
+                                         'against the reference\'s DynibarStatic')
+    worst = max(worst, float(err[..., :3].max()))
+  check_static_net(device, name, S=S)
+  check_static_pass(device, name, S=S)
+  return worst
+
+
 def run_static_pass(device, scene_dev, net, o, d, S, inv_uniform=True, same_matrix=False):
   """BASELINE config 2 on the HIP path: sample -> project/gather -> DynibarStatic -> composite."""
   P = reference_proj_matrices(scene_dev['static_src_cameras'][0]) if same_matrix else None

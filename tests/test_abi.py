@@ -78,38 +78,6 @@ def test_product_package_does_not_import_the_oracle():
         assert 'import oracle' not in text and 'from oracle' not in text and '/root/reference' not in text, f'{f} reaches for test infrastructure'
 
 
-def test_cross_axis_quirk_shapes_warn_once_and_can_be_refused(monkeypatch):
-  """render_ray.py:375,392 call torch.cross without dim: with exactly 3 views, 3 samples or a 3-ray chunk the reference crosses over that axis.  The
-  kernels never do; the reference still runs those shapes, so they render (xyz cross product) behind one RuntimeWarning per axis kind, and
-  DYNIBAR_STRICT_CROSS_QUIRK=1 refuses the two shapes no frame tail can produce."""
-  import warnings
-  from dynibar_amd import ops
-  monkeypatch.delenv('DYNIBAR_STRICT_CROSS_QUIRK', raising=False)
-  ops._CROSS_WARNED.clear()
-  with warnings.catch_warnings(record=True) as w:
-    warnings.simplefilter('always')
-    ops.check_cross_axis_quirk(4096, 64, 8)  # shipped shapes pass silently
-    assert not w
-    ops.check_cross_axis_quirk(3, 64, 8)   # a harmless 3-ray frame tail first: it must not use up the report of the persistent divergences below
-    ops.check_cross_axis_quirk(16, 64, 3)
-    ops.check_cross_axis_quirk(16, 3, 8)
-    ops.check_cross_axis_quirk(16, 64, 3)  # once per process AND axis kind
-    ops.check_cross_axis_quirk(3, 64, 8)
-  msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
-  assert len(msgs) == 3 and 'RAY axis' in msgs[0] and 'VIEW axis' in msgs[1] and 'SAMPLE axis' in msgs[2]
-  monkeypatch.setenv('DYNIBAR_STRICT_CROSS_QUIRK', '1')
-  with pytest.raises(ValueError, match='torch.cross'):
-    ops.check_cross_axis_quirk(16, 3, 8)
-  with pytest.raises(ValueError, match='torch.cross'):
-    ops.check_cross_axis_quirk(16, 64, 3)
-  ops._CROSS_WARNED.clear()
-  with warnings.catch_warnings(record=True) as w:
-    warnings.simplefilter('always')
-    ops.check_cross_axis_quirk(3, 64, 8)  # a frame's tail chunk is never refused
-  assert len(w) == 1
-  ops._CROSS_WARNED.clear()
-
-
 def test_state_dict_encoder_source_with_trainable_tensors_takes_the_training_form():
   """feature_network.ResNet wrapping a {name: tensor} source: tensors that require grad make the call carry a graph (train_encoder), like a module's
   parameters do -- it must not silently run the forward-only kernels and leave the optimizer's tensors without gradients."""

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import cases
 import parity
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +70,15 @@ def test_static_net_ragged_rows_and_mask_rgb(dev, kw):
   many out-of-bounds / behind-camera samples (points without any valid view included), and mask_rgb removing valid rows and whole points (black source
   colours) -- also in the lane-segment flavour (8 views), whose blend must use the product mask too."""
   parity.check_static_net(dev, **kw)
+
+
+@pytest.mark.parametrize('name', list(cases.CROSS_AXIS_SAMPLES))
+def test_cross_axis_shapes_follow_the_reference(dev, golden_dir, name):
+  """render_ray.py:375 / :392 call torch.cross without dim: with exactly 3 static source views, a chunk of exactly 3 rays or 3 samples per ray the
+  reference's Pluecker moments are products over that axis (views before rays before samples), and a DynibarStatic trained on such a shape has learnt
+  from them.  The helper exports and the network kernels against the REAL reference's outputs on five such shapes, the network and the whole static
+  pass against the oracle (itself pinned to the same outputs)."""
+  parity.check_cross_axis(dev, dict(np.load(os.path.join(golden_dir, 'cross_axis.npz'))), name)
 
 
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
@@ -237,7 +247,8 @@ def test_train_gemm(dev):
 
 
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=64, aa=False, mask_rgb=True),
-                                dict(name='small', S=48, R=5, weights='trained'), dict(name='many', S=16, R=3)])
+                                dict(name='small', S=48, R=5, weights='trained'), dict(name='many', S=16, R=3), dict(name='cross_views', S=8),
+                                dict(name='cross_rays_samples', S=3)])
 def test_train_static_step(dev, kw):
   """values of raw / rgb / weights and EVERY gradient (39 or 38 parameters + the static feature maps) of the static bootstrap graph against
   torch autograd through the CPU oracle"""

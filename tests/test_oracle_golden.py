@@ -99,6 +99,35 @@ def test_stages(golden_dir, name):
   assert n == sum(1 for k in g if k.startswith('mono/')), 'oracle mono output key set differs from the reference'
 
 
+@pytest.mark.parametrize('name', list(cases.CROSS_AXIS_SAMPLES))
+def test_cross_axis_shapes(golden_dir, name):
+  """render_ray.py:375 / :392 call torch.cross without dim: with exactly 3 source views, a chunk of exactly 3 rays or 3 samples per ray the
+  reference's moments are products over THAT axis (views before rays before samples).  The oracle follows it -- pinned here on the reference's
+  own Pluecker functions, DynibarStatic on top of them and the static compositing -- and the moments must really differ from the xyz product
+  on these shapes (otherwise the cases would pin nothing)."""
+  g = {k[len(name) + 1:]: v for k, v in load(golden_dir, 'cross_axis.npz').items() if k.startswith(name + '/')}
+  scene, o, d, uv, pix = cases.scene_case(name)
+  S = cases.CROSS_AXIS_SAMPLES[name]
+  W = O.tdict(cases.model_weights(0)['net_coarse_st'])
+  pts, z, s = O.sample_along_camera_ray(o, d, scene['depth_range'], S, True, True)
+  Vs = scene['static_src_rgbs'].shape[1]
+  rf, rd, mk = O.compute_with_motions(pts, pts[None].repeat(Vs, 1, 1, 1), scene['camera'], scene['static_src_rgbs'],
+                                      scene['static_src_cameras'], scene['static_featmaps'])
+  refc, srcc = O.ref_plucker(o, d), O.src_plucker(pts, scene['static_src_cameras'])
+  close(refc, g['plucker/ref']); close(srcc, g['plucker/src'])
+  c = scene['static_src_cameras'][0, :, -16:].reshape(-1, 4, 4)[:, :3, 3]
+  xyz = torch.linalg.cross(c[None, None].expand(pts.shape[0], S, -1, -1), srcc[..., :3], dim=-1)
+  assert (xyz - srcc[..., 3:]).abs().max() > 1e-2, 'the source moments of this shape equal the xyz product: the case pins nothing'
+  if o.shape[0] == 3:
+    assert (torch.linalg.cross(o, refc[:, :3], dim=-1) - refc[:, 3:]).abs().max() > 1e-3  # (the target camera sits near the origin: small moments)
+  ray_dir = F.normalize(d, dim=-1)
+  for aa, mr in ((1, 0), (0, 1)):
+    raw = O.static_net(W, pts, refc, srcc, rf, ray_dir, rd, mk, bool(aa), bool(mr))
+    close(raw, g[f'static_net/aa{aa}_mr{mr}/raw'])
+    if aa == 1:
+      check_group('vanilla_st/', O.raw2outputs_vanilla(raw, z, mk[..., 0].sum(dim=2) > 1), g)
+
+
 def test_stress_mv(golden_dir):
   """BASELINE configs[4]: the oracle's render_rays_mv at 16 + 16 views, 128 + 128 samples against the real reference's outputs."""
   g = load(golden_dir, 'stress_mv.npz')
