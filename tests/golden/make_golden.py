@@ -198,8 +198,9 @@ def sampler_goldens():
   print('sampler', len(out))
 
 
-def image_goldens():
-  """render_single_image_nvi on a tiny frame, 3 chunks (render_image.py:9-217)."""
+def image_goldens(chunk_size=80, fname='image_nvi.npz'):
+  """render_single_image_nvi on a tiny frame, 3 chunks (render_image.py:9-217).  chunk_size = 63: 192 pixels = 3 x 63 + 3, i.e. the frame ends in a
+  chunk of exactly 3 rays, whose Pluecker moments the reference crosses over the RAYS (render_ray.py:375, :392: torch.cross without dim)."""
   cfg = dict(seed=4, H=12, W=16, V=7, n_static=8, smooth=True)
   from dynibar_amd import synthetic as syn
   sc = syn.make_scene(**cfg); fine = syn.make_scene(**dict(cfg, tag=1))
@@ -214,7 +215,7 @@ def image_goldens():
   model = build_ref_model(weights, 64, 128, args)
   fidx, temb, toff = cases.time_args(7)
   with torch.no_grad():
-    ret = RI.render_single_image_nvi((fidx, None), (temb, None), (toff, None), smp, rb, model, PJ.Projector('cpu'), 80, 64, args,
+    ret = RI.render_single_image_nvi((fidx, None), (temb, None), (toff, None), smp, rb, model, PJ.Projector('cpu'), chunk_size, 64, args,
                                      inv_uniform=True, N_importance=64, det=True,
                                      coarse_featmaps=(scene['featmaps'], None, scene['static_featmaps']),
                                      fine_featmaps=(cases.t(fine['featmaps']), None, cases.t(fine['static_featmaps'])), is_train=False)
@@ -223,8 +224,8 @@ def image_goldens():
     for k, v in ret[grp].items():
       if isinstance(v, torch.Tensor):
         out[f'{grp}/{k}'] = npy(v)
-  np.savez_compressed(os.path.join(HERE, 'image_nvi.npz'), **out)
-  print('image', {k: v.shape for k, v in out.items()})
+  np.savez_compressed(os.path.join(HERE, fname), **out)
+  print('image', fname, {k: v.shape for k, v in out.items()})
 
 
 def stress_goldens():
@@ -530,6 +531,7 @@ if __name__ == '__main__':
     sys.exit(0)
   if 'cross_axis' in sys.argv[1:]:
     cross_axis_goldens()
+    image_goldens(63, 'image_nvi_tail3.npz')
     sys.exit(0)
   if 'mono_train_grad' in sys.argv[1:]:
     mono_train_grad_goldens()
@@ -567,3 +569,4 @@ if __name__ == '__main__':
   encoder_goldens()
   camera_format_goldens()
   cross_axis_goldens()
+  image_goldens(63, 'image_nvi_tail3.npz')

@@ -160,6 +160,16 @@ def test_render_single_image_nvi(dev, golden_dir):
   parity.check_render_image_nvi(dev, _golden(golden_dir, 'image_nvi.npz'))
 
 
+def test_render_single_image_nvi_with_a_three_ray_tail_chunk(dev, golden_dir):
+  """192 pixels in chunks of 63: the frame ends in a chunk of exactly 3 rays, whose Pluecker moments the reference crosses over the rays (torch.cross
+  without dim, render_ray.py:375 / :392) -- its last three pixels differ from the chunk-80 frame's by 0.01-0.035 in rgb.  The whole frame against the
+  REAL reference's frame rendered with that chunk size, every pixel."""
+  g80, g63 = _golden(golden_dir, 'image_nvi.npz'), _golden(golden_dir, 'image_nvi_tail3.npz')
+  d = np.abs(g80['outputs_coarse_ref/rgb'] - g63['outputs_coarse_ref/rgb']).reshape(-1, 3).max(axis=1)
+  assert d[:189].max() < 1e-6 and d[189:].min() > 5e-3, 'the golden pair no longer isolates the 3-ray tail'
+  parity.check_render_image_nvi(dev, g63, chunk_size=63)
+
+
 def test_frame_is_identical_on_one_two_and_three_chunk_streams(dev):
   assert parity.check_chunk_stream_invariance(dev) > 0
 
