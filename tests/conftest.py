@@ -45,7 +45,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
   out = os.path.join(ROOT, 'gpurun_out')
   try:
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, 'parity_margins.json'), 'w') as f:
+    import torch
+    # (a CPU session -- oracle and emulator checks -- keeps its own file: it must not overwrite the GPU suite's record, which profiles/ quotes)
+    with open(os.path.join(out, 'parity_margins.json' if torch.cuda.is_available() else 'parity_margins_cpu.json'), 'w') as f:
       json.dump({'margins': rows, 'chain_indices': parity.CHAIN_INDEX_REPORT}, f, indent=1)
   except OSError:
     pass

@@ -52,3 +52,7 @@ def test_ragged_rows_with_dark_colours(emu):
 def test_cross_axis_shapes(emu, golden_dir, name):
   """3 static source views (the reference's torch.cross runs over the views) and a chunk of 3 rays x 3 samples (over the rays, for both moments)."""
   parity.check_cross_axis(emu, dict(np.load(os.path.join(golden_dir, 'cross_axis.npz'))), name)
+
+
+def test_accuracy_against_double(emu):
+  parity.check_accuracy_against_double(emu, 'small', S=16, R=2)

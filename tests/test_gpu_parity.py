@@ -81,6 +81,14 @@ def test_cross_axis_shapes_follow_the_reference(dev, golden_dir, name):
   parity.check_cross_axis(dev, dict(np.load(os.path.join(golden_dir, 'cross_axis.npz'))), name)
 
 
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=64), dict(name='noise', S=64), dict(name='small', S=64, weights='trained'),
+                                dict(name='kid', S=64, aa=False, mask_rgb=True), dict(name='harsh_many', S=64, R=24, weights='trained')])
+def test_accuracy_against_float64(dev, kw):
+  """A check without a tolerance chosen for the kernels: the static pass against the EXACT (float64) values of the reference's formulas, held to twice
+  the fp32 reference's own distance from them (largest error and 99th percentile, per output)."""
+  parity.check_accuracy_against_double(dev, **kw)
+
+
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
