@@ -654,8 +654,12 @@ __device__ __forceinline__ DenseRows ragged_rows(int V, const unsigned short* ro
 }
 
 // ---- the plan of a ragged launch ----
-// e of the anti-alias pooling weight (mlp_network.py:463-466); one function so that the plan's minimum over all views and the rows' own values are the same bits
-__device__ __forceinline__ float aa_exp(float s_abs, float dot) { return expf(s_abs * (dot - 1.0f)); }
+// e - 1 of the anti-alias pooling weight (mlp_network.py:463-466); one function so that the plan's minimum over all views and the rows' own values are the same bits.
+// The reference forms (e_v - min_v e) with e = exp(|s| (dot - 1)) ~ 1: a difference of nearly equal numbers whose fp32 roundings (6e-8 each, more with a 1-ulp exp) are
+// all of its error -- 1e-3 relative on weights of 1e-5 apart, and what tests/parity.check_static_net's conditioning allowance is for.  expm1(a_v) - min_v expm1(a) is the
+// same difference without the rounding of e: against the float64 values of the reference's formula the density logits of a trained-scale net moved from 3 x the fp32
+// reference's own error to below it (tools/fp64_probe.py).
+__device__ __forceinline__ float aa_exp(float s_abs, float dot) { return expm1f(s_abs * (dot - 1.0f)); }
 
 // one block = 256 consecutive points: their V masks and V ray_diff records are contiguous runs, read coalesced (16 bytes per lane for the records) and parked in LDS,
 // then one thread per point walks its V entries there (a thread per point reading its own 44-byte / 176-byte strided runs took ~100 us per call)

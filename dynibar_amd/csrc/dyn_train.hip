@@ -1518,11 +1518,12 @@ __global__ void __launch_bounds__(256) k_train_view_weights(int mode, const floa
   if (mode == 0) {
     if (s_param != nullptr) {
       const float sa = fabsf(s_param[0]);
+      // e_v - min e as expm1(a_v) - min expm1(a): the same difference, without rounding e ~ 1 to 6e-8 first (dyn_nets.hip, aa_expm1)
       float mn = INFINITY;
-      for (int v = 0; v < V; ++v) mn = fminf(mn, expf(sa * (in[(r0 + v) * in_stride] - 1.0f)));
+      for (int v = 0; v < V; ++v) mn = fminf(mn, expm1f(sa * (in[(r0 + v) * in_stride] - 1.0f)));
       float sum = 0.f;
-      for (int v = 0; v < V; ++v) sum += (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
-      for (int v = 0; v < V; ++v) w[r0 + v] = (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v] / (sum + 1e-8f);
+      for (int v = 0; v < V; ++v) sum += (expm1f(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
+      for (int v = 0; v < V; ++v) w[r0 + v] = (expm1f(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v] / (sum + 1e-8f);
     } else {
       float sum = 0.f;
       for (int v = 0; v < V; ++v) sum += mask[r0 + v];
@@ -1563,11 +1564,11 @@ __global__ void __launch_bounds__(256) k_train_view_weights_bwd(int mode, const 
       float mn = INFINITY, U = 0.f, dot = 0.f;
       int amin = 0;
       for (int v = 0; v < V; ++v) {
-        const float e = expf(sa * (in[(r0 + v) * in_stride] - 1.0f));
+        const float e = expm1f(sa * (in[(r0 + v) * in_stride] - 1.0f));
         if (e < mn) { mn = e; amin = v; }
       }
       for (int v = 0; v < V; ++v) {
-        U += (expf(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
+        U += (expm1f(sa * (in[(r0 + v) * in_stride] - 1.0f)) - mn) * mask[r0 + v];
         dot += dw[r0 + v] * w[r0 + v];
       }
       // d/d|s| of u_v = (e_v - e_min) m_v is (e_v x_v - e_min x_min) m_v, x = dot - 1: formed per view as one difference of
