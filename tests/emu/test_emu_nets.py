@@ -56,3 +56,7 @@ def test_cross_axis_shapes(emu, golden_dir, name):
 
 def test_accuracy_against_double(emu):
   parity.check_accuracy_against_double(emu, 'small', S=16, R=2)
+
+
+def test_dual_branch_accuracy_against_double(emu):
+  parity.check_dual_accuracy_against_double(emu, 'small', S=16, R=2)

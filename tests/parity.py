@@ -443,11 +443,17 @@ def check_accuracy_against_double(device, name='small', S=64, R=None, weights='i
   net = ops.StaticNet(_weights(weights)['net_coarse_st'], device, aa, mask_rgb)
   out, raw = run_static_pass(device, to_dev(scene, device), net, o.float().to(device), d.float().to(device), S)
   ours = dict(raw=cpu(raw), rgb=cpu(out['rgb']), depth=cpu(out['depth']), weights=cpu(out['weights']))
+  return _accuracy_table(f'{name}, {weights} weights, S={S}', ('rgb', 'weights', 'depth', 'raw'), ours, v32, v64, keep, sigma_in=('raw',))
+
+
+def _accuracy_table(tag, keys, ours, v32, v64, keep, sigma_in=()):
+  """per output: the kernels' and the fp32 oracle's absolute error against the float64 oracle (largest, 99th, 90th percentile over the kept rays); the
+  kernels are held to twice the fp32 oracle's figures plus 2e-6 of the output's scale"""
   table = {}
-  for k in ('rgb', 'weights', 'depth', 'raw'):
+  for k in keys:
     t64 = v64[k][keep]
     live = torch.ones_like(t64, dtype=torch.bool)
-    if k == 'raw':
+    if k in sigma_in:
       live = live & (t64[..., 3:4] > -1e8)  # points without a valid view: sigma is the constant -1e9 on all three sides (checked elsewhere)
     e_ref = ((v32[k][keep].double() - t64).abs())[live]
     e_our = ((ours[k][keep].double() - t64).abs())[live]
@@ -455,14 +461,36 @@ def check_accuracy_against_double(device, name='small', S=64, R=None, weights='i
     q = lambda e, p=0.99: float(torch.quantile(e.flatten()[:: max(1, e.numel() // 200000)], p))
     table[k] = dict(scale=scale, ref_max=float(e_ref.max()), ours_max=float(e_our.max()), ref_p99=q(e_ref), ours_p99=q(e_our), ref_p90=q(e_ref, 0.9), ours_p90=q(e_our, 0.9))
     floor = 2e-6 * max(scale, 1.0)
-    record_margin(f'{name} ({weights}) {k}: error against float64, kernels vs twice the fp32 reference\'s own (max)', torch.tensor([table[k]['ours_max']]),
+    record_margin(f'{tag} {k}: error against float64, kernels vs twice the fp32 reference\'s own (max)', torch.tensor([table[k]['ours_max']]),
                   torch.tensor([2.0 * table[k]['ref_max'] + floor]))
-    assert table[k]['ours_max'] <= 2.0 * table[k]['ref_max'] + floor, f'{name} {k}: kernels {table[k]["ours_max"]:.3e} from the exact value, the fp32 reference {table[k]["ref_max"]:.3e}'
-    assert table[k]['ours_p99'] <= 2.0 * table[k]['ref_p99'] + floor, f'{name} {k} (99th percentile): kernels {table[k]["ours_p99"]:.3e}, the fp32 reference {table[k]["ref_p99"]:.3e}'
-    assert table[k]['ours_p90'] <= 2.0 * table[k]['ref_p90'] + floor, f'{name} {k} (90th percentile): kernels {table[k]["ours_p90"]:.3e}, the fp32 reference {table[k]["ref_p90"]:.3e}'
-  print(f'  accuracy against float64 [{name}, {weights} weights, S={S}]: ' + '; '.join(
+    # (a sample of a few dozen points -- the emulator's cases -- is held to its 90th percentile only: the largest of 32 heavy-tailed errors says nothing)
+    for stat in (('max', 'p99', 'p90') if e_ref.numel() >= 2000 else ('p90',)):
+      assert table[k]['ours_' + stat] <= 2.0 * table[k]['ref_' + stat] + floor, (
+          f'{tag} {k} ({stat}): kernels {table[k]["ours_" + stat]:.3e} from the exact value, the fp32 reference {table[k]["ref_" + stat]:.3e}')
+  print(f'  accuracy against float64 [{tag}]: ' + '; '.join(
       f'{k}: ours max {v["ours_max"]:.2e} p99 {v["ours_p99"]:.2e} | reference fp32 max {v["ref_max"]:.2e} p99 {v["ref_p99"]:.2e}' for k, v in table.items()))
   return table
+
+
+def check_dual_accuracy_against_double(device, name='small', S=64, R=None, weights='init', shift=5.0):
+  """The same for both branches together: gather at the (given) motion-displaced points -> DynibarDynamic, gather -> DynibarStatic, raw2outputs (the
+  two-branch compositing) -- inference kernels against the float64 oracle, held to twice the fp32 oracle's own error."""
+  di, v32, _, _, keep = train_dual_reference(name, S, R, weights, shift)
+  _, v64, _, _, keep64 = train_dual_reference(name, S, R, weights, shift, dtype=torch.float64)
+  keep = keep & keep64
+  assert int(keep.sum()) > 0
+  sc = to_dev(di['scene'], device)
+  views_dy = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], sc['featmaps'])
+  views_st = ops.SourceViews(sc['camera'], sc['static_src_rgbs'], sc['static_src_cameras'], sc['static_featmaps'])
+  od, dd, pts, pts_seq, z = (di[k].to(device) for k in ('o', 'd', 'pts', 'pts_seq', 'z'))
+  Rn = od.shape[0]
+  rf, _, mk, pm_dy = ops.project_gather(views_dy, Rn, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0)
+  rfs, rds, mks, pm_st = ops.project_gather(views_st, Rn, S, ray_o=od, ray_d=dd, z_vals=z, pix_mask_thresh=1.0)
+  raw_dy = ops.DynamicNet(_weights(weights)['net_coarse_dy'], device, shift=shift)(dd, pts, rf, mk, di['temb'].to(device))
+  raw_st = ops.StaticNet(_weights(weights)['net_coarse_st'], device, True, False)(views_st, od, dd, pts, rfs, rds, mks)
+  out = ops.composite(raw_dy, z, pm_dy, raw_static=raw_st, pix_mask_st=pm_st)
+  ours = dict(raw_dy=cpu(raw_dy), rgb=cpu(out['rgb']), rgb_dy=cpu(out['rgb_dy']), weights=cpu(out['weights']), weights_dy=cpu(out['weights_dy']))
+  return _accuracy_table(f'dual {name}, {weights} weights, S={S}', ('rgb', 'rgb_dy', 'weights', 'weights_dy', 'raw_dy'), ours, v32, v64, keep, sigma_in=('raw_dy',))
 
 
 def check_static_pass_bench_shape_every_ray(device, R=4096, S=64, V=8, block=1024):
@@ -2126,7 +2154,7 @@ def train_dual_reference(name, S, R, weights='init', shift=5.0, seed=0, dtype=to
   grads.update({'st/' + k: v.grad.detach() for k, v in sd_st.items()})
   grads['featmaps_dy'], grads['featmaps_st'] = fm_dy.grad.detach(), fm_st.grad.detach()
   vals = {k: out[k].detach() for k in ('rgb', 'rgb_dy', 'weights', 'weights_dy')}
-  vals['raw_dy'] = raw_dy.detach()
+  vals['raw_dy'], vals['raw_st'] = raw_dy.detach(), raw_st.detach()
   return di, vals, cot, grads, keep
 
 

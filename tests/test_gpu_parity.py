@@ -89,6 +89,13 @@ def test_accuracy_against_float64(dev, kw):
   parity.check_accuracy_against_double(dev, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=48, R=4), dict(name='train_large', S=32, R=96, weights='trained'),
+                                dict(name='stress', S=128, R=3)])
+def test_dual_branch_accuracy_against_float64(dev, kw):
+  """Both branches and the two-branch compositing against the float64 oracle, held to twice the fp32 oracle's own error (no tolerance of ours)."""
+  parity.check_dual_accuracy_against_double(dev, **kw)
+
+
 @pytest.mark.parametrize('name', ['small', 'harsh', 'noise'])
 def test_static_pass(dev, name):
   parity.check_static_pass(dev, name)
