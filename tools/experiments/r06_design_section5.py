@@ -18,7 +18,9 @@ bench line, `r06_bench_kernel_stats.txt` / `r06_frame_kernel_stats.txt` = rocpro
 ({sum(pw['package_power_w']) / 3:.0f} W of the 1400 W cap at {sum(pw['shader_clock_mhz']) / 3000:.2f} GHz under the step loop); CPU oracle on the same box {d['cpu_baseline']['value']:.0f} rays/s (a port, {d['cpu_baseline']['cores']} threads); colours vs the
 oracle {d['check_vs_oracle']['max_abs_rgb_err']:.2e} ({d['check_vs_oracle']['psnr_db']:.0f} dB).  **The exact 6-term engine** (`libdynibar_hip_x6.so`, timed by default since round 6): {d['x6_engine']['value'] / 1e6:.3f} M rays/s, {d['x6_engine']['ms_per_step']:.3f} ms per step =
 **{r['x6_over_shipped_time']:.2f} ×** the shipped step, `k_static_views` {d['x6_engine']['k_static_views_ms']:.2f} ms = {d['x6_engine']['roofline_frac_of_its_own_peak']:.2f} of ITS ceiling (2500 / 6), the same {d['x6_engine']['max_abs_rgb_err_vs_oracle']:.2e} against the oracle: fp32-class products cost 70 % more time and buy nothing
-the 1e-4 contract can see.
+the 1e-4 contract can see.  (The box decides ±4 % of this line: the same kernels on the faster boxes of the round — collection of commit `50704b9`: 1.547 M rays/s, 2.648 ms per step at 2.01 GHz,
+`k_static_views` 1739 µs = 0.50, blend 322 µs = 0.50, frame 630 ms; the A/B session of call 31 (`r06_ab_variants.txt`): 2.574 ms per step, `k_static_views` 1665 µs, frame 634 ms.  The two source changes
+since — the `torch.cross` axis and the `expm1` pooling weights — cost nothing in same-box A/B, calls 23 and 31.)
 
 | kernel | avg µs per launch, HIP events (rocprofv3 `r06_bench_kernel_stats.txt`) | roofline | round 5 (same measure) |
 |---|---|---|---|
