@@ -358,20 +358,42 @@ def _side_streams(dev, n):
 BALANCED_CHUNKS = os.environ.get('DYNIBAR_BALANCED_CHUNKS', 'tiled')  # 'tiled': when the frame is tiled across ranks; 'always'; 'never'
 
 
-def chunk_bounds(lo, hi, chunk_size, balanced):
+def chunk_bounds(lo, hi, chunk_size, balanced, n_rays=None):
   """[(a, b)] covering [lo, hi).  The reference walks range(lo, hi, chunk_size) (render_image.py:68): a rank's tile of 18 432 rays at chunk_size 8192
   would render as 8192 + 8192 + 2048, and the 2048-ray tail pays the full start-up of the one-workgroup-per-CU kernels for a quarter of the rays.
-  Balanced: the same NUMBER of chunks, equal sizes rounded up to 64 rays (18 432 -> 3 x 6144); results do not depend on the chunking (every ray is
-  independent: tests/test_distributed_cpu.py, the chunk-invariance GPU test), only the per-chunk lists of 4-D entries change their split points,
-  and under tiling those are rank-local already."""
+  Balanced: the same NUMBER of chunks, equal sizes rounded up to 64 rays (18 432 -> 3 x 6144); only the per-chunk lists of 4-D entries change their
+  split points, and under tiling those are rank-local already.
+  Results do not depend on the chunking -- every ray is independent (tests/test_distributed_cpu.py, the chunk-invariance GPU test) -- with ONE exception
+  that is the reference's own: a chunk of exactly 3 rays has its Pluecker moments crossed over the rays (torch.cross without dim, render_ray.py:375 /
+  :392; csrc/dyn_device.h).  With ``n_rays`` (the frame's ray count) a walk that differs from the reference's -- a rank's tile, balanced chunks --
+  therefore keeps the reference's 3-ray tail (n_rays = 3 mod chunk_size) as a chunk of its own when the tile holds it, and never forms another chunk
+  of exactly 3 rays (it joins its neighbour: 3 rays above chunk_size, or is rendered as 2 + 1)."""
   n = hi - lo
   if n <= 0:
     return []
   if not balanced or n <= chunk_size:
-    return [(i, min(i + chunk_size, hi)) for i in range(lo, hi, chunk_size)]
-  k = (n + chunk_size - 1) // chunk_size
-  size = min(chunk_size, ((n + k - 1) // k + 63) // 64 * 64)
-  return [(i, min(i + size, hi)) for i in range(lo, hi, size)]
+    bounds = [(i, min(i + chunk_size, hi)) for i in range(lo, hi, chunk_size)]
+  else:
+    k = (n + chunk_size - 1) // chunk_size
+    size = min(chunk_size, ((n + k - 1) // k + 63) // 64 * 64)
+    bounds = [(i, min(i + size, hi)) for i in range(lo, hi, size)]
+  if n_rays is None or chunk_size == 3 or (not balanced and lo == 0 and hi == n_rays):
+    return bounds  # the reference's own walk (or a caller that does not say which frame this is)
+  tail = (n_rays - 3, n_rays) if n_rays % chunk_size == 3 else None
+  if tail is not None and hi == n_rays and lo <= tail[0]:
+    bounds = (chunk_bounds(lo, tail[0], chunk_size, balanced) if lo < tail[0] else []) + [tail]
+  else:
+    tail = None  # (not in this tile, or cut by the tile's edge: its rays are then rendered like any others)
+  out = []
+  for a, b in bounds:
+    if b - a == 3 and (a, b) != tail:
+      if out and out[-1] != tail:
+        out[-1] = (out[-1][0], b)
+      else:
+        out += [(a, a + 2), (a + 2, b)]
+    else:
+      out.append((a, b))
+  return out
 
 
 def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
@@ -383,7 +405,7 @@ def _render_tiles(ray_batch, chunk_size, render_chunk, group_names):
     lo, hi = 0, 1  # an empty tile still joins the collectives: render one placeholder ray for the key / shape structure, contribute none
   chunks = {g: [] for g in group_names}
   balanced = BALANCED_CHUNKS == 'always' or (BALANCED_CHUNKS == 'tiled' and world > 1)
-  bounds = chunk_bounds(lo, hi, chunk_size, balanced)
+  bounds = chunk_bounds(lo, hi, chunk_size, balanced, n_rays=n_rays)
   t0 = _clock() if FRAME_STATS is not None else 0.0
   # per-chunk device times from stream events (no synchronisation inside the loop: a host clock per chunk exposes the launch latency of every
   # chunk's first kernels -- 18 x 2.4 ms of a 730 ms frame when it was tried)

@@ -264,3 +264,32 @@ def test_balanced_chunks_cover_the_tile_without_a_short_tail():
       assert len(b) == -(-(hi - lo) // cs)
     sizes = [y - x for x, y in chunk_bounds(lo, hi, cs, True)]
     assert max(sizes) - min(sizes) <= 64 + (max(sizes) - sizes[-1])  # equal up to the 64-ray rounding; only the last chunk may be shorter
+
+
+def test_chunk_walks_that_differ_from_the_reference_keep_its_three_ray_tail_and_make_no_other():
+  """A chunk of exactly 3 rays is the one place where the reference's result depends on the chunking (torch.cross without dim crosses the Pluecker
+  moments over the rays).  A rank's tile / balanced chunks keep the reference's own 3-ray tail as a chunk and never form another chunk of 3 rays."""
+  from dynibar_amd.render_image import chunk_bounds, ray_tile
+  # the reference's own walk is left alone, 3-ray tail included
+  assert chunk_bounds(0, 8195, 8192, False, n_rays=8195) == [(0, 8192), (8192, 8195)]
+  # two ranks: the second rank's tile ends in the reference's tail -- kept as its own chunk, also with balanced chunks
+  lo, hi, _ = ray_tile(24579, 2, 1)
+  for bal in (False, True):
+    b = chunk_bounds(lo, hi, 8192, bal, n_rays=24579)
+    assert (24579) % 8192 == 3 and b[-1] == (24579 - 3, 24579) and b[0][0] == lo and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert [y - x for x, y in b].count(3) == 1
+  # a tile whose own walk would end in 3 rays that are NOT the reference's tail: they join the previous chunk
+  assert chunk_bounds(1000, 1131, 64, False, n_rays=5000) == [(1000, 1064), (1064, 1131)]
+  assert chunk_bounds(1000, 1131, 64, True, n_rays=5000) == [(1000, 1064), (1064, 1131)]
+  # a tile of exactly 3 rays that are not the reference's tail: 2 + 1
+  assert chunk_bounds(10, 13, 64, True, n_rays=5000) == [(10, 12), (12, 13)]
+  # the whole frame is 3 rays: the reference's only chunk
+  assert chunk_bounds(0, 3, 64, True, n_rays=3) == [(0, 3)]
+  for n_rays, world, cs in ((8195, 3, 512), (1027, 4, 256), (147456, 8, 8192), (67, 5, 16), (35, 8, 8)):
+    for rank in range(world):
+      lo, hi, _ = ray_tile(n_rays, world, rank)
+      for bal in (False, True):
+        b = chunk_bounds(lo, hi, cs, bal, n_rays=n_rays)
+        assert (not b and hi == lo) or (b[0][0] == lo and b[-1][1] == hi and all(x[1] == y[0] for x, y in zip(b, b[1:])))
+        threes = [x for x in b if x[1] - x[0] == 3]
+        assert all(x == (n_rays - 3, n_rays) and n_rays % cs == 3 for x in threes), (n_rays, world, cs, rank, bal, b)
