@@ -425,11 +425,18 @@ def main():
       smp, rb = fc.sampler()
       fc.render(smp, rb)  # warm-up: packs the six networks, prepares the source views
       fence()
-      render_image.FRAME_STATS = {}  # opt-in stage clocks of the next frame (they synchronise the device between the stages)
-      t0 = time.perf_counter()
+      # three timed frames, the median counts (single frames of one session spread by several per cent, with an occasional +10 % outlier) ...
+      frame_times = []
+      for _ in range(1 if dry else 3):
+        t0 = time.perf_counter()
+        ret = fc.render(smp, rb)
+        fence()
+        frame_times.append(max_over_ranks(time.perf_counter() - t0))
+      fdt = sorted(frame_times)[len(frame_times) // 2]
+      # ... and one more for the opt-in stage clocks (they synchronise the device between the stages, so that frame is not the timed one)
+      render_image.FRAME_STATS = {}
       ret = fc.render(smp, rb)
       fence()
-      fdt = max_over_ranks(time.perf_counter() - t0)
       fst, render_image.FRAME_STATS = render_image.FRAME_STATS, None
       fk = {}
       if lib is not None:
@@ -449,7 +456,7 @@ def main():
       extra['frame_nvi_288x512'] = {
           'what': 'ONE render_single_image_nvi call (BASELINE configs[2]): 147456 rays, 64 coarse + 64 fine samples, 7 dynamic + 11 static views, chunk 8192; '
                   + ('rays tiled over %d ranks, one packed [rays,5] all-gather: strong scaling' % world if world > 1 else 'one GPU'),
-          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'rays_per_s': n_frame_rays / fdt, 'gather': render_image.GATHER if multi_rank else None,
+          'n_gpus': world, 'ms_per_frame': fdt * 1e3, 'ms_per_frame_each': [round(t * 1e3, 2) for t in frame_times], 'rays_per_s': n_frame_rays / fdt, 'gather': render_image.GATHER if multi_rank else None,
           'chunk_streams': getattr(render_image, 'CHUNK_STREAMS', 1),
           'per_rank': {'tile_rays': [int(v) for v in every_rank(fst.get('tile_rays', 0))],
                        'render_ms': [round(v, 3) for v in every_rank(fst.get('render_ms', 0.0))],
