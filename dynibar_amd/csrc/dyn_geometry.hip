@@ -350,11 +350,33 @@ __device__ __forceinline__ Taps make_taps(float nx, float ny, int Wm, int Hm) {
   return t;
 }
 
+// ---- compute_traj_pts fused into the consumers of the displaced points (render_ray.py:361-369, :691-725) ----------------------------------------------
+// A point seen at the time of basis row `row` is p + (traj(row) - traj(ref)), traj(row)[a] = sum_b c[a B + b] basis[row, b] (row < 0: the undisplaced point).
+// ONE function for k_trajectory_points (which materialises [V,R,S,3] for callers of the reference's helper and for training), for the gather kernels'
+// fused form (the array never exists) and for the flows: the same sums in the same order, so the three agree bit for bit.
+struct PGTraj {
+  const float* coeff;  // [R,S,3 B] or nullptr
+  const float* basis;  // [frames, B]
+  const int* rows;     // device [V]
+  int B, ref;
+};
+__device__ __forceinline__ void traj_displace(const float* __restrict__ c, const float* __restrict__ basis, int B, int row, int ref, float& x, float& y, float& z) {
+  if (row < 0) return;
+  float d[3];
+  for (int a = 0; a < 3; ++a) {
+    float t0 = 0.f, s = 0.f;
+    for (int b = 0; b < B; ++b) t0 += c[a * B + b] * basis[(long)ref * B + b];
+    for (int b = 0; b < B; ++b) s += c[a * B + b] * basis[(long)row * B + b];
+    d[a] = s - t0;
+  }
+  x = x + d[0]; y = y + d[1]; z = z + d[2];
+}
+
 __global__ void __launch_bounds__(PG_THREADS, PG_OCC)
 k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __restrict__ ray_d, const float* __restrict__ z_vals,
                  const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
                  const float* __restrict__ query_center, const float* __restrict__ src_rgb, const float4* __restrict__ feat4,
-                 float* __restrict__ rgb_feat, float4* __restrict__ ray_diff, float* __restrict__ mask) {
+                 float* __restrict__ rgb_feat, float4* __restrict__ ray_diff, float* __restrict__ mask, PGTraj tj) {
   const int lane = dyn_lane();
   // XCD-aware task id: the (b / 8)-th workgroup of XCD (b % 8) takes tasks from that XCD's contiguous range
   const long wg = blockIdx.x;
@@ -394,6 +416,8 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
   if (xyz != nullptr) {
     const long o = ((long)v * q.R * q.S + rs) * 3;
     x = xyz[o]; y = xyz[o + 1]; z3 = xyz[o + 2];
+  } else if (tj.coeff != nullptr) {
+    traj_displace(tj.coeff + (long)rs * 3 * tj.B, tj.basis, tj.B, tj.rows[v], tj.ref, x, y, z3);
   }
   const float4 P0 = proj4[v * 4], P1 = proj4[v * 4 + 1], P2 = proj4[v * 4 + 2], P3 = proj4[v * 4 + 3];
   const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
@@ -423,7 +447,7 @@ k_project_gather(PGShape q, const float* __restrict__ ray_o, const float* __rest
     normalize3(P3.x - x, P3.y - y, P3.z - z3, bx, by, bz);
     normalize3(ax - bx, ay - by, az - bz, dx, dy, dz);
     if (has) {
-      nt_store4<1>(ray_diff + g, make_float4(dx, dy, dz, ax * bx + ay * by + az * bz));
+      if (ray_diff != nullptr) nt_store4<1>(ray_diff + g, make_float4(dx, dy, dz, ax * bx + ay * by + az * bz));
       nt_store1<1>(mask + g, (inb && (hz > 0.f)) ? 1.0f : 0.0f);
       f32x3u o3;
       o3.x = fmaf(d.x, t.w_se, fmaf(c.x, t.w_sw, fmaf(b.x, t.w_ne, a.x * t.w_nw)));
@@ -531,7 +555,7 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
                                       const float* __restrict__ pts_st, const float* __restrict__ xyz, const float4* __restrict__ proj4,
                                       const float* __restrict__ query_center, const float* __restrict__ src_rgb, const float4* __restrict__ feat4,
                                       float* __restrict__ rgb_feat, float4* __restrict__ ray_diff, float* __restrict__ mask,
-                                      float* __restrict__ pix_mask) {
+                                      float* __restrict__ pix_mask, PGTraj tj) {
   constexpr int VPW = 64 / P;  // views per wave
   float* tile = reinterpret_cast<float*>(dyn_smem);
   const int lane = dyn_lane(), wave = dyn_wave();
@@ -570,6 +594,24 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   const int vv = v < V ? v : V - 1;            // idle lanes shadow a real row: their loads stay in bounds, their results are dropped
   const unsigned rs = (unsigned)(tile_live ? (pt < q.n_pts ? pt : q.n_pts - 1) : 0);
 
+  // the fused trajectory form: the tile's P x 3 B motion coefficients are one contiguous run -- read once, coalesced, and parked in LDS behind the tile's own
+  // regions at an odd point stride (a lane reading its point's 18 values straight from global memory touches ten cache lines per load instruction: the gather of
+  // the 7 dynamic views ran 11 % slower that way than on the materialised [V,R,S,3] array)
+  const float* tj_c = nullptr;
+  if (tj.coeff != nullptr) {
+    // (every wave parks its own copy: its lanes are all P points x its views, and a wave needs no workgroup barrier for its own LDS words)
+    const int C3 = 3 * tj.B, CS = C3 | 1;
+    float* cst = tile + P * V * (C + 5) + wave * (P * CS);
+    if (tile_live) {
+      const long n_here = (q.n_pts - p0 < P ? q.n_pts - p0 : P) * C3;
+      for (int e = lane; e < n_here; e += 64) cst[(e / C3) * CS + (e % C3)] = tj.coeff[p0 * C3 + e];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed (a wave runs in lock step)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    tj_c = cst + (pt < q.n_pts ? pl : 0) * CS;
+  }
   // ---- phase 1: lane = (point, view) ----
   const unsigned r = fast_div(rs, (unsigned)q.S, q.mS);
   float sx, sy, sz;
@@ -585,6 +627,9 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   if (xyz != nullptr) {
     const long o = ((long)vv * q.n_pts + rs) * 3;
     x = xyz[o]; y = xyz[o + 1]; z3 = xyz[o + 2];
+  } else if (tj.coeff != nullptr) {
+    // the displaced point is formed here from the point's 3 B motion coefficients (LDS: the lanes of a point's views read the same words) and two basis rows
+    if (tile_live) traj_displace(tj_c, tj.basis, tj.B, tj.rows[vv], tj.ref, x, y, z3);
   }
   const float4 P0 = proj4[vv * 4], P1 = proj4[vv * 4 + 1], P2 = proj4[vv * 4 + 2], P3 = proj4[vv * 4 + 3];
   const float hx = fmaf(P0.w, 1.0f, fmaf(P0.z, z3, fmaf(P0.y, y, P0.x * x)));
@@ -677,7 +722,8 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   {
     const int nrow = (int)npt * V;
     float4* dst4 = ray_diff + p0 * V;
-    for (int i = tid; i < nrow; i += nthr) nt_store4<1>(dst4 + i, rdt[i]);
+    if (ray_diff != nullptr)  // (the dynamic branch never reads it: DynibarDynamic takes no ray_diff -- 16 of its 160 output bytes per point-view stay home)
+      for (int i = tid; i < nrow; i += nthr) nt_store4<1>(dst4 + i, rdt[i]);
     float* dm = mask + p0 * V;  // p0 * V * 4 bytes: 16-byte aligned
     const float4* m4 = reinterpret_cast<const float4*>(mkt);
     for (int i = tid; i < (nrow >> 2); i += nthr) nt_store4<1>(reinterpret_cast<float4*>(dm) + i, m4[i]);
@@ -690,6 +736,11 @@ __global__ void k_project_gather_tile(PGTile q, const float* __restrict__ ray_o,
   }
 }
 
+static PGTraj pg_traj_of(const DynProjectGatherParams* p) {
+  PGTraj tj;
+  tj.coeff = p->traj_coeff; tj.basis = p->traj_basis; tj.rows = p->traj_rows; tj.B = p->traj_B; tj.ref = p->traj_ref;
+  return tj;
+}
 static int project_gather_rows(const DynProjectGatherParams* p, void* stream) {
   PGShape q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
@@ -705,7 +756,7 @@ static int project_gather_rows(const DynProjectGatherParams* p, void* stream) {
   DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather, dim3((unsigned)nblocks), dim3(PG_THREADS),
              PG_STAGE ? (size_t)(PG_THREADS / 64) * 64 * (3 + p->F) * sizeof(float) : 0, (hipStream_t)stream, q,
              p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
-             reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask);
+             reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, pg_traj_of(p));
   if (p->pix_mask != nullptr) return dyn_sample_mask(p->mask, p->R * p->S, p->V, p->pix_mask_thresh, p->pix_mask, stream);
   return 0;
 }
@@ -714,9 +765,11 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   DYN_REQUIRE(p, "dyn_project_gather: null params");
   DYN_REQUIRE(p->R > 0 && p->S > 0 && p->V > 0, "dyn_project_gather: empty problem");
   DYN_REQUIRE(p->F > 0 && (p->F % 4) == 0 && p->F <= 256, "dyn_project_gather: F must be a multiple of 4 (<=256)");
-  DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->ray_diff && p->mask,
+  DYN_REQUIRE(p->proj && p->query_center && p->src_rgb && p->feat_cl && p->rgb_feat && p->mask,
               "dyn_project_gather: null pointer");
   DYN_REQUIRE(p->pts_st != nullptr || (p->ray_o && p->ray_d && p->z_vals), "dyn_project_gather: need pts_st or (ray_o, ray_d, z_vals)");
+  DYN_REQUIRE(p->traj_coeff == nullptr || (p->xyz == nullptr && p->pts_st != nullptr && p->traj_basis != nullptr && p->traj_rows != nullptr && p->traj_B > 0 && p->traj_ref >= 0),
+              "dyn_project_gather: the fused trajectory form needs pts_st, traj_basis, traj_rows (device), traj_B > 0, traj_ref >= 0 and no xyz");
   DYN_REQUIRE(p->H > 1 && p->W > 1 && p->Hf > 1 && p->Wf > 1, "dyn_project_gather: maps must be at least 2x2");
   const long N = (long)p->R * p->S * p->V;
   DYN_REQUIRE(N < (1L << 31) && (long)p->V * p->H * p->W * 3 < (1L << 31) && (long)p->V * p->Hf * p->Wf * p->F < (1L << 31),
@@ -735,8 +788,9 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   DYN_REQUIRE(force_p == 0 || force_p == 8 || force_p == 16 || force_p == 32 || force_p == 64, "dyn_project_gather: DYN_PG_P must be 8, 16, 32 or 64 (got %d)", force_p);
   const int P = force_p ? force_p : PGT_DEFAULT_P;
   const int waves = (p->V * P + 63) / 64;
-  const size_t lds = (size_t)P * p->V * (C + 5) * sizeof(float);
+  const size_t lds = ((size_t)P * p->V * (C + 5) + (p->traj_coeff != nullptr ? (size_t)waves * P * ((3 * p->traj_B) | 1) : 0)) * sizeof(float);
   if (legacy || waves > 16 || lds > 160 * 1024 || (64 % (p->F / 4)) != 0) return project_gather_rows(p, stream);
+  const PGTraj tj = pg_traj_of(p);
   PGTile q;
   q.R = p->R; q.S = p->S; q.V = p->V; q.H = p->H; q.W = p->W; q.Hf = p->Hf; q.Wf = p->Wf; q.F = p->F;
   q.img_h = p->img_h; q.img_w = p->img_w;
@@ -756,19 +810,19 @@ extern "C" int dyn_project_gather(const DynProjectGatherParams* p, void* stream)
   if (P == 8)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<8>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
-               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask, tj);
   else if (P == 16)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<16>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
-               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask, tj);
   else if (P == 64)
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<64>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
-               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask, tj);
   else
     DYN_LAUNCH(DYN_K_PROJECT_GATHER, "dyn_project_gather", k_project_gather_tile<32>, dim3((unsigned)nblocks), dim3(waves * 64), lds, (hipStream_t)stream, q,
                p->ray_o, p->ray_d, p->z_vals, p->pts_st, p->xyz, reinterpret_cast<const float4*>(p->proj), p->query_center, p->src_rgb,
-               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask);
+               reinterpret_cast<const float4*>(p->feat_cl), p->rgb_feat, reinterpret_cast<float4*>(p->ray_diff), p->mask, p->pix_mask, tj);
   return 0;
 }
 
@@ -1105,25 +1159,12 @@ __global__ void __launch_bounds__(256) k_trajectory_points(const float* __restri
   for (int e = tid; e < np * 3; e += 256) ps[e] = pts[i0 * 3 + e];
   __syncthreads();
   const float* c = cs + tid * CS;
-  float t0[3];
-  for (int a = 0; a < 3; ++a) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += c[a * B + b] * basis[(long)tr.ref * B + b];
-    t0[a] = s;
-  }
   for (int v0 = 0; v0 < tr.n; v0 += TRAJ_GROUP) {
     const int nv = tr.n - v0 < TRAJ_GROUP ? tr.n - v0 : TRAJ_GROUP;
     for (int vv = 0; vv < nv; ++vv) {
-      const int row = tr.rows[v0 + vv];
-      for (int a = 0; a < 3; ++a) {
-        float q = ps[tid * 3 + a];
-        if (row >= 0) {
-          float s = 0.f;
-          for (int b = 0; b < B; ++b) s += c[a * B + b] * basis[(long)row * B + b];
-          q = q + (s - t0[a]);
-        }
-        os[vv * 768 + tid * 3 + a] = q;
-      }
+      float qx = ps[tid * 3], qy = ps[tid * 3 + 1], qz = ps[tid * 3 + 2];
+      traj_displace(c, basis, B, tr.rows[v0 + vv], tr.ref, qx, qy, qz);  // (the sums of the fused consumers: traj_displace)
+      os[vv * 768 + tid * 3] = qx; os[vv * 768 + tid * 3 + 1] = qy; os[vv * 768 + tid * 3 + 2] = qz;
     }
     __syncthreads();
     for (int vv = 0; vv < nv; ++vv) {
@@ -1171,6 +1212,86 @@ __global__ void __launch_bounds__(256) k_render_flows(const float* __restrict__ 
     flows[((long)v * R + r) * 2 + 0] = hx / hz - uv[r * 2 + 0];
     flows[((long)v * R + r) * 2 + 1] = hy / hz - uv[r * 2 + 1];
   }
+}
+// the same from the motion coefficients (the fused form of the eval path: pts_seq does not exist).  The expected point is linear in the coefficients:
+//   sum_s w_s (p_s + traj_row(c_s) - traj_ref(c_s)) = sum_s w_s p_s + sum_b (sum_s w_s c_s[a, b]) (basis[row, b] - basis[ref, b]),
+// so ONE pass over a ray's samples (its S x 3 B coefficients are one contiguous run: coalesced into LDS, odd sample stride) serves all V views: 3 + 3 B weighted
+// sums per ray, then V x 3 B products.  (Recomputing every displaced point per view cost 12 ms per frame against 0.5 ms for the materialised form; the
+// reordering moves the flows by 1e-7 relative -- they are compared with the reference's at 2e-4 px.)  One wavefront per ray.
+#define FLOW_MAX_B 16
+__global__ void __launch_bounds__(256) k_render_flows_traj(const float* __restrict__ weights, const float* __restrict__ pts, PGTraj tj, const float* __restrict__ proj,
+                                                           const float* __restrict__ uv, int R, int S, int V, float* __restrict__ flows) {
+  const int lane = dyn_lane(), wave = dyn_wave();
+  const int C3 = 3 * tj.B, CS = C3 | 1;
+  float* cw = reinterpret_cast<float*>(dyn_smem) + (size_t)wave * (64 * CS + 3 * FLOW_MAX_B + 4);  // [64 samples][CS] staging, then the ray's 3 B + 3 sums
+  float* sums = cw + 64 * CS;
+  const int r = blockIdx.x * 4 + wave;
+  const bool live = r < R;
+  float acc[3 * FLOW_MAX_B + 3];
+#pragma unroll
+  for (int k = 0; k < 3 * FLOW_MAX_B + 3; ++k) acc[k] = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {  // 64 samples at a time through the wave's LDS block (its own: a wave runs in lock step, no workgroup barrier)
+    const int ns = S - s0 < 64 ? S - s0 : 64;
+    if (live) {
+      const float* src = tj.coeff + ((long)r * S + s0) * C3;
+      for (int e = lane; e < ns * C3; e += 64) cw[(e / C3) * CS + (e % C3)] = src[e];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    if (live && lane < ns) {
+      const long i = (long)r * S + s0 + lane;
+      const float wt = weights[i];
+      acc[0] += wt * pts[i * 3]; acc[1] += wt * pts[i * 3 + 1]; acc[2] += wt * pts[i * 3 + 2];
+      const float* c = cw + lane * CS;
+#pragma unroll
+      for (int k = 0; k < 3 * FLOW_MAX_B; ++k)
+        if (k < C3) acc[3 + k] += wt * c[k];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int k = 0; k < 3 * FLOW_MAX_B + 3; ++k)
+    if (k < C3 + 3) {
+      const float t = wave_sum(acc[k]);
+      if (lane == 0) sums[k] = t;
+    }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  for (int v = lane; live && v < V; v += 64) {
+    const int row = tj.rows[v];
+    float e3[3] = {sums[0], sums[1], sums[2]};
+    if (row >= 0) {
+      for (int a = 0; a < 3; ++a) {
+        float d = 0.f;
+        for (int b = 0; b < tj.B; ++b) d += sums[3 + a * tj.B + b] * (tj.basis[(long)row * tj.B + b] - tj.basis[(long)tj.ref * tj.B + b]);
+        e3[a] += d;
+      }
+    }
+    const float* P = proj + v * 16;  // rows of K . inv(c2w)
+    const float hx = P[0] * e3[0] + P[1] * e3[1] + P[2] * e3[2] + P[3];
+    const float hy = P[4] * e3[0] + P[5] * e3[1] + P[6] * e3[2] + P[7];
+    const float hz = P[8] * e3[0] + P[9] * e3[1] + P[10] * e3[2] + P[11];
+    flows[((long)v * R + r) * 2 + 0] = hx / hz - uv[r * 2 + 0];
+    flows[((long)v * R + r) * 2 + 1] = hy / hz - uv[r * 2 + 1];
+  }
+}
+extern "C" int dyn_render_flows_traj(const float* weights, const float* pts, const float* coeff, const float* basis, int B, const int* rows_dev, int row_ref,
+                                     const float* proj, const float* uv, int R, int S, int V, float* flows, void* stream) {
+  DYN_REQUIRE(weights && pts && coeff && basis && rows_dev && proj && uv && flows && R > 0 && S > 0 && V > 0 && B > 0 && B <= FLOW_MAX_B && row_ref >= 0,
+              "dyn_render_flows_traj: bad argument (1 <= B <= %d)", FLOW_MAX_B);
+  PGTraj tj;
+  tj.coeff = coeff; tj.basis = basis; tj.rows = rows_dev; tj.B = B; tj.ref = row_ref;
+  const size_t lds = (size_t)4 * (64 * ((3 * B) | 1) + 3 * FLOW_MAX_B + 4) * sizeof(float);
+  DYN_LAUNCH(DYN_K_RENDER_FLOWS, "dyn_render_flows_traj", k_render_flows_traj, dim3(dyn_cdiv(R, 4)), dim3(256), lds, (hipStream_t)stream, weights, pts, tj,
+             proj, uv, R, S, V, flows);
+  return 0;
 }
 extern "C" int dyn_render_flows(const float* weights, const float* pts_seq, const float* proj, const float* uv, int R, int S, int V, float* flows,
                                 void* stream) {

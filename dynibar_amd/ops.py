@@ -141,21 +141,31 @@ def project_points(cams, xyz, xyz_st=None, query_camera=None, proj_matrices=None
 GATHER_STATS = None  # set to {} to tally calls and algorithmic bytes of project_gather (a measurement hook; never read by the product)
 
 
-def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None, pix_mask_thresh=None):
+def project_gather(views: SourceViews, R, S, ray_o=None, ray_d=None, z_vals=None, pts_st=None, xyz=None, pix_mask_thresh=None, traj=None, want_ray_diff=True):
   """k_project_gather_tile -> rgb_feat [R,S,V,3+F], ray_diff [R,S,V,4], mask [R,S,V,1]; with pix_mask_thresh also the per-sample
-  observation mask ``mask[..., 0].sum(dim=2) > thresh`` [R,S] (render_ray.py:736-741) as a fourth result, from the same launch."""
+  observation mask ``mask[..., 0].sum(dim=2) > thresh`` [R,S] (render_ray.py:736-741) as a fourth result, from the same launch.
+  ``traj`` = (coeff [R,S,3B], basis [frames,B], rows int32 DEVICE [V], ref row): the fused form of compute_traj_pts -- view v sees
+  pts_st + (traj(rows[v]) - traj(ref)), formed inside the kernel; excludes ``xyz`` (which is that array, materialised).
+  ``want_ray_diff=False``: ray_diff is neither written nor returned (None in its place) -- the dynamic branch has no use for it."""
   k = _Keep()
+  tj = {}
+  if traj is not None:
+    assert xyz is None and pts_st is not None, 'the fused trajectory form displaces pts_st itself'
+    coeff, basis, rows_dev, ref = traj
+    assert rows_dev.dtype == torch.int32 and rows_dev.numel() == views.V and rows_dev.device == views.proj.device
+    k.held.append(rows_dev)
+    tj = dict(traj_coeff=k(coeff), traj_basis=k(basis), traj_rows=rows_dev.data_ptr(), traj_B=int(basis.shape[1]), traj_ref=int(ref))
   dev = views.proj.device
   V, C = views.V, 3 + views.F
   rgb_feat = torch.empty((R, S, V, C), dtype=torch.float32, device=dev)
-  ray_diff = torch.empty((R, S, V, 4), dtype=torch.float32, device=dev)
+  ray_diff = torch.empty((R, S, V, 4), dtype=torch.float32, device=dev) if want_ray_diff else None
   mask = torch.empty((R, S, V, 1), dtype=torch.float32, device=dev)
   pix = torch.empty((R, S), dtype=torch.float32, device=dev) if pix_mask_thresh is not None else None
   p = params('DynProjectGatherParams', R=R, S=S, V=V, H=views.H, W=views.W, Hf=views.Hf, Wf=views.Wf, F=views.F,
              img_h=views.img_h, img_w=views.img_w, ray_o=k(ray_o), ray_d=k(ray_d), z_vals=k(z_vals),
              pts_st=k(pts_st), xyz=k(xyz), proj=ptr(views.proj), query_center=ptr(views.query_center),
              src_rgb=ptr(views.src_rgbs), feat_cl=ptr(views.feat_cl), rgb_feat=ptr(rgb_feat), ray_diff=ptr(ray_diff), mask=ptr(mask),
-             pix_mask=ptr(pix), pix_mask_thresh=float(pix_mask_thresh) if pix_mask_thresh is not None else 0.0)
+             pix_mask=ptr(pix), pix_mask_thresh=float(pix_mask_thresh) if pix_mask_thresh is not None else 0.0, **tj)
   call('dyn_project_gather', ctypes.byref(p), stream_of(rgb_feat))
   if GATHER_STATS is not None:  # opt-in tally of the launches' algorithmic bytes (SURVEY.md section 8d): bench.py prices the in-frame gather with it
     GATHER_STATS['calls'] = GATHER_STATS.get('calls', 0) + 1

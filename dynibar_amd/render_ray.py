@@ -18,6 +18,7 @@ the reference detaches them.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -214,6 +215,21 @@ def _needs_graph(*tensors):
   return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
+FUSED_TRAJ = os.environ.get('DYNIBAR_FUSED_TRAJ', '1') != '0'  # developer A/B: 0 materialises the displaced points [V,R,S,3] like rounds 1-5
+_ROWS_DEV = {}
+
+
+def _rows_on_device(rows, dev):
+  """the basis rows of the dynamic source views as a small int32 device tensor (cached: a frame asks for the same rows in every chunk)"""
+  key = (tuple(rows), dev.type, dev.index)
+  t = _ROWS_DEV.get(key)
+  if t is None:
+    if len(_ROWS_DEV) > 64:
+      _ROWS_DEV.clear()
+    t = _ROWS_DEV[key] = torch.tensor(rows, dtype=torch.int32, device=dev)
+  return t
+
+
 def _traj(coeff, basis, pts, rows, row_ref):
   """k_trajectory_points; with a graph (train_motion.TrajectoryFunction) when the coefficients, the basis or the points carry one"""
   if _needs_graph(coeff, basis, pts):
@@ -250,12 +266,26 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
   coeff = _coeff(model, names['motion'], dev, num_basis, pts, time, n_last if n_last > 0 else S)
   nf = basis.shape[0]
   rows = [(int(ref_frame_idx) + int(o)) % nf for o in ref_time_offset] + [-1] * num_vv  # negative rows wrap like basis[idx] does
-  pts_seq = _traj(coeff, basis, pts, rows, int(ref_frame_idx) % nf)
+  # compute_traj_pts (render_ray.py:361-369, :691-725).  Without a graph the displaced points are never materialised: the gather kernel (and the flows) form
+  # them from the coefficients with the same sums as k_trajectory_points, bit for bit (csrc/dyn_geometry.hip: traj_displace) -- [V,R,S,3] neither written nor read.
+  fused = FUSED_TRAJ and not _needs_graph(coeff, basis, pts, featmaps_dy)
+  traj = None
+  if fused:
+    traj = (coeff, basis.float().contiguous(), _rows_on_device(rows, dev), int(ref_frame_idx) % nf)
+    pts_seq = None
+  else:
+    pts_seq = _traj(coeff, basis, pts, rows, int(ref_frame_idx) % nf)
   views_dy = projector.source_views(ray_batch['camera'], ray_batch['src_rgbs'], ray_batch['src_cameras'], featmaps_dy)
   views_st = projector.source_views(ray_batch['camera'], ray_batch['static_src_rgbs'], ray_batch['static_src_cameras'], featmaps_st)
   assert views_dy.V == len(rows), 'one time offset (or virtual view) per dynamic source view'
   # sample masks: at least 2 observations (render_ray.py:736-741), counted by the gather kernel itself
-  rgb_feat_dy, _, mask_dy, pm_dy = _gather(views_dy, featmaps_dy, R, S, 1.0, xyz=pts_seq, pts_st=pts)
+  # (the dynamic branch has no use for ray_diff -- DynibarDynamic takes none, mlp_network.py:236-317 --: the forward-only gather does not write it)
+  if fused:
+    rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, pix_mask_thresh=1.0, traj=traj, want_ray_diff=False)
+  elif _needs_graph(featmaps_dy, pts_seq):
+    rgb_feat_dy, _, mask_dy, pm_dy = _gather(views_dy, featmaps_dy, R, S, 1.0, xyz=pts_seq, pts_st=pts)
+  else:
+    rgb_feat_dy, _, mask_dy, pm_dy = ops.project_gather(views_dy, R, S, pts_st=pts, xyz=pts_seq, pix_mask_thresh=1.0, want_ray_diff=False)
   rgb_feat_st, ray_diff_st, mask_st, pm_st = _gather(views_st, featmaps_st, R, S, 1.0, ray_o=ray_o, ray_d=ray_d, z_vals=z_vals)
   net_dy = getattr(model, names['dy'])
   if train_dynamic.wants_grad(net_dy, rgb_feat_dy):
@@ -270,7 +300,7 @@ def _dual_branch(model, names, args, projector, ray_batch, featmaps_dy, featmaps
     raw_st = train_static.static_raw(net_st, flags, views_st, rgb_feat_st, ray_o, ray_d, pts, ray_diff_st, mask_st)
   else:
     raw_st = _static_net(model, names['st'], args, dev)(views_st, ray_o, ray_d, pts, rgb_feat_st, ray_diff_st, mask_st)
-  return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis)
+  return dict(raw_dy=raw_dy, raw_st=raw_st, pm_dy=pm_dy, pm_st=pm_st, coeff=coeff, pts_seq=pts_seq, views_dy=views_dy, basis=basis, traj=traj, pts=pts, n_views=len(rows))
 
 
 def _finish(stage, z_vals, keys2, keys1):
@@ -297,9 +327,15 @@ def _motion_outputs(out, stage, ray_batch, ref_frame_idx, sf_off, flow_views=Non
   """render_flows (render_ray.py:333-358) and exp_sf (:584-595 / :1086-1096) of a composited stage."""
   R, S = out['weights'].shape
   views = stage['views_dy']
-  fv = stage['pts_seq'].shape[0] if flow_views is None else min(flow_views, stage['pts_seq'].shape[0])
+  fv = stage['n_views'] if flow_views is None else min(flow_views, stage['n_views'])
   uv = ray_batch['uv_grid'].float().contiguous()
-  if _needs_graph(out['weights'], stage['pts_seq']):
+  if stage['pts_seq'] is None:  # the fused eval form: the flows form the displaced points themselves (the first fv views: a prefix of the rows)
+    coeff, basis, rows_dev, ref = stage['traj']
+    flows = torch.empty((fv, R, 2), dtype=torch.float32, device=out['weights'].device)
+    k = ops._Keep()
+    ops.call('dyn_render_flows_traj', k(out['weights']), k(stage['pts']), k(coeff), k(basis), int(basis.shape[1]), rows_dev.data_ptr(), ref, ops.ptr(views.proj), k(uv),
+             R, S, fv, ops.ptr(flows), ops.stream_of(flows))
+  elif _needs_graph(out['weights'], stage['pts_seq']):
     flows = train_motion.render_flows(out['weights'], stage['pts_seq'][:fv], views.proj, uv)  # (a slice of leading views is contiguous)
   else:
     flows = torch.empty((fv, R, 2), dtype=torch.float32, device=out['weights'].device)

@@ -57,7 +57,10 @@ int dyn_points_from_z(const float* ray_o, const float* ray_d, const float* z_val
  * One kernel: K.inv(c2w) projection, clamp, in-front/in-bounds mask, bilinear zero-padded align_corners taps of the
  * RGB images and of the feature maps at the same normalised location, ray-direction difference.
  * Sample points come either from (ray_o, ray_d, z_vals) [pts_st = o + z d] or from an explicit pts_st array; the
- * per-view points xyz are pts_st itself (static branch, xyz = NULL) or an explicit [V,R,S,3] array (scene motion). */
+ * per-view points xyz are pts_st itself (static branch, xyz = NULL), an explicit [V,R,S,3] array (scene motion) or -- traj_coeff != NULL, the fused form of
+ * compute_traj_pts (render_ray.py:361-369, :691-725) -- formed in the kernel from the motion coefficients: view v sees pts_st + (traj(traj_rows[v]) - traj(traj_ref)),
+ * traj(row)[a] = sum_b coeff[.., a B + b] basis[row, b], a negative row = no displacement (virtual views); the same arithmetic, bit for bit, as dyn_trajectory_points,
+ * whose [V,R,S,3] output then never exists.  traj_rows is a DEVICE array of V ints. */
 typedef struct {
   int R, S, V;
   int H, W;                 /* source image size (tensor dims) */
@@ -73,10 +76,14 @@ typedef struct {
   const float* src_rgb;     /* [V,H,W,3] */
   const float* feat_cl;     /* [V,Hf,Wf,F] channels-last */
   float* rgb_feat;          /* [R,S,V,3+F] */
-  float* ray_diff;          /* [R,S,V,4] */
+  float* ray_diff;          /* [R,S,V,4], or NULL when the caller has no use for it (the dynamic branch: DynibarDynamic takes none) */
   float* mask;              /* [R,S,V] (the reference's trailing singleton dim is a view) */
   float* pix_mask;          /* [R,S] or NULL: 1 where more than pix_mask_thresh views see the sample (render_ray.py:736-741), else 0 */
   float pix_mask_thresh;
+  const float* traj_coeff;  /* [R,S,3 B] or NULL (then the fields below are ignored); needs pts_st, excludes xyz */
+  const float* traj_basis;  /* [frames, B] */
+  const int* traj_rows;     /* DEVICE [V]: basis row of each view, negative = the undisplaced point */
+  int traj_B, traj_ref;     /* basis functions per axis; basis row of the reference time */
 } DynProjectGatherParams;
 int dyn_project_gather(const DynProjectGatherParams* p, void* stream);
 
@@ -203,6 +210,11 @@ int dyn_trajectory_points(const float* coeff, const float* basis, const float* p
  * proj: [V,16] from dyn_prepare_cameras (rows of K.inv(c2w)); flows: [V,R,2]. */
 int dyn_render_flows(const float* weights, const float* pts_seq, const float* proj, const float* uv, int R, int S, int V, float* flows,
                      void* stream);
+/* the same from the motion coefficients (the fused eval path: pts_seq [V,R,S,3] is never formed): pts [R,S,3], coeff [R,S,3 B], basis [frames,B],
+ * rows_dev DEVICE [V] basis rows (negative: undisplaced), row_ref the reference time's row, B <= 16.  The expected point is formed through its linearity in the
+ * coefficients (one pass over the samples for all views): equal to dyn_trajectory_points + dyn_render_flows up to the order of the fp32 sums (1e-7 relative) */
+int dyn_render_flows_traj(const float* weights, const float* pts, const float* coeff, const float* basis, int B, const int* rows_dev, int row_ref,
+                          const float* proj, const float* uv, int R, int S, int V, float* flows, void* stream);
 /* ---- expected scene flow (render_ray.py:584-595 / :1086-1096): max(sum_s w (traj(row_p) - traj(row_ref)), sum_s w (traj(row_m) - traj(row_ref))) */
 int dyn_expected_scene_flow(const float* weights, const float* coeff, const float* basis, int R, int S, int B, int row_p, int row_m, int row_ref,
                             float* exp_sf, void* stream);

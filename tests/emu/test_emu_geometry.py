@@ -41,3 +41,8 @@ def test_project_gather_same_matrix(emu, name):
 
 def test_projector_helper_methods(emu):
   print('  compute_angle max |err| vs oracle:', parity.check_projector_helpers(emu, 'small'))
+
+
+def test_trajectory_points_fused_into_gather_and_flows(emu):
+  parity.check_fused_trajectory(emu, 'small', S=16, R=3)
+  parity.check_fused_trajectory(emu, 'kid', S=8, R=2, virtual_views=3)

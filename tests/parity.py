@@ -660,6 +660,47 @@ def check_motion(device, name='small', S=64, R=None, weights='init'):
   return float((cpu(coeff) - di['coeff']).abs().max())
 
 
+def check_fused_trajectory(device, name='small', S=64, R=None, weights='init', virtual_views=0):
+  """compute_traj_pts fused into its consumers (render_ray.py:361-369, :691-725): the gather and the flows that form the displaced points themselves from
+  the motion coefficients must equal -- the gather bit for bit, the flows to 5e-5 px -- the gather / flows on the materialised [V,R,S,3] array of k_trajectory_points (same sums, same order:
+  csrc/dyn_geometry.hip traj_displace), with scaled-up coefficients so that the displacement moves the taps, and with virtual views (row < 0: no motion)."""
+  di = dynamic_inputs(name, S, R, weights)
+  sc = to_dev(di['scene'], device)
+  views = ops.SourceViews(sc['camera'], sc['src_rgbs'], sc['src_cameras'], sc['featmaps'])
+  V = views.V
+  pts = di['pts'].to(device)
+  coeff = (di['coeff'] * 40.0).to(device).contiguous()  # (initialisation-scale motion is ~1e-3 of the scene: scaled so that pixels and masks really move)
+  basis = di['basis'].to(device)
+  rows = [di['fidx'] + k for k in di['toff']]
+  if virtual_views:
+    rows = rows[:V - virtual_views] + [-1] * virtual_views
+  assert len(rows) == V
+  ref = di['fidx']
+  Rn = pts.shape[0]
+  rows_dev = torch.tensor(rows, dtype=torch.int32, device=device)
+  seq = ops.trajectory_points(coeff, basis, pts, rows, ref)
+  assert float((seq - pts[None]).abs().max()) > 1e-2, 'the case does not displace anything'
+  a = ops.project_gather(views, Rn, S, pts_st=pts, xyz=seq, pix_mask_thresh=1.0)
+  b = ops.project_gather(views, Rn, S, pts_st=pts, pix_mask_thresh=1.0, traj=(coeff, basis, rows_dev, ref))
+  for x, y, what in zip(a, b, ('rgb_feat', 'ray_diff', 'mask', 'pix_mask')):
+    assert_bitexact(cpu(y), cpu(x), f'{name} fused trajectory gather: {what}')
+  static = ops.project_gather(views, Rn, S, pts_st=pts, pix_mask_thresh=1.0)
+  assert float((static[0] - a[0]).abs().max()) > 1e-3, 'the displaced gather equals the undisplaced one: the case pins nothing'
+  g = torch.Generator().manual_seed(3)
+  w = torch.rand(Rn, S, generator=g)
+  w = (w / w.sum(dim=1, keepdim=True)).to(device).contiguous()
+  uv = torch.rand(Rn, 2, generator=g).mul(40.0).to(device).contiguous()
+  fa = torch.empty((V, Rn, 2), dtype=torch.float32, device=device)
+  fb = torch.empty_like(fa)
+  ops.call('dyn_render_flows', ops.ptr(w), ops.ptr(seq), ops.ptr(views.proj), ops.ptr(uv), Rn, S, V, ops.ptr(fa), ops.stream_of(fa))
+  ops.call('dyn_render_flows_traj', ops.ptr(w), ops.ptr(pts.contiguous()), ops.ptr(coeff), ops.ptr(basis.contiguous()), int(basis.shape[1]), rows_dev.data_ptr(), int(ref),
+           ops.ptr(views.proj), ops.ptr(uv), Rn, S, V, ops.ptr(fb), ops.stream_of(fb))
+  # (the flows form the expected point through its linearity in the coefficients -- another order of the fp32 sums: 1e-7 of the scene's scale, amplified by the
+  # projection to ~1e-5 px; the reference's own flows are compared at 2e-4 px)
+  assert_close(cpu(fb), cpu(fa), 5e-5, 1e-5, f'{name} fused trajectory flows')
+  return float((seq - pts[None]).abs().max())
+
+
 def check_dynamic_net(device, name='small', S=64, R=None, shift=0.0, atol=1e-4, weights='init'):
   di = dynamic_inputs(name, S, R, weights)
   Vd = di['rgb_feat'].shape[2]

@@ -89,6 +89,13 @@ def test_accuracy_against_float64(dev, kw):
   parity.check_accuracy_against_double(dev, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=40), dict(name='kid', S=64, virtual_views=3), dict(name='stress', S=128), dict(name='few', S=33),
+                                dict(name='train_large', S=64, R=200)])
+def test_trajectory_points_fused_into_gather_and_flows(dev, kw):
+  """compute_traj_pts inside the gather kernel and the flows (the eval path: the displaced points [V,R,S,3] never exist) against the materialised form: the gather bit-exact, the flows to 5e-5 px"""
+  parity.check_fused_trajectory(dev, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=32, R=4), dict(name='kid', S=48, R=4), dict(name='train_large', S=32, R=96, weights='trained'),
                                 dict(name='stress', S=128, R=3)])
 def test_dual_branch_accuracy_against_float64(dev, kw):
