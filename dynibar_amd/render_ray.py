@@ -225,6 +225,8 @@ def _rows_on_device(rows, dev):
   t = _ROWS_DEV.get(key)
   if t is None:
     if len(_ROWS_DEV) > 64:
+      if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)  # kernels of earlier chunks (other streams) may still read the cached arrays: nothing is freed under them
       _ROWS_DEV.clear()
     t = _ROWS_DEV[key] = torch.tensor(rows, dtype=torch.int32, device=dev)
   return t
