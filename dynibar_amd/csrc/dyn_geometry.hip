@@ -1498,14 +1498,26 @@ extern "C" int dyn_render_flows_bwd(const float* dflows, const float* weights, c
 __global__ void __launch_bounds__(256) k_expected_scene_flow(const float* __restrict__ weights, const float* __restrict__ coeff,
                                                              const float* __restrict__ basis, int R, int S, int B, int row_p, int row_m,
                                                              int row_ref, float* __restrict__ out) {
-  const int lane = dyn_lane();
-  const int r = blockIdx.x * 4 + dyn_wave();
-  if (r >= R) return;
+  // (round 6: a ray's S x 3 B coefficients are one contiguous run -- 64 samples at a time they are read coalesced into the wave's own LDS block at an odd
+  // sample stride; a lane reading its sample's 72-byte record straight from global memory ran this kernel at 76 us per 8192 x 128 samples.  Same sums, same order.)
+  const int lane = dyn_lane(), wave = dyn_wave();
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;  // (whole waves leave; no workgroup barrier below)
+  const int C3 = 3 * B, CS = C3 | 1;
+  float* cw = reinterpret_cast<float*>(dyn_smem) + (size_t)wave * 64 * CS;
   float ap[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f};
-  for (int s = lane; s < S; s += 64) {
-    const float wt = weights[(long)r * S + s];
-    const float* c = coeff + ((long)r * S + s) * 3 * B;
-    for (int a = 0; a < 3; ++a) {
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int ns = S - s0 < 64 ? S - s0 : 64;
+    const float* src = coeff + ((long)r * S + s0) * C3;
+    for (int e = lane; e < ns * C3; e += 64) cw[(e / C3) * CS + (e % C3)] = src[e];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const int s = s0 + lane;
+    const float wt = lane < ns ? weights[(long)r * S + s] : 0.f;
+    const float* c = cw + (lane < ns ? lane : 0) * CS;
+    for (int a = 0; a < 3 && lane < ns; ++a) {
       float t0 = 0.f, tp = 0.f, tm = 0.f;
       for (int b = 0; b < B; ++b) {
         const float cb = c[a * B + b];
@@ -1516,6 +1528,10 @@ __global__ void __launch_bounds__(256) k_expected_scene_flow(const float* __rest
       ap[a] += wt * (tp - t0);
       am[a] += wt * (tm - t0);
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
   }
   for (int a = 0; a < 3; ++a) {
     ap[a] = wave_sum(ap[a]);
@@ -1527,7 +1543,7 @@ extern "C" int dyn_expected_scene_flow(const float* weights, const float* coeff,
                                        int row_ref, float* exp_sf, void* stream) {
   DYN_REQUIRE(weights && coeff && basis && exp_sf && R > 0 && S > 0 && B > 0, "dyn_expected_scene_flow: bad argument");
   DYN_REQUIRE(row_p >= 0 && row_m >= 0 && row_ref >= 0, "dyn_expected_scene_flow: basis rows must be non-negative");
-  DYN_LAUNCH(DYN_K_SCENE_FLOW, "dyn_expected_scene_flow", k_expected_scene_flow, dim3(dyn_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, weights,
+  DYN_LAUNCH(DYN_K_SCENE_FLOW, "dyn_expected_scene_flow", k_expected_scene_flow, dim3(dyn_cdiv(R, 4)), dim3(256), (size_t)4 * 64 * ((3 * B) | 1) * sizeof(float), (hipStream_t)stream, weights,
              coeff, basis, R, S, B, row_p, row_m, row_ref, exp_sf);
   return 0;
 }
