@@ -46,3 +46,7 @@ def test_projector_helper_methods(emu):
 def test_trajectory_points_fused_into_gather_and_flows(emu):
   parity.check_fused_trajectory(emu, 'small', S=16, R=3)
   parity.check_fused_trajectory(emu, 'kid', S=8, R=2, virtual_views=3)
+
+
+def test_expected_scene_flow(emu):
+  parity.check_expected_scene_flow(emu)

@@ -701,6 +701,25 @@ def check_fused_trajectory(device, name='small', S=64, R=None, weights='init', v
   return float((seq - pts[None]).abs().max())
 
 
+def check_expected_scene_flow(device, R=37, S=150, B=6, seed=4):
+  """k_expected_scene_flow (render_ray.py:584-595 / :1086-1096) on random weights and coefficients, rays longer than one 64-sample staging block and a ray
+  count that is no multiple of a workgroup's four, against torch in double."""
+  g = torch.Generator().manual_seed(seed)
+  w = torch.rand(R, S, generator=g)
+  w = w / w.sum(dim=1, keepdim=True)
+  coeff = torch.randn(R, S, 3 * B, generator=g)
+  basis = O.init_dct_basis(B, cases.NUM_FRAMES)
+  rp, rm, rr = 12, 10, 11
+  out = torch.empty((R, 3), dtype=torch.float32, device=device)
+  wd, cd, bd = w.to(device).contiguous(), coeff.to(device).contiguous(), basis.to(device).contiguous()
+  ops.call('dyn_expected_scene_flow', ops.ptr(wd), ops.ptr(cd), ops.ptr(bd), R, S, B, rp, rm, rr, ops.ptr(out), ops.stream_of(out))
+  c = coeff.double().reshape(R, S, 3, B)
+  tr = lambda row: (c * basis[row].double()).sum(-1)
+  ref = torch.max((w.double()[..., None] * (tr(rp) - tr(rr))).sum(1), (w.double()[..., None] * (tr(rm) - tr(rr))).sum(1))
+  assert_close(cpu(out).double(), ref, 2e-6, 1e-5, 'expected scene flow')
+  return float((cpu(out).double() - ref).abs().max())
+
+
 def check_dynamic_net(device, name='small', S=64, R=None, shift=0.0, atol=1e-4, weights='init'):
   di = dynamic_inputs(name, S, R, weights)
   Vd = di['rgb_feat'].shape[2]

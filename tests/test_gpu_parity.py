@@ -89,6 +89,11 @@ def test_accuracy_against_float64(dev, kw):
   parity.check_accuracy_against_double(dev, **kw)
 
 
+def test_expected_scene_flow(dev):
+  parity.check_expected_scene_flow(dev)
+  parity.check_expected_scene_flow(dev, R=4099, S=64, seed=9)
+
+
 @pytest.mark.parametrize('kw', [dict(name='small', S=64), dict(name='harsh', S=40), dict(name='kid', S=64, virtual_views=3), dict(name='stress', S=128), dict(name='few', S=33),
                                 dict(name='train_large', S=64, R=200)])
 def test_trajectory_points_fused_into_gather_and_flows(dev, kw):
