@@ -14,7 +14,10 @@ def t(x):
 
 
 def scene_case(name):
-  """name -> (scene dict of torch tensors, ray_o, ray_d, uv, pixel ids)."""
+  """name -> (scene dict of torch tensors, ray_o, ray_d, uv, pixel ids).  'edge_<V>_<n_static>_<R>': an extreme shape (1-2 views, a single ray)."""
+  if name.startswith('edge_'):
+    v, ns, r = (int(x) for x in name.split('_')[1:])
+    return _scene_of(dict(seed=61, H=32, W=48, V=v, n_static=ns, smooth=True), r)
   cfg = {
       # small, smooth maps: well-conditioned parity
       'small': dict(seed=1, H=48, W=64, V=7, n_static=8, smooth=True, R=6),
@@ -45,7 +48,10 @@ def scene_case(name):
       'cross_rays_views': dict(seed=54, H=32, W=48, V=5, n_static=3, smooth=True, R=3),
       'cross_rays_samples': dict(seed=55, H=32, W=48, V=5, n_static=8, smooth=True, R=3),
   }[name]
-  R = cfg.pop('R')
+  return _scene_of(cfg, cfg.pop('R'))
+
+
+def _scene_of(cfg, R):
   seed = cfg['seed']
   sc = syn.make_scene(**cfg)
   fine = syn.make_scene(**dict(cfg, tag=1))  # fine-stage feature maps come from a second encoder

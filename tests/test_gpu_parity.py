@@ -89,6 +89,15 @@ def test_accuracy_against_float64(dev, kw):
   parity.check_accuracy_against_double(dev, **kw)
 
 
+@pytest.mark.parametrize('name,S', [('edge_1_1_4', 8), ('edge_2_2_4', 8), ('edge_1_2_1', 8), ('edge_4_4_4', 2), ('edge_2_1_2', 65), ('edge_1_1_1', 2)])
+def test_extreme_shapes(dev, name, S):
+  """One or two source views in either branch, a single ray, two samples per ray, one sample more than a row tile: networks, the whole static pass and
+  the dynamic network against the oracle (the reference itself yields NaN at one sample per ray: not a case)."""
+  parity.check_static_net(dev, name, S=S)
+  parity.check_static_pass(dev, name, S=S)
+  parity.check_dynamic_net(dev, name, S=S, shift=5.0)
+
+
 def test_expected_scene_flow(dev):
   parity.check_expected_scene_flow(dev)
   parity.check_expected_scene_flow(dev, R=4099, S=64, seed=9)
