@@ -352,8 +352,9 @@ __device__ __forceinline__ Taps make_taps(float nx, float ny, int Wm, int Hm) {
 
 // ---- compute_traj_pts fused into the consumers of the displaced points (render_ray.py:361-369, :691-725) ----------------------------------------------
 // A point seen at the time of basis row `row` is p + (traj(row) - traj(ref)), traj(row)[a] = sum_b c[a B + b] basis[row, b] (row < 0: the undisplaced point).
-// ONE function for k_trajectory_points (which materialises [V,R,S,3] for callers of the reference's helper and for training), for the gather kernels'
-// fused form (the array never exists) and for the flows: the same sums in the same order, so the three agree bit for bit.
+// ONE function for k_trajectory_points (which materialises [V,R,S,3] for callers of the reference's helper and for training) and for the gather kernels'
+// fused form (the array never exists): the same sums in the same order, so the fused gather equals the gather on the materialised points bit for bit.
+// (The flows of the fused path use the linearity of the expected point instead -- k_render_flows_traj.)
 struct PGTraj {
   const float* coeff;  // [R,S,3 B] or nullptr
   const float* basis;  // [frames, B]
